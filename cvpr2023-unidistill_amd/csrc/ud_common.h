@@ -1,0 +1,54 @@
+// Shared device/host helpers for libunidistill_hip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "unidistill_hip.h"
+
+#define UD_WAVE 64
+
+#define UD_LAUNCH_CHECK()                                  \
+  do {                                                     \
+    if (hipGetLastError() != hipSuccess) return UD_ERR_HIP; \
+  } while (0)
+
+#define UD_HIP_TRY(expr)                          \
+  do {                                            \
+    if ((expr) != hipSuccess) return UD_ERR_HIP;  \
+  } while (0)
+
+static inline size_t ud_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller-provided workspace.
+struct UdArena {
+  char* base;
+  size_t cap;
+  size_t used;
+  UdArena(void* p, size_t n) : base((char*)p), cap(n), used(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = ud_align_up(count * sizeof(T));
+    T* r = (T*)(base + used);
+    used += bytes;
+    return r;
+  }
+  bool ok() const { return base != nullptr && used <= cap; }
+};
+
+static inline int ud_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int ud_lane() { return threadIdx.x & (UD_WAVE - 1); }
+
+// Sum over the 64 lanes of a wave; every lane gets the total.
+__device__ __forceinline__ float ud_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int ud_wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+#endif

@@ -1,0 +1,88 @@
+"""ctypes binding of libunidistill_hip.so + per-device scratch workspace.
+
+The library is a plain C ABI (no torch types).  torch is imported first so that the HIP runtime
+(libamdhip64.so.7) already mapped by torch is the one our library binds to.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libunidistill_hip.so")
+_cdll = None
+
+c_void_p, c_int, c_size_t, c_uint, c_i64, c_float = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int64, ctypes.c_float)
+
+# name -> (restype, argtypes); mirrors include/unidistill_hip.h one to one.
+_SIGS = {
+    "ud_version": (ctypes.c_char_p, []),
+    "ud_abi_version": (c_int, []),
+    "ud_error_string": (ctypes.c_char_p, [c_int]),
+    "ud_bev_pool_workspace_bytes": (c_size_t, [c_int] * 6),
+    "ud_bev_pool_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_uint, c_void_p, c_size_t, c_void_p]),
+    "ud_bev_pool_bwd_workspace_bytes": (c_size_t, [c_int] * 4 + [c_i64]),
+    "ud_bev_pool_bwd": (c_int, [c_void_p] + [c_i64] * 4 + [c_void_p, c_void_p] + [c_int] * 5
+                        + [c_void_p, c_size_t, c_void_p]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Return the loaded CDLL; raise HipLibraryMissing (never fall back) if it is not built."""
+    global _cdll
+    if _cdll is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `make -C cvpr2023-unidistill_amd` "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _cdll = lib
+    return _cdll
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().ud_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} ({code})")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    """hipStream_t torch is currently enqueuing on for t's device."""
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("unidistill_amd ops run on the GPU only (no CPU fallback); "
+                               f"got a tensor on {t.device}")
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes, slot="default"):
+    """Grow-only byte scratch per (device, slot); stream-ordered reuse on torch's current stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -1,0 +1,91 @@
+/*
+ * unidistill_hip.h -- C ABI of libunidistill_hip.so (MI355X / gfx950).
+ *
+ * One shared library sits underneath the Python names the UniDistill reference
+ * imports for its BEV feature-extraction + distillation hot path.  Every entry
+ * point takes plain device pointers + sizes + a hipStream_t, never a torch type,
+ * returns 0 on success or a negative UD_ERR_* code, and never throws.
+ * All pointers are DEVICE pointers unless a parameter is documented "host".
+ * Kernels are enqueued on `stream`; nothing in here synchronises the device.
+ *
+ * Reference interface each group replaces (paths relative to the reference tree,
+ * /root/reference/unidistill/...):
+ *
+ *   ud_bev_pool_*      voxel_pooling_ext.voxel_pooling_forward_wrapper
+ *                      layers/blocks_3d/mmdet3d/lss_fpn.py:48-59 (fwd), :64-79 (bwd)
+ *   ud_lss_*           LSSFPN.get_geometry / binning / lift
+ *                      layers/blocks_3d/mmdet3d/lss_fpn.py:200-240, :289-316
+ *   ud_voxelize*       spconv.pytorch.utils.PointToVoxel.__call__ + MeanVFE.forward
+ *                      data/det3d/preprocess/voxelization.py:31-38,54
+ *                      layers/blocks_3d/det3d/vfe/mean_vfe.py:14-34
+ *   ud_spconv_*        spconv.pytorch.{SubMConv3d,SparseConv3d,SparseConvTensor.dense}
+ *                      layers/blocks_3d/det3d/spconv_backbone.py:21-48,71-92,259-340
+ *                      layers/blocks_2d/det3d/map_to_bev/height_compression.py:19-22
+ *   ud_distill_*       FeatureDistillLoss / BEVDistillLoss / ResponseDistillLoss
+ *                      exps/.../BEVFusion_nuscenes_centerhead_camera_exp_distill_lidar.py
+ *                      :196-245, :248-323, :326-385, gaussian mask :100-178
+ */
+#ifndef UNIDISTILL_HIP_H
+#define UNIDISTILL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t is an opaque pointer; spelled void* so this header needs no HIP include. */
+typedef void* ud_stream_t;
+
+#define UD_OK 0
+#define UD_ERR_INVALID_ARG (-1)
+#define UD_ERR_WORKSPACE (-2) /* workspace pointer NULL or too small */
+#define UD_ERR_HIP (-3)       /* a HIP runtime call / launch failed    */
+#define UD_ERR_UNSUPPORTED (-4)
+
+/* Library identity: returns "unidistill_hip <abi-version> gfx950". */
+const char* ud_version(void);
+/* ABI version integer; bumped whenever a signature in this header changes. */
+int ud_abi_version(void);
+/* Human-readable text for a UD_ERR_* code. */
+const char* ud_error_string(int code);
+
+/* ------------------------------------------------------------------------- */
+/* BEV pool (camera LSS splat)                                               */
+/* ------------------------------------------------------------------------- */
+
+/* flags for ud_bev_pool_fwd */
+#define UD_POOL_ACCUMULATE 0u /* out += pooled sums; caller pre-zeroed out (reference contract, lss_fpn.py:43-47) */
+#define UD_POOL_OVERWRITE 1u  /* every cell of out is written (empty cells get 0); no pre-zero needed             */
+
+/* Bytes of scratch ud_bev_pool_fwd needs for these sizes (0 on invalid sizes). */
+size_t ud_bev_pool_workspace_bytes(int B, int N, int C, int nx, int ny, int nz);
+
+/*
+ * out[b, y, x, :] (+)= sum over points n of batch b with geom[b,n]=(x,y,z) inside
+ * 0<=x<nx, 0<=y<ny, 0<=z<nz of feat[b,n,:];  pos[b,n,:] = (b,y,x) for kept points,
+ * (-1,-1,-1) otherwise.  Sums run in ascending point index n (deterministic; the
+ * reference CUDA op used unordered atomicAdd).
+ *   geom  i32[B,N,3]   feat f32[B,N,C]   out f32[B,ny,nx,C]   pos i32[B,N,3]
+ */
+int ud_bev_pool_fwd(const int32_t* geom, const float* feat, float* out, int32_t* pos,
+                    int B, int N, int C, int nx, int ny, int nz, unsigned flags,
+                    void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
+/*
+ * gfeat[b,n,:] = gout[b,:,y,x] for pos[b,n]=(b,y,x) != -1, else 0   (lss_fpn.py:64-79).
+ * gout is addressed through element strides (sb, sc, sy, sx) so both the NCHW grad the
+ * reference produces and an NHWC (channels-last) grad are accepted; NHWC (sc == 1) is the
+ * fast path, anything else is transposed into `workspace` first
+ * (ud_bev_pool_bwd_workspace_bytes).
+ */
+size_t ud_bev_pool_bwd_workspace_bytes(int B, int C, int nx, int ny, int64_t sc);
+int ud_bev_pool_bwd(const float* gout, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                    const int32_t* pos, float* gfeat, int B, int N, int C, int nx, int ny,
+                    void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIDISTILL_HIP_H */
