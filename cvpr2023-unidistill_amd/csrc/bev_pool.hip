@@ -7,14 +7,16 @@
 // Design (not the reference CUDA op's per-(point,channel) atomicAdd):
 //   k_bin    one thread per frustum point: bounds test, write pos_memo, wave-aggregated
 //            integer atomic to count points per BEV cell (gives an arbitrary in-cell rank)
-//   k_scan   one workgroup: exclusive scan of the per-cell counts, list of "heavy" cells
+//   k_cell_partials / k_cell_offsets   two-level exclusive scan of the per-cell counts (1024 cells
+//            per workgroup) + ordered list of "heavy" cells (> 64 points)
 //   k_fill   scatter point ids into per-cell lists
-//   k_light  one WAVE per cell (<= 64 points): in-register rank sort of the cell's point ids,
-//            then each lane owns 4 channels (16 B) of the 1 KiB feature row and adds the rows
-//            in ascending point order -> coalesced 1 KiB reads, one 1 KiB write, no fp atomics,
-//            bit-reproducible and bit-identical to a sequential CPU loop.
-//   k_heavy  one 1024-thread workgroup per cell with > 64 points: LDS bitonic sort of the ids,
-//            16 waves sum contiguous chunks, partials are combined in wave order.
+//   k_pool   light role: one WAVE per cell (<= 64 points): in-register rank sort of the cell's
+//            point ids, then each lane owns 4 channels (16 B) of the 1 KiB feature row and adds
+//            the rows in ascending point order -> coalesced 1 KiB reads, one 1 KiB write, no fp
+//            atomics, bit-reproducible and bit-identical to a sequential CPU loop.
+//            heavy role (first kHeavyBlocks workgroups of the same launch, so the long cells
+//            start first and overlap the light ones): LDS bitonic sort of the ids, 4 waves sum
+//            contiguous chunks, partials are combined in wave order.
 // HBM traffic = every kept feature row once + the output once; that is the algorithmic minimum.
 #include "ud_common.h"
 #include <limits.h>
@@ -22,9 +24,10 @@
 namespace {
 
 constexpr int kLightMax = 64;      // cells with more points go to k_heavy
-constexpr int kHeavySortMax = 8192;  // LDS sort capacity of k_heavy; above: index-range scan
-constexpr int kHeavyThreads = 1024;
-constexpr int kHeavyGrid = 512;
+constexpr int kHeavySortMax = 4096;  // LDS sort capacity of the heavy role; above: index-range scan
+constexpr int kHeavyBlocks = 128;    // persistent heavy-role workgroups at the front of k_pool
+constexpr int kLightBlocks = 2048;   // persistent light-role workgroups (256 CUs x 8)
+constexpr int kScanTile = 1024;      // cells per workgroup in the two-level scan
 
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
@@ -63,49 +66,84 @@ __global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
 }
 
 // ----------------------------------------------------------------------------------------
-// Single-workgroup exclusive scan over the per-cell counts (32400*B entries), plus an ordered
-// compaction of the cells that need the heavy kernel.
-__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ count, int* __restrict__ off,
-                                               int* __restrict__ heavy_list,
-                                               int* __restrict__ heavy_cnt, int ncell) {
-  __shared__ int s_sum[1024];
-  __shared__ int s_hvy[1024];
-  const int tid = threadIdx.x;
-  const int per = (ncell + 1023) / 1024;
-  const int lo = tid * per;
-  const int hi = min(lo + per, ncell);
-  int sum = 0, hv = 0;
-  for (int i = lo; i < hi; ++i) {
-    const int c = count[i];
-    sum += c;
-    hv += (c > kLightMax);
-  }
-  s_sum[tid] = sum;
-  s_hvy[tid] = hv;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials.
-  for (int d = 1; d < 1024; d <<= 1) {
-    int a = 0, h = 0;
-    if (tid >= d) {
-      a = s_sum[tid - d];
-      h = s_hvy[tid - d];
+// Two-level exclusive scan over the per-cell counts (count[] is zero-padded to a multiple of
+// kScanTile).  Pass 1: per-tile (sum, #heavy).  Pass 2: every tile reduces the partials of the
+// tiles before it, scans its own 1024 cells and emits offsets + the ordered heavy-cell list.
+__device__ __forceinline__ int2 block_excl_scan2(int2 v, int2* s_w, int2& total) {
+  // exclusive scan of one int2 per thread across a 256-thread block (4 waves)
+  const int lane = ud_lane(), wave = threadIdx.x >> 6;
+  int2 inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ax = __shfl_up(inc.x, o), ay = __shfl_up(inc.y, o);
+    if (lane >= o) {
+      inc.x += ax;
+      inc.y += ay;
     }
-    __syncthreads();
-    s_sum[tid] += a;
-    s_hvy[tid] += h;
-    __syncthreads();
   }
-  int run = s_sum[tid] - sum;
-  int hrun = s_hvy[tid] - hv;
-  for (int i = lo; i < hi; ++i) {
-    const int c = count[i];
-    off[i] = run;
-    run += c;
-    if (c > kLightMax) heavy_list[hrun++] = i;
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int2 base = make_int2(0, 0);
+  int2 tot = make_int2(0, 0);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int2 t = s_w[w];
+    if (w < wave) {
+      base.x += t.x;
+      base.y += t.y;
+    }
+    tot.x += t.x;
+    tot.y += t.y;
   }
-  if (tid == 1023) {
-    off[ncell] = s_sum[1023];
-    *heavy_cnt = s_hvy[1023];
+  total = tot;
+  __syncthreads();
+  return make_int2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+}
+
+__global__ __launch_bounds__(256) void k_cell_partials(const int* __restrict__ count,
+                                                       int2* __restrict__ part) {
+  __shared__ int2 s_w[4];
+  const int4 c = reinterpret_cast<const int4*>(count)[blockIdx.x * 256 + threadIdx.x];
+  int2 v = make_int2(c.x + c.y + c.z + c.w, (c.x > kLightMax) + (c.y > kLightMax) +
+                                                (c.z > kLightMax) + (c.w > kLightMax));
+  int2 tot;
+  block_excl_scan2(v, s_w, tot);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_cell_offsets(const int* __restrict__ count,
+                                                      const int2* __restrict__ part,
+                                                      int* __restrict__ off,
+                                                      int* __restrict__ heavy_list,
+                                                      int* __restrict__ heavy_cnt, int ncell) {
+  __shared__ int2 s_w[4];
+  // sum of the partials of all tiles before this one
+  int2 pre = make_int2(0, 0);
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
+    const int2 p = part[i];
+    pre.x += p.x;
+    pre.y += p.y;
+  }
+  int2 pre_tot;
+  block_excl_scan2(pre, s_w, pre_tot);
+  const int cell0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int4 c = reinterpret_cast<const int4*>(count)[blockIdx.x * 256 + threadIdx.x];
+  const int hx = c.x > kLightMax, hy = c.y > kLightMax, hz = c.z > kLightMax, hw = c.w > kLightMax;
+  int2 v = make_int2(c.x + c.y + c.z + c.w, hx + hy + hz + hw);
+  int2 tot;
+  const int2 ex = block_excl_scan2(v, s_w, tot);
+  const int o0 = pre_tot.x + ex.x;
+  int4 o = make_int4(o0, o0 + c.x, o0 + c.x + c.y, o0 + c.x + c.y + c.z);
+  reinterpret_cast<int4*>(off)[blockIdx.x * 256 + threadIdx.x] = o;  // off[] is tile-padded too
+  int h = pre_tot.y + ex.y;
+  if (hx) heavy_list[h++] = cell0;
+  if (hy) heavy_list[h++] = cell0 + 1;
+  if (hz) heavy_list[h++] = cell0 + 2;
+  if (hw) heavy_list[h++] = cell0 + 3;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+    // padded cells hold 0, so the running total past the last real cell is the grand total
+    off[ncell] = pre_tot.x + tot.x;
+    *heavy_cnt = pre_tot.y + tot.y;
   }
 }
 
@@ -176,148 +214,181 @@ __device__ __forceinline__ typename RowVec<VEC>::T sum_rows_wave(const float* __
   return acc;
 }
 
+// Heavy role: one 256-thread workgroup per cell with > kLightMax points.
 template <int VEC>
-__global__ __launch_bounds__(256) void k_light(const float* __restrict__ feat,
-                                               float* __restrict__ out,
-                                               const int* __restrict__ count,
-                                               const int* __restrict__ off,
-                                               const int* __restrict__ list, int ncell, int C,
-                                               unsigned flags) {
+__device__ __forceinline__ void pool_heavy_cell(const float* __restrict__ feat,
+                                                float* __restrict__ out,
+                                                const int* __restrict__ off,
+                                                const int* __restrict__ list,
+                                                const int* __restrict__ cellid, int cell, int N,
+                                                int nynx, int C, unsigned flags, int* s_ids,
+                                                float (*s_part)[64 * VEC]) {
   using V = typename RowVec<VEC>::T;
-  const int cell = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (cell >= ncell) return;
-  const int lane = ud_lane();
-  const int k = __builtin_amdgcn_readfirstlane(count[cell]);
-  if (k > kLightMax) return;  // k_heavy owns this cell
-  float* orow = out + (size_t)cell * C;
-  if (k == 0) {
-    if (flags & UD_POOL_OVERWRITE)
-      for (int ch = lane * VEC; ch < C; ch += 64 * VEC)
-        *reinterpret_cast<V*>(orow + ch) = RowVec<VEC>::zero();
-    return;
-  }
-  const int base = __builtin_amdgcn_readfirstlane(off[cell]);
-  const int mine = (lane < k) ? list[base + lane] : INT_MAX;
-  // rank sort: my position = number of ids smaller than mine (ids are distinct)
-  int r = 0;
-  for (int j = 0; j < k; ++j) r += (__builtin_amdgcn_readlane(mine, j) < mine);
-  // push my id to lane r; lanes >= k all push INT_MAX to lane k (never read)
-  const int sorted = __builtin_amdgcn_ds_permute(r << 2, mine);
-  for (int ch = lane * VEC; ch < C; ch += 64 * VEC) {  // C = 256, VEC = 4: exactly one trip
-    V acc = sum_rows_wave<VEC>(feat, sorted, k, C, ch);
-    if (!(flags & UD_POOL_OVERWRITE)) {
-      V old = *reinterpret_cast<const V*>(orow + ch);
-      RowVec<VEC>::add(old, acc);
-      acc = old;
-    }
-    *reinterpret_cast<V*>(orow + ch) = acc;
-  }
-  // lanes whose first channel is past C (C < 64*VEC) simply idle
-}
-
-// ----------------------------------------------------------------------------------------
-// Heavy cells. One 1024-thread workgroup per cell, persistent over the heavy list.
-template <int VEC>
-__global__ __launch_bounds__(kHeavyThreads) void k_heavy(
-    const float* __restrict__ feat, float* __restrict__ out, const int* __restrict__ count,
-    const int* __restrict__ off, const int* __restrict__ list, const int* __restrict__ cellid,
-    const int* __restrict__ heavy_list, const int* __restrict__ heavy_cnt, int N, int nynx, int C,
-    unsigned flags) {
-  using V = typename RowVec<VEC>::T;
-  __shared__ int s_ids[kHeavySortMax];
-  __shared__ float s_part[16][64 * VEC];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int nheavy = *heavy_cnt;
-  for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
-    const int cell = heavy_list[h];
-    const int k = count[cell];
-    const int base = off[cell];
-    float* orow = out + (size_t)cell * C;
-    const bool sortable = (k <= kHeavySortMax);
+  const int base = off[cell];
+  const int k = off[cell + 1] - base;
+  float* orow = out + (size_t)cell * C;
+  const bool sortable = (k <= kHeavySortMax);
+  if (sortable) {
     int npow = 1;
-    if (sortable) {
-      while (npow < k) npow <<= 1;
-      for (int i = tid; i < npow; i += kHeavyThreads) s_ids[i] = (i < k) ? list[base + i] : INT_MAX;
-      __syncthreads();
-      for (int len = 2; len <= npow; len <<= 1) {
-        for (int st = len >> 1; st > 0; st >>= 1) {
-          for (int i = tid; i < (npow >> 1); i += kHeavyThreads) {
-            const int lo = ((i & ~(st - 1)) << 1) | (i & (st - 1));
-            const int hi2 = lo | st;
-            const bool up = ((lo & len) == 0);
-            const int a = s_ids[lo], b2 = s_ids[hi2];
-            if ((a > b2) == up) {
-              s_ids[lo] = b2;
-              s_ids[hi2] = a;
-            }
+    while (npow < k) npow <<= 1;
+    for (int i = tid; i < npow; i += 256) s_ids[i] = (i < k) ? list[base + i] : INT_MAX;
+    __syncthreads();
+    for (int len = 2; len <= npow; len <<= 1) {
+      for (int st = len >> 1; st > 0; st >>= 1) {
+        for (int i = tid; i < (npow >> 1); i += 256) {
+          const int lo = ((i & ~(st - 1)) << 1) | (i & (st - 1));
+          const int hi2 = lo | st;
+          const bool up = ((lo & len) == 0);
+          const int a = s_ids[lo], b2 = s_ids[hi2];
+          if ((a > b2) == up) {
+            s_ids[lo] = b2;
+            s_ids[hi2] = a;
           }
-          __syncthreads();
         }
+        __syncthreads();
       }
     }
-    for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
-      const int ch = c0 + lane * VEC;
-      const bool act = ch < C;
-      V acc = RowVec<VEC>::zero();
-      if (sortable) {
-        const int per = (k + 15) >> 4;
-        const int lo = wave * per;
-        const int hi = min(lo + per, k);
-        if (act) {
-          int j = lo;
-          for (; j + 4 <= hi; j += 4) {
-            V r[4];
+  }
+  for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
+    const int ch = c0 + lane * VEC;
+    const bool act = ch < C;
+    V acc = RowVec<VEC>::zero();
+    if (sortable) {
+      const int per = (k + 3) >> 2;
+      const int lo = wave * per;
+      const int hi = min(lo + per, k);
+      if (act) {
+        int j = lo;
+        for (; j + 8 <= hi; j += 8) {
+          V r[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-              r[u] = *reinterpret_cast<const V*>(feat + (size_t)s_ids[j + u] * C + ch);
+          for (int u = 0; u < 8; ++u)
+            r[u] = *reinterpret_cast<const V*>(feat + (size_t)s_ids[j + u] * C + ch);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) RowVec<VEC>::add(acc, r[u]);
-          }
-          for (; j < hi; ++j) {
-            const V r0 = *reinterpret_cast<const V*>(feat + (size_t)s_ids[j] * C + ch);
+          for (int u = 0; u < 8; ++u) RowVec<VEC>::add(acc, r[u]);
+        }
+        for (; j < hi; ++j) {
+          const V r0 = *reinterpret_cast<const V*>(feat + (size_t)s_ids[j] * C + ch);
+          RowVec<VEC>::add(acc, r0);
+        }
+      }
+    } else {
+      // More points than the LDS sort holds: every wave walks a contiguous slice of this
+      // batch's point ids in ascending order and keeps the ones that belong to the cell.
+      const int b = cell / nynx;
+      const long long p0 = (long long)b * N;
+      const int per = (((N + 3) >> 2) + 63) & ~63;
+      const int lo = wave * per;
+      const int hi = min(lo + per, N);
+      for (int i = lo; i < hi; i += 64) {
+        const int p = i + lane;
+        const bool m = (p < hi) && (cellid[p0 + p] == cell);
+        unsigned long long mask = __ballot(m);
+        while (mask) {
+          const int l = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          if (act) {
+            const V r0 = *reinterpret_cast<const V*>(feat + (size_t)(p0 + i + l) * C + ch);
             RowVec<VEC>::add(acc, r0);
           }
         }
-      } else {
-        // More points than the LDS sort holds: every wave walks a contiguous slice of this
-        // batch's point ids in ascending order and keeps the ones that belong to the cell.
-        const int b = cell / nynx;
-        const long long p0 = (long long)b * N;
-        const int per = (((N + 15) >> 4) + 63) & ~63;
-        const int lo = wave * per;
-        const int hi = min(lo + per, N);
-        for (int i = lo; i < hi; i += 64) {
-          const int p = i + lane;
-          const bool m = (p < hi) && (cellid[p0 + p] == cell);
-          unsigned long long mask = __ballot(m);
-          while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            if (act) {
-              const V r0 = *reinterpret_cast<const V*>(feat + (size_t)(p0 + i + l) * C + ch);
-              RowVec<VEC>::add(acc, r0);
-            }
-          }
-        }
       }
-      if (act) *reinterpret_cast<V*>(&s_part[wave][lane * VEC]) = acc;
-      __syncthreads();
-      if (wave == 0 && act) {
-        V tot = *reinterpret_cast<const V*>(&s_part[0][lane * VEC]);
-#pragma unroll
-        for (int w = 1; w < 16; ++w)
-          RowVec<VEC>::add(tot, *reinterpret_cast<const V*>(&s_part[w][lane * VEC]));
-        if (!(flags & UD_POOL_OVERWRITE)) {
-          V old = *reinterpret_cast<const V*>(orow + ch);
-          RowVec<VEC>::add(old, tot);
-          tot = old;
-        }
-        *reinterpret_cast<V*>(orow + ch) = tot;
-      }
-      __syncthreads();
     }
+    if (act) *reinterpret_cast<V*>(&s_part[wave][lane * VEC]) = acc;
+    __syncthreads();
+    if (wave == 0 && act) {
+      V tot = *reinterpret_cast<const V*>(&s_part[0][lane * VEC]);
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        RowVec<VEC>::add(tot, *reinterpret_cast<const V*>(&s_part[w][lane * VEC]));
+      if (!(flags & UD_POOL_OVERWRITE)) {
+        V old = *reinterpret_cast<const V*>(orow + ch);
+        RowVec<VEC>::add(old, tot);
+        tot = old;
+      }
+      *reinterpret_cast<V*>(orow + ch) = tot;
+    }
+    __syncthreads();
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ feat,
+                                              float* __restrict__ out,
+                                              const int* __restrict__ off,
+                                              const int* __restrict__ list,
+                                              const int* __restrict__ cellid,
+                                              const int* __restrict__ heavy_list,
+                                              const int* __restrict__ heavy_cnt, int ncell, int N,
+                                              int nynx, int C, unsigned flags) {
+  using V = typename RowVec<VEC>::T;
+  __shared__ int s_ids[kHeavySortMax];
+  __shared__ float s_part[4][64 * VEC];
+  if (blockIdx.x < kHeavyBlocks) {
+    const int nheavy = *heavy_cnt;
+    for (int h = blockIdx.x; h < nheavy; h += kHeavyBlocks)
+      pool_heavy_cell<VEC>(feat, out, off, list, cellid, heavy_list[h], N, nynx, C, flags, s_ids,
+                           s_part);
+    return;
+  }
+  // Light role: persistent waves stride over the cells; metadata of the next two cells
+  // (offset pair, then id list) is prefetched while the current cell's rows stream in.
+  const int lane = ud_lane();
+  const int nwaves = (gridDim.x - kHeavyBlocks) * 4;
+  int cell =
+      (blockIdx.x - kHeavyBlocks) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (cell >= ncell) return;
+  int base = __builtin_amdgcn_readfirstlane(off[cell]);
+  int k = __builtin_amdgcn_readfirstlane(off[cell + 1]) - base;
+  int mine = (k <= kLightMax && lane < k) ? list[base + lane] : INT_MAX;
+  int base1 = 0, k1 = 0;
+  if (cell + nwaves < ncell) {
+    base1 = off[cell + nwaves];
+    k1 = off[cell + nwaves + 1] - base1;
+  }
+  while (true) {
+    const int cell1 = cell + nwaves, cell2 = cell + 2 * nwaves;
+    base1 = __builtin_amdgcn_readfirstlane(base1);
+    k1 = __builtin_amdgcn_readfirstlane(k1);
+    int mine1 = INT_MAX, base2 = 0, k2 = 0;
+    if (cell1 < ncell && k1 <= kLightMax && lane < k1) mine1 = list[base1 + lane];
+    if (cell2 < ncell) {
+      base2 = off[cell2];
+      k2 = off[cell2 + 1] - base2;
+    }
+    if (k <= kLightMax) {  // else: heavy role owns this cell
+      float* orow = out + (size_t)cell * C;
+      if (k == 0) {
+        if (flags & UD_POOL_OVERWRITE)
+          for (int ch = lane * VEC; ch < C; ch += 64 * VEC)
+            *reinterpret_cast<V*>(orow + ch) = RowVec<VEC>::zero();
+      } else {
+        // rank sort: my position = number of ids smaller than mine (ids are distinct)
+        int r = 0;
+        for (int j = 0; j < k; ++j) r += (__builtin_amdgcn_readlane(mine, j) < mine);
+        // push my id to lane r; lanes >= k all push INT_MAX to lane k (never read)
+        const int sorted = __builtin_amdgcn_ds_permute(r << 2, mine);
+        for (int ch = lane * VEC; ch < C; ch += 64 * VEC) {  // C = 256, VEC = 4: one trip
+          V acc = sum_rows_wave<VEC>(feat, sorted, k, C, ch);
+          if (!(flags & UD_POOL_OVERWRITE)) {
+            V old = *reinterpret_cast<const V*>(orow + ch);
+            RowVec<VEC>::add(old, acc);
+            acc = old;
+          }
+          *reinterpret_cast<V*>(orow + ch) = acc;
+        }
+      }
+    }
+    if (cell1 >= ncell) break;
+    cell = cell1;
+    base = base1;
+    k = k1;
+    mine = mine1;
+    base1 = base2;
+    k1 = k2;
   }
 }
 
@@ -382,7 +453,9 @@ __global__ __launch_bounds__(256) void k_to_nhwc(const float* __restrict__ src, 
 struct PoolWs {
   int* count;
   int* heavy_cnt;
+  int2* part;
   int* off;
+  int ntile;
   int* rank;
   int* cellid;
   int* list;
@@ -396,10 +469,12 @@ PoolWs carve(void* ws, int B, int N, int nx, int ny) {
   const size_t ncell = (size_t)B * ny * nx;
   const size_t total = (size_t)B * N;
   PoolWs w;
-  w.count = a.take<int>(ncell);
+  w.ntile = (int)((ncell + kScanTile - 1) / kScanTile);
+  w.count = a.take<int>((size_t)w.ntile * kScanTile);  // zero padded to whole scan tiles
   w.heavy_cnt = a.take<int>(1);
   w.zero_bytes = a.used;
-  w.off = a.take<int>(ncell + 1);
+  w.part = a.take<int2>(w.ntile);
+  w.off = a.take<int>((size_t)w.ntile * kScanTile + 1);
   w.rank = a.take<int>(total);
   w.cellid = a.take<int>(total);
   w.list = a.take<int>(total);
@@ -436,26 +511,21 @@ extern "C" int ud_bev_pool_fwd(const int32_t* geom, const float* feat, float* ou
   k_bin<<<ud_div_up(total, 256), 256, 0, stream>>>(geom, pos, w.count, w.rank, w.cellid, total, N,
                                                    nx, ny, nz);
   UD_LAUNCH_CHECK();
-  k_scan<<<1, 1024, 0, stream>>>(w.count, w.off, w.heavy_list, w.heavy_cnt, ncell);
+  k_cell_partials<<<w.ntile, 256, 0, stream>>>(w.count, w.part);
+  UD_LAUNCH_CHECK();
+  k_cell_offsets<<<w.ntile, 256, 0, stream>>>(w.count, w.part, w.off, w.heavy_list, w.heavy_cnt,
+                                              ncell);
   UD_LAUNCH_CHECK();
   k_fill<<<ud_div_up(total, 256), 256, 0, stream>>>(w.cellid, w.rank, w.off, w.list, total);
   UD_LAUNCH_CHECK();
   const bool vec4 = (C % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
-  if (vec4) {
-    k_light<4><<<ud_div_up(ncell, 4), 256, 0, stream>>>(feat, out, w.count, w.off, w.list, ncell,
-                                                        C, flags);
-    UD_LAUNCH_CHECK();
-    k_heavy<4><<<kHeavyGrid, kHeavyThreads, 0, stream>>>(feat, out, w.count, w.off, w.list,
-                                                         w.cellid, w.heavy_list, w.heavy_cnt, N,
-                                                         ny * nx, C, flags);
-  } else {
-    k_light<1><<<ud_div_up(ncell, 4), 256, 0, stream>>>(feat, out, w.count, w.off, w.list, ncell,
-                                                        C, flags);
-    UD_LAUNCH_CHECK();
-    k_heavy<1><<<kHeavyGrid, kHeavyThreads, 0, stream>>>(feat, out, w.count, w.off, w.list,
-                                                         w.cellid, w.heavy_list, w.heavy_cnt, N,
-                                                         ny * nx, C, flags);
-  }
+  const int grid = kHeavyBlocks + min(ud_div_up(ncell, 4), kLightBlocks);
+  if (vec4)
+    k_pool<4><<<grid, 256, 0, stream>>>(feat, out, w.off, w.list, w.cellid, w.heavy_list,
+                                        w.heavy_cnt, ncell, N, ny * nx, C, flags);
+  else
+    k_pool<1><<<grid, 256, 0, stream>>>(feat, out, w.off, w.list, w.cellid, w.heavy_list,
+                                        w.heavy_cnt, ncell, N, ny * nx, C, flags);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

@@ -1,0 +1,144 @@
+"""LiDAR voxelization + MeanVFE: spconv's ``PointToVoxel`` boundary and the reference modules
+built on it.
+
+Reference: unidistill/data/det3d/preprocess/voxelization.py:8-73 (Voxelization),
+unidistill/layers/blocks_3d/det3d/vfe/mean_vfe.py:6-34 (MeanVFE).
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+def _f3(v):
+    return (ctypes.c_float * len(v))(*[float(x) for x in v])
+
+
+def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_voxels=True,
+                   want_mean=True):
+    """points f32[B,N,F] (cuda) -> (voxels[M,P,F] | None, coords i32[M,4] (b,z,y,x), num i32[M],
+    mean f32[M,F] | None, per_sample i32[B]).  One host read of the voxel count sizes the views
+    (spconv's PointToVoxel has the same sync)."""
+    _lib.require_gpu(points)
+    if points.dtype != torch.float32:
+        raise TypeError("points must be float32")
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    points = points.contiguous()
+    B, N, F = points.shape
+    lib = _lib.load()
+    cap = lib.ud_voxelize_capacity(B, N, int(max_voxels))
+    need = lib.ud_voxelize_workspace_bytes(B, N, int(max_points), int(max_voxels))
+    if cap <= 0 or need == 0:
+        raise ValueError("invalid voxelization sizes")
+    dev = points.device
+    ws = _lib.workspace(dev, need, "voxelize")
+    voxels = torch.empty((cap, max_points, F), dtype=torch.float32, device=dev) if want_voxels else None
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, F), dtype=torch.float32, device=dev) if want_mean else None
+    m_out = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range),
+                               int(max_points), int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords),
+                               _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m_out), _lib.ptr(ws),
+                               ws.numel(), _lib.stream_of(points)), "ud_voxelize")
+    m_host = m_out.cpu()
+    M = int(m_host[B])
+    return (voxels[:M] if want_voxels else None, coords[:M], num[:M],
+            mean[:M] if want_mean else None, m_host[:B])
+
+
+class PointToVoxel:
+    """Interface of ``spconv.pytorch.utils.PointToVoxel`` as the reference uses it
+    (voxelization.py:31-38 ctor kwargs, :54 call): one sample per call, returns
+    (voxels f32[M,P,F], coords i32[M,3] as (z,y,x), num_points i32[M])."""
+
+    def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels,
+                 max_num_points_per_voxel, device=None):
+        self.vsize = [float(v) for v in vsize_xyz]
+        self.range = [float(v) for v in coors_range_xyz]
+        self.num_point_features = int(num_point_features)
+        self.max_voxels = int(max_num_voxels)
+        self.max_points = int(max_num_points_per_voxel)
+        self.device = device
+
+    def __call__(self, pc):
+        assert pc.dim() == 2 and pc.shape[1] == self.num_point_features
+        voxels, coords, num, _, _ = voxelize_batch(pc, self.vsize, self.range, self.max_points,
+                                                   self.max_voxels, want_voxels=True, want_mean=False)
+        return voxels, coords[:, 1:], num
+
+
+class Voxelization(nn.Module):
+    """Mirror of the reference ``Voxelization`` module (voxelization.py:8-73).
+
+    forward(points) takes a list of per-sample clouds (or one tensor) and returns
+    (voxels[M,P,F], voxel_coords i32[M,4] (b,z,y,x), voxel_num_points i32[M]) concatenated over
+    the batch.  Equal-length clouds (the collate_fn case) go through ONE batched launch set
+    instead of the reference's per-sample python loop + clone + pad + cat.
+    ``fused_mean=True`` skips the [M,P,F] tensor and returns the MeanVFE output in its place.
+    """
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels,
+                 num_point_features, device=None, fused_mean=False):
+        super().__init__()
+        assert len(voxel_size) == 3 and len(point_cloud_range) == 6
+        self.voxel_size = np.array(voxel_size)
+        self.point_cloud_range = np.array(point_cloud_range)
+        self.max_num_points = max_num_points
+        self.num_point_features = num_point_features
+        self._max_voxels = max_voxels
+        self.fused_mean = fused_mean
+        grid = (self.point_cloud_range[3:6] - self.point_cloud_range[0:3]) / np.array(voxel_size)
+        self.grid_size = np.round(grid).astype(np.int64)
+
+    @property
+    def max_voxels(self):
+        mv = self._max_voxels
+        if isinstance(mv, tuple):
+            # the reference resolves the tuple in __init__, where self.training is always True
+            # (voxelization.py:25-29) -> the training cap is used in both modes
+            return mv[0]
+        return mv
+
+    def forward(self, points):
+        if not isinstance(points, (list, tuple)):
+            points = [points]
+        same = all(p.shape == points[0].shape for p in points)
+        if same:
+            batch = torch.stack(list(points), 0) if len(points) > 1 else points[0].unsqueeze(0)
+            vox, coords, num, mean, _ = voxelize_batch(
+                batch, self.voxel_size, self.point_cloud_range, self.max_num_points,
+                self.max_voxels, want_voxels=not self.fused_mean, want_mean=self.fused_mean)
+            return (mean if self.fused_mean else vox), coords, num
+        outs = []
+        for i, p in enumerate(points):
+            vox, coords, num, mean, _ = voxelize_batch(
+                p, self.voxel_size, self.point_cloud_range, self.max_num_points, self.max_voxels,
+                want_voxels=not self.fused_mean, want_mean=self.fused_mean)
+            coords = coords.clone()
+            coords[:, 0] = i
+            outs.append(((mean if self.fused_mean else vox), coords, num))
+        return tuple(torch.cat([o[k] for o in outs], 0) for k in range(3))
+
+
+class MeanVFE(nn.Module):
+    """Mirror of the reference ``MeanVFE`` (mean_vfe.py:6-34).  When the voxelizer ran with
+    ``fused_mean`` its input is already the [M,F] mean and is passed through."""
+
+    def __init__(self, num_point_features):
+        super().__init__()
+        self.num_point_features = num_point_features
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    def forward(self, voxel_features, voxel_num_points, **kwargs):
+        if voxel_features.dim() == 2:
+            return voxel_features
+        s = voxel_features[:, :, :self.num_point_features].sum(dim=1)
+        den = torch.clamp_min(voxel_num_points.view(-1, 1), min=1.0).type_as(voxel_features)
+        return (s / den).contiguous()

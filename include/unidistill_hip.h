@@ -85,6 +85,31 @@ int ud_bev_pool_bwd(const float* gout, int64_t sb, int64_t sc, int64_t sy, int64
                     const int32_t* pos, float* gfeat, int B, int N, int C, int nx, int ny,
                     void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* LiDAR voxelization (+ fused MeanVFE)                                      */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Replaces spconv.pytorch.utils.PointToVoxel.__call__ (voxelization.py:31-38,54) for a whole
+ * collated batch and, optionally fused, MeanVFE.forward (mean_vfe.py:14-34).
+ *   points      f32[B,N,F]  (F >= 3: x,y,z first; clouds padded to a common N like collate_fn)
+ *   voxel_size  host f32[3] (x,y,z);  range host f32[6] (xmin,ymin,zmin,xmax,ymax,zmax)
+ *   P           max points kept per voxel;  max_voxels  cap PER SAMPLE
+ * Outputs hold ud_voxelize_capacity(B,N,max_voxels) rows; rows [0, m_out[B]) are valid:
+ *   voxels      f32[cap,P,F] zero padded, or NULL to skip materialising it (fused path)
+ *   coords      i32[cap,4]  (b, z, y, x)
+ *   num_points  i32[cap] or NULL;  mean_feats f32[cap,F] or NULL (sum over slots / max(num,1))
+ *   m_out       i32[B+1]    voxels per sample, then the total (device memory)
+ * Deterministic: voxel order = first appearance in the point list, kept points = the first P in
+ * input order, no voxel created beyond max_voxels per sample (oracle/ud_oracle.c:oracle_voxelize).
+ */
+size_t ud_voxelize_workspace_bytes(int B, int N, int P, int max_voxels);
+int ud_voxelize_capacity(int B, int N, int max_voxels);
+int ud_voxelize(const float* points, int B, int N, int F, const float* voxel_size,
+                const float* range, int P, int max_voxels, float* voxels, int32_t* coords,
+                int32_t* num_points, float* mean_feats, int32_t* m_out, void* workspace,
+                size_t workspace_bytes, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

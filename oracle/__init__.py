@@ -66,3 +66,33 @@ def bev_pool_bwd(gout_nchw, pos):
     gfeat = np.empty((B, N, C), np.float32)
     lib().oracle_bev_pool_bwd(_p(gout_nchw, F), _p(pos, I), _p(gfeat, F), B, N, C, nx, ny)
     return gfeat
+
+
+def voxelize(points, voxel_size, pc_range, max_points, max_voxels, with_voxels=True):
+    """points f32[B,N,F] -> dict(voxels[M,P,F]|None, coords i32[M,4] (b,z,y,x), num i32[M],
+    mean f32[M,F], m i32[B+1])."""
+    points = _f32(points)
+    if points.ndim == 2:
+        points = points[None]
+    B, N, Fd = points.shape
+    cap = min(B * max_voxels, B * N)
+    vs, rg = _f32(voxel_size), _f32(pc_range)
+    voxels = np.zeros((cap, max_points, Fd), np.float32) if with_voxels else None
+    coords = np.zeros((cap, 4), np.int32)
+    num = np.zeros((cap,), np.int32)
+    mean = np.zeros((cap, Fd), np.float32)
+    m = np.zeros((B + 1,), np.int32)
+    fn = lib().oracle_voxelize
+    fn.restype = ctypes.c_int
+    M = fn(_p(points, F), B, N, Fd, _p(vs, F), _p(rg, F), max_points, max_voxels,
+           _p(voxels, F) if with_voxels else None, _p(coords, I), _p(num, I), _p(mean, F), _p(m, I))
+    return dict(voxels=voxels[:M] if with_voxels else None, coords=coords[:M], num=num[:M],
+                mean=mean[:M], m=m)
+
+
+def mean_vfe(voxels, num):
+    voxels, num = _f32(voxels), _i32(num)
+    M, P, Fd = voxels.shape
+    out = np.empty((M, Fd), np.float32)
+    lib().oracle_mean_vfe(_p(voxels, F), _p(num, I), _p(out, F), M, P, Fd)
+    return out

@@ -57,3 +57,139 @@ void oracle_bev_pool_bwd(const float* gout_nchw, const int32_t* pos, float* gfea
       gfeat[p * C + c] = gout_nchw[(((size_t)b * C + c) * ny + y) * nx + x];
   }
 }
+
+/* ---------------------------------------------------------------------------------------
+ * Hard voxelization (PointToVoxel) + MeanVFE.
+ * Reference call site: data/det3d/preprocess/voxelization.py:31-38 (ctor), :53-58 (per-sample
+ * call, clone), :59-68 (batch index prepended to coords -> (b, z, y, x)).
+ * The voxelizer itself is spconv.pytorch.utils.PointToVoxel from the third-party wheel
+ * spconv-cu111>=2.1.12 (requirements.txt:16), NOT in the reference tree -> PARITY UNPINNED by
+ * the reference.  This restates spconv's published CPU algorithm (the GPU hash version is order
+ * non-deterministic): for each point in input order: c = floor((p - range_min) / voxel_size) per
+ * axis, skip unless 0 <= c < grid; look the voxel up; if new and the sample already has
+ * max_voxels voxels, skip the point, else create it (voxels numbered by first appearance);
+ * if the voxel holds fewer than P points, append the point; count it.  num = min(count, P)
+ * because appended points stop at P.  grid = round((max - min) / voxel_size)
+ * (voxelization.py:40-43).
+ * MeanVFE (layers/blocks_3d/det3d/vfe/mean_vfe.py:25-32, pinned by tests/golden/mean_vfe.npz):
+ * mean = sum over the P slots / max(num, 1).
+ * Outputs are concatenated over the batch like Voxelization.forward does.
+ * Returns the total number of voxels; m_out[b] = voxels of sample b, m_out[B] = total.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t* keys;
+  int32_t* vals;
+  size_t mask;
+} omap_t;
+
+static void omap_init(omap_t* m, size_t n) {
+  size_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  m->keys = (int64_t*)malloc(cap * sizeof(int64_t));
+  m->vals = (int32_t*)malloc(cap * sizeof(int32_t));
+  for (size_t i = 0; i < cap; ++i) m->keys[i] = -1;
+  m->mask = cap - 1;
+}
+static void omap_free(omap_t* m) {
+  free(m->keys);
+  free(m->vals);
+}
+/* returns pointer to the value slot for key; *found tells whether it existed */
+static int32_t* omap_slot(omap_t* m, int64_t key, int* found) {
+  size_t h = ((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 20 & m->mask;
+  while (m->keys[h] != -1 && m->keys[h] != key) h = (h + 1) & m->mask;
+  *found = (m->keys[h] == key);
+  m->keys[h] = key;
+  return &m->vals[h];
+}
+
+int oracle_voxelize(const float* points, int B, int N, int F, const float* voxel_size,
+                    const float* range, int P, int max_voxels, float* voxels /*[cap,P,F]*/,
+                    int32_t* coords /*[cap,4]*/, int32_t* num /*[cap]*/, float* mean /*[cap,F]*/,
+                    int32_t* m_out /*[B+1]*/) {
+  int grid[3];
+  for (int a = 0; a < 3; ++a)
+    grid[a] = (int)llround(((double)range[a + 3] - (double)range[a]) / (double)voxel_size[a]);
+  int row0 = 0;
+  for (int b = 0; b < B; ++b) {
+    omap_t map;
+    omap_init(&map, (size_t)N);
+    int nvox = 0;
+    for (int n = 0; n < N; ++n) {
+      const float* q = points + ((size_t)b * N + n) * F;
+      int c[3];
+      int ok = 1;
+      for (int a = 0; a < 3; ++a) {
+        const float f = floorf((q[a] - range[a]) / voxel_size[a]);
+        if (!(f >= 0.0f && f < (float)grid[a])) {
+          ok = 0;
+          break;
+        }
+        c[a] = (int)f;
+      }
+      if (!ok) continue;
+      const int64_t key = ((int64_t)c[2] * grid[1] + c[1]) * grid[0] + c[0];
+      int found;
+      int32_t* slot = omap_slot(&map, key, &found);
+      int row;
+      if (!found) {
+        if (nvox >= max_voxels) {
+          *slot = -1; /* remembered as "rejected": later points of this voxel are skipped too */
+          continue;
+        }
+        row = row0 + nvox++;
+        *slot = row;
+        coords[row * 4 + 0] = b;
+        coords[row * 4 + 1] = c[2];
+        coords[row * 4 + 2] = c[1];
+        coords[row * 4 + 3] = c[0];
+        num[row] = 0;
+        if (voxels) memset(voxels + (size_t)row * P * F, 0, (size_t)P * F * sizeof(float));
+      } else {
+        row = *slot;
+        if (row < 0) continue;
+      }
+      if (num[row] < P) {
+        if (voxels)
+          memcpy(voxels + ((size_t)row * P + num[row]) * F, q, (size_t)F * sizeof(float));
+        else if (mean) { /* fused mean without materialised voxels: accumulate in slot order */
+          float* mrow = mean + (size_t)row * F;
+          for (int f = 0; f < F; ++f) mrow[f] = (num[row] == 0 ? 0.0f : mrow[f]) + q[f];
+        }
+        num[row] += 1;
+      }
+    }
+    omap_free(&map);
+    m_out[b] = nvox;
+    row0 += nvox;
+  }
+  m_out[B] = row0;
+  if (mean) {
+    for (int r = 0; r < row0; ++r) {
+      const float den = (float)(num[r] > 1 ? num[r] : 1);
+      for (int f = 0; f < F; ++f) {
+        float acc;
+        if (voxels) {
+          acc = 0.0f;
+          for (int j = 0; j < P; ++j) acc += voxels[((size_t)r * P + j) * F + f];
+        } else {
+          acc = mean[(size_t)r * F + f];
+        }
+        mean[(size_t)r * F + f] = acc / den;
+      }
+    }
+  }
+  return row0;
+}
+
+/* MeanVFE alone (mean_vfe.py:25-32): voxels[M,P,F], num[M] -> out[M,F]. */
+void oracle_mean_vfe(const float* voxels, const int32_t* num, float* out, int M, int P, int F) {
+  for (int r = 0; r < M; ++r) {
+    const float den = (float)(num[r] > 1 ? num[r] : 1);
+    for (int f = 0; f < F; ++f) {
+      float acc = 0.0f;
+      for (int j = 0; j < P; ++j) acc += voxels[((size_t)r * P + j) * F + f];
+      out[(size_t)r * F + f] = acc / den;
+    }
+  }
+}

@@ -16,3 +16,27 @@ def test_bev_pool_bwd_matches_reference(golden):
     g = golden("bev_pool")
     gfeat = oracle.bev_pool_bwd(g["gout_nchw"], g["pos"])
     np.testing.assert_array_equal(gfeat, g["gfeat"])
+
+
+def test_mean_vfe_matches_reference(golden):
+    g = golden("mean_vfe")
+    np.testing.assert_allclose(oracle.mean_vfe(g["voxels"], g["num"]), g["out"], rtol=1e-6, atol=1e-7)
+
+
+def test_voxelize_oracle_invariants():
+    """spconv is not in the reference tree (parity unpinned): check the restated algorithm's own
+    invariants -- every kept point's voxel matches its coordinates, first-appearance order, caps."""
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-60, 60, (2, 4000, 5)).astype(np.float32)
+    pts[..., 2] = rng.uniform(-6, 4, (2, 4000))
+    vs, rg = (1.5, 1.5, 2.0), (-54.0, -54.0, -5.0, 54.0, 54.0, 3.0)
+    r = oracle.voxelize(pts, vs, rg, 3, 500)
+    assert r["m"][0] == 500 and r["m"][1] == 500 and r["m"][2] == 1000
+    assert r["num"].min() >= 1 and r["num"].max() == 3
+    c = r["coords"]
+    assert len(np.unique(c, axis=0)) == len(c)
+    # slot 0 of each voxel is its first point: recompute its key and compare
+    first = r["voxels"][:, 0, :3]
+    key = np.floor((first - np.array(rg[:3], np.float32)) / np.array(vs, np.float32)).astype(np.int32)
+    np.testing.assert_array_equal(key[:, ::-1], c[:, 1:])
+    np.testing.assert_allclose(r["mean"], oracle.mean_vfe(r["voxels"], r["num"]), rtol=0, atol=0)

@@ -1,0 +1,104 @@
+"""GPU parity: HIP voxelize(+MeanVFE) through the C ABI vs the CPU oracle (bit-exact indices)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from unidistill_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+VS, RG = syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE
+
+
+def _gpu(points, P=10, maxM=120000, want_voxels=True, vs=VS, rg=RG):
+    from unidistill_amd.ops.voxelize import voxelize_batch
+    t = torch.from_numpy(points).cuda()
+    vox, coords, num, mean, m = voxelize_batch(t, vs, rg, P, maxM, want_voxels=want_voxels)
+    torch.cuda.synchronize()
+    return (None if vox is None else vox.cpu().numpy(), coords.cpu().numpy(), num.cpu().numpy(),
+            mean.cpu().numpy(), m.numpy())
+
+
+def _check(points, P=10, maxM=120000, vs=VS, rg=RG):
+    ref = oracle.voxelize(points, vs, rg, P, maxM)
+    vox, coords, num, mean, m = _gpu(points, P, maxM, True, vs, rg)
+    np.testing.assert_array_equal(m, ref["m"][:-1])
+    np.testing.assert_array_equal(coords, ref["coords"])          # same voxels, same ORDER
+    np.testing.assert_array_equal(num, ref["num"])
+    np.testing.assert_array_equal(vox, ref["voxels"])             # same points in the same slots
+    np.testing.assert_array_equal(mean, ref["mean"])              # same add order -> bit exact
+    vox2, coords2, num2, mean2, _ = _gpu(points, P, maxM, False, vs, rg)   # fused (no [M,P,F])
+    assert vox2 is None
+    np.testing.assert_array_equal(coords2, coords)
+    np.testing.assert_array_equal(mean2, mean)
+    return ref
+
+
+def test_single_sweep_cloud():
+    pts = syn.lidar_cloud(syn.rng(), 30000, 1)
+    ref = _check(pts[None])
+    assert ref["m"][0] > 20000
+
+
+def test_ten_sweeps_batch2_hits_per_voxel_cap():
+    g = syn.rng(7)
+    clouds = [syn.lidar_cloud(g, 30000, 10), syn.lidar_cloud(g, 30000, 10)]
+    _check(syn.pad_clouds(clouds))            # ragged -> zero padded rows, all in voxel (0,0,0)
+
+
+def test_max_voxels_cap_and_dense_voxels():
+    g = syn.rng(3)
+    # coarse voxels: many points per voxel (> P), and a cap far below the voxel count
+    pts = syn.lidar_cloud_uniform(g, 50000)[None]
+    vs = (2.0, 2.0, 4.0)
+    ref = _check(pts, P=5, maxM=300, vs=vs)
+    assert ref["m"][0] == 300 and ref["num"].max() == 5
+
+
+def test_edge_inputs():
+    g = syn.rng(5)
+    pts = syn.lidar_cloud_uniform(g, 2000)
+    pts[::7, 0] = 54.0                      # exactly on the max edge -> dropped
+    pts[::11, 1] = -54.0                    # exactly on the min edge -> kept (cell 0)
+    pts[::13, 2] = np.nan                   # NaN never lands in a voxel
+    pts[::17] = 1e9
+    _check(pts[None])
+    _check(np.full((1, 64, 5), 100.0, np.float32))   # nothing in range -> zero voxels
+    _check(np.zeros((3, 500, 5), np.float32))        # all padding: one voxel per sample
+
+
+def test_point_to_voxel_interface_and_module():
+    from unidistill_amd.ops.voxelize import PointToVoxel, Voxelization, MeanVFE
+    pts = syn.lidar_cloud(syn.rng(11), 20000, 1)
+    gen = PointToVoxel(vsize_xyz=VS, coors_range_xyz=RG, num_point_features=5,
+                       max_num_voxels=120000, max_num_points_per_voxel=10, device="cuda")
+    vox, coords, num = gen(torch.from_numpy(pts).cuda())
+    ref = oracle.voxelize(pts, VS, RG, 10, 120000)
+    np.testing.assert_array_equal(coords.cpu().numpy(), ref["coords"][:, 1:])   # (z, y, x)
+    np.testing.assert_array_equal(vox.cpu().numpy(), ref["voxels"])
+    mod = Voxelization(VS, RG, 10, (120000, 160000), 5, device="cuda")
+    a = torch.from_numpy(pts).cuda()
+    v, c, n = mod([a, a.flip(0).contiguous()])
+    assert c[:, 0].max().item() == 1 and v.shape[0] == c.shape[0] == n.shape[0]
+    mean = MeanVFE(5)(v, n)
+    refm = oracle.mean_vfe(v.cpu().numpy(), n.cpu().numpy())
+    np.testing.assert_allclose(mean.cpu().numpy(), refm, rtol=1e-6, atol=1e-6)
+    fused = Voxelization(VS, RG, 10, (120000, 160000), 5, device="cuda", fused_mean=True)
+    f, c2, _ = fused([a, a.flip(0).contiguous()])
+    assert torch.equal(c, c2)
+    np.testing.assert_allclose(MeanVFE(5)(f, n).cpu().numpy(), refm, rtol=1e-6, atol=1e-6)
+
+
+def test_mean_vfe_golden(golden):
+    from unidistill_amd.ops.voxelize import MeanVFE
+    g = golden("mean_vfe")
+    out = MeanVFE(5)(torch.from_numpy(g["voxels"]).cuda(), torch.from_numpy(g["num"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-6, atol=1e-6)
+
+
+def test_deterministic_rerun():
+    pts = syn.pad_clouds([syn.lidar_cloud(syn.rng(2), 30000, 10)])
+    a = _gpu(pts)
+    b = _gpu(pts)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
