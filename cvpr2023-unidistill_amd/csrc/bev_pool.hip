@@ -19,6 +19,7 @@
 //            contiguous chunks, partials are combined in wave order.
 // HBM traffic = every kept feature row once + the output once; that is the algorithmic minimum.
 #include "ud_common.h"
+#include "ud_prof.h"
 #include <limits.h>
 
 namespace {
@@ -520,6 +521,7 @@ extern "C" int ud_bev_pool_fwd(const int32_t* geom, const float* feat, float* ou
   UD_LAUNCH_CHECK();
   const bool vec4 = (C % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
   const int grid = kHeavyBlocks + min(ud_div_up(ncell, 4), kLightBlocks);
+  UdProfScope prof("bev_pool.k_pool", stream);
   if (vec4)
     k_pool<4><<<grid, 256, 0, stream>>>(feat, out, w.off, w.list, w.cellid, w.heavy_list,
                                         w.heavy_cnt, ncell, N, ny * nx, C, flags);
@@ -556,6 +558,7 @@ extern "C" int ud_bev_pool_bwd(const float* gout, int64_t sb, int64_t sc, int64_
   const long long total = (long long)B * N;
   const bool vec4 = (C % 4 == 0) && (((uintptr_t)g | (uintptr_t)gfeat) % 16 == 0);
   const int grid = ud_div_up(total, 16);
+  UdProfScope prof("bev_pool.k_bwd", stream);
   if (vec4)
     k_bwd<4><<<grid, 256, 0, stream>>>(g, pos, gfeat, total, C, nx, ny);
   else

@@ -20,6 +20,8 @@ _SIGS = {
     "ud_version": (ctypes.c_char_p, []),
     "ud_abi_version": (c_int, []),
     "ud_error_string": (ctypes.c_char_p, [c_int]),
+    "ud_prof_enable": (None, [c_int]),
+    "ud_prof_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), c_int]),
     "ud_bev_pool_workspace_bytes": (c_size_t, [c_int] * 6),
     "ud_bev_pool_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_uint, c_void_p, c_size_t, c_void_p]),
     "ud_bev_pool_bwd_workspace_bytes": (c_size_t, [c_int] * 4 + [c_i64]),
@@ -90,3 +92,15 @@ def workspace(device, nbytes, slot="default"):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
+
+
+def prof_enable(on=True):
+    load().ud_prof_enable(1 if on else 0)
+
+
+def prof_read(name, reset=True):
+    """-> (total_ms, calls) of the named kernel since the last reset (blocks on its events)."""
+    ms, n = ctypes.c_double(0.0), c_int(0)
+    check(load().ud_prof_read(name.encode(), ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0),
+          "ud_prof_read")
+    return ms.value, n.value

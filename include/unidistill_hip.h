@@ -51,6 +51,14 @@ int ud_abi_version(void);
 /* Human-readable text for a UD_ERR_* code. */
 const char* ud_error_string(int code);
 
+/*
+ * Optional profiler: when enabled, the library brackets its dominant kernels with hipEvents on
+ * the launch stream.  ud_prof_read(name) waits for those events and returns the summed kernel
+ * time in ms and the number of launches (names: "bev_pool.k_pool", "bev_pool.k_bwd", ...).
+ */
+void ud_prof_enable(int on);
+int ud_prof_read(const char* name, double* total_ms, int* calls, int reset);
+
 /* ------------------------------------------------------------------------- */
 /* BEV pool (camera LSS splat)                                               */
 /* ------------------------------------------------------------------------- */
