@@ -181,44 +181,89 @@ struct RowVec<1> {
   static __device__ __forceinline__ void add(T& a, const T& b) { a = __fadd_rn(a, b); }
 };
 
-// Sum rows ids[0..k) (ids held one per lane in `sorted`, ascending) for the channel slice this
-// lane owns; the order of additions is exactly j = 0, 1, ..., k-1.
+// ---- row sources ---------------------------------------------------------------------------
+// A source turns a point id into the feature row that is pooled.  `prep` runs once per id with
+// one id per lane (vector code); `load` runs with a wave-uniform lane index j and returns the
+// slice of that point's row owned by the calling lane.
 template <int VEC>
-__device__ __forceinline__ typename RowVec<VEC>::T sum_rows_wave(const float* __restrict__ feat,
-                                                                 int sorted, int k, int C, int ch) {
+struct SrcFeat {  // materialised feat[B*N, C]  (reference boundary, lss_fpn.py:48-59)
   using V = typename RowVec<VEC>::T;
-  V acc = RowVec<VEC>::zero();
+  const float* __restrict__ feat;
+  int C;
+  struct Meta {
+    int id;
+  };
+  __device__ __forceinline__ Meta prep(int id) const { return Meta{id}; }
+  __device__ __forceinline__ V load(const Meta& m, int j, int ch) const {
+    const int p = __builtin_amdgcn_readlane(m.id, j);
+    return *reinterpret_cast<const V*>(feat + (size_t)p * C + ch);
+  }
+};
+
+template <int VEC>
+struct SrcLift {  // fused lift: row = depth_prob[point] * context[pixel(point), :]  (lss_fpn.py:289-292)
+  using V = typename RowVec<VEC>::T;
+  const float* __restrict__ prob;  // [B*ncam, D, fH*fW]  == point order
+  const float* __restrict__ ctx;   // [B*ncam, fH*fW, C]  pixel-major
+  int C;
+  int DHW;  // D*fH*fW  points per camera
+  int HW;   // fH*fW
+  struct Meta {
+    int pix;
+    float p;
+  };
+  __device__ __forceinline__ Meta prep(int id) const {
+    Meta m;
+    if (id == INT_MAX) id = 0;
+    const int cam = id / DHW;  // global camera index b*ncam + cam
+    m.pix = cam * HW + (id - cam * DHW) % HW;
+    m.p = prob[id];
+    return m;
+  }
+  __device__ __forceinline__ V load(const Meta& m, int j, int ch) const {
+    const int px = __builtin_amdgcn_readlane(m.pix, j);
+    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m.p), j));
+    V v = *reinterpret_cast<const V*>(ctx + (size_t)px * C + ch);
+    if constexpr (VEC == 4) {
+      v.x = __fmul_rn(v.x, w);
+      v.y = __fmul_rn(v.y, w);
+      v.z = __fmul_rn(v.z, w);
+      v.w = __fmul_rn(v.w, w);
+    } else {
+      v = __fmul_rn(v, w);
+    }
+    return v;
+  }
+};
+
+// Add rows j = 0..k-1 (k <= 64; one prepared id per lane, ascending) into acc, in that order.
+template <int VEC, class Src>
+__device__ __forceinline__ void add_rows_wave(const Src& src, const typename Src::Meta& m, int k,
+                                              int ch, typename RowVec<VEC>::T& acc) {
+  using V = typename RowVec<VEC>::T;
   int j = 0;
   for (; j + 8 <= k; j += 8) {
     V r[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int p = __builtin_amdgcn_readlane(sorted, j + u);
-      r[u] = *reinterpret_cast<const V*>(feat + (size_t)p * C + ch);
-    }
+    for (int u = 0; u < 8; ++u) r[u] = src.load(m, j + u, ch);
 #pragma unroll
     for (int u = 0; u < 8; ++u) RowVec<VEC>::add(acc, r[u]);
   }
   for (; j + 2 <= k; j += 2) {
-    const int p0 = __builtin_amdgcn_readlane(sorted, j);
-    const int p1 = __builtin_amdgcn_readlane(sorted, j + 1);
-    const V r0 = *reinterpret_cast<const V*>(feat + (size_t)p0 * C + ch);
-    const V r1 = *reinterpret_cast<const V*>(feat + (size_t)p1 * C + ch);
+    const V r0 = src.load(m, j, ch);
+    const V r1 = src.load(m, j + 1, ch);
     RowVec<VEC>::add(acc, r0);
     RowVec<VEC>::add(acc, r1);
   }
   if (j < k) {
-    const int p = __builtin_amdgcn_readlane(sorted, j);
-    const V r0 = *reinterpret_cast<const V*>(feat + (size_t)p * C + ch);
+    const V r0 = src.load(m, j, ch);
     RowVec<VEC>::add(acc, r0);
   }
-  return acc;
 }
 
 // Heavy role: one 256-thread workgroup per cell with > kLightMax points.
-template <int VEC>
-__device__ __forceinline__ void pool_heavy_cell(const float* __restrict__ feat,
-                                                float* __restrict__ out,
+template <int VEC, class Src>
+__device__ __forceinline__ void pool_heavy_cell(const Src& src, float* __restrict__ out,
                                                 const int* __restrict__ off,
                                                 const int* __restrict__ list,
                                                 const int* __restrict__ cellid, int cell, int N,
@@ -254,27 +299,20 @@ __device__ __forceinline__ void pool_heavy_cell(const float* __restrict__ feat,
     }
   }
   for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
-    const int ch = c0 + lane * VEC;
-    const bool act = ch < C;
+    const int chr = c0 + lane * VEC;
+    const bool act = chr < C;
+    const int ch = act ? chr : 0;  // idle lanes read channel 0 and discard
     V acc = RowVec<VEC>::zero();
     if (sortable) {
-      const int per = (k + 3) >> 2;
+      // wave w sums the contiguous chunk [w*per, (w+1)*per) of the sorted ids, 64 at a time
+      const int per = (((k + 3) >> 2) + 63) & ~63;
       const int lo = wave * per;
       const int hi = min(lo + per, k);
-      if (act) {
-        int j = lo;
-        for (; j + 8 <= hi; j += 8) {
-          V r[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            r[u] = *reinterpret_cast<const V*>(feat + (size_t)s_ids[j + u] * C + ch);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) RowVec<VEC>::add(acc, r[u]);
-        }
-        for (; j < hi; ++j) {
-          const V r0 = *reinterpret_cast<const V*>(feat + (size_t)s_ids[j] * C + ch);
-          RowVec<VEC>::add(acc, r0);
-        }
+      for (int j0 = lo; j0 < hi; j0 += 64) {
+        const int kk = min(64, hi - j0);
+        const int id = (lane < kk) ? s_ids[j0 + lane] : INT_MAX;
+        const typename Src::Meta m = src.prep(id);
+        add_rows_wave<VEC>(src, m, kk, ch, acc);
       }
     } else {
       // More points than the LDS sort holds: every wave walks a contiguous slice of this
@@ -286,16 +324,18 @@ __device__ __forceinline__ void pool_heavy_cell(const float* __restrict__ feat,
       const int hi = min(lo + per, N);
       for (int i = lo; i < hi; i += 64) {
         const int p = i + lane;
-        const bool m = (p < hi) && (cellid[p0 + p] == cell);
-        unsigned long long mask = __ballot(m);
-        while (mask) {
-          const int l = __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          if (act) {
-            const V r0 = *reinterpret_cast<const V*>(feat + (size_t)(p0 + i + l) * C + ch);
-            RowVec<VEC>::add(acc, r0);
-          }
-        }
+        const bool mt = (p < hi) && (cellid[p0 + p] == cell);
+        const unsigned long long mask = __ballot(mt);
+        if (mask == 0ull) continue;
+        // compact the matching ids to the low lanes, ascending
+        const int kk = __popcll(mask);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // matching lanes take slots [0,kk) in lane order, the others the distinct slots [kk,64)
+        const int dst = mt ? __popcll(mask & below) : kk + __popcll(~mask & below);
+        const int pushed = __builtin_amdgcn_ds_permute(dst << 2, mt ? (int)(p0 + p) : INT_MAX);
+        const int id = (lane < kk) ? pushed : INT_MAX;
+        const typename Src::Meta m = src.prep(id);
+        add_rows_wave<VEC>(src, m, kk, ch, acc);
       }
     }
     if (act) *reinterpret_cast<V*>(&s_part[wave][lane * VEC]) = acc;
@@ -316,9 +356,8 @@ __device__ __forceinline__ void pool_heavy_cell(const float* __restrict__ feat,
   }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ feat,
-                                              float* __restrict__ out,
+template <int VEC, class Src>
+__global__ __launch_bounds__(256) void k_pool(Src src, float* __restrict__ out,
                                               const int* __restrict__ off,
                                               const int* __restrict__ list,
                                               const int* __restrict__ cellid,
@@ -331,7 +370,7 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ feat,
   if (blockIdx.x < kHeavyBlocks) {
     const int nheavy = *heavy_cnt;
     for (int h = blockIdx.x; h < nheavy; h += kHeavyBlocks)
-      pool_heavy_cell<VEC>(feat, out, off, list, cellid, heavy_list[h], N, nynx, C, flags, s_ids,
+      pool_heavy_cell<VEC>(src, out, off, list, cellid, heavy_list[h], N, nynx, C, flags, s_ids,
                            s_part);
     return;
   }
@@ -372,14 +411,24 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ feat,
         for (int j = 0; j < k; ++j) r += (__builtin_amdgcn_readlane(mine, j) < mine);
         // push my id to lane r; lanes >= k all push INT_MAX to lane k (never read)
         const int sorted = __builtin_amdgcn_ds_permute(r << 2, mine);
-        for (int ch = lane * VEC; ch < C; ch += 64 * VEC) {  // C = 256, VEC = 4: one trip
-          V acc = sum_rows_wave<VEC>(feat, sorted, k, C, ch);
-          if (!(flags & UD_POOL_OVERWRITE)) {
-            V old = *reinterpret_cast<const V*>(orow + ch);
-            RowVec<VEC>::add(old, acc);
-            acc = old;
+        const typename Src::Meta m = src.prep(lane < k ? sorted : INT_MAX);
+        // Wave-uniform channel loop: the cross-lane reads inside add_rows_wave must run with all
+        // lanes active (idle lanes compute on channel 0 and discard), otherwise the compiler may
+        // sink the per-lane metadata into a divergent region and readlane would see stale lanes.
+        for (int c0 = 0; c0 < C; c0 += 64 * VEC) {  // C = 256, VEC = 4: one trip
+          const int chr = c0 + lane * VEC;
+          const bool act = chr < C;
+          const int ch = act ? chr : 0;
+          V acc = RowVec<VEC>::zero();
+          add_rows_wave<VEC>(src, m, k, ch, acc);
+          if (act) {
+            if (!(flags & UD_POOL_OVERWRITE)) {
+              V old = *reinterpret_cast<const V*>(orow + ch);
+              RowVec<VEC>::add(old, acc);
+              acc = old;
+            }
+            *reinterpret_cast<V*>(orow + ch) = acc;
           }
-          *reinterpret_cast<V*>(orow + ch) = acc;
         }
       }
     }
@@ -498,14 +547,9 @@ extern "C" size_t ud_bev_pool_workspace_bytes(int B, int N, int C, int nx, int n
   return carve(nullptr, B, N, nx, ny).total_bytes;
 }
 
-extern "C" int ud_bev_pool_fwd(const int32_t* geom, const float* feat, float* out, int32_t* pos,
-                               int B, int N, int C, int nx, int ny, int nz, unsigned flags,
-                               void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
-  if (!sizes_ok(B, N, C, nx, ny, nz) || !geom || !feat || !out || !pos) return UD_ERR_INVALID_ARG;
-  if (flags > 1u) return UD_ERR_INVALID_ARG;
-  PoolWs w = carve(workspace, B, N, nx, ny);
-  if (!workspace || workspace_bytes < w.total_bytes) return UD_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
+// Build the per-cell point lists for geom (bins) and write pos_memo.
+static int build_lists(const int32_t* geom, int32_t* pos, int B, int N, int nx, int ny, int nz,
+                       const PoolWs& w, hipStream_t stream) {
   const long long total = (long long)B * N;
   const int ncell = B * ny * nx;
   UD_HIP_TRY(hipMemsetAsync(w.count, 0, w.zero_bytes, stream));
@@ -519,17 +563,63 @@ extern "C" int ud_bev_pool_fwd(const int32_t* geom, const float* feat, float* ou
   UD_LAUNCH_CHECK();
   k_fill<<<ud_div_up(total, 256), 256, 0, stream>>>(w.cellid, w.rank, w.off, w.list, total);
   UD_LAUNCH_CHECK();
-  const bool vec4 = (C % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
+  return UD_OK;
+}
+
+template <int VEC, class Src>
+static int launch_pool(const Src& src, float* out, const PoolWs& w, int B, int N, int C, int nx,
+                       int ny, unsigned flags, const char* prof_name, hipStream_t stream) {
+  const int ncell = B * ny * nx;
   const int grid = kHeavyBlocks + min(ud_div_up(ncell, 4), kLightBlocks);
-  UdProfScope prof("bev_pool.k_pool", stream);
-  if (vec4)
-    k_pool<4><<<grid, 256, 0, stream>>>(feat, out, w.off, w.list, w.cellid, w.heavy_list,
-                                        w.heavy_cnt, ncell, N, ny * nx, C, flags);
-  else
-    k_pool<1><<<grid, 256, 0, stream>>>(feat, out, w.off, w.list, w.cellid, w.heavy_list,
-                                        w.heavy_cnt, ncell, N, ny * nx, C, flags);
+  UdProfScope prof(prof_name, stream);
+  k_pool<VEC, Src><<<grid, 256, 0, stream>>>(src, out, w.off, w.list, w.cellid, w.heavy_list,
+                                             w.heavy_cnt, ncell, N, ny * nx, C, flags);
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+extern "C" int ud_bev_pool_fwd(const int32_t* geom, const float* feat, float* out, int32_t* pos,
+                               int B, int N, int C, int nx, int ny, int nz, unsigned flags,
+                               void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  if (!sizes_ok(B, N, C, nx, ny, nz) || !geom || !feat || !out || !pos) return UD_ERR_INVALID_ARG;
+  if (flags > 1u) return UD_ERR_INVALID_ARG;
+  PoolWs w = carve(workspace, B, N, nx, ny);
+  if (!workspace || workspace_bytes < w.total_bytes) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = build_lists(geom, pos, B, N, nx, ny, nz, w, stream);
+  if (rc != UD_OK) return rc;
+  const bool vec4 = (C % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
+  if (vec4) {
+    SrcFeat<4> src{feat, C};
+    return launch_pool<4>(src, out, w, B, N, C, nx, ny, flags, "bev_pool.k_pool", stream);
+  }
+  SrcFeat<1> src{feat, C};
+  return launch_pool<1>(src, out, w, B, N, C, nx, ny, flags, "bev_pool.k_pool", stream);
+}
+
+// Fused lift + splat (a7-a9): the [B,N,C] lifted tensor is never materialised.
+extern "C" int ud_lss_splat_fwd(const int32_t* geom, const float* prob, const float* ctx_pm,
+                                float* out, int32_t* pos, int B, int ncam, int D, int fH, int fW,
+                                int C, int nx, int ny, int nz, void* workspace,
+                                size_t workspace_bytes, ud_stream_t stream_) {
+  if (ncam <= 0 || D <= 0 || fH <= 0 || fW <= 0) return UD_ERR_INVALID_ARG;
+  const long long Nll = (long long)ncam * D * fH * fW;
+  if (Nll >= INT_MAX) return UD_ERR_INVALID_ARG;
+  const int N = (int)Nll;
+  if (!sizes_ok(B, N, C, nx, ny, nz) || !geom || !prob || !ctx_pm || !out || !pos)
+    return UD_ERR_INVALID_ARG;
+  PoolWs w = carve(workspace, B, N, nx, ny);
+  if (!workspace || workspace_bytes < w.total_bytes) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = build_lists(geom, pos, B, N, nx, ny, nz, w, stream);
+  if (rc != UD_OK) return rc;
+  const bool vec4 = (C % 4 == 0) && (((uintptr_t)ctx_pm | (uintptr_t)out) % 16 == 0);
+  if (vec4) {
+    SrcLift<4> src{prob, ctx_pm, C, D * fH * fW, fH * fW};
+    return launch_pool<4>(src, out, w, B, N, C, nx, ny, UD_POOL_OVERWRITE, "lss.k_splat", stream);
+  }
+  SrcLift<1> src{prob, ctx_pm, C, D * fH * fW, fH * fW};
+  return launch_pool<1>(src, out, w, B, N, C, nx, ny, UD_POOL_OVERWRITE, "lss.k_splat", stream);
 }
 
 extern "C" size_t ud_bev_pool_bwd_workspace_bytes(int B, int C, int nx, int ny, int64_t sc) {

@@ -1,0 +1,151 @@
+"""Camera lift-splat ops: frustum geometry + binning, depth softmax, lift, fused lift+splat.
+
+Reference: unidistill/layers/blocks_3d/mmdet3d/lss_fpn.py:173-240 (frustum/geometry), :289-316
+(softmax (x) context, permute, binning, voxel_pooling).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import bev_pool as _bp
+
+
+def _f3(v):
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+def bin_origin_fp32(voxel_coord, voxel_size):
+    """(voxel_coord - voxel_size / 2) evaluated in fp32 exactly as lss_fpn.py:311-312 does."""
+    vc = np.asarray(voxel_coord, np.float32)
+    vs = np.asarray(voxel_size, np.float32)
+    return (vc - vs / np.float32(2.0)).astype(np.float32), vs
+
+
+def prepare_mats(sensor2ego, intrin, ida, bda):
+    """[B,ncam,4,4] x3 (+ bda [B,4,4] or None) -> mats f32[B*ncam,3,16] on the GPU."""
+    _lib.require_gpu(sensor2ego, intrin, ida, bda)
+    B, ncam = sensor2ego.shape[:2]
+    s2e, k, a = (t.contiguous().float() for t in (sensor2ego, intrin, ida))
+    bd = None if bda is None else bda.contiguous().float()
+    mats = torch.empty((B * ncam, 3, 16), dtype=torch.float32, device=s2e.device)
+    _lib.check(_lib.load().ud_lss_prepare_mats(_lib.ptr(s2e), _lib.ptr(k), _lib.ptr(a), _lib.ptr(bd),
+                                               B, ncam, _lib.ptr(mats), _lib.stream_of(s2e)),
+               "ud_lss_prepare_mats")
+    return mats
+
+
+def geometry(mats, fu, fv, fd, B, ncam, lo, size, has_bda=True, want_geom=False):
+    """-> (bins i32[B, ncam*D*fH*fW, 3], geom f32[B,ncam,D,fH,fW,3] | None)."""
+    D, fH, fW = fd.numel(), fv.numel(), fu.numel()
+    dev = mats.device
+    bins = torch.empty((B, ncam * D * fH * fW, 3), dtype=torch.int32, device=dev)
+    geom = torch.empty((B, ncam, D, fH, fW, 3), dtype=torch.float32, device=dev) if want_geom else None
+    _lib.check(_lib.load().ud_lss_geometry(_lib.ptr(mats), _lib.ptr(fu), _lib.ptr(fv), _lib.ptr(fd),
+                                           B, ncam, D, fH, fW, _f3(lo), _f3(size), 1 if has_bda else 0,
+                                           _lib.ptr(geom), _lib.ptr(bins), _lib.stream_of(mats)),
+               "ud_lss_geometry")
+    return bins, geom
+
+
+def depth_ctx(depth_feature, D, C):
+    """depth_feature f32[BN, D+C, fH, fW] (any strides) -> prob [BN,D,fH*fW], ctx_pm [BN,fH*fW,C]."""
+    _lib.require_gpu(depth_feature)
+    BN, ch, fH, fW = depth_feature.shape
+    assert ch >= D + C
+    x = depth_feature if depth_feature.dtype == torch.float32 else depth_feature.float()
+    sn, sc, sh, sw = x.stride()
+    if sw * fW != sh:
+        x = x.contiguous()
+        sn, sc, sh, sw = x.stride()
+    prob = torch.empty((BN, D, fH * fW), dtype=torch.float32, device=x.device)
+    ctx = torch.empty((BN, fH * fW, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ud_lss_depth_ctx(_lib.ptr(x), sn, sc, sh, sw, BN, D, C, fH, fW,
+                                            _lib.ptr(prob), _lib.ptr(ctx), _lib.stream_of(x)),
+               "ud_lss_depth_ctx")
+    return prob, ctx
+
+
+def _lift_bwd(gsrc, pos, prob, ctx, like, ncam, D, C, nx, ny):
+    BN, _, fH, fW = like.shape
+    g = torch.zeros_like(like, dtype=torch.float32) if like.shape[1] > D + C else \
+        torch.empty_like(like, dtype=torch.float32)
+    sn, sc, sh, sw = g.stride()
+    if sw * fW != sh:
+        g = torch.empty(like.shape, dtype=torch.float32, device=like.device)
+        sn, sc, sh, sw = g.stride()
+    lib = _lib.load()
+    need = lib.ud_lss_lift_bwd_workspace_bytes(BN, D, C, fH, fW)
+    ws = _lib.workspace(like.device, need, "lss_bwd")
+    _lib.check(lib.ud_lss_lift_bwd(_lib.ptr(gsrc), _lib.ptr(pos), _lib.ptr(prob), _lib.ptr(ctx),
+                                   _lib.ptr(g), sn, sc, sh, sw, BN, ncam, D, C, fH, fW, nx, ny,
+                                   _lib.ptr(ws), ws.numel(), _lib.stream_of(like)), "ud_lss_lift_bwd")
+    return g
+
+
+class Lift(torch.autograd.Function):
+    """Materialised lift (reference boundary): depth_feature [BN,D+C,fH,fW] ->
+    [BN, D, fH, fW, C] == (softmax(depth) (x) context).permute(...,2 last)  (lss_fpn.py:289-310)."""
+
+    @staticmethod
+    def forward(ctx, depth_feature, D, C):
+        prob, cpm = depth_ctx(depth_feature, D, C)
+        BN, _, fH, fW = depth_feature.shape
+        lifted = torch.empty((BN, D, fH, fW, C), dtype=torch.float32, device=depth_feature.device)
+        _lib.check(_lib.load().ud_lss_lift_fwd(_lib.ptr(prob), _lib.ptr(cpm), _lib.ptr(lifted), BN, D,
+                                               C, fH, fW, _lib.stream_of(lifted)), "ud_lss_lift_fwd")
+        ctx.save_for_backward(prob, cpm)
+        ctx.meta = (depth_feature, D, C)
+        ctx.mark_non_differentiable()
+        return lifted
+
+    @staticmethod
+    def backward(ctx, g_lifted):
+        prob, cpm = ctx.saved_tensors
+        like, D, C = ctx.meta
+        g = _lift_bwd(g_lifted.contiguous().float(), None, prob, cpm, like, 1, D, C, 1, 1)
+        return g, None, None
+
+
+class LiftSplat(torch.autograd.Function):
+    """Fused lift + splat: depth_feature [B*ncam, D+C, fH, fW] + bins i32[B,N,3] -> BEV map, a
+    [B, C, ny, nx] view of an NHWC buffer (same return convention as VoxelPooling).  The
+    [B,N,C] tensor (484 MB at the BASELINE shape) is never materialised, forward or backward."""
+
+    @staticmethod
+    def forward(ctx, depth_feature, bins, B, ncam, D, C, nx, ny, nz):
+        _lib.require_gpu(depth_feature, bins)
+        prob, cpm = depth_ctx(depth_feature, D, C)
+        BN, _, fH, fW = depth_feature.shape
+        assert BN == B * ncam and bins.dtype == torch.int32 and bins.is_contiguous()
+        N = ncam * D * fH * fW
+        assert bins.shape[0] == B and bins.shape[1] == N
+        dev = depth_feature.device
+        out = torch.empty((B, ny, nx, C), dtype=torch.float32, device=dev)
+        pos = torch.empty((B, N, 3), dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        need = lib.ud_bev_pool_workspace_bytes(B, N, C, nx, ny, nz)
+        ws = _lib.workspace(dev, need, "bev_pool")
+        _lib.check(lib.ud_lss_splat_fwd(_lib.ptr(bins), _lib.ptr(prob), _lib.ptr(cpm), _lib.ptr(out),
+                                        _lib.ptr(pos), B, ncam, D, fH, fW, C, nx, ny, nz,
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_of(out)),
+                   "ud_lss_splat_fwd")
+        ctx.save_for_backward(prob, cpm, pos)
+        ctx.meta = (depth_feature, ncam, D, C, nx, ny)
+        ctx.mark_non_differentiable(bins)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gout):
+        prob, cpm, pos = ctx.saved_tensors
+        like, ncam, D, C, nx, ny = ctx.meta
+        g_nhwc = gout.permute(0, 2, 3, 1)
+        if not g_nhwc.is_contiguous() or g_nhwc.dtype != torch.float32:
+            g_nhwc = g_nhwc.contiguous().float()
+        g = _lift_bwd(g_nhwc, pos, prob, cpm, like, ncam, D, C, nx, ny)
+        return g, None, None, None, None, None, None, None, None
+
+
+lift = Lift.apply
+lift_splat = LiftSplat.apply

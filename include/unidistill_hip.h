@@ -94,6 +94,65 @@ int ud_bev_pool_bwd(const float* gout, int64_t sb, int64_t sc, int64_t sy, int64
                     void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* Camera lift-splat (LSS): geometry, depth softmax, lift, fused lift+splat  */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * mats[b*ncam+cam] = { inverse(ida), sensor2ego @ inverse(intrin), bda }  f32[B*ncam,3,16]
+ * (lss_fpn.py:221-222,233,235-239).  sensor2ego/intrin/ida f32[B,ncam,4,4]; bda f32[B,4,4] or NULL.
+ */
+int ud_lss_prepare_mats(const float* sensor2ego, const float* intrin, const float* ida,
+                        const float* bda, int B, int ncam, float* mats, ud_stream_t stream);
+
+/*
+ * LSSFPN.get_geometry + binning (lss_fpn.py:200-240, :311-313) for every frustum point
+ * (b, cam, d, h, w): geom f32[B,ncam,D,fH,fW,3] (optional, NULL to skip) and
+ * bins i32[B,ncam,D,fH,fW,3] = ((geom - lo) / size).int()  with host lo/size f32[3]
+ * (lo = voxel_coord - voxel_size/2 evaluated in fp32 by the caller).  frustum_u[fW], frustum_v[fH],
+ * frustum_d[D] are the device vectors of create_frustum (lss_fpn.py:173-198).
+ */
+int ud_lss_geometry(const float* mats, const float* frustum_u, const float* frustum_v,
+                    const float* frustum_d, int B, int ncam, int D, int fH, int fW,
+                    const float* lo, const float* size, int has_bda, float* geom, int32_t* bins,
+                    ud_stream_t stream);
+
+/*
+ * depth_feature f32[BN, D+C, fH, fW] addressed by element strides (sn, sc, sh, sw) ->
+ *   prob   f32[BN, D, fH*fW]   softmax over the first D channels (lss_fpn.py:289)
+ *   ctx_pm f32[BN, fH*fW, C]   context channels D..D+C, pixel-major
+ */
+int ud_lss_depth_ctx(const float* depth_feature, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                     int BN, int D, int C, int fH, int fW, float* prob, float* ctx_pm,
+                     ud_stream_t stream);
+
+/* Materialised lift (reference boundary, lss_fpn.py:290-310):
+ * lifted f32[BN, D, fH*fW, C] = prob (x) ctx  == img_feat_with_depth.permute(0,1,3,4,5,2). */
+int ud_lss_lift_fwd(const float* prob, const float* ctx_pm, float* lifted, int BN, int D, int C,
+                    int fH, int fW, ud_stream_t stream);
+
+/*
+ * Fused lift + splat forward (a7-a9): out[b,y,x,:] = sum over points of prob[point] *
+ * ctx_pm[pixel(point), :], in ascending point order; the [B,N,C] tensor is never formed.
+ * geom i32[B,N,3] with N = ncam*D*fH*fW; out f32[B,ny,nx,C] (every cell written);
+ * pos i32[B,N,3] as ud_bev_pool_fwd.  Workspace: ud_bev_pool_workspace_bytes(B,N,C,nx,ny,nz).
+ */
+int ud_lss_splat_fwd(const int32_t* geom, const float* prob, const float* ctx_pm, float* out,
+                     int32_t* pos, int B, int ncam, int D, int fH, int fW, int C, int nx, int ny,
+                     int nz, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
+/*
+ * Backward of softmax (x) context.  pos == NULL: gsrc is the dense grad of the materialised
+ * lifted tensor f32[BN, D, fH*fW, C].  pos != NULL (fused splat backward): gsrc is the dense NHWC
+ * BEV grad f32[B, ny, nx, C] and each point gathers its cell's row through pos i32[B*N,3].
+ * Writes g_depth_feature f32[BN, D+C, fH, fW] through element strides (sn, sc, sh, sw).
+ */
+size_t ud_lss_lift_bwd_workspace_bytes(int BN, int D, int C, int fH, int fW);
+int ud_lss_lift_bwd(const float* gsrc, const int32_t* pos, const float* prob, const float* ctx_pm,
+                    float* g_depth_feature, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int BN,
+                    int ncam, int D, int C, int fH, int fW, int nx, int ny, void* workspace,
+                    size_t workspace_bytes, ud_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* LiDAR voxelization (+ fused MeanVFE)                                      */
 /* ------------------------------------------------------------------------- */
 

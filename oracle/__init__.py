@@ -96,3 +96,51 @@ def mean_vfe(voxels, num):
     out = np.empty((M, Fd), np.float32)
     lib().oracle_mean_vfe(_p(voxels, F), _p(num, I), _p(out, F), M, P, Fd)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# numpy restatements (small cases only)
+# --------------------------------------------------------------------------------------------
+def lss_frustum(final_dim, downsample, d_bound):
+    """create_frustum (lss_fpn.py:173-198): u[fW], v[fH], d[D] float32 vectors."""
+    H, W = final_dim
+    fH, fW = H // downsample, W // downsample
+    d = np.arange(d_bound[0], d_bound[1], d_bound[2], dtype=np.float32)
+    u = np.linspace(0, W - 1, fW, dtype=np.float32)
+    v = np.linspace(0, H - 1, fH, dtype=np.float32)
+    return u, v, d
+
+
+def lss_geometry(sensor2ego, intrin, ida, bda, u, v, d, voxel_coord, voxel_size):
+    """get_geometry + binning (lss_fpn.py:200-240, 311-313) in float32 numpy.
+    sensor2ego/intrin/ida [B,ncam,4,4], bda [B,4,4] -> geom f32[B,ncam,D,fH,fW,3], bins i32[...,3]."""
+    f32 = np.float32
+    D, fH, fW = len(d), len(v), len(u)
+    fr = np.stack([np.broadcast_to(u.reshape(1, 1, fW), (D, fH, fW)),
+                   np.broadcast_to(v.reshape(1, fH, 1), (D, fH, fW)),
+                   np.broadcast_to(d.reshape(D, 1, 1), (D, fH, fW)),
+                   np.ones((D, fH, fW), f32)], -1).astype(f32)              # [D,fH,fW,4]
+    B, ncam = sensor2ego.shape[:2]
+    ida_inv = np.linalg.inv(ida.astype(np.float64)).astype(f32)
+    k_inv = np.linalg.inv(intrin.astype(np.float64)).astype(f32)
+    combine = np.matmul(sensor2ego.astype(f32), k_inv)
+    p = np.einsum("bnij,dhwj->bndhwi", ida_inv, fr).astype(f32)
+    p = np.concatenate([p[..., :2] * p[..., 2:3], p[..., 2:]], -1).astype(f32)
+    p = np.einsum("bnij,bndhwj->bndhwi", combine, p).astype(f32)
+    if bda is not None:
+        p = np.einsum("bij,bndhwj->bndhwi", bda.astype(f32), p).astype(f32)
+    geom = p[..., :3]
+    vc, vs = np.asarray(voxel_coord, f32), np.asarray(voxel_size, f32)
+    lo = (vc - vs / f32(2.0)).astype(f32)
+    bins = np.trunc(((geom - lo) / vs).astype(f32)).astype(np.int32)
+    return geom, bins
+
+
+def lss_lift(depth_feature, D, C):
+    """softmax(depth) (x) context, permuted to [BN, D, fH, fW, C] (lss_fpn.py:289-310)."""
+    x = depth_feature.astype(np.float32)
+    z = x[:, :D]
+    e = np.exp(z - z.max(1, keepdims=True))
+    prob = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    feat = prob[:, None] * x[:, D:D + C][:, :, None]           # [BN, C, D, fH, fW]
+    return np.ascontiguousarray(feat.transpose(0, 2, 3, 4, 1)), prob
