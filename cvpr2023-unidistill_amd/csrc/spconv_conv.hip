@@ -1,0 +1,367 @@
+// Sparse 3-D convolution compute kernels for MI355X / gfx950 (fp32, exact-f32 MFMA).
+//
+// Replaces spconv's gather-GEMM-scatter (ConvAlgo.Native) behind SubMConv3d / SparseConv3d
+// (unidistill/layers/blocks_3d/det3d/spconv_backbone.py:21-48,71-92,259-340).
+//
+// Output-stationary implicit GEMM over the dense rulebook nbr[site][K] of spconv_index.hip:
+//   out[o, :] = bias + sum_k sum_c in[nbr[o][k], c] * W[:, k, c]
+// A 256-thread workgroup owns 64 output rows; per kernel offset k (skipped when no row of the
+// tile has that neighbour) the gathered input rows and W[:,k,:] are staged in LDS and multiplied
+// with v_mfma_f32_16x16x4_f32 (exact fp32, f32 accumulate).  No scatter-add, no fp atomics: the
+// result is deterministic.  dgrad is the same kernel on the transposed rulebook with W's n/c
+// strides swapped; wgrad reduces over row chunks into ordered partials.
+#include "ud_common.h"
+#include "ud_prof.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTM = 64;  // output rows per workgroup
+
+// W element (n, k, c) lives at W[n*sn + k*sk + c*sc]
+struct WStrides {
+  long long sn, sk, sc;
+};
+
+template <int CIN_P, int COUT_P>
+__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, int cin,
+                                                   const int32_t* __restrict__ nbr, int K,
+                                                   int mirror, const float* __restrict__ W,
+                                                   WStrides ws, const float* __restrict__ bias,
+                                                   float* __restrict__ out, int cout, int Mout) {
+  constexpr int LDA = CIN_P + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);       // [kTM][LDA]
+  float* Bs = As + kTM * LDA;                        // [COUT_P][LDA]
+  int* s_nbr = reinterpret_cast<int*>(Bs + COUT_P * LDA);  // [kTM]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int row0 = blockIdx.x * kTM;
+  constexpr int NT = COUT_P / 16;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k = 0; k < K; ++k) {
+    const int kk = mirror ? (K - 1 - k) : k;  // rulebook column to read for weight offset k
+    int r = -1;
+    if (tid < kTM && row0 + tid < Mout) r = nbr[(size_t)(row0 + tid) * K + kk];
+    if (tid < kTM) s_nbr[tid] = r;
+    if (!__syncthreads_or(r >= 0)) continue;  // nobody in this tile has neighbour k
+    // ---- stage gathered input rows (zeros where the neighbour is missing / padded channels)
+    if ((cin & 3) == 0) {
+      for (int idx = tid; idx < kTM * (CIN_P / 4); idx += 256) {
+        const int row = idx / (CIN_P / 4), c4 = (idx - row * (CIN_P / 4)) * 4;
+        const int rr = s_nbr[row];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr >= 0 && c4 < cin) v = *reinterpret_cast<const float4*>(in + (size_t)rr * cin + c4);
+        *reinterpret_cast<float4*>(As + row * LDA + c4) = v;
+      }
+    } else {
+      for (int idx = tid; idx < kTM * CIN_P; idx += 256) {
+        const int row = idx / CIN_P, c = idx - row * CIN_P;
+        const int rr = s_nbr[row];
+        As[row * LDA + c] = (rr >= 0 && c < cin) ? in[(size_t)rr * cin + c] : 0.f;
+      }
+    }
+    // ---- stage W[:, k, :] as Bs[n][c]
+    if (ws.sc == 1 && (cin & 3) == 0) {
+      for (int idx = tid; idx < COUT_P * (CIN_P / 4); idx += 256) {
+        const int n = idx / (CIN_P / 4), c4 = (idx - n * (CIN_P / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < cout && c4 < cin)
+          v = *reinterpret_cast<const float4*>(W + n * ws.sn + k * ws.sk + c4);
+        *reinterpret_cast<float4*>(Bs + n * LDA + c4) = v;
+      }
+    } else {
+      // strided weights (dgrad reads W with n/c swapped): make n the fast thread index when sn == 1
+      for (int idx = tid; idx < COUT_P * CIN_P; idx += 256) {
+        int n, c;
+        if (ws.sn == 1) {
+          c = idx / COUT_P;
+          n = idx - c * COUT_P;
+        } else {
+          n = idx / CIN_P;
+          c = idx - n * CIN_P;
+        }
+        Bs[n * LDA + c] = (n < cout && c < cin) ? W[n * ws.sn + k * ws.sk + c * ws.sc] : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: wave owns rows [16*wave, 16*wave+16) x all COUT_P columns
+    const float* arow = As + (wave * 16 + li) * LDA + 4 * g;
+#pragma unroll 2
+    for (int cb = 0; cb < CIN_P / 16; ++cb) {
+      const float4 a = *reinterpret_cast<const float4*>(arow + cb * 16);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(Bs + (t * 16 + li) * LDA + cb * 16 + 4 * g);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: acc[t][r] = out[row0 + 16*wave + 4*g + r][16*t + li]
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = t * 16 + li;
+    if (col >= cout) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + wave * 16 + 4 * g + r;
+      if (row < Mout) out[(size_t)row * cout + col] = acc[t][r] + bv;
+    }
+  }
+}
+
+// Any-size fallback (and the cross-check in tests): one thread per (row, n), sequential k, c.
+__global__ __launch_bounds__(256) void k_conv_generic(const float* __restrict__ in, int cin,
+                                                      const int32_t* __restrict__ nbr, int K,
+                                                      int mirror, const float* __restrict__ W,
+                                                      WStrides ws, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int cout, int Mout) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)Mout * cout) return;
+  const int row = (int)(t / cout), n = (int)(t - (long long)row * cout);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int r = nbr[(size_t)row * K + (mirror ? K - 1 - k : k)];
+    if (r < 0) continue;
+    const float* x = in + (size_t)r * cin;
+    const float* w = W + n * ws.sn + k * ws.sk;
+    for (int c = 0; c < cin; ++c) acc = fmaf(x[c], w[c * ws.sc], acc);
+  }
+  out[t] = acc + (bias ? bias[n] : 0.f);
+}
+
+// ---- weight gradient ------------------------------------------------------------------------
+// partial[g][k][n][c] = sum over the rows o of chunk g of gout[o][n] * in[nbr[o][k]][c]
+template <int CIN_P, int COUT_P>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in, int cin,
+                                                    const int32_t* __restrict__ nbr, int K,
+                                                    const float* __restrict__ gout, int cout,
+                                                    float* __restrict__ partial, int Mout,
+                                                    int rows_per_chunk) {
+  constexpr int LDO = kTM + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Gs = reinterpret_cast<float*>(smem);  // [COUT_P][LDO]   gout tile, transposed
+  float* Is = Gs + COUT_P * LDO;                // [CIN_P][LDO]    gathered input tile, transposed
+  int* s_nbr = reinterpret_cast<int*>(Is + CIN_P * LDO);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int k = blockIdx.x;
+  const int chunk = blockIdx.y;
+  constexpr int NTILES = (COUT_P / 16) * (CIN_P / 16);
+  constexpr int TPW = (NTILES + 3) / 4;  // tiles per wave
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int r_begin = chunk * rows_per_chunk;
+  const int r_end = min(r_begin + rows_per_chunk, Mout);
+  for (int row0 = r_begin; row0 < r_end; row0 += kTM) {
+    int r = -1;
+    if (tid < kTM && row0 + tid < r_end) r = nbr[(size_t)(row0 + tid) * K + k];
+    if (tid < kTM) s_nbr[tid] = r;
+    if (!__syncthreads_or(r >= 0)) continue;
+    // gout tile transposed: Gs[n][o]; rows whose neighbour is missing contribute zero anyway
+    // because the matching Is column is zero.
+    for (int idx = tid; idx < kTM * COUT_P; idx += 256) {
+      const int o = idx / COUT_P, n = idx - o * COUT_P;
+      const int row = row0 + o;
+      Gs[n * LDO + o] = (row < r_end && n < cout) ? gout[(size_t)row * cout + n] : 0.f;
+    }
+    for (int idx = tid; idx < kTM * CIN_P; idx += 256) {
+      const int o = idx / CIN_P, c = idx - o * CIN_P;
+      const int rr = s_nbr[o];
+      Is[c * LDO + o] = (rr >= 0 && c < cin) ? in[(size_t)rr * cin + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < NTILES) {
+        const int nt = tile / (CIN_P / 16), ct = tile - nt * (CIN_P / 16);
+        const float* ga = Gs + (nt * 16 + li) * LDO + 4 * g;
+        const float* ib = Is + (ct * 16 + li) * LDO + 4 * g;
+#pragma unroll
+        for (int ob = 0; ob < kTM / 16; ++ob) {
+          const float4 a = *reinterpret_cast<const float4*>(ga + ob * 16);
+          const float4 b = *reinterpret_cast<const float4*>(ib + ob * 16);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* p = partial + ((size_t)chunk * K + k) * COUT_P * CIN_P;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wave + 4 * t;
+    if (tile < NTILES) {
+      const int nt = tile / (CIN_P / 16), ct = tile - nt * (CIN_P / 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        p[(size_t)(nt * 16 + 4 * g + r) * CIN_P + ct * 16 + li] = acc[t][r];
+    }
+  }
+}
+
+// gW[n][k][c] (KRSC, dense) = sum over chunks in order of partial[g][k][n][c]
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int G,
+                                                      int K, int cinp, int coutp, int cin, int cout,
+                                                      float* __restrict__ gW) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)cout * K * cin) return;
+  const int c = (int)(t % cin);
+  const int k = (int)((t / cin) % K);
+  const int n = (int)(t / ((long long)cin * K));
+  float acc = 0.f;
+  for (int gi = 0; gi < G; ++gi)
+    acc += partial[(((size_t)gi * K + k) * coutp + n) * cinp + c];
+  gW[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__ in, int cin,
+                                                       const int32_t* __restrict__ nbr, int K,
+                                                       const float* __restrict__ gout, int cout,
+                                                       float* __restrict__ gW, int Mout) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)cout * K * cin) return;
+  const int c = (int)(t % cin);
+  const int k = (int)((t / cin) % K);
+  const int n = (int)(t / ((long long)cin * K));
+  float acc = 0.f;
+  for (int o = 0; o < Mout; ++o) {
+    const int r = nbr[(size_t)o * K + k];
+    if (r >= 0) acc = fmaf(gout[(size_t)o * cout + n], in[(size_t)r * cin + c], acc);
+  }
+  gW[t] = acc;
+}
+
+inline int pad16(int c) { return (c + 15) / 16 * 16; }
+
+template <int CIN_P, int COUT_P>
+int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
+                WStrides ws, const float* bias, float* out, int cout, int Mout,
+                hipStream_t stream) {
+  const size_t lds = (size_t)(kTM + COUT_P) * (CIN_P + 4) * sizeof(float) + kTM * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma<CIN_P, COUT_P>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  k_conv_mfma<CIN_P, COUT_P><<<ud_div_up(Mout, kTM), 256, lds, stream>>>(
+      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+template <int CIN_P, int COUT_P>
+int launch_wgrad(const float* in, int cin, const int32_t* nbr, int K, const float* gout, int cout,
+                 float* gW, int Mout, float* partial, int G, int rows_per_chunk,
+                 hipStream_t stream) {
+  const size_t lds = (size_t)(CIN_P + COUT_P) * (kTM + 4) * sizeof(float) + kTM * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_mfma<CIN_P, COUT_P>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(K, G);
+  k_wgrad_mfma<CIN_P, COUT_P><<<grid, 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
+                                                          Mout, rows_per_chunk);
+  UD_LAUNCH_CHECK();
+  k_wgrad_reduce<<<ud_div_up((long long)cout * K * cin, 256), 256, 0, stream>>>(
+      partial, G, K, CIN_P, COUT_P, cin, cout, gW);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+#define UD_CONV_CASES(X) \
+  X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) X(64, 64) X(64, 128) X(128, 64) X(128, 128)
+
+int wgrad_chunks(int Mout, int* rows_per_chunk) {
+  int G = (Mout + 4095) / 4096;  // >= 4096 rows (64 tiles) per chunk
+  if (G > 32) G = 32;
+  if (G < 1) G = 1;
+  int rpc = (Mout + G - 1) / G;
+  rpc = (rpc + kTM - 1) / kTM * kTM;
+  *rows_per_chunk = rpc;
+  return (Mout + rpc - 1) / rpc > 0 ? (Mout + rpc - 1) / rpc : 1;
+}
+
+}  // namespace
+
+// out f32[Mout,Cout] = bias + implicit-GEMM over nbr i32[Mout,K] of in f32[Min,Cin] with weights
+// addressed as W[n*w_sn + k*w_sk + c*w_sc] (n < Cout, k < K, c < Cin).  mirror != 0 reads rulebook
+// column K-1-k for weight offset k (submanifold dgrad).  algo: 0 = auto (MFMA when the padded
+// channel pair is instantiated), 1 = force the generic VALU kernel.
+extern "C" int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t w_sn,
+                              int64_t w_sk, int64_t w_sc, int mirror, const float* bias,
+                              float* out, int Mout, int K, int Cin, int Cout, int algo,
+                              ud_stream_t stream_) {
+  if (Mout < 0 || K <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if (Mout == 0) return UD_OK;
+  if (!in || !nbr || !W || !out) return UD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  WStrides ws{w_sn, w_sk, w_sc};
+  const int cp = pad16(Cin), np = pad16(Cout);
+  UdProfScope prof("spconv.k_conv", stream);
+  if (algo == 0) {
+#define X(A, B) \
+  if (cp == A && np == B) \
+    return launch_conv<A, B>(in, Cin, nbr, K, mirror, W, ws, bias, out, Cout, Mout, stream);
+    UD_CONV_CASES(X)
+#undef X
+  }
+  k_conv_generic<<<ud_div_up((long long)Mout * Cout, 256), 256, 0, stream>>>(
+      in, Cin, nbr, K, mirror, W, ws, bias, out, Cout, Mout);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+extern "C" size_t ud_spconv_wgrad_workspace_bytes(int Mout, int K, int Cin, int Cout) {
+  if (Mout < 0 || K <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  int rpc;
+  const int G = wgrad_chunks(Mout > 0 ? Mout : 1, &rpc);
+  return ud_align_up((size_t)G * K * pad16(Cin) * pad16(Cout) * sizeof(float));
+}
+
+// gW f32[Cout,K,Cin] (dense KRSC) = sum_o gout[o,:]^T (x) in[nbr[o][k], :]
+extern "C" int ud_spconv_wgrad(const float* in, const int32_t* nbr, const float* gout, float* gW,
+                               int Mout, int K, int Cin, int Cout, int algo, void* workspace,
+                               size_t workspace_bytes, ud_stream_t stream_) {
+  if (Mout < 0 || K <= 0 || Cin <= 0 || Cout <= 0 || !gW) return UD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (Mout == 0) {
+    UD_HIP_TRY(hipMemsetAsync(gW, 0, (size_t)Cout * K * Cin * sizeof(float), stream));
+    return UD_OK;
+  }
+  if (!in || !nbr || !gout) return UD_ERR_INVALID_ARG;
+  const int cp = pad16(Cin), np = pad16(Cout);
+  UdProfScope prof("spconv.k_wgrad", stream);
+  if (algo == 0) {
+    int rpc;
+    const int G = wgrad_chunks(Mout, &rpc);
+    if (!workspace || workspace_bytes < ud_spconv_wgrad_workspace_bytes(Mout, K, Cin, Cout))
+      return UD_ERR_WORKSPACE;
+#define X(A, B) \
+  if (cp == A && np == B) \
+    return launch_wgrad<A, B>(in, Cin, nbr, K, gout, Cout, gW, Mout, (float*)workspace, G, rpc, stream);
+    UD_CONV_CASES(X)
+#undef X
+  }
+  k_wgrad_generic<<<ud_div_up((long long)Cout * K * Cin, 256), 256, 0, stream>>>(
+      in, Cin, nbr, K, gout, Cout, gW, Mout);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}

@@ -36,6 +36,19 @@ _SIGS = {
     "ud_lss_lift_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_lss_lift_bwd": (c_int, [c_void_p] * 5 + [c_i64] * 4 + [c_int] * 8
                         + [c_void_p, c_size_t, c_void_p]),
+    "ud_spconv_index_bytes": (c_size_t, [c_int] * 5),
+    "ud_spconv_build_index": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "ud_spconv_subm_rulebook": (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
+    "ud_spconv_down_outputs": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3
+                               + [c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),
+    "ud_spconv_down_rulebook": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p] * 3
+                                + [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "ud_spconv_conv": (c_int, [c_void_p] * 3 + [c_i64] * 3 + [c_int, c_void_p, c_void_p]
+                       + [c_int] * 5 + [c_void_p]),
+    "ud_spconv_wgrad_workspace_bytes": (c_size_t, [c_int] * 4),
+    "ud_spconv_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "ud_dense_to_sparse": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "ud_voxelize_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_voxelize_capacity": (c_int, [c_int] * 3),
     "ud_voxelize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int]

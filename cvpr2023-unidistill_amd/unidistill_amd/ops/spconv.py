@@ -1,0 +1,341 @@
+"""Sparse 3-D convolution: the slice of spconv's python API the reference uses, on HIP kernels.
+
+Reference call sites: unidistill/layers/blocks_3d/det3d/spconv_backbone.py:3-5 (imports),
+:21-48 (SubMConv3d / SparseConv3d / SparseInverseConv3d kwargs), :354-359 (SparseConvTensor),
+:61-113 (replace_feature, .features), height_compression.py:19 (.dense()).
+
+Differences by design (MI355X-first, see csrc/spconv_index.hip):
+  * every site set owns a rank-bitmap index; rulebooks are dense [sites, K] neighbour tables and
+    are cached per SITE SET and conv geometry, so two layers with different ``indice_key`` but the
+    same sites/geometry ("subm1" / "res1") share one rulebook;
+  * strided-conv outputs come out in ascending (b, z, y, x) order, deterministically;
+  * conv / dgrad / wgrad are output-stationary fp32-MFMA kernels without scatter-add atomics.
+Weights use spconv 2.x's KRSC layout [out, kz, ky, kx, in].
+"""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return tuple(int(x) for x in v)
+    return (int(v),) * 3
+
+
+def _i3(v):
+    return (ctypes.c_int * 3)(*v)
+
+
+class _SiteSet:
+    """Active sites of one resolution level + lazily built index and rulebooks."""
+
+    def __init__(self, indices, spatial_shape, batch_size, rows_sorted):
+        self.indices = indices                      # i32[M,4] (b,z,y,x), contiguous, cuda
+        self.spatial_shape = tuple(int(s) for s in spatial_shape)
+        self.batch_size = int(batch_size)
+        self.rows_sorted = bool(rows_sorted)
+        self._index = None
+        self._subm = {}
+        self._down = {}
+
+    @property
+    def M(self):
+        return self.indices.shape[0]
+
+    def _grid(self):
+        return (self.batch_size,) + self.spatial_shape
+
+    def index(self):
+        if self._index is None:
+            lib = _lib.load()
+            B, Dz, Hy, Wx = self._grid()
+            nbytes = lib.ud_spconv_index_bytes(B, Dz, Hy, Wx, self.M)
+            if nbytes == 0:
+                raise ValueError(f"invalid sparse grid {self._grid()}")
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.indices.device)
+            _lib.check(lib.ud_spconv_build_index(_lib.ptr(self.indices), self.M, B, Dz, Hy, Wx,
+                                                 1 if self.rows_sorted else 0, _lib.ptr(buf), nbytes,
+                                                 _lib.stream_of(buf)), "ud_spconv_build_index")
+            self._index = buf
+        return self._index
+
+    def subm_rulebook(self, ksize):
+        rb = self._subm.get(ksize)
+        if rb is None:
+            B, Dz, Hy, Wx = self._grid()
+            K = ksize[0] * ksize[1] * ksize[2]
+            rb = torch.empty((self.M, K), dtype=torch.int32, device=self.indices.device)
+            _lib.check(_lib.load().ud_spconv_subm_rulebook(
+                _lib.ptr(self.index()), 1 if self.rows_sorted else 0, _lib.ptr(self.indices), self.M,
+                B, Dz, Hy, Wx, ksize[0], ksize[1], ksize[2], _lib.ptr(rb), _lib.stream_of(rb)),
+                "ud_spconv_subm_rulebook")
+            self._subm[ksize] = rb
+        return rb
+
+    def down(self, ksize, stride, pad):
+        """-> (output _SiteSet, out_nbr i32[Mout,K], in_nbr i32[Min,K])."""
+        key = (ksize, stride, pad)
+        hit = self._down.get(key)
+        if hit is not None:
+            return hit
+        lib = _lib.load()
+        dev = self.indices.device
+        B, Dz, Hy, Wx = self._grid()
+        out_shape = tuple((d + 2 * p - k) // s + 1 for d, k, s, p in
+                          zip(self.spatial_shape, ksize, stride, pad))
+        K = ksize[0] * ksize[1] * ksize[2]
+        reach = 1
+        for k, s in zip(ksize, stride):
+            reach *= (k + s - 1) // s             # outputs one input can touch per axis
+        cells = B * out_shape[0] * out_shape[1] * out_shape[2]
+        cap = max(min(self.M * reach, cells), 1)
+        nbytes = lib.ud_spconv_index_bytes(B, *out_shape, cap)
+        out_index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out_coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        m_out = torch.empty(1, dtype=torch.int32, device=dev)
+        st = _lib.stream_of(out_coords)
+        _lib.check(lib.ud_spconv_down_outputs(_lib.ptr(self.indices), self.M, B, Dz, Hy, Wx,
+                                              _i3(ksize), _i3(stride), _i3(pad), _lib.ptr(out_index),
+                                              nbytes, _lib.ptr(out_coords), cap, _lib.ptr(m_out), st),
+                   "ud_spconv_down_outputs")
+        Mout = int(m_out.item())                  # one host read per new level (sizes the tensors)
+        out_coords = out_coords[:Mout]
+        out_set = _SiteSet(out_coords, out_shape, B, rows_sorted=True)
+        out_set._index = out_index
+        out_nbr = torch.empty((Mout, K), dtype=torch.int32, device=dev)
+        in_nbr = torch.empty((self.M, K), dtype=torch.int32, device=dev)
+        _lib.check(lib.ud_spconv_down_rulebook(_lib.ptr(self.index()), 1 if self.rows_sorted else 0,
+                                               self.M, B, Dz, Hy, Wx, _i3(ksize), _i3(stride),
+                                               _i3(pad), _lib.ptr(out_coords), Mout,
+                                               _lib.ptr(out_nbr), _lib.ptr(in_nbr), st),
+                   "ud_spconv_down_rulebook")
+        hit = (out_set, out_nbr, in_nbr)
+        self._down[key] = hit
+        return hit
+
+
+def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0):
+    Mout, K = nbr.shape
+    out = torch.empty((Mout, cout), dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.load().ud_spconv_conv(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(weight),
+                                          w_strides[0], w_strides[1], w_strides[2],
+                                          1 if mirror else 0, _lib.ptr(bias), _lib.ptr(out), Mout, K,
+                                          cin, cout, algo, _lib.stream_of(feat)), "ud_spconv_conv")
+    return out
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """out = conv(features; nbr, W, bias).  nbr_t / mirror describe the transposed rulebook."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, nbr, nbr_t, mirror_t, algo):
+        _lib.require_gpu(features, weight, nbr)
+        features = features.contiguous().float()
+        w = weight.contiguous().float()
+        cout, cin = w.shape[0], w.shape[-1]
+        K = nbr.shape[1]
+        assert w.numel() == cout * K * cin and features.shape[1] == cin
+        out = _conv(features, nbr, w, (K * cin, cin, 1), False,
+                    None if bias is None else bias.contiguous().float(), cin, cout, algo)
+        ctx.save_for_backward(features, w, nbr, nbr_t)
+        ctx.cfg = (mirror_t, algo, bias is not None, weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        features, w, nbr, nbr_t = ctx.saved_tensors
+        mirror_t, algo, has_bias, wshape = ctx.cfg
+        gout = gout.contiguous().float()
+        cout, cin = w.shape[0], w.shape[-1]
+        K = nbr.shape[1]
+        gin = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # transposed conv: reduce over cout; W element (n'=c, k, c'=n) at c + k*cin + n*K*cin
+            gin = _conv(gout, nbr_t, w, (1, cin, K * cin), mirror_t, None, cout, cin, algo)
+        if ctx.needs_input_grad[1]:
+            lib = _lib.load()
+            Mout = nbr.shape[0]
+            gw = torch.empty(wshape, dtype=torch.float32, device=w.device)
+            need = lib.ud_spconv_wgrad_workspace_bytes(Mout, K, cin, cout)
+            ws = _lib.workspace(w.device, need, "spconv_wgrad")
+            _lib.check(lib.ud_spconv_wgrad(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
+                                           _lib.ptr(gw), Mout, K, cin, cout, algo, _lib.ptr(ws),
+                                           ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad")
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gout.sum(0)
+        return gin, gw, gb, None, None, None, None
+
+
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, grid):
+        features = features.contiguous().float()
+        B, Dz, Hy, Wx = grid
+        M, C = features.shape
+        dense = torch.empty((B, C, Dz, Hy, Wx), dtype=torch.float32, device=features.device)
+        _lib.check(_lib.load().ud_sparse_to_dense(_lib.ptr(features), _lib.ptr(indices), M, C, B, Dz,
+                                                  Hy, Wx, _lib.ptr(dense), _lib.stream_of(dense)),
+                   "ud_sparse_to_dense")
+        ctx.save_for_backward(indices)
+        ctx.grid = grid
+        ctx.mc = (M, C)
+        return dense
+
+    @staticmethod
+    def backward(ctx, gdense):
+        (indices,) = ctx.saved_tensors
+        B, Dz, Hy, Wx = ctx.grid
+        M, C = ctx.mc
+        gdense = gdense.contiguous().float()
+        g = torch.empty((M, C), dtype=torch.float32, device=gdense.device)
+        _lib.check(_lib.load().ud_dense_to_sparse(_lib.ptr(gdense), _lib.ptr(indices), M, C, B, Dz,
+                                                  Hy, Wx, _lib.ptr(g), _lib.stream_of(g)),
+                   "ud_dense_to_sparse")
+        return g, None, None
+
+
+class SparseConvTensor:
+    """features f32[M,C] + indices i32[M,4] (b,z,y,x) on a (spatial_shape, batch_size) grid."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, _sites=None, _indice_dict=None):
+        _lib.require_gpu(features, indices)
+        self.features = features
+        if _sites is None:
+            idx = indices if indices.dtype == torch.int32 else indices.int()
+            _sites = _SiteSet(idx.contiguous(), spatial_shape, batch_size, rows_sorted=False)
+        self._sites = _sites
+        self.indice_dict = {} if _indice_dict is None else _indice_dict
+
+    @property
+    def indices(self):
+        return self._sites.indices
+
+    @property
+    def spatial_shape(self):
+        return list(self._sites.spatial_shape)
+
+    @property
+    def batch_size(self):
+        return self._sites.batch_size
+
+    def replace_feature(self, feature):
+        return SparseConvTensor(feature, None, None, None, _sites=self._sites,
+                                _indice_dict=self.indice_dict)
+
+    def dense(self, channels_first=True):
+        grid = (self.batch_size,) + tuple(self._sites.spatial_shape)
+        out = _DenseFn.apply(self.features, self.indices, grid)
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class SparseModule(nn.Module):
+    """Marker base: modules that take and return SparseConvTensor."""
+
+
+class SparseSequential(SparseModule):
+    """nn.Sequential that routes dense layers (BatchNorm1d, ReLU, ...) over ``.features``."""
+
+    def __init__(self, *mods):
+        super().__init__()
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]
+
+    def forward(self, x):
+        for m in self._modules.values():
+            if isinstance(m, SparseModule):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.indices.shape[0] != 0:
+                    x = x.replace_feature(m(x.features))
+            else:
+                x = m(x)
+        return x
+
+
+class _SparseConvBase(SparseModule):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, subm=False, inverse=False, indice_key=None, algo=None, **_):
+        super().__init__()
+        assert groups == 1 and _triple(dilation) == (1, 1, 1), "groups/dilation are not used by UniDistill"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.subm, self.inverse = subm, inverse
+        self.indice_key = indice_key
+        self.algo = algo
+        self.kernel_algo = 0     # 0 = MFMA where instantiated, 1 = generic VALU (tests)
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        bound = 1.0 / math.sqrt(fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)   # == kaiming_uniform_(a=sqrt(5))
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        sites = x._sites
+        if self.subm:
+            nbr = sites.subm_rulebook(self.kernel_size)
+            out_sites, nbr_t, mirror = sites, nbr, True
+        elif self.inverse:
+            src = x.indice_dict.get(self.indice_key)
+            if src is None:
+                raise ValueError(f"SparseInverseConv3d needs the SparseConv3d with indice_key "
+                                 f"{self.indice_key!r} to have run first")
+            in_sites, out_nbr, in_nbr = src
+            assert sites is in_sites[1], "inverse conv input must be that conv's output"
+            out_sites, nbr, nbr_t, mirror = in_sites[0], in_nbr, out_nbr, False
+        else:
+            out_sites, nbr, nbr_t = sites.down(self.kernel_size, self.stride, self.padding)
+            mirror = False
+            if self.indice_key is not None:
+                x.indice_dict[self.indice_key] = ((sites, out_sites), nbr, nbr_t)
+        feats = _SparseConvFn.apply(x.features, self.weight, self.bias, nbr, nbr_t, mirror,
+                                    self.kernel_algo)
+        return SparseConvTensor(feats, None, None, None, _sites=out_sites, _indice_dict=x.indice_dict)
+
+
+class SubMConv3d(_SparseConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, algo=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, subm=True, indice_key=indice_key, algo=algo)
+
+
+class SparseConv3d(_SparseConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, algo=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         bias, subm=False, indice_key=indice_key, algo=algo)
+
+
+class SparseInverseConv3d(_SparseConvBase):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True,
+                 algo=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, 1, 0, 1, 1, bias, subm=False,
+                         inverse=True, indice_key=indice_key, algo=algo)
+
+
+class ConvAlgo:
+    """spconv.core.ConvAlgo stand-in; the value is accepted and ignored (one algorithm here)."""
+    Native = 0
+    MaskImplicitGemm = 1
+    MaskSplitImplicitGemm = 2

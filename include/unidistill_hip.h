@@ -177,6 +177,68 @@ int ud_voxelize(const float* points, int B, int N, int F, const float* voxel_siz
                 int32_t* num_points, float* mean_feats, int32_t* m_out, void* workspace,
                 size_t workspace_bytes, ud_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Sparse 3-D convolution (spconv boundary) + densify                        */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Site index of one level: a rank bitmap over the (B, Dz, Hy, Wx) voxel grid (spconv_index.hip).
+ * coords are i32[M,4] = (b, z, y, x) like SparseConvTensor.indices (spconv_backbone.py:354-359).
+ * rows_sorted != 0 promises that row i is the i-th site in ascending (b,z,y,x) order (true for
+ * the outputs of ud_spconv_down_outputs); otherwise a rank->row permutation is built.
+ */
+size_t ud_spconv_index_bytes(int B, int Dz, int Hy, int Wx, int M);
+int ud_spconv_build_index(const int32_t* coords, int M, int B, int Dz, int Hy, int Wx,
+                          int rows_sorted, void* index, size_t index_bytes, ud_stream_t stream);
+
+/* SubMConv3d rulebook (odd kernel, implicit padding k/2): nbr i32[M, kz*ky*kx] = row of the
+ * active site at coord + (k - centre) or -1.  Offsets enumerate z slowest, x fastest. */
+int ud_spconv_subm_rulebook(const void* index, int rows_sorted, const int32_t* coords, int M,
+                            int B, int Dz, int Hy, int Wx, int kz, int ky, int kx, int32_t* nbr,
+                            ud_stream_t stream);
+
+/*
+ * SparseConv3d(kernel, stride, padding) output sites = every cell reachable from an active
+ * input; ksize/stride/pad are host int[3] in (z, y, x) order; the output grid is
+ * floor((in + 2p - k)/s) + 1 per axis.  Builds the OUTPUT level's index (rows sorted), writes
+ * out_coords i32[out_cap,4] in ascending (b,z,y,x) order and the count into m_out (device int).
+ */
+int ud_spconv_down_outputs(const int32_t* in_coords, int Min, int B, int Dz, int Hy, int Wx,
+                           const int* ksize, const int* stride, const int* pad, void* out_index,
+                           size_t out_index_bytes, int32_t* out_coords, int out_cap,
+                           int32_t* m_out, ud_stream_t stream);
+
+/* out_nbr i32[Mout,K]: input row at o*s - p + k or -1; in_nbr i32[Min,K] (optional, for dgrad):
+ * output row that input i feeds through offset k, or -1. */
+int ud_spconv_down_rulebook(const void* in_index, int in_rows_sorted, int Min, int B, int Dz,
+                            int Hy, int Wx, const int* ksize, const int* stride, const int* pad,
+                            const int32_t* out_coords, int Mout, int32_t* out_nbr,
+                            int32_t* in_nbr, ud_stream_t stream);
+
+/*
+ * out f32[Mout,Cout] = bias + sum_k sum_c in[nbr[o][k], c] * W[n*w_sn + k*w_sk + c*w_sc].
+ * Forward with spconv-2.x KRSC weights [Cout,K,Cin]: (w_sn, w_sk, w_sc) = (K*Cin, Cin, 1).
+ * Input gradient: in := gout, nbr := in_nbr (strided conv) or the subm rulebook with mirror = 1,
+ * (w_sn, w_sk, w_sc) = (1, Cin, K*Cin), Cin/Cout swapped.  Exact-fp32 MFMA, deterministic.
+ * algo 0 = auto, 1 = generic VALU kernel (any channel counts).
+ */
+int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t w_sn, int64_t w_sk,
+                   int64_t w_sc, int mirror, const float* bias, float* out, int Mout, int K,
+                   int Cin, int Cout, int algo, ud_stream_t stream);
+
+/* gW f32[Cout,K,Cin] = sum_o gout[o,n] * in[nbr[o][k], c]  (ordered partial sums, deterministic). */
+size_t ud_spconv_wgrad_workspace_bytes(int Mout, int K, int Cin, int Cout);
+int ud_spconv_wgrad(const float* in, const int32_t* nbr, const float* gout, float* gW, int Mout,
+                    int K, int Cin, int Cout, int algo, void* workspace, size_t workspace_bytes,
+                    ud_stream_t stream);
+
+/* SparseConvTensor.dense() (height_compression.py:19): dense f32[B,C,Dz,Hy,Wx], zero filled, and
+ * its backward gather gfeat[row,:] = gdense[b,:,z,y,x]. */
+int ud_sparse_to_dense(const float* feat, const int32_t* coords, int M, int C, int B, int Dz,
+                       int Hy, int Wx, float* dense, ud_stream_t stream);
+int ud_dense_to_sparse(const float* gdense, const int32_t* coords, int M, int C, int B, int Dz,
+                       int Hy, int Wx, float* gfeat, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

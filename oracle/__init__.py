@@ -144,3 +144,77 @@ def lss_lift(depth_feature, D, C):
     prob = (e / e.sum(1, keepdims=True)).astype(np.float32)
     feat = prob[:, None] * x[:, D:D + C][:, :, None]           # [BN, C, D, fH, fW]
     return np.ascontiguousarray(feat.transpose(0, 2, 3, 4, 1)), prob
+
+
+I64 = ctypes.c_int64
+
+
+def spconv_subm_rulebook(coords, shape, ksize):
+    """coords i32[M,4], shape (B,Dz,Hy,Wx), ksize (kz,ky,kx) -> nbr i32[M,K]."""
+    coords = _i32(coords)
+    M = coords.shape[0]
+    K = ksize[0] * ksize[1] * ksize[2]
+    nbr = np.empty((M, K), np.int32)
+    lib().oracle_spconv_subm_rulebook(_p(coords, I), M, *[int(v) for v in shape],
+                                      *[int(v) for v in ksize], _p(nbr, I))
+    return nbr
+
+
+def spconv_down(coords, shape, ksize, stride, pad):
+    """-> (out_coords i32[Mout,4] sorted, out_nbr i32[Mout,K], in_nbr i32[Min,K], out_shape)."""
+    coords = _i32(coords)
+    Min = coords.shape[0]
+    K = ksize[0] * ksize[1] * ksize[2]
+    ks, st, pd = (np.asarray(v, np.int32) for v in (ksize, stride, pad))
+    fn = lib().oracle_spconv_down
+    fn.restype = ctypes.c_int
+    cap = max(Min * K, 1)
+    oc = np.zeros((cap, 4), np.int32)
+    Mout = fn(_p(coords, I), Min, *[int(v) for v in shape], _p(ks, I), _p(st, I), _p(pd, I),
+              _p(oc, I), None, None)
+    out_nbr = np.empty((Mout, K), np.int32)
+    in_nbr = np.empty((Min, K), np.int32)
+    fn(_p(coords, I), Min, *[int(v) for v in shape], _p(ks, I), _p(st, I), _p(pd, I), _p(oc, I),
+       _p(out_nbr, I), _p(in_nbr, I))
+    B, Dz, Hy, Wx = shape
+    od = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip((Dz, Hy, Wx), ksize, stride, pad)]
+    return oc[:Mout].copy(), out_nbr, in_nbr, (B, *od)
+
+
+def spconv_conv(feat, nbr, W, bias=None, mirror=False, transpose=False):
+    """feat f32[Min,Cin], nbr i32[Mout,K], W f32[Cout,K,Cin] (KRSC).  transpose=True computes the
+    input gradient: feat is gout[.,Cout], result has Cin columns."""
+    feat, nbr, W = _f32(feat), _i32(nbr), _f32(W)
+    Cout, K, Cin = W.shape
+    Mout = nbr.shape[0]
+    fn = lib().oracle_spconv_conv
+    fn.argtypes = [ctypes.c_void_p] * 3 + [I64] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] \
+        + [ctypes.c_int] * 4
+    if transpose:
+        out = np.empty((Mout, Cin), np.float32)
+        fn(feat.ctypes.data, nbr.ctypes.data, W.ctypes.data, 1, Cin, K * Cin, int(mirror), None,
+           out.ctypes.data, Mout, K, Cout, Cin)
+    else:
+        b = None if bias is None else _f32(bias)
+        out = np.empty((Mout, Cout), np.float32)
+        fn(feat.ctypes.data, nbr.ctypes.data, W.ctypes.data, K * Cin, Cin, 1, int(mirror),
+           None if b is None else b.ctypes.data, out.ctypes.data, Mout, K, Cin, Cout)
+    return out
+
+
+def spconv_wgrad(feat, nbr, gout, Cout):
+    feat, nbr, gout = _f32(feat), _i32(nbr), _f32(gout)
+    Mout, K = nbr.shape
+    Cin = feat.shape[1]
+    gW = np.empty((Cout, K, Cin), np.float32)
+    lib().oracle_spconv_wgrad(_p(feat, F), _p(nbr, I), _p(gout, F), _p(gW, F), Mout, K, Cin, Cout)
+    return gW
+
+
+def sparse_to_dense(feat, coords, shape):
+    feat, coords = _f32(feat), _i32(coords)
+    M, C = feat.shape
+    B, Dz, Hy, Wx = shape
+    dense = np.empty((B, C, Dz, Hy, Wx), np.float32)
+    lib().oracle_sparse_to_dense(_p(feat, F), _p(coords, I), M, C, B, Dz, Hy, Wx, _p(dense, F))
+    return dense

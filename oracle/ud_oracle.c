@@ -193,3 +193,170 @@ void oracle_mean_vfe(const float* voxels, const int32_t* num, float* out, int M,
     }
   }
 }
+
+/* ---------------------------------------------------------------------------------------
+ * Sparse 3-D convolution (spconv, third-party wheel spconv-cu111>=2.1.12, requirements.txt:16;
+ * NOT in the reference tree -> PARITY UNPINNED by the reference).  Call sites:
+ * layers/blocks_3d/det3d/spconv_backbone.py:21-48 (post_act_block), :71-92 (SparseBasicBlock),
+ * :259-340 (VoxelResBackBone8x layers), :354-359 (SparseConvTensor(features, indices(b,z,y,x),
+ * spatial_shape, batch_size)).  Textbook semantics restated here:
+ *   SubMConv3d(k odd): output sites = input sites; out[o] = bias + sum over offsets d in the
+ *     k-cube of W[:, d, :] . in[site at coord(o) + d - k/2] (missing neighbours contribute 0).
+ *   SparseConv3d(k, s, p): output grid floor((in + 2p - k)/s) + 1; output sites = every cell
+ *     reachable from an active input (o*s - p + d = i for some d); out[o] = bias + sum_d
+ *     W[:, d, :] . in[site at o*s - p + d].  Output rows are emitted in ascending (b,z,y,x).
+ * Weights are KRSC: W[n][d][c] with d enumerating (dz, dy, dx), dz slowest.
+ * ------------------------------------------------------------------------------------- */
+static int64_t lin4(int b, int z, int y, int x, int Dz, int Hy, int Wx) {
+  return (((int64_t)b * Dz + z) * Hy + y) * Wx + x;
+}
+
+void oracle_spconv_subm_rulebook(const int32_t* coords, int M, int B, int Dz, int Hy, int Wx,
+                                 int kz, int ky, int kx, int32_t* nbr) {
+  (void)B;
+  omap_t map;
+  omap_init(&map, (size_t)M + 1);
+  int found;
+  for (int i = 0; i < M; ++i)
+    *omap_slot(&map, lin4(coords[i * 4], coords[i * 4 + 1], coords[i * 4 + 2], coords[i * 4 + 3],
+                          Dz, Hy, Wx), &found) = i;
+  const int K = kz * ky * kx;
+  for (int o = 0; o < M; ++o)
+    for (int k = 0; k < K; ++k) {
+      const int z = coords[o * 4 + 1] + k / (ky * kx) - kz / 2;
+      const int y = coords[o * 4 + 2] + (k / kx) % ky - ky / 2;
+      const int x = coords[o * 4 + 3] + k % kx - kx / 2;
+      int r = -1;
+      if (z >= 0 && z < Dz && y >= 0 && y < Hy && x >= 0 && x < Wx) {
+        const int64_t key = lin4(coords[o * 4], z, y, x, Dz, Hy, Wx);
+        size_t h = ((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 20 & map.mask;
+        while (map.keys[h] != -1 && map.keys[h] != key) h = (h + 1) & map.mask;
+        if (map.keys[h] == key) r = map.vals[h];
+      }
+      nbr[(size_t)o * K + k] = r;
+    }
+  omap_free(&map);
+}
+
+static int cmp_i64(const void* a, const void* b) {
+  const int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+  return (x > y) - (x < y);
+}
+
+/* returns Mout; out_coords must hold 8*Min rows for k=3,s=2 (generally k^3 * Min). */
+int oracle_spconv_down(const int32_t* in_coords, int Min, int B, int Dz, int Hy, int Wx,
+                       const int* ks, const int* st, const int* pd, int32_t* out_coords,
+                       int32_t* out_nbr /* [Mout,K] or NULL */, int32_t* in_nbr /* [Min,K] or NULL */) {
+  (void)B;
+  int od[3];
+  const int id[3] = {Dz, Hy, Wx};
+  for (int a = 0; a < 3; ++a) od[a] = (id[a] + 2 * pd[a] - ks[a]) / st[a] + 1;
+  const int K = ks[0] * ks[1] * ks[2];
+  int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * (size_t)(Min > 0 ? Min : 1) * K);
+  size_t nk = 0;
+  for (int i = 0; i < Min; ++i) {
+    const int b = in_coords[i * 4];
+    for (int k = 0; k < K; ++k) {
+      const int d[3] = {k / (ks[1] * ks[2]), (k / ks[2]) % ks[1], k % ks[2]};
+      int o[3], ok = 1;
+      for (int a = 0; a < 3; ++a) {
+        const int t = in_coords[i * 4 + 1 + a] + pd[a] - d[a];
+        if (t < 0 || t % st[a] || t / st[a] >= od[a]) {
+          ok = 0;
+          break;
+        }
+        o[a] = t / st[a];
+      }
+      if (ok) keys[nk++] = lin4(b, o[0], o[1], o[2], od[0], od[1], od[2]);
+    }
+  }
+  qsort(keys, nk, sizeof(int64_t), cmp_i64);
+  int Mout = 0;
+  for (size_t j = 0; j < nk; ++j)
+    if (j == 0 || keys[j] != keys[j - 1]) {
+      int64_t l = keys[j];
+      out_coords[Mout * 4 + 3] = (int)(l % od[2]);
+      l /= od[2];
+      out_coords[Mout * 4 + 2] = (int)(l % od[1]);
+      l /= od[1];
+      out_coords[Mout * 4 + 1] = (int)(l % od[0]);
+      out_coords[Mout * 4 + 0] = (int)(l / od[0]);
+      ++Mout;
+    }
+  free(keys);
+  if (out_nbr) {
+    omap_t map;
+    omap_init(&map, (size_t)Min + 1);
+    int found;
+    for (int i = 0; i < Min; ++i)
+      *omap_slot(&map, lin4(in_coords[i * 4], in_coords[i * 4 + 1], in_coords[i * 4 + 2],
+                            in_coords[i * 4 + 3], Dz, Hy, Wx), &found) = i;
+    if (in_nbr)
+      for (size_t j = 0; j < (size_t)Min * K; ++j) in_nbr[j] = -1;
+    for (int o = 0; o < Mout; ++o)
+      for (int k = 0; k < K; ++k) {
+        const int d[3] = {k / (ks[1] * ks[2]), (k / ks[2]) % ks[1], k % ks[2]};
+        int c[3], ok = 1;
+        for (int a = 0; a < 3; ++a) {
+          c[a] = out_coords[o * 4 + 1 + a] * st[a] - pd[a] + d[a];
+          if (c[a] < 0 || c[a] >= id[a]) ok = 0;
+        }
+        int r = -1;
+        if (ok) {
+          const int64_t key = lin4(out_coords[o * 4], c[0], c[1], c[2], Dz, Hy, Wx);
+          size_t h = ((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 20 & map.mask;
+          while (map.keys[h] != -1 && map.keys[h] != key) h = (h + 1) & map.mask;
+          if (map.keys[h] == key) r = map.vals[h];
+        }
+        out_nbr[(size_t)o * K + k] = r;
+        if (r >= 0 && in_nbr) in_nbr[(size_t)r * K + k] = o;
+      }
+    omap_free(&map);
+  }
+  return Mout;
+}
+
+/* out[o][n] = bias[n] + sum_k sum_c in[nbr[o][k']][c] * W[n*sn + k*sk + c*sc], k' = mirror ? K-1-k : k */
+void oracle_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t sn,
+                        int64_t sk, int64_t sc, int mirror, const float* bias, float* out, int Mout,
+                        int K, int Cin, int Cout) {
+  for (int o = 0; o < Mout; ++o)
+    for (int n = 0; n < Cout; ++n) {
+      double acc = 0.0; /* double accumulator: the oracle is the "true" value, kernels get a tolerance */
+      for (int k = 0; k < K; ++k) {
+        const int r = nbr[(size_t)o * K + (mirror ? K - 1 - k : k)];
+        if (r < 0) continue;
+        for (int c = 0; c < Cin; ++c)
+          acc += (double)in[(size_t)r * Cin + c] * (double)W[n * sn + k * sk + c * sc];
+      }
+      out[(size_t)o * Cout + n] = (float)(acc + (bias ? (double)bias[n] : 0.0));
+    }
+}
+
+/* gW[n][k][c] = sum_o gout[o][n] * in[nbr[o][k]][c] */
+void oracle_spconv_wgrad(const float* in, const int32_t* nbr, const float* gout, float* gW,
+                         int Mout, int K, int Cin, int Cout) {
+  double* acc = (double*)calloc((size_t)Cout * K * Cin, sizeof(double));
+  for (int o = 0; o < Mout; ++o)
+    for (int k = 0; k < K; ++k) {
+      const int r = nbr[(size_t)o * K + k];
+      if (r < 0) continue;
+      for (int n = 0; n < Cout; ++n) {
+        const double g = gout[(size_t)o * Cout + n];
+        for (int c = 0; c < Cin; ++c)
+          acc[((size_t)n * K + k) * Cin + c] += g * (double)in[(size_t)r * Cin + c];
+      }
+    }
+  for (size_t j = 0; j < (size_t)Cout * K * Cin; ++j) gW[j] = (float)acc[j];
+  free(acc);
+}
+
+/* SparseConvTensor.dense() (height_compression.py:19): [B, C, Dz, Hy, Wx] */
+void oracle_sparse_to_dense(const float* feat, const int32_t* coords, int M, int C, int B, int Dz,
+                            int Hy, int Wx, float* dense) {
+  memset(dense, 0, sizeof(float) * (size_t)B * C * Dz * Hy * Wx);
+  for (int r = 0; r < M; ++r)
+    for (int c = 0; c < C; ++c)
+      dense[((((size_t)coords[r * 4] * C + c) * Dz + coords[r * 4 + 1]) * Hy + coords[r * 4 + 2]) * Wx +
+            coords[r * 4 + 3]] = feat[(size_t)r * C + c];
+}

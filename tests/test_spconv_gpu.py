@@ -1,0 +1,151 @@
+"""GPU parity: sparse conv index/rulebooks (bit-exact) and conv/dgrad/wgrad (fp32 tolerance)
+vs the CPU oracle and vs dense torch conv3d."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _sites(rng, B, Dz, Hy, Wx, p, shuffle=True):
+    occ = rng.random((B, Dz, Hy, Wx)) < p
+    coords = np.argwhere(occ).astype(np.int32)
+    if shuffle:
+        rng.shuffle(coords)
+    return coords
+
+
+def _tensor(coords, feat, shape):
+    from unidistill_amd.ops import spconv as sp
+    return sp.SparseConvTensor(torch.from_numpy(feat).cuda(), torch.from_numpy(coords).cuda(),
+                               shape[1:], shape[0])
+
+
+@pytest.mark.parametrize("shape,p,ks", [((2, 6, 9, 8), 0.3, (3, 3, 3)),
+                                         ((1, 41, 60, 70), 0.02, (3, 3, 3)),
+                                         ((3, 5, 17, 130), 0.5, (3, 1, 1)),
+                                         ((1, 2, 3, 3), 1.0, (3, 3, 3))])
+def test_subm_rulebook_bitexact(shape, p, ks):
+    rng = np.random.default_rng(sum(shape))
+    coords = _sites(rng, *shape, p)
+    x = _tensor(coords, np.zeros((len(coords), 4), np.float32), shape)
+    nbr = x._sites.subm_rulebook(ks).cpu().numpy()
+    np.testing.assert_array_equal(nbr, oracle.spconv_subm_rulebook(coords, shape, ks))
+
+
+@pytest.mark.parametrize("shape,p,ks,st,pd", [
+    ((2, 6, 9, 8), 0.3, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ((1, 41, 64, 64), 0.01, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ((2, 11, 20, 20), 0.1, (3, 3, 3), (2, 2, 2), (0, 1, 1)),     # conv4 padding (0,1,1)
+    ((2, 5, 12, 12), 0.2, (3, 1, 1), (2, 1, 1), (0, 0, 0)),      # conv_out
+])
+def test_down_rulebooks_bitexact(shape, p, ks, st, pd):
+    rng = np.random.default_rng(sum(shape) + 1)
+    coords = _sites(rng, *shape, p)
+    x = _tensor(coords, np.zeros((len(coords), 4), np.float32), shape)
+    out_sites, out_nbr, in_nbr = x._sites.down(ks, st, pd)
+    oc, onbr, inbr, oshape = oracle.spconv_down(coords, shape, ks, st, pd)
+    assert tuple(out_sites.spatial_shape) == tuple(oshape[1:])
+    np.testing.assert_array_equal(out_sites.indices.cpu().numpy(), oc)     # sorted (b,z,y,x)
+    np.testing.assert_array_equal(out_nbr.cpu().numpy(), onbr)
+    np.testing.assert_array_equal(in_nbr.cpu().numpy(), inbr)
+    # the output level's own index must be usable: a subm rulebook on it matches the oracle
+    nb2 = out_sites.subm_rulebook((3, 3, 3)).cpu().numpy()
+    np.testing.assert_array_equal(nb2, oracle.spconv_subm_rulebook(oc, oshape, (3, 3, 3)))
+
+
+def _tol(ref):
+    return dict(rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64),
+                                      (64, 128), (128, 128), (7, 9)])
+@pytest.mark.parametrize("algo", [0, 1])
+def test_conv_dgrad_wgrad_vs_oracle(cin, cout, algo):
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(cin * 1000 + cout)
+    shape = (2, 7, 18, 20)
+    coords = _sites(rng, *shape, 0.25)
+    M = len(coords)
+    feat = rng.standard_normal((M, cin)).astype(np.float32)
+    W = (rng.standard_normal((cout, 27, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    nbr = oracle.spconv_subm_rulebook(coords, shape, (3, 3, 3))
+    conv = sp.SubMConv3d(cin, cout, 3, padding=1, bias=True).cuda()
+    conv.kernel_algo = algo
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(W).view(cout, 3, 3, 3, cin))
+        conv.bias.copy_(torch.from_numpy(bias))
+    x = _tensor(coords, feat, shape)
+    x.features.requires_grad_(True)
+    y = conv(x)
+    ref = oracle.spconv_conv(feat, nbr, W, bias)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, **_tol(ref))
+    gout = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(torch.from_numpy(gout).cuda())
+    ref_gin = oracle.spconv_conv(gout, nbr, W, mirror=True, transpose=True)
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), ref_gin, **_tol(ref_gin))
+    ref_gw = oracle.spconv_wgrad(feat, nbr, gout, cout)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(cout, 27, cin), ref_gw, **_tol(ref_gw))
+    np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), gout.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_strided_conv_and_dense_vs_torch_conv3d():
+    """SparseConv3d + .dense() == dense conv3d evaluated on the reachable set; grads too."""
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(5)
+    shape = (2, 9, 14, 16)
+    coords = _sites(rng, *shape, 0.15)
+    cin, cout = 16, 32
+    feat = rng.standard_normal((len(coords), cin)).astype(np.float32)
+    conv = sp.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False, indice_key="d").cuda()
+    x = _tensor(coords, feat, shape)
+    x.features.requires_grad_(True)
+    y = conv(x)
+    dense = y.dense()
+    # dense reference
+    xd = torch.from_numpy(oracle.sparse_to_dense(feat, coords, shape)).cuda().requires_grad_(True)
+    wt = conv.weight.detach().permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    ref = torch.nn.functional.conv3d(xd, wt, stride=2, padding=1)
+    occ = torch.zeros((shape[0], 1) + shape[1:], device="cuda")
+    occ[coords[:, 0], 0, coords[:, 1], coords[:, 2], coords[:, 3]] = 1
+    reach = torch.nn.functional.conv3d(occ, torch.ones(1, 1, 3, 3, 3, device="cuda"), stride=2, padding=1) > 0
+    ref_m = ref * reach
+    np.testing.assert_allclose(dense.detach().cpu().numpy(), ref_m.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(dense)
+    dense.backward(g)
+    ref_m.backward(g)
+    gx_ref = xd.grad[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]]
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), gx_ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    gw_ref = wt.grad.permute(0, 2, 3, 4, 1)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), gw_ref.cpu().numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_inverse_conv_shapes_and_empty_input():
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(6)
+    shape = (1, 8, 12, 12)
+    coords = _sites(rng, *shape, 0.2)
+    x = _tensor(coords, rng.standard_normal((len(coords), 16)).astype(np.float32), shape)
+    down = sp.SparseConv3d(16, 32, 3, stride=2, padding=1, indice_key="k").cuda()
+    up = sp.SparseInverseConv3d(32, 16, 3, indice_key="k").cuda()
+    z = up(down(x))
+    assert z.features.shape == (len(coords), 16) and z.indices is x.indices
+    empty = _tensor(np.zeros((0, 4), np.int32), np.zeros((0, 16), np.float32), shape)
+    e = sp.SubMConv3d(16, 16, 3, padding=1).cuda()(empty)
+    assert e.features.shape == (0, 16)
+    assert e.dense().abs().sum().item() == 0
+
+
+def test_rulebook_shared_between_indice_keys():
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(8)
+    shape = (1, 6, 10, 10)
+    coords = _sites(rng, *shape, 0.3)
+    x = _tensor(coords, rng.standard_normal((len(coords), 16)).astype(np.float32), shape)
+    a = sp.SubMConv3d(16, 16, 3, padding=1, indice_key="subm1").cuda()
+    b = sp.SubMConv3d(16, 16, 3, padding=1, indice_key="res1").cuda()
+    y = b(a(x))
+    assert len(y._sites._subm) == 1          # one rulebook for both keys
