@@ -1,0 +1,137 @@
+"""LiDAR branch: sparse 3-D backbone + BEV densification.
+
+Mirrors (state_dict-compatible) of
+  VoxelResBackBone8x / SparseBasicBlock / post_act_block
+      unidistill/layers/blocks_3d/det3d/spconv_backbone.py:10-58, :61-113, :252-384
+  HeightCompression
+      unidistill/layers/blocks_2d/det3d/map_to_bev/height_compression.py:4-22
+  LidarEncoder
+      unidistill/exps/multisensor_fusion/nuscenes/BEVFusion/BEVFusion_nuscenes_base_exp.py:40-85
+"""
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..ops import spconv as sp
+from ..ops.voxelize import MeanVFE, Voxelization
+
+
+def _conv_bn_relu(cin, cout, kernel, norm_fn, *, stride=1, padding=0, key=None, kind="subm"):
+    """(conv, norm, ReLU) triple; conv kinds as in post_act_block (spconv_backbone.py:10-58)."""
+    if kind == "subm":
+        conv = sp.SubMConv3d(cin, cout, kernel, bias=False, indice_key=key)
+    elif kind == "spconv":
+        conv = sp.SparseConv3d(cin, cout, kernel, stride=stride, padding=padding, bias=False,
+                               indice_key=key)
+    elif kind == "inverseconv":
+        conv = sp.SparseInverseConv3d(cin, cout, kernel, indice_key=key, bias=False)
+    else:
+        raise NotImplementedError(kind)
+    return sp.SparseSequential(conv, norm_fn(cout), nn.ReLU())
+
+
+class SparseBasicBlock(sp.SparseModule):
+    """Two 3x3x3 submanifold convs (bias=True, spconv_backbone.py:70) with BN and a residual."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm_fn=None, downsample=None, indice_key=None):
+        super().__init__()
+        assert norm_fn is not None
+        self.conv1 = sp.SubMConv3d(inplanes, planes, 3, stride=stride, padding=1, bias=True,
+                                   indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = sp.SubMConv3d(planes, planes, 3, stride=stride, padding=1, bias=True,
+                                   indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.conv1(x)
+        y = y.replace_feature(self.relu(self.bn1(y.features)))
+        y = self.conv2(y)
+        y = y.replace_feature(self.relu(self.bn2(y.features) + skip.features))
+        return y
+
+
+class VoxelResBackBone8x(nn.Module):
+    """5 -> 16 -> 32 -> 64 -> 128 -> 128 sparse residual encoder, 8x down in x/y, z 41 -> 2."""
+
+    def __init__(self, input_channels, grid_size, last_pad=0):
+        super().__init__()
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        gs = [int(v) for v in grid_size]
+        self.sparse_shape = np.array(gs[::-1]) + [1, 0, 0]            # (z+1, y, x)
+        self.conv_input = sp.SparseSequential(
+            sp.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key="subm1"),
+            norm_fn(16), nn.ReLU())
+        bb = partial(SparseBasicBlock, norm_fn=norm_fn)
+        down = partial(_conv_bn_relu, norm_fn=norm_fn, kind="spconv", stride=2)
+        self.conv1 = sp.SparseSequential(bb(16, 16, indice_key="res1"), bb(16, 16, indice_key="res1"))
+        self.conv2 = sp.SparseSequential(down(16, 32, 3, padding=1, key="spconv2"),
+                                         bb(32, 32, indice_key="res2"), bb(32, 32, indice_key="res2"))
+        self.conv3 = sp.SparseSequential(down(32, 64, 3, padding=1, key="spconv3"),
+                                         bb(64, 64, indice_key="res3"), bb(64, 64, indice_key="res3"))
+        self.conv4 = sp.SparseSequential(down(64, 128, 3, padding=(0, 1, 1), key="spconv4"),
+                                         bb(128, 128, indice_key="res4"), bb(128, 128, indice_key="res4"))
+        self.conv_out = sp.SparseSequential(
+            sp.SparseConv3d(128, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                            indice_key="spconv_down2"),
+            norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+
+    def forward(self, voxel_features, voxel_coords, batch_size):
+        x = sp.SparseConvTensor(voxel_features, voxel_coords.int(), self.sparse_shape, batch_size)
+        x = self.conv_input(x)
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c4 = self.conv4(c3)
+        out = self.conv_out(c4)
+        return out, 8, {"x_conv1": c1, "x_conv2": c2, "x_conv3": c3, "x_conv4": c4}
+
+
+class HeightCompression(nn.Module):
+    """dense() then fold z into channels: [N, C, D, H, W] -> [N, C*D, H, W]."""
+
+    def __init__(self, num_bev_features):
+        super().__init__()
+        self.num_bev_features = num_bev_features
+
+    def forward(self, encoded_spconv_tensor, encoded_spconv_tensor_stride):
+        d = encoded_spconv_tensor.dense()
+        n, c, dz, h, w = d.shape
+        return d.view(n, c * dz, h, w), encoded_spconv_tensor_stride
+
+
+class LidarEncoder(nn.Module):
+    """points -> voxelize -> MeanVFE -> VoxelResBackBone8x -> HeightCompression -> [B,256,180,180].
+
+    cfg needs: voxel_size, point_cloud_range, grid_size, max_num_points, max_voxels,
+    src_num_point_features, use_num_point_features, map_to_bev_num_features
+    (base_nuscenes_cfg.py:107-116).  The voxelizer runs fused with MeanVFE (no [M,10,5] tensor).
+    """
+
+    def __init__(self, cfg, fused_mean=True):
+        super().__init__()
+        self.cfg = cfg
+        g = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+        self.voxelizer = Voxelization(voxel_size=g("voxel_size"), point_cloud_range=g("point_cloud_range"),
+                                      max_num_points=g("max_num_points"), max_voxels=g("max_voxels"),
+                                      num_point_features=g("src_num_point_features"),
+                                      device=torch.device("cuda"), fused_mean=fused_mean)
+        self.vfe = MeanVFE(num_point_features=g("use_num_point_features"))
+        self.backbone_3d = VoxelResBackBone8x(input_channels=self.vfe.get_output_feature_dim(),
+                                              grid_size=np.array(g("grid_size")), last_pad=0)
+        self.map_to_bev = HeightCompression(num_bev_features=g("map_to_bev_num_features"))
+
+    def forward(self, lidar_points):
+        voxels, coords, num = self.voxelizer(lidar_points)
+        feats = self.vfe(voxels, num)
+        enc, stride, _ = self.backbone_3d(feats, coords, len(lidar_points))
+        bev, _ = self.map_to_bev(enc, stride)
+        return bev
