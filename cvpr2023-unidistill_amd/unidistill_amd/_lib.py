@@ -49,6 +49,21 @@ _SIGS = {
     "ud_spconv_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "ud_dense_to_sparse": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "ud_distill_box_corners": (c_int, [c_void_p, c_int, c_int, c_int] + [ctypes.c_double] * 4
+                               + [c_void_p, c_void_p, c_void_p]),
+    "ud_distill_box_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+                           + [c_int] * 5 + [c_void_p, c_void_p]),
+    "ud_distill_box_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+                           + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ud_distill_mask_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ud_distill_gaussian_mask": (c_int, [c_void_p, c_int, c_int, c_int] + [ctypes.c_double] * 4
+                                 + [c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_distill_resp_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                    c_void_p, c_void_p]),
+    "ud_distill_resp_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
+                                    c_float, c_void_p, c_void_p, c_void_p]),
     "ud_voxelize_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_voxelize_capacity": (c_int, [c_int] * 3),
     "ud_voxelize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int]

@@ -239,6 +239,62 @@ int ud_sparse_to_dense(const float* feat, const int32_t* coords, int M, int C, i
 int ud_dense_to_sparse(const float* gdense, const int32_t* coords, int M, int C, int B, int Dz,
                        int Hy, int Wx, float* gfeat, ud_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Distillation losses (feature / relation / response) + gaussian box mask   */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * training_step's box prep on the device (distill_lidar.py:449-455, :466-483, :73-97):
+ * gt f32[B,M,S>=7] (x,y,z,dx,dy,dz,yaw,...) -> corners_px f32[B,M,4,2] = rotated BEV corners in
+ * BEV pixels ((corner - pc_min) / pixel), valid u8[B,M] = 1 for rows up to the last non-zero row.
+ */
+int ud_distill_box_corners(const float* gt, int B, int M, int S, double pc_min_x, double pc_min_y,
+                           double pixel_x, double pixel_y, float* corners_px, unsigned char* valid,
+                           ud_stream_t stream);
+
+/*
+ * kind 0 = FeatureDistillLoss (distill_lidar.py:196-245), kind 1 = BEVDistillLoss (:248-323).
+ * s / t: student / teacher BEV maps [B,C,H,W] addressed through host element strides
+ * int64[4] = (sb, sc, sy, sx).  Forward writes box_loss f32[B,M] (per-box loss, 0 for invalid boxes;
+ * the scalar loss is sum(box_loss) / (reduce_mean(n_valid) + 1e-4)).  Backward accumulates
+ * (*gscale) * d sum(box_loss)/ds into the pre-zeroed gs (gscale: DEVICE scalar).
+ */
+int ud_distill_box_fwd(int kind, const float* s, const int64_t* s_strides, const float* t,
+                       const int64_t* t_strides, const float* corners_px,
+                       const unsigned char* valid, int B, int M, int C, int H, int W,
+                       float* box_loss, ud_stream_t stream);
+int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_strides, const float* t,
+                       const int64_t* t_strides, const float* corners_px,
+                       const unsigned char* valid, int B, int M, int C, int H, int W,
+                       const float* gscale, float* gs, const int64_t* gs_strides,
+                       ud_stream_t stream);
+
+/* calculate_box_mask_gaussian (distill_lidar.py:100-178) on the device: mask f32[B,H,W]. */
+size_t ud_distill_mask_workspace_bytes(int B, int M);
+int ud_distill_gaussian_mask(const float* gt, int B, int M, int S, double pc_min_x,
+                             double pc_min_y, double pixel_x, double pixel_y, int H, int W,
+                             float* mask, void* workspace, size_t workspace_bytes,
+                             ud_stream_t stream);
+
+/*
+ * ResponseDistillLoss (distill_lidar.py:326-385).  HOST arrays of DEVICE pointers: n_hm heat-map
+ * tensors [B,hm_ch[i],H,W] (student: probabilities as produced by the head's clamped sigmoid;
+ * teacher: logits, turned into clamp(sigmoid(x/2), lo, hi)) and n_reg regression tensors
+ * [B,reg_ch[i],H,W], all dense NCHW.  Forward: partial f32[B*ceil(H*W/256), 2] per-workgroup sums
+ * of (|max_c s - max_c t| * mask, mean_c|s - t| * mask).  Backward writes every element of the
+ * student-side grads; gscale_* are device scalars.
+ */
+int ud_distill_resp_fwd(const float* const* s_hm, const float* const* t_hm, const int* hm_ch,
+                        int n_hm, const float* const* s_reg, const float* const* t_reg,
+                        const int* reg_ch, int n_reg, const float* mask, int B, int H, int W,
+                        float clamp_lo, float clamp_hi, float* partial, ud_stream_t stream);
+int ud_distill_resp_bwd(const float* const* s_hm, const float* const* t_hm, float* const* g_hm,
+                        const int* hm_ch, int n_hm, const float* const* s_reg,
+                        const float* const* t_reg, float* const* g_reg, const int* reg_ch,
+                        int n_reg, const float* mask, int B, int H, int W, float clamp_lo,
+                        float clamp_hi, const float* gscale_cls, const float* gscale_reg,
+                        ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,92 @@ ALL = {
     "mean_vfe": gold_mean_vfe,
 }
 
+
+
+def gold_distill():
+    """FeatureDistillLoss / BEVDistillLoss / ResponseDistillLoss (+ gaussian mask, box corners)
+    forward values and student-side grads -- BEVFusion_nuscenes_centerhead_camera_exp_distill_lidar.py
+    :73-97 (center_to_corner_box2d), :100-178 (gaussian mask), :196-245, :248-323, :326-385,
+    and the coordinate prep of training_step :466-483.  1e-4 and 1e-3 sigmoid clamps (:191-193)."""
+    import importlib
+    base = "unidistill.exps.multisensor_fusion.nuscenes.BEVFusion."
+    mod_a = importlib.import_module(base + "BEVFusion_nuscenes_centerhead_camera_exp_distill_lidar")
+    mod_b = importlib.import_module(base + "BEVFusion_nuscenes_centerhead_camera_exp_distill_fusion")
+    g = torch.Generator().manual_seed(107)
+    B, M, H, W = 2, 6, 20, 20
+    pc_range = [-6.0, -6.0, -5.0, 6.0, 6.0, 3.0]
+    voxel = [0.075, 0.075, 0.2]
+    osf = 8                                  # 0.6 m per BEV pixel -> 20 px over 12 m
+    gt = torch.zeros(B, M, 10)
+    nvalid = [5, 3]
+    for b in range(B):
+        n = nvalid[b]
+        gt[b, :n, 0:2] = (torch.rand(n, 2, generator=g) - 0.5) * 11.0
+        gt[b, :n, 2] = torch.randn(n, generator=g) * 0.5 - 1.0
+        gt[b, :n, 3:6] = torch.rand(n, 3, generator=g) * 3.0 + 0.5
+        gt[b, :n, 6] = (torch.rand(n, generator=g) - 0.5) * 6.28
+        gt[b, :n, 7:9] = torch.randn(n, 2, generator=g)
+        gt[b, :n, 9] = torch.randint(1, 11, (n,), generator=g).float()
+    gt[0, 0, 0:2] = torch.tensor([5.7, -5.8])        # a box hanging over the map border
+    # training_step's valid-box scan (:449-455): trailing zero rows are invalid
+    idx = torch.zeros(B, M)
+    for i in range(B):
+        cnt = M - 1
+        while cnt > 0 and gt[i][cnt].sum() == 0:
+            cnt -= 1
+        idx[i][:cnt + 1] = 1
+    idx = idx.bool()
+    corners = torch.zeros(B, M, 4, 2)
+    for i in range(B):
+        corners[i] = mod_a.center_to_corner_box2d(gt[i][:, :2].numpy(), gt[i][:, 3:5].numpy(),
+                                                  gt[i][:, 6].numpy(), origin=(0.5, 0.5))
+    corners_m = corners.clone()
+    corners[..., 0] = (corners[..., 0] - pc_range[0]) / (voxel[0] * osf)
+    corners[..., 1] = (corners[..., 1] - pc_range[1]) / (voxel[1] * osf)
+    out = dict(gt=gt, valid=idx, corners_m=corners_m, corners_px=corners, pc_range=pc_range,
+               voxel=voxel, osf=osf)
+    # feature / relation losses
+    for name, fn, C in (("feat", mod_a.FeatureDistillLoss, 16), ("rel", mod_a.BEVDistillLoss, 24)):
+        s = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+        t = torch.randn(B, C, H, W, generator=g)
+        loss = fn(s, t, corners.clone(), idx)
+        loss.backward()
+        out.update({f"{name}_s": s.detach(), f"{name}_t": t, f"{name}_loss": loss.detach(),
+                    f"{name}_grad": s.grad})
+    # response loss: 2 tasks with 1 and 2 classes
+    heads = (("reg", 2), ("height", 1), ("dim", 3), ("rot", 2), ("vel", 2), ("iou", 1))
+    ncls = (1, 2)
+    for tag, mod in (("a", mod_a), ("b", mod_b)):
+        rs, rt, leaves = [], [], []
+        for ti, nc in enumerate(ncls):
+            ds, dt = {}, {}
+            hm_logit = torch.randn(B, nc, H, W, generator=g, requires_grad=True)
+            leaves.append(hm_logit)
+            ds["hm"] = mod._sigmoid(hm_logit)            # student hm is post-sigmoid (quirk 1)
+            dt["hm"] = torch.randn(B, nc, H, W, generator=g) * 2.0
+            for hn, hc in heads:
+                v = torch.randn(B, hc, H, W, generator=g, requires_grad=True)
+                leaves.append(v)
+                ds[hn] = v
+                dt[hn] = torch.randn(B, hc, H, W, generator=g)
+            rs.append(ds)
+            rt.append(dt)
+        lc, lr = mod.ResponseDistillLoss(rs, rt, gt, pc_range, voxel, osf)
+        (lc + 2.0 * lr).backward()
+        mask = mod.calculate_box_mask_gaussian((B, 22, H, W), gt.numpy(), pc_range, voxel, osf)
+        k = 0
+        for ti in range(len(ncls)):
+            for hn in ("hm",) + tuple(h for h, _ in heads):
+                out[f"resp_{tag}_s{ti}_{hn}"] = (rs[ti][hn] if hn != "hm" else leaves[k]).detach()
+                out[f"resp_{tag}_t{ti}_{hn}"] = rt[ti][hn]
+                out[f"resp_{tag}_g{ti}_{hn}"] = leaves[k].grad
+                k += 1
+        out.update({f"resp_{tag}_cls": lc.detach(), f"resp_{tag}_reg": lr.detach(), f"resp_{tag}_mask": mask})
+    _save("distill", **out)
+
+
+ALL["distill"] = gold_distill
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)
     for n in names:
