@@ -1,0 +1,416 @@
+"""CenterPoint-style IoU-aware detection head, FCOS target assigner and the detection losses.
+
+State_dict-compatible mirrors of
+  CenterHead / SepHead            unidistill/layers/head/det3d/center_head.py:14-146, :311-375
+  CenterHeadIouAware              unidistill/layers/head/det3d/center_head_iou_aware.py:12-298
+  FCOSAssigner                    unidistill/layers/head/det3d/target_assigner/fcos_assigner.py:9-285
+  FocalLoss / CenterNetRegLoss / AutomaticWeightedLoss
+                                  unidistill/layers/losses/det3d.py:10-34, :287-319, :382-421
+  boxes3d_nearest_bev_iou         unidistill/utils/det3d_utils/box_utils.py:343-373
+Same numbers, different execution: the reference walks python loops over samples x tasks with
+boolean-mask indexing (dynamic shapes -> a device sync per step of the loop), ``.item()`` on ~15
+scalars per task and a python ``if`` on ``loc_loss.item() < 1``.  Everything here is static-shape
+tensor code with device-side selects: no host synchronisation anywhere in forward or loss.
+The dense convs run through PyTorch-ROCm (MIOpen).
+"""
+import copy
+import math
+
+import torch
+from torch import nn
+
+from ..dist import reduce_mean, reduce_mean_many
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+class AutomaticWeightedLoss(nn.Module):
+    """sum_i 0.5 / p_i^2 * loss_i + log(1 + p_i^2)  with learnable p (init 1)."""
+
+    def __init__(self, num=2):
+        super().__init__()
+        self.params = nn.Parameter(torch.ones(num))
+
+    def forward(self, *losses):
+        total = 0
+        for i, l in enumerate(losses):
+            p2 = self.params[i] ** 2
+            total = total + 0.5 / p2 * l + torch.log(1 + p2)
+        return total
+
+
+class FocalLoss(nn.Module):
+    """CornerNet focal loss on post-sigmoid heat maps (losses/det3d.py:287-319)."""
+
+    def __init__(self, alpha, gamma):
+        super().__init__()
+        self.alpha, self.gamma = alpha, gamma
+
+    def forward(self, pred, gt, num_pos=None):
+        pos = gt.eq(1)
+        neg = gt.eq(0)
+        pos_loss = (torch.log(pred) * torch.pow(1 - pred, self.gamma) * pos.long() * self.alpha).sum()
+        neg_loss = (torch.log(1 - pred + 1e-4) * torch.pow(pred, self.gamma) * neg.long()
+                    * (1 - self.alpha)).sum()
+        if num_pos is None:
+            num_pos = reduce_mean(pos.float().sum())
+        # reference: ``if num_pos == 0: -neg else -(pos + neg) / num_pos`` (a host-side branch)
+        safe = torch.where(num_pos == 0, torch.ones_like(num_pos), num_pos)
+        return torch.where(num_pos == 0, -neg_loss, -(pos_loss + neg_loss) / safe)
+
+
+def _transpose_and_gather_feat(feat, ind):
+    """feat [B,C,H,W], ind i64[B,K] (flattened y*W+x) -> [B,K,C]."""
+    b, c = feat.shape[:2]
+    flat = feat.reshape(b, c, -1)
+    return flat.gather(2, ind.unsqueeze(1).expand(b, c, ind.shape[1])).transpose(1, 2).contiguous()
+
+
+class CenterNetRegLoss(nn.Module):
+    """Masked L1 per code dimension, normalised by the (global mean) number of objects."""
+
+    def forward(self, output, mask, ind, target, num=None):
+        pred = _transpose_and_gather_feat(output, ind)
+        if num is None:
+            num = reduce_mean(mask.float().sum())
+        m = mask.unsqueeze(2).float() * (~torch.isnan(target)).float()
+        loss = torch.abs(pred * m - target * m)          # [B,K,dim]
+        return loss.sum(dim=(0, 1)) / (num + 1e-4)
+
+
+def limit_period(val, offset=0.5, period=math.pi):
+    return val - torch.floor(val / period + offset) * period
+
+
+def nearest_bev_iou_pairwise(boxes_a, boxes_b):
+    """Diagonal of boxes3d_nearest_bev_iou(a, b): IoU of the axis-aligned BEV boxes of a[i], b[i].
+    (The reference builds the full N x N matrix, N = B*2500, and keeps the diagonal.)"""
+    def aligned(b):
+        rot = limit_period(b[:, 6], 0.5, math.pi).abs()
+        dims = torch.where(rot[:, None] < math.pi / 4, b[:, [3, 4]], b[:, [4, 3]])
+        return b[:, 0:2] - dims / 2, b[:, 0:2] + dims / 2
+    a0, a1 = aligned(boxes_a)
+    b0, b1 = aligned(boxes_b)
+    inter = torch.clamp_min(torch.min(a1, b1) - torch.max(a0, b0), 0)
+    inter = inter[:, 0] * inter[:, 1]
+    area_a = (a1[:, 0] - a0[:, 0]) * (a1[:, 1] - a0[:, 1])
+    area_b = (b1[:, 0] - b0[:, 0]) * (b1[:, 1] - b0[:, 1])
+    return inter / torch.clamp_min(area_a + area_b - inter, 1e-6)
+
+
+def boxes3d_nearest_bev_iou(boxes_a, boxes_b):
+    """Full [N,M] matrix variant (box_utils.py:361-373), for API parity."""
+    n, m = boxes_a.shape[0], boxes_b.shape[0]
+    a = boxes_a[:, None, :].expand(n, m, boxes_a.shape[1]).reshape(n * m, -1)
+    b = boxes_b[None, :, :].expand(n, m, boxes_b.shape[1]).reshape(n * m, -1)
+    return nearest_bev_iou_pairwise(a, b).reshape(n, m)
+
+
+# --------------------------------------------------------------------------------------------
+# target assignment
+# --------------------------------------------------------------------------------------------
+class FCOSAssigner:
+    """Top-k nearest anchor points per GT box, per task (fcos_assigner.py:73-285), batched."""
+
+    def __init__(self, out_size_factor, tasks, dense_reg, gaussian_overlap, max_objs, min_radius,
+                 mapping, grid_size, pc_range, voxel_size, assign_topk, no_log=False,
+                 with_velocity=False):
+        self.out_size_factor = out_size_factor
+        self.tasks = tasks
+        self.task_classes = [list(t["class_names"]) for t in tasks]
+        self.num_classes = sum(len(c) for c in self.task_classes)
+        self.dense_reg = dense_reg
+        self._max_objs = max_objs
+        self.class_to_idx = mapping
+        self.grid_size = [int(g) for g in grid_size]
+        self.pc_range = pc_range
+        self.voxel_size = voxel_size
+        self.assign_topk = assign_topk
+        self.with_velocity = with_velocity
+        self.default_box_dims = 10 if with_velocity else 8
+        self._anchors = {}
+
+    def anchor_points(self, device):
+        a = self._anchors.get(device)
+        if a is None:
+            w, h = self.grid_size[0] // self.out_size_factor, self.grid_size[1] // self.out_size_factor
+            s = self.out_size_factor
+            gx = torch.linspace(0.0, (w - 1) * s, steps=w, device=device)
+            gy = torch.linspace(0.0, (h - 1) * s, steps=h, device=device)
+            a = torch.stack([gx.repeat(h), gy.repeat_interleave(w)], 1)    # [H*W, 2], x fastest
+            self._anchors[device] = a
+        return a
+
+    @torch.no_grad()
+    def assign_targets(self, gt_boxes):
+        """gt_boxes f32[B,M,C+1] (last column = 1-based class) -> dict of per-task targets."""
+        dev = gt_boxes.device
+        B, M = gt_boxes.shape[:2]
+        K = self._max_objs * self.dense_reg
+        w, h = self.grid_size[0] // self.out_size_factor, self.grid_size[1] // self.out_size_factor
+        anchors = self.anchor_points(dev)
+        A = anchors.shape[0]
+        cls = gt_boxes[:, :, -1].int()
+        box = gt_boxes[:, :, :-1]
+        idx = torch.arange(M, device=dev)
+        # rows up to the last one that does not sum to zero are kept (row 0 always is)
+        nz = box.sum(-1) != 0
+        last = torch.where(nz, idx, torch.zeros_like(idx)).amax(1, keepdim=True)
+        valid = idx[None, :] <= last
+        vs0, vs1 = self.voxel_size[0], self.voxel_size[1]
+        cx = (box[:, :, 0] - self.pc_range[0]) / vs0
+        cy = (box[:, :, 1] - self.pc_range[1]) / vs1
+        dxv, dyv = box[:, :, 3] / vs0, box[:, :, 4] / vs1
+        yaw = limit_period(box[:, :, 6], offset=0.5, period=math.pi * 2)
+        out = {k: {} for k in ("heatmap", "ind", "mask", "cat", "box_encoding")}
+        barange = torch.arange(B, device=dev)[:, None]
+        for t, names in enumerate(self.task_classes):
+            nc = len(names)
+            # class offset inside the task, -1 for boxes of other tasks / invalid rows
+            coff = torch.full((B, M), -1, dtype=torch.long, device=dev)
+            for o, name in enumerate(names):
+                coff = torch.where(valid & (cls == self.class_to_idx[name]), torch.full_like(coff, o), coff)
+            member = coff >= 0
+            # task order = (class offset, original index): order matters only for argmin ties
+            key = torch.where(member, coff * M + idx[None, :], torch.full_like(coff, nc * M + M))
+            perm = key.argsort(1)
+            mem = member.gather(1, perm)
+            pcx, pcy = cx.gather(1, perm), cy.gather(1, perm)
+            d = (anchors[None, :, None, 0] - pcx[:, None, :]) ** 2 + (anchors[None, :, None, 1] - pcy[:, None, :]) ** 2
+            d = torch.where(mem[:, None, :], d, torch.full_like(d, float("inf")))      # [B,A,M]
+            topk = min(self.assign_topk, A)
+            tk = torch.topk(d.transpose(1, 2), topk, dim=2, largest=False).indices       # [B,M,topk]
+            hits = torch.zeros((B, A), device=dev)
+            hits.scatter_add_(1, tk.reshape(B, -1), mem[:, :, None].expand(B, M, topk).reshape(B, -1).float())
+            pos = hits > 0                                                               # [B,A]
+            gid = d.argmin(2)                                                            # nearest GT (task order)
+            # compact the positive anchors, ascending, into K slots
+            rank = pos.long().cumsum(1) - 1
+            slot = torch.where(pos & (rank < K), rank, torch.full_like(rank, K))
+            aidx = torch.arange(A, device=dev)[None, :].expand(B, A)
+            ind = torch.zeros((B, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, aidx)[:, :K]
+            sgt = torch.zeros((B, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, gid)[:, :K]
+            mask = torch.zeros((B, K + 1), dtype=torch.bool, device=dev).scatter_(1, slot, pos)[:, :K]
+            sperm = perm.gather(1, sgt)                                                  # original box row
+            cat = torch.where(mask, coff.gather(1, sperm), torch.zeros_like(sgt))
+            # heat map: one-hot of the assigned class at every positive anchor
+            cat_anchor = coff.gather(1, perm.gather(1, gid)).clamp_min(0)
+            hm = torch.zeros((B, nc, A), device=dev)
+            hm.scatter_(1, cat_anchor[:, None, :], pos[:, None, :].float())
+            # box encoding of the assigned GT relative to its anchor point
+            g = lambda v: v.gather(1, sperm)
+            ax, ay = anchors[:, 0][ind], anchors[:, 1][ind]
+            cols = [(g(cx) - ax) / self.out_size_factor, (g(cy) - ay) / self.out_size_factor,
+                    g(box[:, :, 2]), torch.log(g(dxv) * vs0), torch.log(g(dyv) * vs1),
+                    torch.log(g(box[:, :, 5])), torch.sin(g(yaw)), torch.cos(g(yaw))]
+            cols += [g(box[:, :, j]) for j in range(7, box.shape[2])]
+            enc = torch.stack(cols, 2) * mask[:, :, None]
+            enc = torch.where(mask[:, :, None], enc, torch.zeros_like(enc))             # -inf * 0 = nan guard
+            if enc.shape[2] < self.default_box_dims:
+                enc = torch.cat([enc, enc.new_zeros(B, K, self.default_box_dims - enc.shape[2])], 2)
+            out["heatmap"][t] = hm.reshape(B, nc, h, w)
+            out["ind"][t] = torch.where(mask, ind, torch.zeros_like(ind))
+            out["mask"][t] = mask
+            out["cat"][t] = cat
+            out["box_encoding"][t] = enc.float()
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# head
+# --------------------------------------------------------------------------------------------
+class _HeadSeq(nn.Sequential):
+    """nn.Sequential with the ``add`` of the reference's tiny Sequential (center_head.py:260-308)."""
+
+    def add(self, module, name=None):
+        self.add_module(str(len(self._modules)) if name is None else name, module)
+
+
+class SepHead(nn.Module):
+    """One small conv stack per output quantity (center_head.py:311-375)."""
+
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19,
+                 directional_classifier=False, **_):
+        super().__init__()
+        assert directional_classifier is False
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            fc = _HeadSeq()
+            for _i in range(num_conv - 1):
+                fc.add(nn.Conv2d(in_channels, head_conv, final_kernel, padding=final_kernel // 2, bias=True))
+                if bn:
+                    fc.add(nn.BatchNorm2d(head_conv))
+                fc.add(nn.ReLU())
+            fc.add(nn.Conv2d(head_conv, classes, final_kernel, padding=final_kernel // 2, bias=True))
+            if "hm" in head:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        nn.init.kaiming_normal_(m.weight, a=0, mode="fan_out", nonlinearity="relu")
+                        nn.init.constant_(m.bias, 0)
+            setattr(self, head, fc)
+
+    def forward(self, x):
+        return {head: getattr(self, head)(x) for head in self.heads}
+
+
+class CenterHead(nn.Module):
+    def __init__(self, dataset_name, tasks, target_assigner, proposal_layer, input_channels,
+                 grid_size, point_cloud_range, code_weights, loc_weight, share_conv_channel,
+                 common_heads, upsample_for_pedestrian=False, predict_boxes_when_training=False,
+                 mode="3d", init_bias=-2.19, distill=False):
+        super().__init__()
+        self.in_channels = input_channels
+        self.grid_size = grid_size
+        self.point_cloud_range = point_cloud_range
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.code_weights = code_weights
+        self.weight = loc_weight
+        self.dataset = dataset_name
+        self.box_n_dim = 9 if dataset_name == "nuscenes" else 7
+        self.distill = distill
+        self.shared_conv = nn.Sequential(
+            nn.Conv2d(input_channels, share_conv_channel, 3, padding=1, bias=True),
+            nn.BatchNorm2d(share_conv_channel), nn.ReLU(inplace=True))
+        self.upsample_for_pedestrian = upsample_for_pedestrian
+        if upsample_for_pedestrian:
+            self.upsample_conv = nn.Sequential(
+                nn.ConvTranspose2d(share_conv_channel, share_conv_channel, 2, stride=2, bias=False),
+                nn.BatchNorm2d(share_conv_channel), nn.ReLU())
+        self.common_heads = common_heads
+        self.init_bias = init_bias
+        self.tasks = nn.ModuleList()
+        for num_cls in self.num_classes:
+            heads = copy.deepcopy(dict(common_heads))
+            heads.update(dict(hm=(num_cls, 2)))
+            self.tasks.append(SepHead(share_conv_channel, heads, bn=True, init_bias=init_bias,
+                                      final_kernel=3))
+        self.target_assigner = target_assigner
+        self.proposal_layer = proposal_layer
+
+    def assign_targets(self, gt_boxes):
+        return self.target_assigner.assign_targets(gt_boxes)
+
+    def forward(self, spatial_features_2d, gt_boxes=None):
+        x = self.shared_conv(spatial_features_2d)
+        if self.upsample_for_pedestrian:
+            x = self.upsample_conv(x)
+        ret = {"multi_head_features": [task(x) for task in self.tasks]}
+        if self.training or self.distill:
+            # The reference also assigns targets for the frozen distillation teacher
+            # (center_head.py:137); they are never read, so the teacher skips the work here.
+            if gt_boxes is not None and not self.distill:
+                ret.update(self.assign_targets(gt_boxes))
+            return ret
+        if self.proposal_layer is None:
+            return ret
+        return self.proposal_layer.generate_predicted_boxes(ret, {})
+
+    @staticmethod
+    def _sigmoid(x):
+        return torch.clamp(x.sigmoid(), min=1e-4, max=1 - 1e-4)
+
+
+class CenterHeadIouAware(CenterHead):
+    def __init__(self, dataset_name, tasks, target_assigner, proposal_layer, out_size_factor,
+                 input_channels, grid_size, point_cloud_range, code_weights, loc_weight, iou_weight,
+                 share_conv_channel, common_heads, upsample_for_pedestrian=False,
+                 predict_boxes_when_training=False, mode="3d", init_bias=-2.19,
+                 focal_alpha=0.25, focal_gamma=2, voxel_size_xy=None):
+        super().__init__(dataset_name, tasks, target_assigner, proposal_layer, input_channels,
+                         grid_size, point_cloud_range, code_weights, loc_weight, share_conv_channel,
+                         common_heads, upsample_for_pedestrian, predict_boxes_when_training, mode,
+                         init_bias)
+        self.auto_loss = AutomaticWeightedLoss(num=len(code_weights) + 2)
+        self.iou_weight = iou_weight
+        self.out_size_factor = out_size_factor
+        # DetHead._build_losses (centerhead_fusion_exp.py:106-117)
+        self.crit = FocalLoss(focal_alpha, focal_gamma)
+        self.crit_reg = CenterNetRegLoss()
+        self.crit_iou_aware = CenterNetRegLoss()
+        self._voxel_size_xy = voxel_size_xy
+
+    def _voxel_xy(self):
+        if self._voxel_size_xy is not None:
+            return self._voxel_size_xy
+        return self.proposal_layer.voxel_size
+
+    def get_loss(self, forward_ret_dict):
+        """-> (loss, tb_dict of DEVICE scalars).  Mutates each task's ``hm`` to its clamped sigmoid
+        like the reference does (center_head_iou_aware.py:61) -- the response distillation relies
+        on it."""
+        preds = forward_ret_dict["multi_head_features"]
+        T = len(preds)
+        masks = [forward_ret_dict["mask"][t] for t in range(T)]
+        # every normaliser of the step in ONE collective: focal num_pos and #objects per task
+        norm = reduce_mean_many([forward_ret_dict["heatmap"][t].eq(1).float().sum() for t in range(T)]
+                                + [m.float().sum() for m in masks])
+        tb = {}
+        total = 0
+        forward_ret_dict["pred_box_encoding"] = {}
+        stride, vs = self.out_size_factor, self._voxel_xy()
+        cw = None
+        for t, pd in enumerate(preds):
+            pd["hm"] = self._sigmoid(pd["hm"])
+            hm_loss = self.crit(pd["hm"], forward_ret_dict["heatmap"][t], num_pos=norm[t])
+            tgt = forward_ret_dict["box_encoding"][t]
+            if self.dataset == "nuscenes":
+                enc = torch.cat([pd["reg"], pd["height"], pd["dim"], pd["rot"], pd["vel"], pd["iou"]], 1)
+                nb = 10
+            else:
+                enc = torch.cat([pd["reg"], pd["height"], pd["dim"], pd["rot"], pd["iou"]], 1)
+                nb = 8
+            forward_ret_dict["pred_box_encoding"][t] = enc
+            ind, mask, num = forward_ret_dict["ind"][t], masks[t], norm[T + t]
+            gathered = _transpose_and_gather_feat(enc, ind)                 # [B,K,nb+1]
+            iou_loss, iou_aware = self._iou_losses(gathered, tgt[:, :, :nb], mask, num, stride, vs)
+            m = mask.unsqueeze(2).float() * (~torch.isnan(tgt[:, :, :nb])).float()
+            box_loss = torch.abs(gathered[:, :, :nb] * m - tgt[:, :, :nb] * m).sum(dim=(0, 1)) / (num + 1e-4)
+            if cw is None:
+                cw = box_loss.new_tensor(self.code_weights)
+            loc_loss = (box_loss * cw).sum()
+            loss = self.auto_loss(hm_loss, loc_loss, iou_aware)
+            # reference: ``if loc_loss.item() < 1: loss += iou_loss * w``  -> device-side select
+            loss = loss + torch.where(loc_loss.detach() < 1, iou_loss * self.iou_weight,
+                                      torch.zeros_like(iou_loss))
+            key = f"task_{t}/"
+            tb.update({key + "loss": loss.detach(), key + "hm_loss": hm_loss.detach(),
+                       key + "loc_loss": loc_loss.detach(), key + "box_loss": box_loss.detach(),
+                       key + "num_positive": mask.float().sum()})
+            total = total + loss
+        return total, tb
+
+    def _iou_losses(self, pred, tgt, mask, num_pos, stride, vs):
+        """pred [B,K,nb+1] gathered predictions (last = iou head), tgt [B,K,nb]."""
+        def decode(e):
+            x = (e[..., 0:1] * stride * vs[0]).reshape(-1, 1)
+            y = (e[..., 1:2] * stride * vs[1]).reshape(-1, 1)
+            whl = torch.clamp(torch.exp(e[..., 3:6]).reshape(-1, 3), min=0.001, max=30)
+            rot = torch.atan2(e[..., 6], e[..., 7]).reshape(-1, 1)
+            z = e[..., 2].reshape(-1, 1)
+            return x, y, z, whl, rot
+        tx, ty, tz, twhl, trot = decode(tgt)
+        px, py, pz, pwhl, prot = decode(pred)
+        # axis-aligned "3-D IoU" with the reference's (x<->whl0, y<->whl2, z<->whl1) pairing
+        def overlap(pc, pe, tc, te):
+            return torch.clamp(torch.min(pc + pe / 2, tc + te / 2) - torch.max(pc - pe / 2, tc - te / 2), min=1e-3)
+        ix = overlap(px, pwhl[:, 0:1], tx, twhl[:, 0:1])
+        iy = overlap(py, pwhl[:, 2:3], ty, twhl[:, 2:3])
+        iz = overlap(pz, pwhl[:, 1:2], tz, twhl[:, 1:2])
+        inter = ix * iy * iz
+        vp = torch.clamp(pwhl[:, 0:1] * pwhl[:, 2:3] * pwhl[:, 1:2], min=1e-3)
+        vt = torch.clamp(twhl[:, 0:1] * twhl[:, 2:3] * twhl[:, 1:2], min=1e-3)
+        iou = inter / (vp + vt - inter)
+        mflat = mask.reshape(-1, 1).float()
+        iou_loss = ((1 - torch.clamp(iou, 0, 1)) * mflat).sum() / torch.clamp_min(num_pos, 1)
+        # IoU-aware target: nearest-BEV IoU between target and (detached) predicted box
+        tb3 = torch.cat([tx, ty, tz, twhl, trot], -1)
+        pb3 = torch.cat([px, py, pz, pwhl, prot], -1).detach()
+        tar = 2 * (nearest_bev_iou_pairwise(tb3, pb3).reshape(*mask.shape, 1) - 0.5)
+        m = mask.unsqueeze(2).float() * (~torch.isnan(tar)).float()
+        aware = torch.abs(pred[:, :, -1:] * m - tar * m).sum() / (num_pos + 1e-4)
+        return iou_loss, aware

@@ -234,6 +234,124 @@ def gold_distill():
 
 ALL["distill"] = gold_distill
 
+
+def _ref_head(tasks, share, in_ch, grid, pc_range, voxel, osf, max_objs=200):
+    """Build the reference CenterHeadIouAware + FCOSAssigner exactly like DetHead.build_dense_head
+    (BEVFusion_nuscenes_centerhead_fusion_exp.py:51-119) for a shrunk configuration."""
+    from unidistill.layers.head.det3d import CenterHeadIouAware, FCOSAssigner
+    from unidistill.layers.losses.det3d import CenterNetRegLoss, FocalLoss
+    names = [n for t in tasks for n in t["class_names"]]
+    tasks_cfg = [_ref_import._AttrDict(t) for t in tasks]
+    assigner = FCOSAssigner(out_size_factor=osf, tasks=tasks_cfg, dense_reg=1, gaussian_overlap=0.1,
+                            max_objs=max_objs, min_radius=2,
+                            mapping={n: i + 1 for i, n in enumerate(names)}, grid_size=grid,
+                            pc_range=pc_range[0:2], voxel_size=voxel[0:2], assign_topk=9,
+                            no_log=False, with_velocity=True)
+
+    class _Prop:                      # only .voxel_size / .training are touched in training
+        voxel_size = voxel[0:2]
+        training = True
+    head = CenterHeadIouAware(
+        dataset_name="nuscenes", tasks=tasks_cfg, target_assigner=assigner, proposal_layer=_Prop(),
+        out_size_factor=osf, input_channels=in_ch, grid_size=grid, point_cloud_range=pc_range,
+        code_weights=[1.0] * 8 + [0.2, 0.2], loc_weight=0.25, iou_weight=5.0,
+        share_conv_channel=share,
+        common_heads={"iou": [1, 2], "reg": [2, 2], "height": [1, 2], "dim": [3, 2], "rot": [2, 2],
+                      "vel": [2, 2]},
+        upsample_for_pedestrian=False, mode="3d", init_bias=-2.19, predict_boxes_when_training=False)
+    head.add_module("crit", FocalLoss(0.25, 2))
+    head.add_module("crit_reg", CenterNetRegLoss())
+    head.add_module("crit_iou_aware", CenterNetRegLoss())
+    return head
+
+
+def _rand_gt(g, B, M, nvalid, ncls, lo, hi):
+    gt = torch.zeros(B, M, 10)
+    for b in range(B):
+        n = nvalid[b]
+        gt[b, :n, 0:2] = lo + (hi - lo) * torch.rand(n, 2, generator=g)
+        gt[b, :n, 2] = torch.randn(n, generator=g) * 0.5 - 1.0
+        gt[b, :n, 3:6] = torch.rand(n, 3, generator=g) * 3.0 + 0.4
+        gt[b, :n, 6] = (torch.rand(n, generator=g) - 0.5) * 12.0
+        gt[b, :n, 7:9] = torch.randn(n, 2, generator=g)
+        gt[b, :n, 9] = torch.randint(1, ncls + 1, (n,), generator=g).float()
+    return gt
+
+
+def gold_dense_head():
+    """BaseBEVBackbone (base_bev_backbone.py:10-174), CenterHeadIouAware forward + FCOSAssigner
+    targets + get_loss (center_head.py:124-146, fcos_assigner.py:73-285,
+    center_head_iou_aware.py:55-298), FocalLoss / CenterNetRegLoss (losses/det3d.py:287-421),
+    boxes3d_nearest_bev_iou (box_utils.py:343-373) -- shrunk widths, seeded state_dicts."""
+    from unidistill.layers.blocks_2d.det3d import BaseBEVBackbone
+    from unidistill.utils.det3d_utils import box_utils
+    torch.manual_seed(104)
+    g = torch.Generator().manual_seed(104)
+    out = {}
+    # ---- trunk
+    trunk = BaseBEVBackbone(layer_nums=[2, 2], layer_strides=[1, 2], num_filters=[8, 16],
+                            upsample_strides=[1, 2], num_upsample_filters=[12, 12], input_channels=6)
+    for m in trunk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    x = torch.randn(2, 6, 32, 32, generator=g)
+    for k, v in trunk.state_dict().items():         # before the train-mode pass moves the BN stats
+        out["trunk_sd/" + k] = v.clone()
+    trunk.eval()
+    with torch.no_grad():
+        y_eval, pyr = trunk(x)
+    trunk.train()
+    y_train, _ = trunk(x)
+    out.update({"trunk_x": x, "trunk_y_eval": y_eval, "trunk_y_train": y_train.detach(),
+                "trunk_pyr2": pyr["spatial_features_2x"]})
+    # ---- head + assigner + loss  (32x32 map, 8 voxels per pixel, 0.25 m voxels -> 64 m square)
+    tasks = [dict(num_class=1, class_names=["car"]), dict(num_class=2, class_names=["truck", "bus"]),
+             dict(num_class=1, class_names=["barrier"])]
+    pc_range = [-32.0, -32.0, -5.0, 32.0, 32.0, 3.0]
+    voxel = [0.25, 0.25, 0.2]
+    head = _ref_head(tasks, share=16, in_ch=24, grid=[256, 256, 40], pc_range=pc_range, voxel=voxel,
+                     osf=8)
+    for m in head.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    with torch.no_grad():
+        head.auto_loss.params.copy_(torch.linspace(0.8, 1.3, 12))
+    B, M = 2, 12
+    gt = _rand_gt(g, B, M, [9, 0], 3, -30.0, 30.0)      # sample 1 has no boxes at all; class 4 absent
+    gt[0, 3, 3:6] = 0.0                                    # a zero-size box -> log(0) = -inf -> zeroed
+    feat = torch.randn(B, 24, 32, 32, generator=g, requires_grad=True)
+    for k, v in head.state_dict().items():
+        out["head_sd/" + k] = v.clone()
+    head.train()
+    ret = head(feat, gt.clone())
+    for _, enc in ret["box_encoding"].items():
+        enc[torch.isinf(enc)] = 0
+    loss, tb = head.get_loss(ret)
+    loss.backward()
+    out.update({"head_feat": feat.detach(), "head_gt": gt, "head_loss": loss.detach(),
+                "head_feat_grad": feat.grad, "head_params_grad": head.auto_loss.params.grad})
+    for t in range(len(tasks)):
+        for k in ("heatmap", "ind", "mask", "cat", "box_encoding"):
+            out[f"head_tgt{t}_{k}"] = ret[k][t]
+        for hn, v in ret["multi_head_features"][t].items():
+            out[f"head_out{t}_{hn}"] = v.detach()      # hm is post-sigmoid after get_loss (quirk 1)
+        out[f"head_tb{t}"] = np.array([tb[f"task_{t}/{k}"] for k in
+                                       ("loss", "hm_loss", "loc_loss", "x_loss", "vy_loss")], np.float64)
+    # ---- standalone box helpers
+    a = torch.randn(40, 7, generator=g)
+    a[:, 3:6] = a[:, 3:6].abs() + 0.3
+    b = a + 0.3 * torch.randn(40, 7, generator=g)
+    b[:, 3:6] = b[:, 3:6].abs() + 0.3
+    out.update({"iou_a": a, "iou_b": b, "iou_bev": box_utils.boxes3d_nearest_bev_iou(a, b)})
+    _save("dense_head", **out)
+
+
+ALL["dense_head"] = gold_dense_head
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)
     for n in names:
