@@ -389,7 +389,9 @@ class CenterHeadIouAware(CenterHead):
         def decode(e):
             x = (e[..., 0:1] * stride * vs[0]).reshape(-1, 1)
             y = (e[..., 1:2] * stride * vs[1]).reshape(-1, 1)
-            whl = torch.clamp(torch.exp(e[..., 3:6]).reshape(-1, 3), min=0.001, max=30)
+            # clamp(exp(x), .001, 30) as in the reference; the inner clamp only keeps exp() finite so
+            # that an overflowing logit gets the zero gradient of the outer clamp instead of 0*inf = NaN
+            whl = torch.clamp(torch.exp(torch.clamp(e[..., 3:6], max=80.0)).reshape(-1, 3), min=0.001, max=30)
             rot = torch.atan2(e[..., 6], e[..., 7]).reshape(-1, 1)
             z = e[..., 2].reshape(-1, 1)
             return x, y, z, whl, rot

@@ -1,0 +1,128 @@
+"""Image branch: ResNet-50 backbone + SECONDFPN neck in plain PyTorch-ROCm (MIOpen convs).
+
+The reference builds these through mmdet / mmdet3d (lss_fpn.py:143-149, configs
+BEVFusion_nuscenes_centerhead_fusion_exp.py:24-39); neither package nor its source is part of the
+reference tree, so these are the standard published architectures (parity unpinned, random
+weights in the benchmark).  Parameter names follow mmdet's ResNet (conv1/bn1/layerN.M.convK/bnK/
+downsample.0/1) and mmdet3d's SECONDFPN (deblocks.i.0 / deblocks.i.1) so their checkpoints map 1:1.
+SURVEY 8f.3 ranks a hand-written NHWC bf16 image branch as "next"; north_star keeps hand-written
+MFMA to the BEV trunk + head.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)   # "pytorch" style
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + idt)
+
+
+class ResNet(nn.Module):
+    """ResNet-50/101 trunk returning the feature maps listed in ``out_indices``."""
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+    def __init__(self, depth=50, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False, **_):
+        super().__init__()
+        self.out_indices = tuple(out_indices)
+        self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        inplanes = 64
+        for i, n in enumerate(self.arch[depth]):
+            planes, stride = 64 * 2 ** i, (1 if i == 0 else 2)
+            down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * 4))
+            blocks = [Bottleneck(inplanes, planes, stride, down)]
+            inplanes = planes * 4
+            blocks += [Bottleneck(inplanes, planes) for _ in range(1, n)]
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i in range(4):
+            x = getattr(self, f"layer{i + 1}")(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+
+class SECONDFPN(nn.Module):
+    """Per-level (de)conv to a common stride, BN(eps 1e-3, momentum 0.01) + ReLU, concat."""
+
+    def __init__(self, in_channels, out_channels, upsample_strides, **_):
+        super().__init__()
+        assert len(in_channels) == len(out_channels) == len(upsample_strides)
+        self.deblocks = nn.ModuleList()
+        for cin, cout, s in zip(in_channels, out_channels, upsample_strides):
+            if s >= 1:
+                k = int(s)
+                op = nn.ConvTranspose2d(cin, cout, k, stride=k, bias=False)
+            else:
+                k = int(np.round(1 / s))
+                op = nn.Conv2d(cin, cout, k, stride=k, bias=False)
+            self.deblocks.append(nn.Sequential(op, nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01),
+                                               nn.ReLU(inplace=True)))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, feats):
+        ups = [blk(f) for blk, f in zip(self.deblocks, feats)]
+        return [torch.cat(ups, 1) if len(ups) > 1 else ups[0]]
+
+
+def build_backbone(cfg):
+    cfg = dict(cfg)
+    kind = cfg.pop("type")
+    if kind != "ResNet":
+        raise NotImplementedError(f"image backbone {kind!r}: every experiment overrides the default "
+                                  "Swin config with ResNet-50 (centerhead_fusion_exp.py:24-31)")
+    cfg.pop("init_cfg", None)
+    return ResNet(**cfg)
+
+
+def build_neck(cfg):
+    cfg = dict(cfg)
+    kind = cfg.pop("type")
+    if kind != "SECONDFPN":
+        raise NotImplementedError(kind)
+    return SECONDFPN(**cfg)

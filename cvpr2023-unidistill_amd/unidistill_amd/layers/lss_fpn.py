@@ -1,0 +1,116 @@
+"""Camera encoder: Lift-Splat-Shoot with the fused HIP lift+splat.
+
+Mirror of LSSFPN (unidistill/layers/blocks_3d/mmdet3d/lss_fpn.py:85-368): same constructor
+arguments, buffers (voxel_size / voxel_coord / voxel_num / frustum), sub-module names
+(img_backbone, img_neck, depth_net) and forward signature.  What changes underneath:
+  * get_geometry + binning: one HIP kernel over the frustum (ud_lss_geometry) instead of ~10
+    batched 4x4 matmuls and two torch.inverse calls;
+  * depth softmax (x) context, permute and voxel_pooling: ud_lss_splat_fwd pools
+    depth_prob * context straight into the BEV grid -- the [B,6,112,16,44,256] tensor (484 MB,
+    written twice per step in the reference) never exists; backward likewise.
+``materialise=True`` switches to the reference's op boundary (lift -> voxel_pooling) for A/B.
+"""
+import torch
+from torch import nn
+
+from ..ops import bev_pool as _bp
+from ..ops import lss as _lss
+from .image import build_backbone, build_neck
+
+
+class LSSFPN(nn.Module):
+    def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, downsample_factor,
+                 output_channels, img_backbone_conf, img_neck_conf, depth_net_conf,
+                 timestamp_net_conf=None, materialise=False):
+        super().__init__()
+        self.downsample_factor = downsample_factor
+        self.d_bound = d_bound
+        self.final_dim = final_dim
+        self.output_channels = output_channels
+        self.materialise = materialise
+        bounds = [x_bound, y_bound, z_bound]
+        self.register_buffer("voxel_size", torch.Tensor([r[2] for r in bounds]))
+        self.register_buffer("voxel_coord", torch.Tensor([r[0] + r[2] / 2.0 for r in bounds]))
+        self.register_buffer("voxel_num", torch.LongTensor([round((r[1] - r[0]) / r[2]) for r in bounds]))
+        self._nxyz = tuple(int(round((r[1] - r[0]) / r[2])) for r in bounds)   # host copy: no .cuda()/sync
+        self._lo, self._size = _lss.bin_origin_fp32([r[0] + r[2] / 2.0 for r in bounds],
+                                                    [r[2] for r in bounds])
+        self.register_buffer("frustum", self.create_frustum())
+        self.depth_channels = self.frustum.shape[0]
+        self.img_backbone = build_backbone(img_backbone_conf)
+        self.img_neck = build_neck(img_neck_conf)
+        self.depth_net = self._configure_depth_net(depth_net_conf)
+        self.timestamp_net = None
+        self.img_neck.init_weights()
+        self.img_backbone.init_weights()
+
+    def _configure_depth_net(self, conf):
+        out_ch = self.depth_channels + self.output_channels
+        if conf.get("num_res_layer", 0) != 0:
+            raise NotImplementedError("depth_net with residual layers is not used by any experiment")
+        return nn.Sequential(nn.Conv2d(conf["in_channels"], out_ch, kernel_size=1))
+
+    def create_frustum(self):
+        """[D, fH, fW, 4] = (u, v, d, 1) in image pixels / metres (lss_fpn.py:173-198)."""
+        H, W = self.final_dim
+        fH, fW = H // self.downsample_factor, W // self.downsample_factor
+        d = torch.arange(*self.d_bound, dtype=torch.float)
+        u = torch.linspace(0, W - 1, fW, dtype=torch.float)
+        v = torch.linspace(0, H - 1, fH, dtype=torch.float)
+        D = d.numel()
+        return torch.stack([u.view(1, 1, fW).expand(D, fH, fW), v.view(1, fH, 1).expand(D, fH, fW),
+                            d.view(D, 1, 1).expand(D, fH, fW), torch.ones(D, fH, fW)], -1).contiguous()
+
+    def _frustum_axes(self):
+        fr = self.frustum
+        return fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous()
+
+    def get_geometry_bins(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat, want_geom=False):
+        """-> bins i32[B, N, 3] (and optionally ego coordinates f32[B,ncam,D,fH,fW,3])."""
+        B, ncam = sensor2ego_mat.shape[:2]
+        mats = _lss.prepare_mats(sensor2ego_mat, intrin_mat, ida_mat, bda_mat)
+        fu, fv, fd = self._frustum_axes()
+        return _lss.geometry(mats, fu, fv, fd, B, ncam, self._lo, self._size,
+                             has_bda=bda_mat is not None, want_geom=want_geom)
+
+    def get_geometry(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat):
+        return self.get_geometry_bins(sensor2ego_mat, intrin_mat, ida_mat, bda_mat, True)[1]
+
+    def get_cam_feats(self, imgs):
+        B, S, N, C, H, W = imgs.shape
+        x = imgs.reshape(B * S * N, C, H, W)
+        f = self.img_neck(self.img_backbone(x))[0]
+        return f.reshape(B, S, N, f.shape[1], f.shape[2], f.shape[3])
+
+    def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, is_return_depth=False):
+        B, S, ncam = sweep_imgs.shape[:3]
+        feats = self.get_cam_feats(sweep_imgs)[:, 0]
+        depth_feature = self.depth_net(feats.reshape(B * ncam, *feats.shape[2:]))
+        D, C = self.depth_channels, self.output_channels
+        bins, _ = self.get_geometry_bins(mats_dict["sensor2ego_mats"][:, sweep_index],
+                                         mats_dict["intrin_mats"][:, sweep_index],
+                                         mats_dict["ida_mats"][:, sweep_index],
+                                         mats_dict.get("bda_mat", None))
+        nx, ny, nz = self._nxyz
+        if self.materialise:
+            lifted = _lss.lift(depth_feature, D, C)                      # [B*ncam, D, fH, fW, C]
+            bev = _bp.voxel_pooling(bins, lifted.reshape(B, -1, C), (nx, ny, nz))
+        else:
+            bev = _lss.lift_splat(depth_feature, bins, B, ncam, D, C, nx, ny, nz)
+        if is_return_depth:
+            return bev, depth_feature[:, :D].softmax(1)
+        return bev
+
+    def forward(self, sweep_imgs, mats_dict, timestamps=None, is_return_depth=False):
+        """sweep_imgs f32[B, num_sweeps, num_cams, 3, H, W] -> BEV map [B, C*num_sweeps, ny, nx]
+        (a channels-last view: the splat writes NHWC and returns its NCHW permutation)."""
+        S = sweep_imgs.shape[1]
+        key = self._forward_single_sweep(0, sweep_imgs[:, 0:1], mats_dict, is_return_depth)
+        if S == 1:
+            return key
+        maps = [key[0] if is_return_depth else key]
+        for s in range(1, S):
+            with torch.no_grad():
+                maps.append(self._forward_single_sweep(s, sweep_imgs[:, s:s + 1], mats_dict, False))
+        out = torch.cat(maps, 1)
+        return (out, key[1]) if is_return_depth else out
