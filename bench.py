@@ -1,11 +1,18 @@
-"""bench.py -- UniDistill hot path on MI355X: one JSON line per run (driver contract).
+"""bench.py -- UniDistill distillation training on MI355X: one JSON line per run (driver contract).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one per-GPU batch of synthetic nuScenes-shaped input
-(SURVEY.md 8d).  The path shards by sample (pure data parallel): every rank works on its own
-batch, so `scaling` is "weak" and value = (samples all ranks processed) / max-over-ranks time.
+A "step" is one full distillation training step (student fwd + frozen-teacher fwd + detection and
+distillation losses + backward + grad clip + AdamW) over one per-GPU batch of synthetic
+nuScenes-shaped input.  The path is pure data parallel: every rank trains on its
+own samples and gradients are averaged with RCCL, so `scaling` is "weak" and
+value = samples of all ranks / max-over-ranks wall time.
+
+After the timed region (never counted in `value`) two extra legs run on rank 0:
+  * roofline: the reference-boundary bev_pool forward (BASELINE.json: "bev_pool+voxelize HBM GB/s")
+    at the BASELINE shape, its dominant kernel timed with HIP events on its launch stream;
+  * cpu_baseline: the CPU oracle (oracle/, scalar C) on a bounded sample of the same hot path.
 """
 import argparse
 import json
@@ -25,6 +32,16 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
+WORKLOADS = {
+    # BASELINE.json configs[2]: camera student + LiDAR teacher, 6-cam nuScenes shape
+    "camera_exp_distill_lidar": dict(kind="distill", sweeps=1),
+    "camera_exp_distill_fusion": dict(kind="distill", sweeps=10),   # configs[4] models
+    "lidar_exp_distill_fusion": dict(kind="distill", sweeps=1),     # configs[3] models
+    "lidar_exp_distill_camera": dict(kind="distill", sweeps=1),
+    "lidar": dict(kind="detect", sweeps=1),                         # configs[1]
+    "camera": dict(kind="detect", sweeps=1),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -32,74 +49,82 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU")
-    ap.add_argument("--workload", default="bev_extract", choices=["bev_extract"])
+    ap.add_argument("--workload", default="camera_exp_distill_lidar", choices=sorted(WORKLOADS))
+    ap.add_argument("--autocast", default="none", choices=["none", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-class BevExtract:
-    """Camera splat + LiDAR voxelisation leg of the hot path, fwd + bwd of the splat.
+def roofline_leg(device, batch):
+    """bev_pool forward (reference op boundary) at N = 6*112*16*44 points, C = 256, 180x180."""
+    from unidistill_amd import _lib, synthetic as syn
+    from unidistill_amd.ops import bev_pool as bp
+    g = syn.rng(7)
+    s2e, intr, ida, bda = syn.camera_rig(g, batch, 6)
+    geom, _ = syn.frustum_bins_torch(s2e, intr, ida, bda, device)
+    B, N = geom.shape[:2]
+    C, nx, ny = 256, 180, 180
+    feat = torch.randn(B, N, C, device=device)
+    out = torch.empty(B, ny, nx, C, device=device)
+    pos = torch.empty(B, N, 3, dtype=torch.int32, device=device)
+    scrub = torch.empty(512 << 20, dtype=torch.uint8, device=device)   # > Infinity Cache (256 MiB)
+    for _ in range(2):
+        bp._pool_fwd(geom, feat, out, pos, B, N, C, nx, ny, 1, bp.POOL_OVERWRITE)
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    op_ms = 0.0
+    for _ in range(reps):
+        scrub.zero_()                       # evict feat from the Infinity Cache: honest HBM reads
+        e0.record()
+        bp._pool_fwd(geom, feat, out, pos, B, N, C, nx, ny, 1, bp.POOL_OVERWRITE)
+        e1.record()
+        torch.cuda.synchronize()
+        op_ms += e0.elapsed_time(e1)
+    _lib.prof_enable(False)
+    k_ms, k_calls = _lib.prof_read("bev_pool.k_pool")
+    alg = B * N * (12 + C * 4 + 12) + B * ny * nx * C * 4          # SURVEY 8d bev_pool fwd row
+    k_us = k_ms / max(k_calls, 1) * 1e3
+    achieved = alg / (k_us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "bev_pool.k_pool (ud_bev_pool_fwd, reference op boundary)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "avg_kernel_us": k_us, "launches": k_calls, "algorithmic_bytes_per_launch": alg,
+            "op_avg_us": op_ms / reps * 1e3, "op_GBps": alg / (op_ms / reps * 1e-3) / 1e9,
+            "traffic": None,
+            "note": "measured after the timed region; the training step itself uses the fused "
+                    "lift+splat (no [B,N,C] tensor), see DESIGN.md"}
 
-    per sample: voxelize+MeanVFE of a 10-sweep cloud (300 k pts, cap 120 k voxels), and
-    bev_pool fwd + bwd over the 6-camera frustum (N = 473 088 points, C = 256, 180x180 BEV).
-    """
-    name = "bev_extract(6cam bev_pool fwd+bwd C=256 180x180 + 10-sweep voxelize+meanVFE)"
 
-    def __init__(self, device, batch, rank):
-        from unidistill_amd import synthetic as syn
-        from unidistill_amd.ops import bev_pool as bp, voxelize as vx
-        self.bp, self.vx, self.syn = bp, vx, syn
-        g = syn.rng(rank=rank)
-        self.B = batch
-        s2e, intr, ida, bda = syn.camera_rig(g, batch, 6)
-        self.geom, _ = syn.frustum_bins_torch(s2e, intr, ida, bda, device)
-        self.N = self.geom.shape[1]
-        self.C, self.nx, self.ny = 256, 180, 180
-        self.feat = torch.randn(batch, self.N, self.C, device=device)
-        self.out = torch.empty(batch, self.ny, self.nx, self.C, device=device)
-        self.pos = torch.empty(batch, self.N, 3, dtype=torch.int32, device=device)
-        self.gout = torch.randn(batch, self.ny, self.nx, self.C, device=device).permute(0, 3, 1, 2)
-        clouds = [syn.lidar_cloud(g, 30000, 10) for _ in range(batch)]
-        self.points = torch.from_numpy(syn.pad_clouds(clouds)).to(device)
-        self.dominant = "bev_pool.k_pool"
-        # algorithmic bytes of one k_pool launch = the bev_pool fwd op's bytes (SURVEY 8d)
-        self.alg_bytes = batch * self.N * (12 + self.C * 4 + 12) + batch * self.ny * self.nx * self.C * 4
-
-    def step(self):
-        bp = self.bp
-        B, N, C = self.B, self.N, self.C
-        self.vx.voxelize_batch(self.points, self.syn.VOXEL_SIZE, self.syn.POINT_CLOUD_RANGE, 10,
-                               120000, want_voxels=False, want_mean=True)
-        bp._pool_fwd(self.geom, self.feat, self.out, self.pos, B, N, C, self.nx, self.ny, 1,
-                     bp.POOL_OVERWRITE)
-        bp._pool_bwd(self.gout, self.pos, B, N, C, self.nx, self.ny)
-
-    def cpu_baseline(self):
-        """Oracle (scalar C, 1 thread) on a bounded sample: 1 camera of the splat fwd+bwd +
-        a single-sweep voxelize; scaled to samples/s of the full step by work ratio."""
-        import oracle
-        syn = self.syn
-        g = syn.rng(99)
-        s2e, intr, ida, bda = syn.camera_rig(g, 1, 1)
-        geom, _ = syn.frustum_bins_torch(s2e, intr, ida, bda, "cpu")
-        geom = geom.numpy()
-        n1 = geom.shape[1]
-        feat = np.random.default_rng(0).standard_normal((1, n1, self.C)).astype(np.float32)
-        gout = np.random.default_rng(1).standard_normal((1, self.C, self.ny, self.nx)).astype(np.float32)
-        pts = syn.lidar_cloud(g, 30000, 1)
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < 10.0:
-            _, pos = oracle.bev_pool_fwd(geom, feat, self.nx, self.ny, 1)
-            oracle.bev_pool_bwd(gout, pos)
-            oracle.voxelize(pts, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 10, 120000, with_voxels=False)
-            reps += 1
-        dt = (time.perf_counter() - t0) / reps
-        # full step = 6 cameras and 10 sweeps: 6x / 10x the sampled work
-        est = 6.0 * dt
-        return {"value": 1.0 / est, "unit": "samples/s", "cores": 1, "kind": "port",
-                "sample": "oracle C, 1 thread: 1 of 6 cameras of bev_pool fwd+bwd (78848 pts x 256 ch) + "
-                          "1-sweep (30k pt) voxelize+mean, time x6 extrapolated to the 6-cam step"}
+def cpu_baseline_leg():
+    """Oracle (scalar C, 1 thread) on a bounded sample: 1 of 6 cameras of lift + bev_pool fwd+bwd,
+    a single-sweep voxelize+mean, a 2k-voxel slice of one 64->64 sparse conv, the 3 distill losses'
+    mask; extrapolated by the work ratio to one distillation step of the BEV extraction path."""
+    import oracle
+    from unidistill_amd import synthetic as syn
+    g = syn.rng(99)
+    s2e, intr, ida, bda = syn.camera_rig(g, 1, 1)
+    geom, _ = syn.frustum_bins_torch(s2e, intr, ida, bda, "cpu")
+    geom = geom.numpy()
+    n1 = geom.shape[1]
+    rs = np.random.default_rng(0)
+    feat = rs.standard_normal((1, n1, 256)).astype(np.float32)
+    gout = rs.standard_normal((1, 256, 180, 180)).astype(np.float32)
+    pts = syn.lidar_cloud(g, 30000, 1)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 12.0:
+        _, pos = oracle.bev_pool_fwd(geom, feat, 180, 180, 1)
+        oracle.bev_pool_bwd(gout, pos)
+        oracle.voxelize(pts, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 10, 120000, with_voxels=False)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    est = 6.0 * dt      # 6 cameras; the sparse/dense conv stacks are NOT included (they dominate on CPU)
+    return {"value": 1.0 / est, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": "oracle C, 1 thread, BEV-extraction ops only: 1 of 6 cameras of bev_pool "
+                      "fwd+bwd (78848 pts x 256 ch) + 1-sweep (30k pt) voxelize+mean, x6 -> upper "
+                      "bound on the CPU samples/s of a full step (conv trunks excluded)"}
 
 
 def main():
@@ -113,9 +138,20 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
-    from unidistill_amd import _lib
+    from unidistill_amd import _lib, train
     _lib.load()
-    wl = BevExtract(device, args.batch, rank)
+    torch.manual_seed(1234)          # identical initial weights on every rank
+    wl = WORKLOADS[args.workload]
+    if wl["kind"] == "distill":
+        step = train.DistillStep(args.workload)
+        batch = train.synthetic_batch(device, args.batch, rank=rank, sweeps=wl["sweeps"])
+    else:
+        step = train.DetectStep(args.workload)
+        batch = train.synthetic_batch(device, args.batch, rank=rank, sweeps=wl["sweeps"],
+                                      with_imgs=args.workload != "lidar",
+                                      with_points=args.workload != "camera")
+    ac = torch.bfloat16 if args.autocast == "bf16" else None
+    trainer = train.Trainer(step, device=device, autocast_dtype=ac)
 
     def barrier():
         if world > 1:
@@ -123,40 +159,39 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        wl.step()
+        trainer.step(batch)
     barrier()
-    _lib.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step()
+        out = trainer.step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    _lib.prof_enable(False)
+    loss = float(out["loss"].item())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    k_ms, k_calls = _lib.prof_read(wl.dominant)
     if rank == 0:
         samples = args.batch * world * args.steps
-        avg_us = (k_ms / max(k_calls, 1)) * 1e3
-        achieved = wl.alg_bytes / (avg_us * 1e-6) / 1e9 if k_calls else None
         line = {
             "metric": "distill-train samples/sec (nuScenes frame); bev_pool+voxelize HBM GB/s",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl.name, "batch_per_gpu": args.batch, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": wl.dominant, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "avg_kernel_us": avg_us, "launches": k_calls,
-                         "algorithmic_bytes_per_launch": wl.alg_bytes, "traffic": None},
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if ac is None else "bf16(dense convs)+f32(HIP ops)", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: student+teacher distillation step, 6 cams 256x704, "
+                                   f"{30000 * wl['sweeps']}-pt cloud, 40 GT boxes, fwd+bwd+AdamW"
+                       if wl["kind"] == "distill" else f"{args.workload} detector training step",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "final_loss": loss},
         }
+        if not args.no_roofline:
+            line["roofline"] = roofline_leg(device, 1)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = wl.cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline_leg()
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
