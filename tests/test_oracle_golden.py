@@ -40,3 +40,58 @@ def test_voxelize_oracle_invariants():
     key = np.floor((first - np.array(rg[:3], np.float32)) / np.array(vs, np.float32)).astype(np.int32)
     np.testing.assert_array_equal(key[:, ::-1], c[:, 1:])
     np.testing.assert_allclose(r["mean"], oracle.mean_vfe(r["voxels"], r["num"]), rtol=0, atol=0)
+
+
+def test_lss_geometry_and_lift_oracle_vs_reference(golden):
+    g = golden("lss_geometry")
+    fr = g["frustum"]
+    u, v, d = oracle.lss_frustum(tuple(g["final_dim"]), 16, tuple(g["d_bound"]))
+    np.testing.assert_array_equal(u, fr[0, 0, :, 0])
+    np.testing.assert_array_equal(v, fr[0, :, 0, 1])
+    np.testing.assert_array_equal(d, fr[:, 0, 0, 2])
+    geom, bins = oracle.lss_geometry(g["sensor2ego"], g["intrin"], g["ida"], g["bda"], u, v, d,
+                                     g["voxel_coord"], g["voxel_size"])
+    np.testing.assert_allclose(geom, g["geom"], rtol=2e-5, atol=2e-4)
+    assert (bins != g["geom_xyz"]).mean() < 1e-3
+    l = golden("lss_lift")
+    lifted, prob = oracle.lss_lift(l["depth_feature"], int(l["D"]), int(l["C"]))
+    np.testing.assert_allclose(lifted.reshape(l["lifted"].shape), l["lifted"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(prob, l["depth"], rtol=1e-5, atol=1e-7)
+
+
+def test_spconv_oracle_vs_dense_conv3d():
+    """spconv is absent from the reference tree; pin the restated semantics against torch's dense
+    conv3d evaluated on the site sets (submanifold, strided, reachable-set, dgrad, wgrad)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    shape = (2, 6, 9, 8)
+    occ = rng.random(shape) < 0.3
+    coords = np.argwhere(occ).astype(np.int32)
+    rng.shuffle(coords)
+    cin, cout = 5, 7
+    feat = rng.standard_normal((len(coords), cin)).astype(np.float32)
+    W = rng.standard_normal((cout, 27, cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    dense = torch.from_numpy(oracle.sparse_to_dense(feat, coords, shape)).requires_grad_(True)
+    wt = torch.from_numpy(W).view(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    sel = lambda t, c: t[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]]
+    nbr = oracle.spconv_subm_rulebook(coords, shape, (3, 3, 3))
+    ref = F.conv3d(dense, wt, torch.from_numpy(bias), padding=1)
+    np.testing.assert_allclose(oracle.spconv_conv(feat, nbr, W, bias), sel(ref, coords).detach().numpy(),
+                               rtol=1e-5, atol=1e-5)
+    gout = rng.standard_normal((len(coords), cout)).astype(np.float32)
+    gd = torch.zeros_like(ref)
+    gd[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]] = torch.from_numpy(gout)
+    ref.backward(gd)
+    np.testing.assert_allclose(oracle.spconv_conv(gout, nbr, W, mirror=True, transpose=True),
+                               sel(dense.grad, coords).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(oracle.spconv_wgrad(feat, nbr, gout, cout),
+                               wt.grad.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).numpy(), rtol=1e-4, atol=1e-4)
+    oc, onbr, inbr, oshape = oracle.spconv_down(coords, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    ref2 = F.conv3d(dense.detach(), wt.detach(), None, stride=2, padding=1)
+    np.testing.assert_allclose(oracle.spconv_conv(feat, onbr, W), sel(ref2, oc).numpy(), rtol=1e-5, atol=1e-5)
+    reach = F.conv3d(torch.from_numpy(occ[:, None].astype(np.float32)), torch.ones(1, 1, 3, 3, 3),
+                     stride=2, padding=1).numpy()[:, 0] > 0
+    np.testing.assert_array_equal(np.argwhere(reach).astype(np.int32), oc)
+    assert ((inbr >= 0).sum() == (onbr >= 0).sum())
