@@ -119,13 +119,31 @@ def require_gpu(*tensors):
 
 
 _workspaces = {}
+_scope = ["eager"]
+
+
+class workspace_scope:
+    """Workspaces requested inside the scope get their own buffers.  A captured hipGraph bakes the
+    scratch pointers in, so a graph must never share (or lose to a re-allocation) the buffers that
+    eager code may grow later."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _scope.append(self.name)
+
+    def __exit__(self, *a):
+        _scope.pop()
 
 
 def workspace(device, nbytes, slot="default"):
-    """Grow-only byte scratch per (device, slot); stream-ordered reuse on torch's current stream."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    """Grow-only byte scratch per (device, scope, slot); stream-ordered reuse on torch's stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _scope[-1], slot)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"workspace {key} would be re-allocated during graph capture")
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf

@@ -88,7 +88,7 @@ def nearest_bev_iou_pairwise(boxes_a, boxes_b):
     (The reference builds the full N x N matrix, N = B*2500, and keeps the diagonal.)"""
     def aligned(b):
         rot = limit_period(b[:, 6], 0.5, math.pi).abs()
-        dims = torch.where(rot[:, None] < math.pi / 4, b[:, [3, 4]], b[:, [4, 3]])
+        dims = torch.where(rot[:, None] < math.pi / 4, b[:, 3:5], b[:, 3:5].flip(1))   # no host index lists (graph capture)
         return b[:, 0:2] - dims / 2, b[:, 0:2] + dims / 2
     a0, a1 = aligned(boxes_a)
     b0, b1 = aligned(boxes_b)
@@ -177,14 +177,16 @@ class FCOSAssigner:
             perm = key.argsort(1)
             mem = member.gather(1, perm)
             pcx, pcy = cx.gather(1, perm), cy.gather(1, perm)
-            d = (anchors[None, :, None, 0] - pcx[:, None, :]) ** 2 + (anchors[None, :, None, 1] - pcy[:, None, :]) ** 2
-            d = torch.where(mem[:, None, :], d, torch.full_like(d, float("inf")))      # [B,A,M]
+            # squared centre distances, laid out [B, M, A] so that topk runs on a CONTIGUOUS tensor
+            # (topk on a transposed view keeps hidden state that breaks hipGraph replays on ROCm)
+            d = (anchors[None, None, :, 0] - pcx[:, :, None]) ** 2 + (anchors[None, None, :, 1] - pcy[:, :, None]) ** 2
+            d = torch.where(mem[:, :, None], d, torch.full_like(d, float("inf")))      # [B,M,A]
             topk = min(self.assign_topk, A)
-            tk = torch.topk(d.transpose(1, 2), topk, dim=2, largest=False).indices       # [B,M,topk]
+            tk = torch.topk(d, topk, dim=2, largest=False).indices                       # [B,M,topk]
             hits = torch.zeros((B, A), device=dev)
             hits.scatter_add_(1, tk.reshape(B, -1), mem[:, :, None].expand(B, M, topk).reshape(B, -1).float())
             pos = hits > 0                                                               # [B,A]
-            gid = d.argmin(2)                                                            # nearest GT (task order)
+            gid = d.argmin(1)                                                            # nearest GT (task order)
             # compact the positive anchors, ascending, into K slots
             rank = pos.long().cumsum(1) - 1
             slot = torch.where(pos & (rank < K), rank, torch.full_like(rank, K))
@@ -295,7 +297,7 @@ class CenterHead(nn.Module):
     def assign_targets(self, gt_boxes):
         return self.target_assigner.assign_targets(gt_boxes)
 
-    def forward(self, spatial_features_2d, gt_boxes=None):
+    def forward(self, spatial_features_2d, gt_boxes=None, targets=None):
         x = self.shared_conv(spatial_features_2d)
         if self.upsample_for_pedestrian:
             x = self.upsample_conv(x)
@@ -303,7 +305,9 @@ class CenterHead(nn.Module):
         if self.training or self.distill:
             # The reference also assigns targets for the frozen distillation teacher
             # (center_head.py:137); they are never read, so the teacher skips the work here.
-            if gt_boxes is not None and not self.distill:
+            if targets is not None:
+                ret.update(targets)
+            elif gt_boxes is not None and not self.distill:
                 ret.update(self.assign_targets(gt_boxes))
             return ret
         if self.proposal_layer is None:
@@ -334,21 +338,34 @@ class CenterHeadIouAware(CenterHead):
         self.crit_iou_aware = CenterNetRegLoss()
         self._voxel_size_xy = voxel_size_xy
 
+    def _code_weights(self, like):
+        cw = getattr(self, "_cw_cache", None)
+        if cw is None or cw.device != like.device or cw.dtype != like.dtype:
+            cw = self._cw_cache = like.new_tensor(self.code_weights)   # built once (no per-step H2D)
+        return cw
+
     def _voxel_xy(self):
         if self._voxel_size_xy is not None:
             return self._voxel_size_xy
         return self.proposal_layer.voxel_size
 
-    def get_loss(self, forward_ret_dict):
+    @staticmethod
+    def local_normalisers(targets):
+        """[focal num_pos per task] + [#objects per task] as 0-dim tensors (before the all-reduce)."""
+        T = len(targets["mask"])
+        return [targets["heatmap"][t].eq(1).float().sum() for t in range(T)] + \
+               [targets["mask"][t].float().sum() for t in range(T)]
+
+    def get_loss(self, forward_ret_dict, norm=None):
         """-> (loss, tb_dict of DEVICE scalars).  Mutates each task's ``hm`` to its clamped sigmoid
         like the reference does (center_head_iou_aware.py:61) -- the response distillation relies
-        on it."""
+        on it.  ``norm``: the 2T globally averaged normalisers if the caller already reduced them."""
         preds = forward_ret_dict["multi_head_features"]
         T = len(preds)
         masks = [forward_ret_dict["mask"][t] for t in range(T)]
-        # every normaliser of the step in ONE collective: focal num_pos and #objects per task
-        norm = reduce_mean_many([forward_ret_dict["heatmap"][t].eq(1).float().sum() for t in range(T)]
-                                + [m.float().sum() for m in masks])
+        if norm is None:
+            # every normaliser of the step in ONE collective: focal num_pos and #objects per task
+            norm = reduce_mean_many(self.local_normalisers(forward_ret_dict))
         tb = {}
         total = 0
         forward_ret_dict["pred_box_encoding"] = {}
@@ -371,7 +388,7 @@ class CenterHeadIouAware(CenterHead):
             m = mask.unsqueeze(2).float() * (~torch.isnan(tgt[:, :, :nb])).float()
             box_loss = torch.abs(gathered[:, :, :nb] * m - tgt[:, :, :nb] * m).sum(dim=(0, 1)) / (num + 1e-4)
             if cw is None:
-                cw = box_loss.new_tensor(self.code_weights)
+                cw = self._code_weights(box_loss)
             loc_loss = (box_loss * cw).sum()
             loss = self.auto_loss(hm_loss, loc_loss, iou_aware)
             # reference: ``if loc_loss.item() < 1: loss += iou_loss * w``  -> device-side select

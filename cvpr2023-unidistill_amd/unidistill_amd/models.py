@@ -45,8 +45,8 @@ class DetHead(nn.Module):
             init_bias=cfg["init_bias"], focal_alpha=cfg["focal_alpha"], focal_gamma=cfg["focal_gamma"],
             voxel_size_xy=cfg["voxel_size"][0:2])
 
-    def forward(self, x, gt_boxes):
-        ret = self.dense_head(x, gt_boxes)
+    def forward(self, x, gt_boxes, targets=None):
+        ret = self.dense_head(x, gt_boxes, targets=targets)
         if self.training and "box_encoding" in ret:
             for enc in ret["box_encoding"].values():
                 enc[torch.isinf(enc)] = 0          # log(0) of zero-size boxes (fusion_exp.py:124-126)
@@ -89,14 +89,16 @@ class BEVFusionCenterHead(nn.Module):
         return camera_out if camera_out is not None else lidar_out
 
     def forward(self, lidar_points=None, cameras_imgs=None, metas=None, gt_boxes=None,
-                return_feature=False, **_):
+                return_feature=False, targets=None, loss_norm=None, **_):
+        """targets / loss_norm: optional precomputed FCOS targets and globally reduced loss
+        normalisers (train.py computes them up front so the network pass holds no collective)."""
         bev = self.extract_bev(lidar_points, cameras_imgs, metas)
         trunk, _ = self.bev_encoder(bev)
-        ret = self.det_head(trunk, gt_boxes)
+        ret = self.det_head(trunk, gt_boxes, targets=targets)
         if return_feature:
             return bev, trunk, ret["multi_head_features"]
         if self.training:
-            loss, tb = self.det_head.dense_head.get_loss(ret)
+            loss, tb = self.det_head.dense_head.get_loss(ret, norm=loss_norm)
             tb["loss_rpn"] = loss.detach()
             return {"loss": loss}, tb, bev, trunk, ret["multi_head_features"], {}
         return ret

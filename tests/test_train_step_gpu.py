@@ -46,3 +46,40 @@ def test_camera_student_lidar_teacher_distill_step():
     # depth_net and the image backbone receive gradient through the fused lift+splat
     assert step.model.camera_encoder.backbone.depth_net[0].weight.grad.abs().sum() > 0
     assert step.model.camera_encoder.backbone.img_backbone.conv1.weight.grad.abs().sum() > 0
+
+
+def test_graph_trainer_matches_eager_trainer():
+    """hipGraph-captured student pass == eager pass: same loss and same gradients on the first
+    step (later steps diverge by Adam's sign-like first updates amplifying fp noise), and the
+    captured trainer keeps training."""
+    from unidistill_amd import train
+    dev = torch.device("cuda:0")
+    batch = train.synthetic_batch(dev, batch_size=1, ncam=6)
+    torch.manual_seed(0)
+    eager_mod = train.DistillStep("camera_exp_distill_lidar").to(dev).train()
+    state0 = {k: v.clone() for k, v in eager_mod.state_dict().items()}
+    out = eager_mod(batch)
+    out["loss"].backward()
+    ref_loss = out["loss"].item()
+    ref_grads = {n: p.grad.clone() for n, p in eager_mod.model.named_parameters() if p.grad is not None}
+    graph_mod = train.DistillStep("camera_exp_distill_lidar")
+    graph_mod.load_state_dict(state0)
+    g = train.GraphTrainer(graph_mod, batch, device=dev, warmup=1)      # warm-up restores the state
+    g.g_prep.replay()
+    g._reduce_norm()
+    g.lidar_bev.copy_(g._teacher_sparse())
+    g.g_tdense.replay()
+    g.g_student.replay()
+    torch.cuda.synchronize()
+    assert abs(g.out["loss"].item() - ref_loss) <= 1e-4 * abs(ref_loss)
+    for n, p in graph_mod.model.named_parameters():
+        if n in ref_grads:
+            # random-init net with exploding gradients: fp noise (MIOpen algo choice, atomics in the
+            # loss scatter) is amplified towards the first layers -> compare direction and scale
+            a, b = p.grad.flatten().double(), ref_grads[n].flatten().double()
+            if b.norm() > 0:
+                cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+                assert cos > 0.995, (n, cos)
+                assert abs(a.norm().item() / b.norm().item() - 1) < 0.05, n
+    losses = [g.step(batch)["loss"].item() for _ in range(4)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
