@@ -119,6 +119,171 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
   }
 }
 
+// ---- v2: 128-row tiles, 8 waves, register-prefetched staging (wide channels) --------------------
+// Used when both padded channel counts are >= 64.  Differences to k_conv_mfma:
+//   * the tile's whole rulebook slice (K x 128 neighbour ids) is read once into LDS and turned
+//     into a block-level and per-wave activity mask -> no global read / block reduction per offset;
+//   * the gathered rows and W[:,k,:] of the NEXT active offset are fetched into registers before
+//     the MFMA phase of the current one (global latency hidden under the matrix work) and written
+//     to LDS after it; a wave skips the MFMAs of offsets none of its 16 rows uses;
+//   * MFMAs are issued round-robin over the accumulators (no back-to-back dependent pairs).
+constexpr int kTM2 = 128;
+
+template <int CIN_P, int COUT_P>
+__global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ in, int cin,
+                                                      const int32_t* __restrict__ nbr, int K,
+                                                      int mirror, const float* __restrict__ W,
+                                                      WStrides ws, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int cout, int Mout) {
+  constexpr int LDA = CIN_P + 4;
+  constexpr int NT = COUT_P / 16;
+  constexpr int A4 = kTM2 * (CIN_P / 4) / 512;    // float4 per thread for the A tile
+  constexpr int B4 = COUT_P * (CIN_P / 4) / 512;  // float4 per thread for the B tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);          // [kTM2][LDA]
+  float* Bs = As + kTM2 * LDA;                          // [COUT_P][LDA]
+  int* s_nbr = reinterpret_cast<int*>(Bs + COUT_P * LDA);  // [K][kTM2]
+  // all LDS lives in the dynamic region (a static __shared__ in front would shift its base off
+  // the 16-byte alignment the b128 reads need)
+  unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int row0 = blockIdx.x * kTM2;
+  if (tid == 0) s_active = 0u;
+  __syncthreads();
+  // rulebook slice -> LDS (column kk of the rulebook serves weight offset k)
+  unsigned mine = 0u;
+  for (int idx = tid; idx < kTM2 * K; idx += 512) {
+    const int r = idx / K, k = idx - r * K;
+    int v = -1;
+    if (row0 + r < Mout) v = nbr[(size_t)(row0 + r) * K + (mirror ? K - 1 - k : k)];
+    s_nbr[k * kTM2 + r] = v;
+    if (v >= 0) mine |= 1u << k;
+  }
+  // block-wide OR of the per-thread masks
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor((int)mine, o);
+  if (lane == 0 && mine) atomicOr(&s_active, mine);
+  __syncthreads();
+  const unsigned active = s_active;
+  // per-wave mask: which offsets do my 16 rows use
+  unsigned wmask = 0u;
+  for (int k = 0; k < K; ++k) {
+    const int v = (lane < 16) ? s_nbr[k * kTM2 + wave * 16 + lane] : -1;
+    if (__any(v >= 0)) wmask |= 1u << k;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool vecA = (cin & 3) == 0;
+  const bool vecB = (ws.sc == 1) && vecA;
+  float4 ra[A4];
+
+  // A (gathered rows, DRAM/L2 latency) is prefetched into registers one offset ahead;
+  // W[:,k,:] is L2-resident and goes global -> registers -> LDS inside the commit step.
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < A4; ++j) {
+      const int u = tid + 512 * j;
+      const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
+      const int rr = s_nbr[k * kTM2 + row];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr >= 0) {
+        const float* src = in + (size_t)rr * cin + c4;
+        if (vecA) {
+          if (c4 < cin) v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (c4 + 0 < cin) v.x = src[0];
+          if (c4 + 1 < cin) v.y = src[1];
+          if (c4 + 2 < cin) v.z = src[2];
+          if (c4 + 3 < cin) v.w = src[3];
+        }
+      }
+      ra[j] = v;
+    }
+  };
+  auto commit = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < A4; ++j) {
+      const int u = tid + 512 * j;
+      const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
+      *reinterpret_cast<float4*>(As + row * LDA + c4) = ra[j];
+    }
+    if (vecB) {
+#pragma unroll
+      for (int j = 0; j < B4; ++j) {
+        const int u = tid + 512 * j;
+        const int n = u / (CIN_P / 4), c4 = (u - n * (CIN_P / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < cout && c4 < cin) v = *reinterpret_cast<const float4*>(W + n * ws.sn + k * ws.sk + c4);
+        *reinterpret_cast<float4*>(Bs + n * LDA + c4) = v;
+      }
+    } else {
+      // strided weights (dgrad: n is the fast axis in memory): thread <-> (c, 4 consecutive n)
+#pragma unroll
+      for (int j = 0; j < B4; ++j) {
+        const int u = tid + 512 * j;
+        const int c = u / (COUT_P / 4), n4 = (u - c * (COUT_P / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < cin) {
+          const float* src = W + k * ws.sk + c * ws.sc;
+          if (n4 + 0 < cout) v.x = src[(n4 + 0) * ws.sn];
+          if (n4 + 1 < cout) v.y = src[(n4 + 1) * ws.sn];
+          if (n4 + 2 < cout) v.z = src[(n4 + 2) * ws.sn];
+          if (n4 + 3 < cout) v.w = src[(n4 + 3) * ws.sn];
+        }
+        Bs[(n4 + 0) * LDA + c] = v.x;
+        Bs[(n4 + 1) * LDA + c] = v.y;
+        Bs[(n4 + 2) * LDA + c] = v.z;
+        Bs[(n4 + 3) * LDA + c] = v.w;
+      }
+    }
+  };
+
+  unsigned todo = active;
+  int k = todo ? (__ffs((int)todo) - 1) : -1;
+  if (k >= 0) fetch(k);
+  while (k >= 0) {
+    todo &= todo - 1;
+    commit(k);
+    __syncthreads();
+    const int knext = todo ? (__ffs((int)todo) - 1) : -1;
+    if (knext >= 0) fetch(knext);  // in flight during the MFMA phase
+    if ((wmask >> k) & 1u) {
+      const float* arow = As + (wave * 16 + li) * LDA + 4 * g;
+#pragma unroll 1
+      for (int cb = 0; cb < CIN_P / 16; ++cb) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + cb * 16);
+        float4 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          b[t] = *reinterpret_cast<const float4*>(Bs + (t * 16 + li) * LDA + cb * 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    k = knext;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = t * 16 + li;
+    if (col >= cout) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + wave * 16 + 4 * g + r;
+      if (row < Mout) out[(size_t)row * cout + col] = acc[t][r] + bv;
+    }
+  }
+}
+
 // Any-size fallback (and the cross-check in tests): one thread per (row, n), sequential k, c.
 __global__ __launch_bounds__(256) void k_conv_generic(const float* __restrict__ in, int cin,
                                                       const int32_t* __restrict__ nbr, int K,
@@ -249,9 +414,30 @@ __global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__
 inline int pad16(int c) { return (c + 15) / 16 * 16; }
 
 template <int CIN_P, int COUT_P>
+int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
+                   WStrides ws, const float* bias, float* out, int cout, int Mout,
+                   hipStream_t stream) {
+  const size_t lds = (size_t)(kTM2 + COUT_P) * (CIN_P + 4) * sizeof(float) + (size_t)K * kTM2 * sizeof(int) + 16;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  k_conv_mfma_v2<CIN_P, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(
+      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+template <int CIN_P, int COUT_P>
 int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
                 WStrides ws, const float* bias, float* out, int cout, int Mout,
                 hipStream_t stream) {
+  if constexpr (CIN_P >= 64 && COUT_P >= 64) {
+    if (K <= 32)   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles
+      return launch_conv_v2<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, stream);
+  }
   const size_t lds = (size_t)(kTM + COUT_P) * (CIN_P + 4) * sizeof(float) + kTM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {

@@ -142,16 +142,37 @@ class FCOSAssigner:
             self._anchors[device] = a
         return a
 
+    def _class_tables(self, device):
+        tabs = getattr(self, "_tabs", {}).get(device)
+        if tabs is None:
+            ncls = max(self.class_to_idx.values()) + 1
+            task_of = torch.full((ncls,), -1, dtype=torch.long)
+            off_of = torch.zeros((ncls,), dtype=torch.long)
+            for t, names in enumerate(self.task_classes):
+                for o, name in enumerate(names):
+                    task_of[self.class_to_idx[name]] = t
+                    off_of[self.class_to_idx[name]] = o
+            tabs = (task_of.to(device), off_of.to(device))
+            if not hasattr(self, "_tabs"):
+                self._tabs = {}
+            self._tabs[device] = tabs
+        return tabs
+
     @torch.no_grad()
     def assign_targets(self, gt_boxes):
-        """gt_boxes f32[B,M,C+1] (last column = 1-based class) -> dict of per-task targets."""
+        """gt_boxes f32[B,M,C+1] (last column = 1-based class) -> dict of per-task targets.
+        All tasks are processed at once: the task index is folded into the batch dimension
+        (TB = T*B "samples"), so the op count does not grow with the number of tasks."""
         dev = gt_boxes.device
         B, M = gt_boxes.shape[:2]
+        T = len(self.task_classes)
         K = self._max_objs * self.dense_reg
         w, h = self.grid_size[0] // self.out_size_factor, self.grid_size[1] // self.out_size_factor
         anchors = self.anchor_points(dev)
         A = anchors.shape[0]
-        cls = gt_boxes[:, :, -1].int()
+        ncmax = max(len(c) for c in self.task_classes)
+        task_of, off_of = self._class_tables(dev)
+        cls = gt_boxes[:, :, -1].long().clamp(0, task_of.numel() - 1)
         box = gt_boxes[:, :, :-1]
         idx = torch.arange(M, device=dev)
         # rows up to the last one that does not sum to zero are kept (row 0 always is)
@@ -163,59 +184,63 @@ class FCOSAssigner:
         cy = (box[:, :, 1] - self.pc_range[1]) / vs1
         dxv, dyv = box[:, :, 3] / vs0, box[:, :, 4] / vs1
         yaw = limit_period(box[:, :, 6], offset=0.5, period=math.pi * 2)
+        # class offset inside each task, -1 for boxes of other tasks / invalid rows: [T,B,M] -> [TB,M]
+        tsel = torch.arange(T, device=dev)[:, None, None]
+        member = valid[None] & (task_of[cls][None] == tsel)
+        coff = torch.where(member, off_of[cls][None].expand(T, B, M), torch.full((T, B, M), -1, device=dev))
+        coff = coff.reshape(T * B, M)
+        member = member.reshape(T * B, M)
+        rep = lambda v: v[None].expand(T, *v.shape).reshape(T * B, *v.shape[1:])
+        TB = T * B
+        # task order = (class offset, original index): order matters only for argmin ties
+        key = torch.where(member, coff * M + idx[None, :], torch.full_like(coff, ncmax * M + M))
+        perm = key.argsort(1)
+        mem = member.gather(1, perm)
+        pcx, pcy = rep(cx).gather(1, perm), rep(cy).gather(1, perm)
+        # squared centre distances, laid out [TB, M, A] so that topk runs on a CONTIGUOUS tensor
+        # (topk on a transposed view keeps hidden state that breaks hipGraph replays on ROCm)
+        d = (anchors[None, None, :, 0] - pcx[:, :, None]) ** 2 + (anchors[None, None, :, 1] - pcy[:, :, None]) ** 2
+        d = torch.where(mem[:, :, None], d, torch.full_like(d, float("inf")))
+        topk = min(self.assign_topk, A)
+        tk = torch.topk(d, topk, dim=2, largest=False).indices                           # [TB,M,topk]
+        hits = torch.zeros((TB, A), device=dev)
+        hits.scatter_add_(1, tk.reshape(TB, -1), mem[:, :, None].expand(TB, M, topk).reshape(TB, -1).float())
+        pos = hits > 0                                                                   # [TB,A]
+        gid = d.argmin(1)                                                                # nearest GT (task order)
+        # compact the positive anchors, ascending, into K slots
+        rank = pos.long().cumsum(1) - 1
+        slot = torch.where(pos & (rank < K), rank, torch.full_like(rank, K))
+        aidx = torch.arange(A, device=dev)[None, :].expand(TB, A)
+        ind = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, aidx)[:, :K]
+        sgt = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, gid)[:, :K]
+        mask = torch.zeros((TB, K + 1), dtype=torch.bool, device=dev).scatter_(1, slot, pos)[:, :K]
+        sperm = perm.gather(1, sgt)                                                      # original box row
+        cat = torch.where(mask, coff.gather(1, sperm), torch.zeros_like(sgt))
+        # heat map: one-hot of the assigned class at every positive anchor
+        cat_anchor = coff.gather(1, perm.gather(1, gid)).clamp_min(0)
+        hm = torch.zeros((TB, ncmax, A), device=dev)
+        hm.scatter_(1, cat_anchor[:, None, :], pos[:, None, :].float())
+        # box encoding of the assigned GT relative to its anchor point
+        g = lambda v: rep(v).gather(1, sperm)
+        ax, ay = anchors[:, 0][ind], anchors[:, 1][ind]
+        cols = [(g(cx) - ax) / self.out_size_factor, (g(cy) - ay) / self.out_size_factor,
+                g(box[:, :, 2]), torch.log(g(dxv) * vs0), torch.log(g(dyv) * vs1),
+                torch.log(g(box[:, :, 5])), torch.sin(g(yaw)), torch.cos(g(yaw))]
+        cols += [g(box[:, :, j]) for j in range(7, box.shape[2])]
+        enc = torch.stack(cols, 2)
+        enc = torch.where(mask[:, :, None], enc, torch.zeros_like(enc))                 # padded slots = 0
+        if enc.shape[2] < self.default_box_dims:
+            enc = torch.cat([enc, enc.new_zeros(TB, K, self.default_box_dims - enc.shape[2])], 2)
+        ind = torch.where(mask, ind, torch.zeros_like(ind))
+        hm = hm.reshape(T, B, ncmax, h, w)
+        ind, mask, cat, enc = (v.reshape(T, B, *v.shape[1:]) for v in (ind, mask, cat, enc.float()))
         out = {k: {} for k in ("heatmap", "ind", "mask", "cat", "box_encoding")}
-        barange = torch.arange(B, device=dev)[:, None]
         for t, names in enumerate(self.task_classes):
-            nc = len(names)
-            # class offset inside the task, -1 for boxes of other tasks / invalid rows
-            coff = torch.full((B, M), -1, dtype=torch.long, device=dev)
-            for o, name in enumerate(names):
-                coff = torch.where(valid & (cls == self.class_to_idx[name]), torch.full_like(coff, o), coff)
-            member = coff >= 0
-            # task order = (class offset, original index): order matters only for argmin ties
-            key = torch.where(member, coff * M + idx[None, :], torch.full_like(coff, nc * M + M))
-            perm = key.argsort(1)
-            mem = member.gather(1, perm)
-            pcx, pcy = cx.gather(1, perm), cy.gather(1, perm)
-            # squared centre distances, laid out [B, M, A] so that topk runs on a CONTIGUOUS tensor
-            # (topk on a transposed view keeps hidden state that breaks hipGraph replays on ROCm)
-            d = (anchors[None, None, :, 0] - pcx[:, :, None]) ** 2 + (anchors[None, None, :, 1] - pcy[:, :, None]) ** 2
-            d = torch.where(mem[:, :, None], d, torch.full_like(d, float("inf")))      # [B,M,A]
-            topk = min(self.assign_topk, A)
-            tk = torch.topk(d, topk, dim=2, largest=False).indices                       # [B,M,topk]
-            hits = torch.zeros((B, A), device=dev)
-            hits.scatter_add_(1, tk.reshape(B, -1), mem[:, :, None].expand(B, M, topk).reshape(B, -1).float())
-            pos = hits > 0                                                               # [B,A]
-            gid = d.argmin(1)                                                            # nearest GT (task order)
-            # compact the positive anchors, ascending, into K slots
-            rank = pos.long().cumsum(1) - 1
-            slot = torch.where(pos & (rank < K), rank, torch.full_like(rank, K))
-            aidx = torch.arange(A, device=dev)[None, :].expand(B, A)
-            ind = torch.zeros((B, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, aidx)[:, :K]
-            sgt = torch.zeros((B, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, gid)[:, :K]
-            mask = torch.zeros((B, K + 1), dtype=torch.bool, device=dev).scatter_(1, slot, pos)[:, :K]
-            sperm = perm.gather(1, sgt)                                                  # original box row
-            cat = torch.where(mask, coff.gather(1, sperm), torch.zeros_like(sgt))
-            # heat map: one-hot of the assigned class at every positive anchor
-            cat_anchor = coff.gather(1, perm.gather(1, gid)).clamp_min(0)
-            hm = torch.zeros((B, nc, A), device=dev)
-            hm.scatter_(1, cat_anchor[:, None, :], pos[:, None, :].float())
-            # box encoding of the assigned GT relative to its anchor point
-            g = lambda v: v.gather(1, sperm)
-            ax, ay = anchors[:, 0][ind], anchors[:, 1][ind]
-            cols = [(g(cx) - ax) / self.out_size_factor, (g(cy) - ay) / self.out_size_factor,
-                    g(box[:, :, 2]), torch.log(g(dxv) * vs0), torch.log(g(dyv) * vs1),
-                    torch.log(g(box[:, :, 5])), torch.sin(g(yaw)), torch.cos(g(yaw))]
-            cols += [g(box[:, :, j]) for j in range(7, box.shape[2])]
-            enc = torch.stack(cols, 2) * mask[:, :, None]
-            enc = torch.where(mask[:, :, None], enc, torch.zeros_like(enc))             # -inf * 0 = nan guard
-            if enc.shape[2] < self.default_box_dims:
-                enc = torch.cat([enc, enc.new_zeros(B, K, self.default_box_dims - enc.shape[2])], 2)
-            out["heatmap"][t] = hm.reshape(B, nc, h, w)
-            out["ind"][t] = torch.where(mask, ind, torch.zeros_like(ind))
-            out["mask"][t] = mask
-            out["cat"][t] = cat
-            out["box_encoding"][t] = enc.float()
+            out["heatmap"][t] = hm[t, :, :len(names)].contiguous()
+            out["ind"][t], out["mask"][t], out["cat"][t] = ind[t], mask[t], cat[t]
+            out["box_encoding"][t] = enc[t]
+        # stacked views for the task-vectorised loss
+        out["_stacked"] = {"heatmap": hm, "ind": ind, "mask": mask, "box_encoding": enc}
         return out
 
 
@@ -352,84 +377,116 @@ class CenterHeadIouAware(CenterHead):
     @staticmethod
     def local_normalisers(targets):
         """[focal num_pos per task] + [#objects per task] as 0-dim tensors (before the all-reduce)."""
+        st = targets.get("_stacked")
+        if st is not None:          # two reductions instead of 2T
+            return list(torch.cat([st["heatmap"].eq(1).float().sum(dim=(1, 2, 3, 4)),
+                                   st["mask"].float().sum(dim=(1, 2))]).unbind(0))
         T = len(targets["mask"])
         return [targets["heatmap"][t].eq(1).float().sum() for t in range(T)] + \
                [targets["mask"][t].float().sum() for t in range(T)]
 
     def get_loss(self, forward_ret_dict, norm=None):
-        """-> (loss, tb_dict of DEVICE scalars).  Mutates each task's ``hm`` to its clamped sigmoid
+        """-> (loss, tb_dict of DEVICE scalars).  Replaces each task's ``hm`` by its clamped sigmoid
         like the reference does (center_head_iou_aware.py:61) -- the response distillation relies
-        on it.  ``norm``: the 2T globally averaged normalisers if the caller already reduced them."""
+        on it.  ``norm``: the 2T globally averaged normalisers if the caller already reduced them.
+        All tasks are evaluated together on [T, B, ...] tensors (class maps padded to the widest
+        task with "ignore" labels), so the op count is independent of the number of tasks."""
         preds = forward_ret_dict["multi_head_features"]
         T = len(preds)
-        masks = [forward_ret_dict["mask"][t] for t in range(T)]
+        st = forward_ret_dict.get("_stacked")
+        if st is None:
+            ncm = max(self.num_classes)
+            st = {"heatmap": torch.stack([torch.nn.functional.pad(forward_ret_dict["heatmap"][t],
+                                                                  (0, 0, 0, 0, 0, ncm - self.num_classes[t]))
+                                          for t in range(T)]),
+                  "ind": torch.stack([forward_ret_dict["ind"][t] for t in range(T)]),
+                  "mask": torch.stack([forward_ret_dict["mask"][t] for t in range(T)]),
+                  "box_encoding": torch.stack([forward_ret_dict["box_encoding"][t] for t in range(T)])}
         if norm is None:
             # every normaliser of the step in ONE collective: focal num_pos and #objects per task
             norm = reduce_mean_many(self.local_normalisers(forward_ret_dict))
-        tb = {}
-        total = 0
-        forward_ret_dict["pred_box_encoding"] = {}
-        stride, vs = self.out_size_factor, self._voxel_xy()
-        cw = None
+        norm = torch.stack(list(norm)) if isinstance(norm, (list, tuple)) else norm
+        num_pos_f, num_obj = norm[:T], norm[T:2 * T]
+        gt_hm, ind, mask, tgt_all = st["heatmap"], st["ind"], st["mask"], st["box_encoding"]
+        ncm = gt_hm.shape[2]
+        B, K = ind.shape[1], ind.shape[2]
+        # ---- heat maps: pad every task to ncm classes; padded channels are "ignore" (gt = -1)
+        logits = torch.stack([torch.nn.functional.pad(pd["hm"], (0, 0, 0, 0, 0, ncm - pd["hm"].shape[1]))
+                              for pd in preds])                                      # [T,B,ncm,H,W]
+        prob = self._sigmoid(logits)
         for t, pd in enumerate(preds):
-            pd["hm"] = self._sigmoid(pd["hm"])
-            hm_loss = self.crit(pd["hm"], forward_ret_dict["heatmap"][t], num_pos=norm[t])
-            tgt = forward_ret_dict["box_encoding"][t]
-            if self.dataset == "nuscenes":
-                enc = torch.cat([pd["reg"], pd["height"], pd["dim"], pd["rot"], pd["vel"], pd["iou"]], 1)
-                nb = 10
-            else:
-                enc = torch.cat([pd["reg"], pd["height"], pd["dim"], pd["rot"], pd["iou"]], 1)
-                nb = 8
-            forward_ret_dict["pred_box_encoding"][t] = enc
-            ind, mask, num = forward_ret_dict["ind"][t], masks[t], norm[T + t]
-            gathered = _transpose_and_gather_feat(enc, ind)                 # [B,K,nb+1]
-            iou_loss, iou_aware = self._iou_losses(gathered, tgt[:, :, :nb], mask, num, stride, vs)
-            m = mask.unsqueeze(2).float() * (~torch.isnan(tgt[:, :, :nb])).float()
-            box_loss = torch.abs(gathered[:, :, :nb] * m - tgt[:, :, :nb] * m).sum(dim=(0, 1)) / (num + 1e-4)
-            if cw is None:
-                cw = self._code_weights(box_loss)
-            loc_loss = (box_loss * cw).sum()
-            loss = self.auto_loss(hm_loss, loc_loss, iou_aware)
-            # reference: ``if loc_loss.item() < 1: loss += iou_loss * w``  -> device-side select
-            loss = loss + torch.where(loc_loss.detach() < 1, iou_loss * self.iou_weight,
-                                      torch.zeros_like(iou_loss))
+            pd["hm"] = prob[t, :, :self.num_classes[t]]
+        cls_valid = (torch.arange(ncm, device=prob.device)[None, :]
+                     < torch.tensor(self.num_classes, device=prob.device)[:, None]) \
+            if not hasattr(self, "_cls_valid") or self._cls_valid.device != prob.device else self._cls_valid
+        self._cls_valid = cls_valid
+        cv = cls_valid[:, None, :, None, None]
+        pos = gt_hm.eq(1) & cv
+        neg = gt_hm.eq(0) & cv
+        a, gm = self.crit.alpha, self.crit.gamma
+        pos_l = (torch.log(prob) * torch.pow(1 - prob, gm) * pos.long() * a).sum(dim=(1, 2, 3, 4))
+        neg_l = (torch.log(1 - prob + 1e-4) * torch.pow(prob, gm) * neg.long() * (1 - a)).sum(dim=(1, 2, 3, 4))
+        safe = torch.where(num_pos_f == 0, torch.ones_like(num_pos_f), num_pos_f)
+        hm_loss = torch.where(num_pos_f == 0, -neg_l, -(pos_l + neg_l) / safe)          # [T]
+        # ---- regression / IoU terms on the gathered predictions
+        if self.dataset == "nuscenes":
+            heads, nb = ("reg", "height", "dim", "rot", "vel", "iou"), 10
+        else:
+            heads, nb = ("reg", "height", "dim", "rot", "iou"), 8
+        enc = torch.cat([torch.stack([pd[hn] for pd in preds]) for hn in heads], 2)    # [T,B,nb+1,H,W]
+        forward_ret_dict["pred_box_encoding"] = {t: enc[t] for t in range(T)}
+        g = _transpose_and_gather_feat(enc.reshape(T * B, nb + 1, *enc.shape[3:]), ind.reshape(T * B, K))
+        g = g.reshape(T, B, K, nb + 1)
+        tgt = tgt_all[..., :nb]
+        stride, vs = self.out_size_factor, self._voxel_xy()
+        iou_loss, iou_aware = self._iou_losses(g, tgt, mask, num_obj, stride, vs)        # [T], [T]
+        m = mask.unsqueeze(3).float() * (~torch.isnan(tgt)).float()
+        box_loss = torch.abs(g[..., :nb] * m - tgt * m).sum(dim=(1, 2)) / (num_obj[:, None] + 1e-4)   # [T,nb]
+        loc_loss = (box_loss * self._code_weights(box_loss)[None, :]).sum(1)                         # [T]
+        p2 = self.auto_loss.params[:3] ** 2
+        loss = (0.5 / p2[0] * hm_loss + 0.5 / p2[1] * loc_loss + 0.5 / p2[2] * iou_aware) \
+            + torch.log(1 + p2).sum()
+        # reference: ``if loc_loss.item() < 1: loss += iou_loss * w``  -> device-side select
+        loss = loss + torch.where(loc_loss.detach() < 1, iou_loss * self.iou_weight, torch.zeros_like(iou_loss))
+        npos = mask.float().sum(dim=(1, 2))
+        tb = {}
+        for t in range(T):
             key = f"task_{t}/"
-            tb.update({key + "loss": loss.detach(), key + "hm_loss": hm_loss.detach(),
-                       key + "loc_loss": loc_loss.detach(), key + "box_loss": box_loss.detach(),
-                       key + "num_positive": mask.float().sum()})
-            total = total + loss
-        return total, tb
+            tb.update({key + "loss": loss[t].detach(), key + "hm_loss": hm_loss[t].detach(),
+                       key + "loc_loss": loc_loss[t].detach(), key + "box_loss": box_loss[t].detach(),
+                       key + "num_positive": npos[t]})
+        return loss.sum(), tb
 
     def _iou_losses(self, pred, tgt, mask, num_pos, stride, vs):
-        """pred [B,K,nb+1] gathered predictions (last = iou head), tgt [B,K,nb]."""
+        """pred [T,B,K,nb+1] gathered predictions (last = iou head), tgt [T,B,K,nb], mask [T,B,K],
+        num_pos [T]  ->  (iou_loss [T], iou_aware_loss [T])."""
         def decode(e):
-            x = (e[..., 0:1] * stride * vs[0]).reshape(-1, 1)
-            y = (e[..., 1:2] * stride * vs[1]).reshape(-1, 1)
+            x = e[..., 0:1] * stride * vs[0]
+            y = e[..., 1:2] * stride * vs[1]
             # clamp(exp(x), .001, 30) as in the reference; the inner clamp only keeps exp() finite so
             # that an overflowing logit gets the zero gradient of the outer clamp instead of 0*inf = NaN
-            whl = torch.clamp(torch.exp(torch.clamp(e[..., 3:6], max=80.0)).reshape(-1, 3), min=0.001, max=30)
-            rot = torch.atan2(e[..., 6], e[..., 7]).reshape(-1, 1)
-            z = e[..., 2].reshape(-1, 1)
+            whl = torch.clamp(torch.exp(torch.clamp(e[..., 3:6], max=80.0)), min=0.001, max=30)
+            rot = torch.atan2(e[..., 6:7], e[..., 7:8])
+            z = e[..., 2:3]
             return x, y, z, whl, rot
         tx, ty, tz, twhl, trot = decode(tgt)
         px, py, pz, pwhl, prot = decode(pred)
         # axis-aligned "3-D IoU" with the reference's (x<->whl0, y<->whl2, z<->whl1) pairing
         def overlap(pc, pe, tc, te):
             return torch.clamp(torch.min(pc + pe / 2, tc + te / 2) - torch.max(pc - pe / 2, tc - te / 2), min=1e-3)
-        ix = overlap(px, pwhl[:, 0:1], tx, twhl[:, 0:1])
-        iy = overlap(py, pwhl[:, 2:3], ty, twhl[:, 2:3])
-        iz = overlap(pz, pwhl[:, 1:2], tz, twhl[:, 1:2])
+        ix = overlap(px, pwhl[..., 0:1], tx, twhl[..., 0:1])
+        iy = overlap(py, pwhl[..., 2:3], ty, twhl[..., 2:3])
+        iz = overlap(pz, pwhl[..., 1:2], tz, twhl[..., 1:2])
         inter = ix * iy * iz
-        vp = torch.clamp(pwhl[:, 0:1] * pwhl[:, 2:3] * pwhl[:, 1:2], min=1e-3)
-        vt = torch.clamp(twhl[:, 0:1] * twhl[:, 2:3] * twhl[:, 1:2], min=1e-3)
+        vp = torch.clamp(pwhl[..., 0:1] * pwhl[..., 2:3] * pwhl[..., 1:2], min=1e-3)
+        vt = torch.clamp(twhl[..., 0:1] * twhl[..., 2:3] * twhl[..., 1:2], min=1e-3)
         iou = inter / (vp + vt - inter)
-        mflat = mask.reshape(-1, 1).float()
-        iou_loss = ((1 - torch.clamp(iou, 0, 1)) * mflat).sum() / torch.clamp_min(num_pos, 1)
+        mf = mask.unsqueeze(3).float()
+        iou_loss = ((1 - torch.clamp(iou, 0, 1)) * mf).sum(dim=(1, 2, 3)) / torch.clamp_min(num_pos, 1)
         # IoU-aware target: nearest-BEV IoU between target and (detached) predicted box
         tb3 = torch.cat([tx, ty, tz, twhl, trot], -1)
         pb3 = torch.cat([px, py, pz, pwhl, prot], -1).detach()
-        tar = 2 * (nearest_bev_iou_pairwise(tb3, pb3).reshape(*mask.shape, 1) - 0.5)
-        m = mask.unsqueeze(2).float() * (~torch.isnan(tar)).float()
-        aware = torch.abs(pred[:, :, -1:] * m - tar * m).sum() / (num_pos + 1e-4)
+        tar = 2 * (nearest_bev_iou_pairwise(tb3.reshape(-1, 7), pb3.reshape(-1, 7)).reshape(*mask.shape, 1) - 0.5)
+        m = mf * (~torch.isnan(tar)).float()
+        aware = torch.abs(pred[..., -1:] * m - tar * m).sum(dim=(1, 2, 3)) / (num_pos + 1e-4)
         return iou_loss, aware

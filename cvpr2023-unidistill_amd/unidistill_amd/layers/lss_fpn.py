@@ -79,6 +79,9 @@ class LSSFPN(nn.Module):
     def get_cam_feats(self, imgs):
         B, S, N, C, H, W = imgs.shape
         x = imgs.reshape(B * S * N, C, H, W)
+        if self.img_backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last) and \
+                not self.img_backbone.conv1.weight.is_contiguous():
+            x = x.contiguous(memory_format=torch.channels_last)        # NHWC model -> NHWC input
         f = self.img_neck(self.img_backbone(x))[0]
         return f.reshape(B, S, N, f.shape[1], f.shape[2], f.shape[3])
 

@@ -114,13 +114,25 @@ class DistillStep(nn.Module):
         return self.student_loss(batch, prep, self.teacher(batch, prep))
 
 
+def to_channels_last(module):
+    """NHWC weights for every 2-D conv / deconv / BN (MIOpen's implicit-GEMM kernels are NHWC
+    native; NCHW tensors get transposed around every call).  Sparse-conv weights (rank 5) and
+    everything else are left alone."""
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return module
+
+
 class Trainer:
     """AdamW + grad clip + (optional) DDP around a module whose forward(batch) returns {'loss'}."""
 
     def __init__(self, step_module, lr=2e-4, weight_decay=1e-7, grad_clip=0.1, device=None,
-                 bucket_cap_mb=64, autocast_dtype=None):
+                 bucket_cap_mb=64, autocast_dtype=None, channels_last=False):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.module = step_module.to(self.device)
+        if channels_last:
+            to_channels_last(self.module)
         self.module.train()
         trainable = [p for p in self.module.parameters() if p.requires_grad]
         self.ddp = None

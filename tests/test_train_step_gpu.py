@@ -72,12 +72,15 @@ def test_graph_trainer_matches_eager_trainer():
     g.g_student.replay()
     torch.cuda.synchronize()
     assert abs(g.out["loss"].item() - ref_loss) <= 1e-4 * abs(ref_loss)
+    gmax = max(v.double().norm().item() for v in ref_grads.values())
     for n, p in graph_mod.model.named_parameters():
         if n in ref_grads:
             # random-init net with exploding gradients: fp noise (MIOpen algo choice, atomics in the
             # loss scatter) is amplified towards the first layers -> compare direction and scale
             a, b = p.grad.flatten().double(), ref_grads[n].flatten().double()
-            if b.norm() > 0:
+            # biases in front of a train-mode BatchNorm have a mathematically zero gradient (pure
+            # rounding noise): only parameters with a real gradient are compared
+            if b.norm() > 1e-3 * gmax:
                 cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
                 assert cos > 0.995, (n, cos)
                 assert abs(a.norm().item() / b.norm().item() - 1) < 0.05, n

@@ -15,15 +15,14 @@ else:
     step = train.DistillStep(wl)
     batch = train.synthetic_batch(dev, B, sweeps=int(os.environ.get("SWEEPS", 1)))
 ac = {"bf16": torch.bfloat16, "": None}[os.environ.get("AC", "")]
-tr = train.Trainer(step, device=dev, autocast_dtype=ac)
-if os.environ.get("CL", "0") == "1":
-    tr.module.to(memory_format=torch.channels_last)
+tr = train.Trainer(step, device=dev, autocast_dtype=ac, channels_last=os.environ.get("CL", "0") == "1")
 for _ in range(3):
     out = tr.step(batch)
-torch.cuda.synchronize()
+torch.cuda._sleep(1000); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     out = tr.step(batch)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+torch.cuda._sleep(1000); torch.cuda.synchronize()
 print(f"{wl} B={B}: {dt*1e3:.1f} ms/step -> {B/dt:.2f} samples/s  loss={out['loss'].item():.3f}  mem={torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
