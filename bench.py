@@ -48,9 +48,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="samples per GPU")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="samples per GPU (reference Exp default batch_size_per_device=4; BASELINE configs[3])")
     ap.add_argument("--workload", default="camera_exp_distill_lidar", choices=sorted(WORKLOADS))
-    ap.add_argument("--autocast", default="none", choices=["none", "bf16"])
+    ap.add_argument("--autocast", default="bf16", choices=["none", "bf16"],
+                    help="bf16 autocast for the dense (MIOpen) convs; the HIP ops always compute in fp32")
+    ap.add_argument("--nchw", action="store_true", help="keep dense convs NCHW (default: channels-last)")
+    ap.add_argument("--graph", action="store_true",
+                    help="hipGraph-captured student pass (train.GraphTrainer; camera students only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -134,10 +139,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("UD_DIST_BACKEND", "nccl")       # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:                                                     # functional test of the N>1 path
+            dist.init_process_group(backend)
     from unidistill_amd import _lib, train
     _lib.load()
     torch.manual_seed(1234)          # identical initial weights on every rank
@@ -151,7 +161,11 @@ def main():
                                       with_imgs=args.workload != "lidar",
                                       with_points=args.workload != "camera")
     ac = torch.bfloat16 if args.autocast == "bf16" else None
-    trainer = train.Trainer(step, device=device, autocast_dtype=ac)
+    if args.graph and wl["kind"] == "distill" and args.workload.startswith("camera"):
+        trainer = train.GraphTrainer(step, batch, device=device, autocast_dtype=ac,
+                                     channels_last=not args.nchw)
+    else:
+        trainer = train.Trainer(step, device=device, autocast_dtype=ac, channels_last=not args.nchw)
 
     def barrier():
         if world > 1:
@@ -178,12 +192,16 @@ def main():
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if ac is None else "bf16(dense convs)+f32(HIP ops)", "data": "synthetic",
+            "dtype": "f32" if ac is None else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: student+teacher distillation step, 6 cams 256x704, "
                                    f"{30000 * wl['sweeps']}-pt cloud, 40 GT boxes, fwd+bwd+AdamW"
                        if wl["kind"] == "distill" else f"{args.workload} detector training step",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "final_loss": loss},
+                       "parallelism": f"dp{world}", "final_loss": loss,
+                       "precision": "fp32 everywhere" if ac is None else
+                       "bf16 autocast on dense convs, fp32 HIP ops (voxelize/spconv/splat/losses), fp32 master weights",
+                       "layout": "NCHW" if args.nchw else "channels-last dense convs",
+                       "executor": "hipGraph" if isinstance(trainer, train.GraphTrainer) else "eager+DDP"},
         }
         if not args.no_roofline:
             line["roofline"] = roofline_leg(device, 1)

@@ -24,6 +24,14 @@ struct WStrides {
   long long sn, sk, sc;
 };
 
+// Optional fused epilogue: y = relu?((conv + bias) * scale + shift + residual)
+struct ConvEpilogue {
+  const float* scale;     // [Cout] or nullptr
+  const float* shift;     // [Cout] or nullptr
+  const float* residual;  // [Mout, Cout] or nullptr
+  int relu;
+};
+
 template <int CIN_P, int COUT_P>
 __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, int cin,
                                                    const int32_t* __restrict__ nbr, int K,
@@ -134,11 +142,14 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
                                                       const int32_t* __restrict__ nbr, int K,
                                                       int mirror, const float* __restrict__ W,
                                                       WStrides ws, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int cout, int Mout) {
+                                                      float* __restrict__ out, int cout, int Mout,
+                                                      const int32_t* __restrict__ order,
+                                                      ConvEpilogue ep) {
   constexpr int LDA = CIN_P + 4;
   constexpr int NT = COUT_P / 16;
-  constexpr int A4 = kTM2 * (CIN_P / 4) / 512;    // float4 per thread for the A tile
-  constexpr int B4 = COUT_P * (CIN_P / 4) / 512;  // float4 per thread for the B tile
+  constexpr int A4 = kTM2 * (CIN_P / 4) / 512;                  // float4 per thread for the A tile
+  constexpr int B4 = (COUT_P * (CIN_P / 4) + 511) / 512;        // float4 per thread for the B tile
+  constexpr int BU = COUT_P * (CIN_P / 4);                      // float4 units in the B tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);          // [kTM2][LDA]
   float* Bs = As + kTM2 * LDA;                          // [COUT_P][LDA]
@@ -146,17 +157,26 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
   // all LDS lives in the dynamic region (a static __shared__ in front would shift its base off
   // the 16-byte alignment the b128 reads need)
   unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
+  int* s_row = s_nbr + K * kTM2 + 4;                    // [kTM2] output row of each tile row (-1: none)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int row0 = blockIdx.x * kTM2;
   if (tid == 0) s_active = 0u;
+  __syncthreads();
+  // tile row -> output row: identity, or the caller's mask-sorted order (rows with similar
+  // neighbour masks share a tile, so far fewer offsets are active per tile)
+  if (tid < kTM2) {
+    const int p = row0 + tid;
+    s_row[tid] = (p < Mout) ? (order ? order[p] : p) : -1;
+  }
   __syncthreads();
   // rulebook slice -> LDS (column kk of the rulebook serves weight offset k)
   unsigned mine = 0u;
   for (int idx = tid; idx < kTM2 * K; idx += 512) {
     const int r = idx / K, k = idx - r * K;
     int v = -1;
-    if (row0 + r < Mout) v = nbr[(size_t)(row0 + r) * K + (mirror ? K - 1 - k : k)];
+    const int orow = s_row[r];
+    if (orow >= 0) v = nbr[(size_t)orow * K + (mirror ? K - 1 - k : k)];
     s_nbr[k * kTM2 + r] = v;
     if (v >= 0) mine |= 1u << k;
   }
@@ -213,6 +233,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < B4; ++j) {
         const int u = tid + 512 * j;
+        if (u >= BU) break;
         const int n = u / (CIN_P / 4), c4 = (u - n * (CIN_P / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < cout && c4 < cin) v = *reinterpret_cast<const float4*>(W + n * ws.sn + k * ws.sk + c4);
@@ -223,6 +244,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < B4; ++j) {
         const int u = tid + 512 * j;
+        if (u >= BU) break;
         const int c = u / (COUT_P / 4), n4 = (u - c * (COUT_P / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < cin) {
@@ -276,10 +298,18 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
     const int col = t * 16 + li;
     if (col >= cout) continue;
     const float bv = bias ? bias[col] : 0.f;
+    const float sc = ep.scale ? ep.scale[col] : 1.f;
+    const float sh = ep.shift ? ep.shift[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = row0 + wave * 16 + 4 * g + r;
-      if (row < Mout) out[(size_t)row * cout + col] = acc[t][r] + bv;
+      const int row = s_row[wave * 16 + 4 * g + r];
+      if (row >= 0) {
+        float v = acc[t][r] + bv;
+        if (ep.scale) v = v * sc + sh;                       // folded eval-mode BatchNorm
+        if (ep.residual) v += ep.residual[(size_t)row * cout + col];
+        if (ep.relu) v = fmaxf(v, 0.f);
+        out[(size_t)row * cout + col] = v;
+      }
     }
   }
 }
@@ -416,8 +446,8 @@ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 template <int CIN_P, int COUT_P>
 int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
                    WStrides ws, const float* bias, float* out, int cout, int Mout,
-                   hipStream_t stream) {
-  const size_t lds = (size_t)(kTM2 + COUT_P) * (CIN_P + 4) * sizeof(float) + (size_t)K * kTM2 * sizeof(int) + 16;
+                   const int32_t* order, ConvEpilogue ep, hipStream_t stream) {
+  const size_t lds = (size_t)(kTM2 + COUT_P) * (CIN_P + 4) * sizeof(float) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P>,
@@ -425,7 +455,7 @@ int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirr
     attr_set = true;
   }
   k_conv_mfma_v2<CIN_P, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(
-      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout);
+      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -433,11 +463,11 @@ int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirr
 template <int CIN_P, int COUT_P>
 int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
                 WStrides ws, const float* bias, float* out, int cout, int Mout,
-                hipStream_t stream) {
-  if constexpr (CIN_P >= 64 && COUT_P >= 64) {
-    if (K <= 32)   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles
-      return launch_conv_v2<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, stream);
-  }
+                const int32_t* order, ConvEpilogue ep, int algo, hipStream_t stream) {
+  // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles
+  if (K <= 32 && algo != 2)
+    return launch_conv_v2<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, stream);
+  if (ep.scale || ep.residual || ep.relu) return UD_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(kTM + COUT_P) * (CIN_P + 4) * sizeof(float) + kTM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
@@ -494,21 +524,26 @@ int wgrad_chunks(int Mout, int* rows_per_chunk) {
 extern "C" int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t w_sn,
                               int64_t w_sk, int64_t w_sc, int mirror, const float* bias,
                               float* out, int Mout, int K, int Cin, int Cout, int algo,
+                              const int32_t* row_order, const float* ep_scale,
+                              const float* ep_shift, const float* ep_residual, int ep_relu,
                               ud_stream_t stream_) {
   if (Mout < 0 || K <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
   if (Mout == 0) return UD_OK;
   if (!in || !nbr || !W || !out) return UD_ERR_INVALID_ARG;
+  if ((ep_scale == nullptr) != (ep_shift == nullptr)) return UD_ERR_INVALID_ARG;
+  ConvEpilogue ep{ep_scale, ep_shift, ep_residual, ep_relu};
   hipStream_t stream = (hipStream_t)stream_;
   WStrides ws{w_sn, w_sk, w_sc};
   const int cp = pad16(Cin), np = pad16(Cout);
   UdProfScope prof("spconv.k_conv", stream);
-  if (algo == 0) {
+  if (algo == 0 || algo == 2) {   // 0: v2 MFMA kernel, 2: first-generation 64-row MFMA kernel
 #define X(A, B) \
   if (cp == A && np == B) \
-    return launch_conv<A, B>(in, Cin, nbr, K, mirror, W, ws, bias, out, Cout, Mout, stream);
+    return launch_conv<A, B>(in, Cin, nbr, K, mirror, W, ws, bias, out, Cout, Mout, row_order, ep, algo, stream);
     UD_CONV_CASES(X)
 #undef X
   }
+  if (ep.scale || ep.residual || ep.relu) return UD_ERR_UNSUPPORTED;
   k_conv_generic<<<ud_div_up((long long)Mout * Cout, 256), 256, 0, stream>>>(
       in, Cin, nbr, K, mirror, W, ws, bias, out, Cout, Mout);
   UD_LAUNCH_CHECK();

@@ -51,6 +51,11 @@ class SparseBasicBlock(sp.SparseModule):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
+        if x.indices.shape[0] != 0 and sp.can_fuse_inference(x, self.bn1) and not self.bn2.training \
+                and self.conv1.kernel_algo == 0:
+            # inference: two kernels for the whole block (BN folded, residual + ReLU in the epilogue)
+            y = self.conv1.forward_fused(x, self.bn1, relu=True)
+            return self.conv2.forward_fused(y, self.bn2, relu=True, residual=skip.features)
         y = self.conv1(x)
         y = y.replace_feature(self.relu(self.bn1(y.features)))
         y = self.conv2(y)

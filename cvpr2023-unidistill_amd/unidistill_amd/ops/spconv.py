@@ -120,14 +120,64 @@ class _SiteSet:
         return hit
 
 
-def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0):
+_ORDER_CACHE_ATTR = "_ud_mask_order"
+
+
+def mask_order(nbr, mirror=False):
+    """Permutation of the rulebook rows sorted by their neighbour bit mask (cached on the rulebook
+    tensor).  Rows with equal / similar masks become neighbours, so a 128-row tile activates only a
+    few of the K kernel offsets instead of nearly all of them."""
+    key = _ORDER_CACHE_ATTR + ("_m" if mirror else "")
+    order = getattr(nbr, key, None)
+    if order is None:
+        K = nbr.shape[1]
+        if K > 31 or nbr.shape[0] == 0:
+            order = False
+        else:
+            bits = (1 << torch.arange(K, device=nbr.device, dtype=torch.int32))
+            if mirror:
+                bits = bits.flip(0)
+            mask = ((nbr >= 0).int() * bits[None, :]).sum(1, dtype=torch.int32)
+            order = torch.argsort(mask).int().contiguous()
+        setattr(nbr, key, order)
+    return None if order is False else order
+
+
+def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0, scale=None, shift=None,
+          residual=None, relu=False):
     Mout, K = nbr.shape
     out = torch.empty((Mout, cout), dtype=torch.float32, device=feat.device)
+    order = mask_order(nbr, mirror) if algo == 0 else None
     _lib.check(_lib.load().ud_spconv_conv(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(weight),
                                           w_strides[0], w_strides[1], w_strides[2],
                                           1 if mirror else 0, _lib.ptr(bias), _lib.ptr(out), Mout, K,
-                                          cin, cout, algo, _lib.stream_of(feat)), "ud_spconv_conv")
+                                          cin, cout, algo, _lib.ptr(order), _lib.ptr(scale),
+                                          _lib.ptr(shift), _lib.ptr(residual), 1 if relu else 0,
+                                          _lib.stream_of(feat)), "ud_spconv_conv")
     return out
+
+
+def folded_batchnorm(bn):
+    """(scale, shift) of an eval-mode BatchNorm1d: y = x * scale + shift.  Cached on the module
+    and refreshed when any of its tensors changed (version counters)."""
+    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.device)
+    hit = getattr(bn, "_ud_folded", None)
+    if hit is None or hit[0] != ver:
+        with torch.no_grad():
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        hit = (ver, scale, shift)
+        bn._ud_folded = hit
+    return hit[1], hit[2]
+
+
+def can_fuse_inference(x, bn=None):
+    """The fused conv(+BN+residual+ReLU) epilogue is inference-only: no autograd graph, BN in eval."""
+    if torch.is_grad_enabled() and x.features.requires_grad:
+        return False
+    return bn is None or (isinstance(bn, nn.BatchNorm1d) and not bn.training and bn.affine
+                          and bn.track_running_stats)
 
 
 class _SparseConvFn(torch.autograd.Function):
@@ -253,7 +303,20 @@ class SparseSequential(SparseModule):
         return list(self._modules.values())[i]
 
     def forward(self, x):
-        for m in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, _SparseConvBase) and isinstance(x, SparseConvTensor) and m.kernel_algo == 0:
+                # inference fast path: conv [+ BatchNorm1d(eval)] [+ ReLU] as one kernel
+                bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+                if x.indices.shape[0] != 0 and can_fuse_inference(x, bn) and (bn is None or not bn.training):
+                    j = i + (2 if bn is not None else 1)
+                    relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+                    if bn is not None or relu:
+                        x = m.forward_fused(x, bn, relu)
+                        i = j + (1 if relu else 0)
+                        continue
             if isinstance(m, SparseModule):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
@@ -261,6 +324,7 @@ class SparseSequential(SparseModule):
                     x = x.replace_feature(m(x.features))
             else:
                 x = m(x)
+            i += 1
         return x
 
 
@@ -289,27 +353,46 @@ class _SparseConvBase(SparseModule):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
-    def forward(self, x):
-        assert isinstance(x, SparseConvTensor)
+    def _rulebooks(self, x):
+        """-> (out_sites, nbr, nbr_t, mirror_t) for this conv on tensor x (cached per site set)."""
         sites = x._sites
         if self.subm:
             nbr = sites.subm_rulebook(self.kernel_size)
-            out_sites, nbr_t, mirror = sites, nbr, True
-        elif self.inverse:
+            return sites, nbr, nbr, True
+        if self.inverse:
             src = x.indice_dict.get(self.indice_key)
             if src is None:
                 raise ValueError(f"SparseInverseConv3d needs the SparseConv3d with indice_key "
                                  f"{self.indice_key!r} to have run first")
             in_sites, out_nbr, in_nbr = src
             assert sites is in_sites[1], "inverse conv input must be that conv's output"
-            out_sites, nbr, nbr_t, mirror = in_sites[0], in_nbr, out_nbr, False
-        else:
-            out_sites, nbr, nbr_t = sites.down(self.kernel_size, self.stride, self.padding)
-            mirror = False
-            if self.indice_key is not None:
-                x.indice_dict[self.indice_key] = ((sites, out_sites), nbr, nbr_t)
+            return in_sites[0], in_nbr, out_nbr, False
+        out_sites, nbr, nbr_t = sites.down(self.kernel_size, self.stride, self.padding)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = ((sites, out_sites), nbr, nbr_t)
+        return out_sites, nbr, nbr_t, False
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        out_sites, nbr, nbr_t, mirror = self._rulebooks(x)
         feats = _SparseConvFn.apply(x.features, self.weight, self.bias, nbr, nbr_t, mirror,
                                     self.kernel_algo)
+        return SparseConvTensor(feats, None, None, None, _sites=out_sites, _indice_dict=x.indice_dict)
+
+    def forward_fused(self, x, bn=None, relu=False, residual=None):
+        """Inference only: conv + bias (+ folded BatchNorm1d) (+ residual) (+ ReLU) in ONE kernel."""
+        out_sites, nbr, _, _ = self._rulebooks(x)
+        w = self.weight.detach().contiguous().float()
+        cout, cin = w.shape[0], w.shape[-1]
+        K = nbr.shape[1]
+        scale = shift = None
+        if bn is not None:
+            scale, shift = folded_batchnorm(bn)
+        with torch.no_grad():
+            feats = _conv(x.features.detach().contiguous().float(), nbr, w, (K * cin, cin, 1), False,
+                          None if self.bias is None else self.bias.detach().contiguous().float(),
+                          cin, cout, 0, scale, shift,
+                          None if residual is None else residual.detach().contiguous().float(), relu)
         return SparseConvTensor(feats, None, None, None, _sites=out_sites, _indice_dict=x.indice_dict)
 
 

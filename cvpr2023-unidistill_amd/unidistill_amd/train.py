@@ -119,7 +119,8 @@ def to_channels_last(module):
     native; NCHW tensors get transposed around every call).  Sparse-conv weights (rank 5) and
     everything else are left alone."""
     for m in module.modules():
-        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and m.weight.shape[2] * m.weight.shape[3] > 1:
+            # (1x1 kernels are layout-ambiguous; converting them only confuses DDP's bucket views)
             m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
     return module
 
@@ -139,7 +140,8 @@ class Trainer:
         if get_world_size() > 1:
             # gradients are all-reduced over RCCL/xGMI in ~64 MB buckets, overlapped with backward
             self.ddp = nn.parallel.DistributedDataParallel(
-                self.module, device_ids=[self.device.index], bucket_cap_mb=bucket_cap_mb,
+                self.module, device_ids=[self.device.index], output_device=self.device.index,
+                bucket_cap_mb=bucket_cap_mb,
                 gradient_as_bucket_view=True, broadcast_buffers=False, find_unused_parameters=False)
         self.opt = torch.optim.AdamW(trainable, lr=lr, weight_decay=weight_decay, fused=True)
         self.params = trainable
@@ -242,10 +244,12 @@ class GraphTrainer:
     """
 
     def __init__(self, step_module, example_batch, lr=2e-4, weight_decay=1e-7, grad_clip=0.1,
-                 device=None, autocast_dtype=None, warmup=3):
+                 device=None, autocast_dtype=None, warmup=3, channels_last=False):
         assert isinstance(step_module, DistillStep)
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.m = step_module.to(self.device)
+        if channels_last:
+            to_channels_last(self.m)
         self.m.train()
         self.world = get_world_size()
         self.grad_clip = grad_clip

@@ -220,11 +220,19 @@ int ud_spconv_down_rulebook(const void* in_index, int in_rows_sorted, int Min, i
  * Forward with spconv-2.x KRSC weights [Cout,K,Cin]: (w_sn, w_sk, w_sc) = (K*Cin, Cin, 1).
  * Input gradient: in := gout, nbr := in_nbr (strided conv) or the subm rulebook with mirror = 1,
  * (w_sn, w_sk, w_sc) = (1, Cin, K*Cin), Cin/Cout swapped.  Exact-fp32 MFMA, deterministic.
- * algo 0 = auto, 1 = generic VALU kernel (any channel counts).
+ * algo 0 = auto (128-row MFMA kernel), 1 = generic VALU kernel (any channel counts),
+ * 2 = first-generation 64-row MFMA kernel.
+ * Fused epilogue (MFMA kernel, algo 0): y = relu?((conv + bias) * ep_scale + ep_shift + ep_residual)
+ * with ep_scale/ep_shift f32[Cout] (a folded eval-mode BatchNorm1d; both or neither),
+ * ep_residual f32[Mout,Cout] (a SparseBasicBlock skip), ep_relu 0/1; pass NULL/0 to disable.
+ * row_order (optional, may be NULL): a permutation i32[Mout] of the output rows; tiles are formed
+ * over row_order so rows with similar neighbour masks share a tile (same results, fewer active
+ * kernel offsets per tile; only the wide-channel MFMA kernel uses it).
  */
 int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t w_sn, int64_t w_sk,
                    int64_t w_sc, int mirror, const float* bias, float* out, int Mout, int K,
-                   int Cin, int Cout, int algo, ud_stream_t stream);
+                   int Cin, int Cout, int algo, const int32_t* row_order, const float* ep_scale,
+                   const float* ep_shift, const float* ep_residual, int ep_relu, ud_stream_t stream);
 
 /* gW f32[Cout,K,Cin] = sum_o gout[o,n] * in[nbr[o][k], c]  (ordered partial sums, deterministic). */
 size_t ud_spconv_wgrad_workspace_bytes(int Mout, int K, int Cin, int Cout);

@@ -62,7 +62,7 @@ def _tol(ref):
 
 @pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64),
                                       (64, 128), (128, 128), (7, 9)])
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 def test_conv_dgrad_wgrad_vs_oracle(cin, cout, algo):
     from unidistill_amd.ops import spconv as sp
     rng = np.random.default_rng(cin * 1000 + cout)
@@ -149,3 +149,33 @@ def test_rulebook_shared_between_indice_keys():
     b = sp.SubMConv3d(16, 16, 3, padding=1, indice_key="res1").cuda()
     y = b(a(x))
     assert len(y._sites._subm) == 1          # one rulebook for both keys
+
+
+def test_fused_inference_epilogue_matches_module_chain():
+    """conv + eval BatchNorm1d + residual + ReLU fused in the kernel epilogue == the op chain."""
+    from unidistill_amd.ops import spconv as sp
+    from unidistill_amd.layers.lidar import SparseBasicBlock
+    from functools import partial
+    rng = np.random.default_rng(21)
+    shape = (2, 7, 18, 20)
+    coords = _sites(rng, *shape, 0.3)
+    torch.manual_seed(3)
+    norm = partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+    for c in (16, 64):
+        feat = rng.standard_normal((len(coords), c)).astype(np.float32)
+        blk = SparseBasicBlock(c, c, norm_fn=norm, indice_key="r").cuda().eval()
+        seq = sp.SparseSequential(sp.SparseConv3d(c, 2 * c, 3, stride=2, padding=1, bias=False), norm(2 * c),
+                                  torch.nn.ReLU()).cuda().eval()
+        for m in list(blk.modules()) + list(seq.modules()):
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0)
+                m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.3)
+        x = _tensor(coords, feat, shape)
+        with torch.no_grad():
+            fused = seq(blk(x)).features
+        # unfused reference: force the autograd path by requiring grad on the input
+        xr = _tensor(coords, feat, shape)
+        xr.features.requires_grad_(True)
+        ref = seq(blk(xr)).features
+        assert ref.requires_grad and not fused.requires_grad
+        np.testing.assert_allclose(fused.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
