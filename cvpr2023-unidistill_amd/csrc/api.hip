@@ -84,3 +84,73 @@ extern "C" int ud_prof_read(const char* name, double* total_ms, int* calls, int 
   if (calls) *calls = n;
   return UD_OK;
 }
+
+// ---- HBM calibration kernels (tools/exp_stream.py): what a plain streaming read / copy reaches ----
+namespace {
+__global__ __launch_bounds__(256) void k_stream_read(const float4* __restrict__ p, size_t n4,
+                                                     float* __restrict__ sink) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n4; i += 8 * stride) {
+    float4 r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = p[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += r[u].x;
+      acc.y += r[u].y;
+      acc.z += r[u].z;
+      acc.w += r[u].w;
+    }
+  }
+  for (; i < n4; i += stride) acc.x += p[i].x;
+  if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;  // keep the loads alive
+}
+// block-contiguous variant: every workgroup walks its own contiguous span, 32 KiB per trip
+__global__ __launch_bounds__(256) void k_stream_read_blk(const float4* __restrict__ p, size_t n4,
+                                                         float* __restrict__ sink) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = (lo + per < n4) ? lo + per : n4;
+  size_t i = lo + threadIdx.x;
+  for (; i + 7 * 256 < hi; i += 8 * 256) {
+    float4 r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      typedef float vf4 __attribute__((ext_vector_type(4)));
+      const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(&p[i + u * 256]));
+      r[u] = make_float4(t.x, t.y, t.z, t.w);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += r[u].x;
+      acc.y += r[u].y;
+      acc.z += r[u].z;
+      acc.w += r[u].w;
+    }
+  }
+  for (; i < hi; i += 256) acc.x += p[i].x;
+  if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;
+}
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ p,
+                                                     float4* __restrict__ q, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) q[i] = p[i];
+}
+}  // namespace
+
+extern "C" int ud_bench_stream(const float* src, float* dst, size_t n_floats, int mode,
+                               ud_stream_t stream_) {
+  if (!src || !dst || n_floats < 4) return UD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  UdProfScope prof(mode == 0 ? "bench.stream_read" : (mode == 1 ? "bench.stream_copy" : "bench.stream_read_blk"), stream);
+  if (mode == 0)
+    k_stream_read<<<2048, 256, 0, stream>>>((const float4*)src, n_floats / 4, dst);
+  else if (mode >= 2)
+    k_stream_read_blk<<<mode, 256, 0, stream>>>((const float4*)src, n_floats / 4, dst);
+  else
+    k_stream_copy<<<2048, 256, 0, stream>>>((const float4*)src, (float4*)dst, n_floats / 4);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}

@@ -196,7 +196,14 @@ struct SrcFeat {  // materialised feat[B*N, C]  (reference boundary, lss_fpn.py:
   __device__ __forceinline__ Meta prep(int id) const { return Meta{id}; }
   __device__ __forceinline__ V load(const Meta& m, int j, int ch) const {
     const int p = __builtin_amdgcn_readlane(m.id, j);
-    return *reinterpret_cast<const V*>(feat + (size_t)p * C + ch);
+    // every feature row is read exactly once: stream it past the caches (nontemporal)
+    if constexpr (VEC == 4) {
+      typedef float vf4 __attribute__((ext_vector_type(4)));
+      const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(feat + (size_t)p * C + ch));
+      return make_float4(t.x, t.y, t.z, t.w);
+    } else {
+      return __builtin_nontemporal_load(feat + (size_t)p * C + ch);
+    }
   }
 };
 
@@ -465,8 +472,11 @@ __global__ __launch_bounds__(256) void k_bwd(const float* __restrict__ gout,
     float* dst = gfeat + (size_t)row * C;
     for (int ch = lane * VEC; ch < C; ch += 64 * VEC) {
       V v = RowVec<VEC>::zero();
-      if (kept) v = *reinterpret_cast<const V*>(src + ch);
-      *reinterpret_cast<V*>(dst + ch) = v;
+      if (kept) v = *reinterpret_cast<const V*>(src + ch);   // grad rows are re-read: keep cached
+      if constexpr (VEC == 4)
+        ud_stg_stream(dst + ch, v);                          // 484 MB written once: stream out
+      else
+        *reinterpret_cast<V*>(dst + ch) = v;
     }
   }
 }

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_lift_fwd(const float* __restrict__ prob
         const float p = prob[((size_t)bn * D + d) * HW + pix];
         float4 o = make_float4(__fmul_rn(p, c.x), __fmul_rn(p, c.y), __fmul_rn(p, c.z),
                                __fmul_rn(p, c.w));
-        *reinterpret_cast<float4*>(lifted + (((size_t)bn * D + d) * HW + pix) * C + ch) = o;
+        ud_stg_stream(lifted + (((size_t)bn * D + d) * HW + pix) * C + ch, o);   // written once
       }
     }
   }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_lift_bwd(const float* __restrict__ gsrc
         const float* src = GRAD_FROM_CELLS ? gsrc + (size_t)cl * C
                                            : gsrc + (((size_t)bn * D + d) * HW + pix) * C;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act) g = *reinterpret_cast<const float4*>(src + ch);
+        if (act) g = GRAD_FROM_CELLS ? *reinterpret_cast<const float4*>(src + ch) : ud_ldg_stream(src + ch);
         gc.x = fmaf(p, g.x, gc.x);
         gc.y = fmaf(p, g.y, gc.y);
         gc.z = fmaf(p, g.z, gc.z);

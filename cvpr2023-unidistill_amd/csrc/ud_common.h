@@ -46,6 +46,18 @@ __device__ __forceinline__ float ud_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Streaming (read-once / write-once) accesses bypass cache allocation: on MI355X a 1 KiB-row
+// gather of a 484 MB tensor runs 131 us -> 92 us with nontemporal loads (tools/exp_pool.py).
+typedef float ud_vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ud_ldg_stream(const float* p) {
+  const ud_vf4 t = __builtin_nontemporal_load(reinterpret_cast<const ud_vf4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void ud_stg_stream(float* p, const float4& v) {
+  ud_vf4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<ud_vf4*>(p));
+}
+
 __device__ __forceinline__ int ud_wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -22,6 +22,7 @@ _SIGS = {
     "ud_error_string": (ctypes.c_char_p, [c_int]),
     "ud_prof_enable": (None, [c_int]),
     "ud_prof_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), c_int]),
+    "ud_bench_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ud_bev_pool_workspace_bytes": (c_size_t, [c_int] * 6),
     "ud_bev_pool_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_uint, c_void_p, c_size_t, c_void_p]),
     "ud_bev_pool_bwd_workspace_bytes": (c_size_t, [c_int] * 4 + [c_i64]),

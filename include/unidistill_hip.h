@@ -59,6 +59,10 @@ const char* ud_error_string(int code);
 void ud_prof_enable(int on);
 int ud_prof_read(const char* name, double* total_ms, int* calls, int reset);
 
+/* HBM calibration: mode 0 = streaming read of src (dst only keeps the loads alive), mode 1 = copy
+ * src -> dst; n_floats elements.  Timed through ud_prof ("bench.stream_read" / "bench.stream_copy"). */
+int ud_bench_stream(const float* src, float* dst, size_t n_floats, int mode, ud_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* BEV pool (camera LSS splat)                                               */
 /* ------------------------------------------------------------------------- */
