@@ -53,7 +53,7 @@ _SIGS = {
     "ud_distill_box_corners": (c_int, [c_void_p, c_int, c_int, c_int] + [ctypes.c_double] * 4
                                + [c_void_p, c_void_p, c_void_p]),
     "ud_distill_box_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-                           + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                           + [c_int] * 5 + [c_void_p, c_void_p]),
     "ud_distill_box_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                            + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "ud_distill_mask_workspace_bytes": (c_size_t, [c_int, c_int]),
