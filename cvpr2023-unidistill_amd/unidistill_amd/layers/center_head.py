@@ -283,11 +283,146 @@ class SepHead(nn.Module):
         return {head: getattr(self, head)(x) for head in self.heads}
 
 
+class PackedSepHeads(nn.Module):
+    """All SepHeads of all tasks as TWO convolutions.
+
+    The reference runs 6 tasks x 7 heads = 42 independent (conv3x3 64->64, BN, ReLU, conv3x3 64->k)
+    stacks: 84 tiny convolutions + 42 batch norms per pass (x3 with backward).  Every first conv
+    reads the same shared feature map, so they are ONE conv 64 -> 42*64; the BatchNorms are one
+    BatchNorm over 42*64 channels (per-channel statistics are unaffected by packing); the second
+    convs are ONE grouped conv (42 groups, outputs padded to the widest head, unused rows stay 0).
+    Parameters live packed; ``state_dict`` / ``load_state_dict`` speak the reference's key names
+    (``{t}.{head}.0.weight`` ... relative to this module, i.e. ``tasks.{t}.{head}...`` in the head).
+    """
+
+    def __init__(self, in_channels, task_heads, head_conv=64, final_kernel=3, init_bias=-2.19):
+        super().__init__()
+        self.in_channels, self.head_conv, self.k = in_channels, head_conv, final_kernel
+        self.layout = []                                   # (task, head name, out channels)
+        for t, heads in enumerate(task_heads):
+            for name, (classes, num_conv) in heads.items():
+                assert num_conv == 2, "UniDistill's heads are (conv, BN, ReLU, conv)"
+                self.layout.append((t, name, int(classes)))
+        self.num_tasks = len(task_heads)
+        G = len(self.layout)
+        self.kmax = max(k for _, _, k in self.layout)
+        hc = head_conv
+        self.c1_weight = nn.Parameter(torch.empty(G * hc, in_channels, final_kernel, final_kernel))
+        self.c1_bias = nn.Parameter(torch.empty(G * hc))
+        self.bn_weight = nn.Parameter(torch.ones(G * hc))
+        self.bn_bias = nn.Parameter(torch.zeros(G * hc))
+        self.register_buffer("bn_running_mean", torch.zeros(G * hc))
+        self.register_buffer("bn_running_var", torch.ones(G * hc))
+        self.register_buffer("bn_num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.c2_weight = nn.Parameter(torch.zeros(G * self.kmax, hc, final_kernel, final_kernel))
+        self.c2_bias = nn.Parameter(torch.zeros(G * self.kmax))
+        self.bn_eps, self.bn_momentum = 1e-5, 0.1
+        self.register_buffer("_c2_rows", torch.arange(G * self.kmax), persistent=False)
+        self.register_buffer("_c2_grp", torch.arange(G * self.kmax) // self.kmax, persistent=False)
+        # initialise exactly like the reference's per-head modules (center_head.py:323-362)
+        with torch.no_grad():
+            for g, (_t, name, kout) in enumerate(self.layout):
+                c1 = nn.Conv2d(in_channels, hc, final_kernel, padding=final_kernel // 2, bias=True)
+                c2 = nn.Conv2d(hc, kout, final_kernel, padding=final_kernel // 2, bias=True)
+                if "hm" in name:
+                    c2.bias.fill_(init_bias)
+                else:
+                    for m in (c1, c2):
+                        nn.init.kaiming_normal_(m.weight, a=0, mode="fan_out", nonlinearity="relu")
+                        nn.init.constant_(m.bias, 0)
+                self.c1_weight[g * hc:(g + 1) * hc] = c1.weight
+                self.c1_bias[g * hc:(g + 1) * hc] = c1.bias
+                self.c2_weight[g * self.kmax:g * self.kmax + kout] = c2.weight
+                self.c2_bias[g * self.kmax:g * self.kmax + kout] = c2.bias
+        self._register_state_dict_hook(self._to_reference_keys)
+        self._register_load_state_dict_pre_hook(self._from_reference_keys)
+
+    def __len__(self):
+        return self.num_tasks
+
+    def forward(self, x):
+        """-> list (per task) of {head: [B, k, H, W]} like [SepHead(x) for each task]."""
+        pad = self.k // 2
+        y = torch.nn.functional.conv2d(x, self.c1_weight, self.c1_bias, padding=pad)
+        if self.training:
+            self.bn_num_batches_tracked += 1
+        y = torch.nn.functional.batch_norm(y, self.bn_running_mean, self.bn_running_var, self.bn_weight,
+                                           self.bn_bias, self.training, self.bn_momentum, self.bn_eps)
+        y = torch.relu(y)
+        # second layer: ONE dense conv with a block-diagonal weight built from the compact per-head
+        # parameters (rows padded to a multiple of 64).  A 42-group conv with 3 outputs per group is
+        # ~5x slower in MIOpen/CK than the dense conv despite 42x fewer FLOPs (tools/exp_gconv.py).
+        G = len(self.layout)
+        rows = G * self.kmax
+        rows_p = (rows + 63) // 64 * 64
+        wd = self.c2_weight.new_zeros(rows_p, G, self.head_conv, self.k, self.k)
+        wd = wd.index_put((self._c2_rows, self._c2_grp), self.c2_weight)
+        bd = torch.nn.functional.pad(self.c2_bias, (0, rows_p - rows))
+        z = torch.nn.functional.conv2d(y, wd.view(rows_p, G * self.head_conv, self.k, self.k), bd, padding=pad)
+        outs = [dict() for _ in range(self.num_tasks)]
+        for g, (t, name, kout) in enumerate(self.layout):
+            outs[t][name] = z[:, g * self.kmax:g * self.kmax + kout]
+        return outs
+
+    # ---- reference-compatible (de)serialisation ------------------------------------------------
+    def _slices(self):
+        hc, km = self.head_conv, self.kmax
+        for g, (t, name, kout) in enumerate(self.layout):
+            yield f"{t}.{name}.", slice(g * hc, (g + 1) * hc), slice(g * km, g * km + kout)
+
+    def _to_reference_keys(self, module, state, prefix, local_metadata):
+        packed = {k: state.pop(prefix + k) for k in ("c1_weight", "c1_bias", "bn_weight", "bn_bias",
+                                                      "bn_running_mean", "bn_running_var",
+                                                      "bn_num_batches_tracked", "c2_weight", "c2_bias")}
+        for key, s1, s2 in self._slices():
+            state[prefix + key + "0.weight"] = packed["c1_weight"][s1]
+            state[prefix + key + "0.bias"] = packed["c1_bias"][s1]
+            state[prefix + key + "1.weight"] = packed["bn_weight"][s1]
+            state[prefix + key + "1.bias"] = packed["bn_bias"][s1]
+            state[prefix + key + "1.running_mean"] = packed["bn_running_mean"][s1]
+            state[prefix + key + "1.running_var"] = packed["bn_running_var"][s1]
+            state[prefix + key + "1.num_batches_tracked"] = packed["bn_num_batches_tracked"].clone()
+            state[prefix + key + "3.weight"] = packed["c2_weight"][s2]
+            state[prefix + key + "3.bias"] = packed["c2_bias"][s2]
+        return state
+
+    def _from_reference_keys(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
+        if prefix + "c1_weight" in state:
+            return                                          # already packed
+        first = prefix + self.layout[0][1].join([f"{self.layout[0][0]}.", ".0.weight"])
+        if first not in state:
+            return                                          # nothing for us: let strict mode report it
+        ref = {k: state.pop(k) for k in list(state) if k.startswith(prefix)}
+        like = lambda p: torch.zeros_like(p.detach())
+        new = {"c1_weight": like(self.c1_weight), "c1_bias": like(self.c1_bias),
+               "bn_weight": like(self.bn_weight), "bn_bias": like(self.bn_bias),
+               "bn_running_mean": torch.zeros_like(self.bn_running_mean),
+               "bn_running_var": torch.ones_like(self.bn_running_var),
+               "bn_num_batches_tracked": self.bn_num_batches_tracked.detach().clone(),
+               "c2_weight": like(self.c2_weight), "c2_bias": like(self.c2_bias)}
+        names = {"0.weight": ("c1_weight", 1), "0.bias": ("c1_bias", 1), "1.weight": ("bn_weight", 1),
+                 "1.bias": ("bn_bias", 1), "1.running_mean": ("bn_running_mean", 1),
+                 "1.running_var": ("bn_running_var", 1), "3.weight": ("c2_weight", 2), "3.bias": ("c2_bias", 2)}
+        for key, s1, s2 in self._slices():
+            for suffix, (dst, which) in names.items():
+                k = prefix + key + suffix
+                if k in ref:
+                    new[dst][s1 if which == 1 else s2] = ref.pop(k).to(new[dst].dtype)
+                elif strict:
+                    missing.append(k)
+            k = prefix + key + "1.num_batches_tracked"
+            if k in ref:
+                new["bn_num_batches_tracked"] = ref.pop(k).to(torch.long).reshape(())
+        for k, v in new.items():
+            state[prefix + k] = v
+        state.update(ref)                                   # leftovers become "unexpected" in strict mode
+
+
 class CenterHead(nn.Module):
     def __init__(self, dataset_name, tasks, target_assigner, proposal_layer, input_channels,
                  grid_size, point_cloud_range, code_weights, loc_weight, share_conv_channel,
                  common_heads, upsample_for_pedestrian=False, predict_boxes_when_training=False,
-                 mode="3d", init_bias=-2.19, distill=False):
+                 mode="3d", init_bias=-2.19, distill=False, packed_heads=True):
         super().__init__()
         self.in_channels = input_channels
         self.grid_size = grid_size
@@ -310,12 +445,16 @@ class CenterHead(nn.Module):
                 nn.BatchNorm2d(share_conv_channel), nn.ReLU())
         self.common_heads = common_heads
         self.init_bias = init_bias
-        self.tasks = nn.ModuleList()
+        task_heads = []
         for num_cls in self.num_classes:
             heads = copy.deepcopy(dict(common_heads))
             heads.update(dict(hm=(num_cls, 2)))
-            self.tasks.append(SepHead(share_conv_channel, heads, bn=True, init_bias=init_bias,
-                                      final_kernel=3))
+            task_heads.append(heads)
+        if packed_heads:
+            self.tasks = PackedSepHeads(share_conv_channel, task_heads, init_bias=init_bias, final_kernel=3)
+        else:
+            self.tasks = nn.ModuleList([SepHead(share_conv_channel, h, bn=True, init_bias=init_bias,
+                                                final_kernel=3) for h in task_heads])
         self.target_assigner = target_assigner
         self.proposal_layer = proposal_layer
 
@@ -326,7 +465,10 @@ class CenterHead(nn.Module):
         x = self.shared_conv(spatial_features_2d)
         if self.upsample_for_pedestrian:
             x = self.upsample_conv(x)
-        ret = {"multi_head_features": [task(x) for task in self.tasks]}
+        if isinstance(self.tasks, PackedSepHeads):
+            ret = {"multi_head_features": self.tasks(x)}
+        else:
+            ret = {"multi_head_features": [task(x) for task in self.tasks]}
         if self.training or self.distill:
             # The reference also assigns targets for the frozen distillation teacher
             # (center_head.py:137); they are never read, so the teacher skips the work here.
@@ -349,11 +491,11 @@ class CenterHeadIouAware(CenterHead):
                  input_channels, grid_size, point_cloud_range, code_weights, loc_weight, iou_weight,
                  share_conv_channel, common_heads, upsample_for_pedestrian=False,
                  predict_boxes_when_training=False, mode="3d", init_bias=-2.19,
-                 focal_alpha=0.25, focal_gamma=2, voxel_size_xy=None):
+                 focal_alpha=0.25, focal_gamma=2, voxel_size_xy=None, packed_heads=True):
         super().__init__(dataset_name, tasks, target_assigner, proposal_layer, input_channels,
                          grid_size, point_cloud_range, code_weights, loc_weight, share_conv_channel,
                          common_heads, upsample_for_pedestrian, predict_boxes_when_training, mode,
-                         init_bias)
+                         init_bias, packed_heads=packed_heads)
         self.auto_loss = AutomaticWeightedLoss(num=len(code_weights) + 2)
         self.iou_weight = iou_weight
         self.out_size_factor = out_size_factor

@@ -85,6 +85,39 @@ def test_head_forward_loss_and_grads(golden):
     np.testing.assert_allclose(head.auto_loss.params.grad.numpy(), g["head_params_grad"], rtol=1e-4, atol=1e-7)
 
 
+def test_packed_heads_speak_reference_state_dict(golden):
+    """The packed 2-conv head saves / loads the reference's per-head key names and shapes, and is
+    numerically the per-head module stack."""
+    g = golden("dense_head")
+    ref_sd = _sd(g, "head_sd/")
+    packed, plain = _head(), None
+    packed.load_state_dict(ref_sd, strict=True)
+    out_sd = packed.state_dict()
+    assert set(out_sd.keys()) == set(ref_sd.keys())
+    for k, v in ref_sd.items():
+        assert tuple(out_sd[k].shape) == tuple(v.shape), k
+        if v.dtype.is_floating_point:
+            np.testing.assert_array_equal(out_sd[k].numpy(), v.numpy())
+    from unidistill_amd.layers import center_head as chm
+    names = [n for t in TASKS for n in t["class_names"]]
+    plain = chm.CenterHeadIouAware(
+        dataset_name="nuscenes", tasks=TASKS, target_assigner=packed.target_assigner, proposal_layer=None,
+        out_size_factor=8, input_channels=24, grid_size=[256, 256, 40],
+        point_cloud_range=[-32.0, -32.0, -5.0, 32.0, 32.0, 3.0], code_weights=[1.0] * 8 + [0.2, 0.2],
+        loc_weight=0.25, iou_weight=5.0, share_conv_channel=16,
+        common_heads={"iou": [1, 2], "reg": [2, 2], "height": [1, 2], "dim": [3, 2], "rot": [2, 2], "vel": [2, 2]},
+        voxel_size_xy=[0.25, 0.25], packed_heads=False)
+    plain.load_state_dict(ref_sd, strict=True)
+    x = torch.from_numpy(g["head_feat"])
+    packed.eval(); plain.eval()
+    with torch.no_grad():
+        a = packed(x)["multi_head_features"]
+        b = plain(x)["multi_head_features"]
+    for t in range(3):
+        for k in b[t]:
+            np.testing.assert_allclose(a[t][k].numpy(), b[t][k].numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_nearest_bev_iou(golden):
     g = golden("dense_head")
     a, b = torch.from_numpy(g["iou_a"]), torch.from_numpy(g["iou_b"])
