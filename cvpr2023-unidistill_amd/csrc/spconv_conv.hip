@@ -314,6 +314,179 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
   }
 }
 
+// ---- bf16-MFMA variant (algo 3, mixed-precision mode) -------------------------------------------
+// Same tiling / masks / prefetch as k_conv_mfma_v2, but the gathered rows and the weights are
+// rounded to bf16 when they are written to LDS and multiplied with v_mfma_f32_16x16x32_bf16
+// (fp32 accumulate): 8x fewer matrix instructions at ~2x the issue rate, so the wide layers stop
+// being bound by the fp32 matrix pipe (157 TF) and become staging bound.  Inputs/outputs in HBM
+// stay fp32.  Used when the caller runs under bf16 autocast; NOT bit-compatible with the fp32 path.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7FFFu + ((ua >> 16) & 1u);   // round to nearest even
+  ub += 0x7FFFu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+
+template <int CIN_P, int COUT_P>   // CIN_P multiple of 32
+__global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict__ in, int cin,
+                                                        const int32_t* __restrict__ nbr, int K,
+                                                        int mirror, const float* __restrict__ W,
+                                                        WStrides ws, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int cout, int Mout,
+                                                        const int32_t* __restrict__ order,
+                                                        ConvEpilogue ep) {
+  constexpr int LDB = CIN_P + 8;                                 // bf16 elements per LDS row
+  constexpr int NT = COUT_P / 16;
+  constexpr int A4 = kTM2 * (CIN_P / 4) / 512;
+  constexpr int B4 = (COUT_P * (CIN_P / 4) + 511) / 512;
+  constexpr int BU = COUT_P * (CIN_P / 4);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);  // [kTM2][LDB]
+  unsigned short* Bs = As + kTM2 * LDB;                           // [COUT_P][LDB]
+  int* s_nbr = reinterpret_cast<int*>(Bs + COUT_P * LDB);         // [K][kTM2]
+  unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
+  int* s_row = s_nbr + K * kTM2 + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int row0 = blockIdx.x * kTM2;
+  if (tid == 0) s_active = 0u;
+  if (tid < kTM2) {
+    const int p = row0 + tid;
+    s_row[tid] = (p < Mout) ? (order ? order[p] : p) : -1;
+  }
+  __syncthreads();
+  unsigned mine = 0u;
+  for (int idx = tid; idx < kTM2 * K; idx += 512) {
+    const int r = idx / K, k = idx - r * K;
+    int v = -1;
+    const int orow = s_row[r];
+    if (orow >= 0) v = nbr[(size_t)orow * K + (mirror ? K - 1 - k : k)];
+    s_nbr[k * kTM2 + r] = v;
+    if (v >= 0) mine |= 1u << k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor((int)mine, o);
+  if (lane == 0 && mine) atomicOr(&s_active, mine);
+  __syncthreads();
+  const unsigned active = s_active;
+  unsigned wmask = 0u;
+  for (int k = 0; k < K; ++k) {
+    const int v = (lane < 16) ? s_nbr[k * kTM2 + wave * 16 + lane] : -1;
+    if (__any(v >= 0)) wmask |= 1u << k;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool vecA = (cin & 3) == 0;
+  const bool vecB = (ws.sc == 1) && vecA;
+  float4 ra[A4];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < A4; ++j) {
+      const int u = tid + 512 * j;
+      const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
+      const int rr = s_nbr[k * kTM2 + row];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr >= 0) {
+        const float* src = in + (size_t)rr * cin + c4;
+        if (vecA) {
+          if (c4 < cin) v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (c4 + 0 < cin) v.x = src[0];
+          if (c4 + 1 < cin) v.y = src[1];
+          if (c4 + 2 < cin) v.z = src[2];
+          if (c4 + 3 < cin) v.w = src[3];
+        }
+      }
+      ra[j] = v;
+    }
+  };
+  auto commit = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < A4; ++j) {
+      const int u = tid + 512 * j;
+      const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
+      *reinterpret_cast<uint2*>(As + row * LDB + c4) =
+          make_uint2(pack_bf16x2(ra[j].x, ra[j].y), pack_bf16x2(ra[j].z, ra[j].w));
+    }
+    if (vecB) {
+#pragma unroll
+      for (int j = 0; j < B4; ++j) {
+        const int u = tid + 512 * j;
+        if (u >= BU) break;
+        const int n = u / (CIN_P / 4), c4 = (u - n * (CIN_P / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < cout && c4 < cin) v = *reinterpret_cast<const float4*>(W + n * ws.sn + k * ws.sk + c4);
+        *reinterpret_cast<uint2*>(Bs + n * LDB + c4) =
+            make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < B4; ++j) {
+        const int u = tid + 512 * j;
+        if (u >= BU) break;
+        const int c = u / (COUT_P / 4), n4 = (u - c * (COUT_P / 4)) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < cin) {
+          const float* src = W + k * ws.sk + c * ws.sc;
+          for (int q = 0; q < 4; ++q)
+            if (n4 + q < cout) v[q] = src[(n4 + q) * ws.sn];
+        }
+        for (int q = 0; q < 4; ++q) {
+          unsigned u32 = __float_as_uint(v[q]);
+          u32 += 0x7FFFu + ((u32 >> 16) & 1u);
+          Bs[(n4 + q) * LDB + c] = (unsigned short)(u32 >> 16);
+        }
+      }
+    }
+  };
+  unsigned todo = active;
+  int k = todo ? (__ffs((int)todo) - 1) : -1;
+  if (k >= 0) fetch(k);
+  while (k >= 0) {
+    todo &= todo - 1;
+    commit(k);
+    __syncthreads();
+    const int knext = todo ? (__ffs((int)todo) - 1) : -1;
+    if (knext >= 0) fetch(knext);
+    if ((wmask >> k) & 1u) {
+      const unsigned short* arow = As + (wave * 16 + li) * LDB + 8 * g;
+#pragma unroll
+      for (int cb = 0; cb < CIN_P / 32; ++cb) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + cb * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (t * 16 + li) * LDB + cb * 32 + 8 * g);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    k = knext;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = t * 16 + li;
+    if (col >= cout) continue;
+    const float bv = bias ? bias[col] : 0.f;
+    const float sc = ep.scale ? ep.scale[col] : 1.f;
+    const float sh = ep.shift ? ep.shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = s_row[wave * 16 + 4 * g + r];
+      if (row >= 0) {
+        float v = acc[t][r] + bv;
+        if (ep.scale) v = v * sc + sh;
+        if (ep.residual) v += ep.residual[(size_t)row * cout + col];
+        if (ep.relu) v = fmaxf(v, 0.f);
+        out[(size_t)row * cout + col] = v;
+      }
+    }
+  }
+}
+
 // Any-size fallback (and the cross-check in tests): one thread per (row, n), sequential k, c.
 __global__ __launch_bounds__(256) void k_conv_generic(const float* __restrict__ in, int cin,
                                                       const int32_t* __restrict__ nbr, int K,
@@ -461,9 +634,30 @@ int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirr
 }
 
 template <int CIN_P, int COUT_P>
+int launch_conv_bf16(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
+                     WStrides ws, const float* bias, float* out, int cout, int Mout,
+                     const int32_t* order, ConvEpilogue ep, hipStream_t stream) {
+  constexpr int CP = CIN_P < 32 ? 32 : CIN_P;
+  const size_t lds = (size_t)(kTM2 + COUT_P) * (CP + 8) * sizeof(unsigned short) +
+                     (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_bf16<CP, COUT_P>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  k_conv_mfma_bf16<CP, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(
+      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+template <int CIN_P, int COUT_P>
 int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
                 WStrides ws, const float* bias, float* out, int cout, int Mout,
                 const int32_t* order, ConvEpilogue ep, int algo, hipStream_t stream) {
+  if (K <= 32 && algo == 3)
+    return launch_conv_bf16<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, stream);
   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles
   if (K <= 32 && algo != 2)
     return launch_conv_v2<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, stream);
@@ -536,7 +730,7 @@ extern "C" int ud_spconv_conv(const float* in, const int32_t* nbr, const float* 
   WStrides ws{w_sn, w_sk, w_sc};
   const int cp = pad16(Cin), np = pad16(Cout);
   UdProfScope prof("spconv.k_conv", stream);
-  if (algo == 0 || algo == 2) {   // 0: v2 MFMA kernel, 2: first-generation 64-row MFMA kernel
+  if (algo == 0 || algo == 2 || algo == 3) {   // 0: fp32 MFMA, 2: first-generation kernel, 3: bf16 MFMA
 #define X(A, B) \
   if (cp == A && np == B) \
     return launch_conv<A, B>(in, Cin, nbr, K, mirror, W, ws, bias, out, Cout, Mout, row_order, ep, algo, stream);
@@ -570,7 +764,7 @@ extern "C" int ud_spconv_wgrad(const float* in, const int32_t* nbr, const float*
   if (!in || !nbr || !gout) return UD_ERR_INVALID_ARG;
   const int cp = pad16(Cin), np = pad16(Cout);
   UdProfScope prof("spconv.k_wgrad", stream);
-  if (algo == 0) {
+  if (algo != 1) {   // weight gradients accumulate in fp32 MFMA for every MFMA algo (0, 2, 3)
     int rpc;
     const int G = wgrad_chunks(Mout, &rpc);
     if (!workspace || workspace_bytes < ud_spconv_wgrad_workspace_bytes(Mout, K, Cin, Cout))

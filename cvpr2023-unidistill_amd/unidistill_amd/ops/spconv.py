@@ -147,7 +147,7 @@ def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0, scale=N
           residual=None, relu=False):
     Mout, K = nbr.shape
     out = torch.empty((Mout, cout), dtype=torch.float32, device=feat.device)
-    order = mask_order(nbr, mirror) if algo == 0 else None
+    order = mask_order(nbr, mirror) if algo in (0, 3) else None
     _lib.check(_lib.load().ud_spconv_conv(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(weight),
                                           w_strides[0], w_strides[1], w_strides[2],
                                           1 if mirror else 0, _lib.ptr(bias), _lib.ptr(out), Mout, K,
@@ -180,6 +180,14 @@ def can_fuse_inference(x, bn=None):
                           and bn.track_running_stats)
 
 
+def effective_algo(algo):
+    """Kernel choice for this call: under bf16 autocast the default MFMA path (0) becomes the
+    bf16-operand / fp32-accumulate kernel (3); explicit choices (1, 2, 3) are kept."""
+    if algo == 0 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return 3
+    return algo
+
+
 class _SparseConvFn(torch.autograd.Function):
     """out = conv(features; nbr, W, bias).  nbr_t / mirror describe the transposed rulebook."""
 
@@ -191,6 +199,7 @@ class _SparseConvFn(torch.autograd.Function):
         cout, cin = w.shape[0], w.shape[-1]
         K = nbr.shape[1]
         assert w.numel() == cout * K * cin and features.shape[1] == cin
+        algo = effective_algo(algo)
         out = _conv(features, nbr, w, (K * cin, cin, 1), False,
                     None if bias is None else bias.contiguous().float(), cin, cout, algo)
         ctx.save_for_backward(features, w, nbr, nbr_t)
@@ -391,7 +400,7 @@ class _SparseConvBase(SparseModule):
         with torch.no_grad():
             feats = _conv(x.features.detach().contiguous().float(), nbr, w, (K * cin, cin, 1), False,
                           None if self.bias is None else self.bias.detach().contiguous().float(),
-                          cin, cout, 0, scale, shift,
+                          cin, cout, effective_algo(0), scale, shift,
                           None if residual is None else residual.detach().contiguous().float(), relu)
         return SparseConvTensor(feats, None, None, None, _sites=out_sites, _indice_dict=x.indice_dict)
 

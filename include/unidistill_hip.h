@@ -225,7 +225,8 @@ int ud_spconv_down_rulebook(const void* in_index, int in_rows_sorted, int Min, i
  * Input gradient: in := gout, nbr := in_nbr (strided conv) or the subm rulebook with mirror = 1,
  * (w_sn, w_sk, w_sc) = (1, Cin, K*Cin), Cin/Cout swapped.  Exact-fp32 MFMA, deterministic.
  * algo 0 = auto (128-row MFMA kernel), 1 = generic VALU kernel (any channel counts),
- * 2 = first-generation 64-row MFMA kernel.
+ * 2 = first-generation 64-row MFMA kernel, 3 = bf16-input MFMA with fp32 accumulation
+ * (mixed-precision mode: operands are rounded to bf16 in LDS; tensors in HBM stay fp32).
  * Fused epilogue (MFMA kernel, algo 0): y = relu?((conv + bias) * ep_scale + ep_shift + ep_residual)
  * with ep_scale/ep_shift f32[Cout] (a folded eval-mode BatchNorm1d; both or neither),
  * ep_residual f32[Mout,Cout] (a SparseBasicBlock skip), ep_relu 0/1; pass NULL/0 to disable.

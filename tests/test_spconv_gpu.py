@@ -92,6 +92,49 @@ def test_conv_dgrad_wgrad_vs_oracle(cin, cout, algo):
     np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), gout.sum(0), rtol=1e-4, atol=1e-4)
 
 
+def _bf16(a):
+    """Round an fp32 array to bf16 (nearest even) and back -- what algo 3 does when it stages tiles."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 32), (32, 32), (64, 64), (64, 128), (128, 128), (7, 9)])
+def test_bf16_mfma_conv_equals_oracle_on_bf16_rounded_operands(cin, cout):
+    """algo 3 rounds activations and weights to bf16 and accumulates in fp32: it must match the
+    oracle fed the same rounded operands to fp32-accumulation accuracy (a far tighter check than
+    a bf16-sized tolerance against the unrounded result).  wgrad stays fp32."""
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(cin * 77 + cout)
+    shape = (2, 7, 18, 20)
+    coords = _sites(rng, *shape, 0.3)
+    M = len(coords)
+    feat = rng.standard_normal((M, cin)).astype(np.float32)
+    W = (rng.standard_normal((cout, 27, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    nbr = oracle.spconv_subm_rulebook(coords, shape, (3, 3, 3))
+    conv = sp.SubMConv3d(cin, cout, 3, padding=1, bias=True).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(W).view(cout, 3, 3, 3, cin))
+        conv.bias.copy_(torch.from_numpy(bias))
+    x = _tensor(coords, feat, shape)
+    x.features.requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):     # default algo 0 -> 3 under autocast
+        assert sp.effective_algo(0) == 3
+        y = conv(x)
+    assert y.features.dtype == torch.float32
+    ref = oracle.spconv_conv(_bf16(feat), nbr, _bf16(W), bias)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, **_tol(ref))
+    full = oracle.spconv_conv(feat, nbr, W, bias)
+    assert np.abs(y.features.detach().cpu().numpy() - full).max() < 3e-2 * max(1.0, np.abs(full).max())
+    gout = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(torch.from_numpy(gout).cuda())
+    ref_gin = oracle.spconv_conv(_bf16(gout), nbr, _bf16(W), mirror=True, transpose=True)
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), ref_gin, **_tol(ref_gin))
+    ref_gw = oracle.spconv_wgrad(feat, nbr, gout, cout)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(cout, 27, cin), ref_gw, **_tol(ref_gw))
+
+
 def test_strided_conv_and_dense_vs_torch_conv3d():
     """SparseConv3d + .dense() == dense conv3d evaluated on the reachable set; grads too."""
     from unidistill_amd.ops import spconv as sp

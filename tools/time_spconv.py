@@ -11,7 +11,9 @@ enc = LidarEncoder(C.LIDAR_ENCODER).to(dev).eval()
 g = syn.rng()
 pts = [torch.from_numpy(syn.lidar_cloud(g, 30000, sweeps)).to(dev) for _ in range(B)]
 n = min(p.shape[0] for p in pts); pts = [p[:n] for p in pts]
-with torch.no_grad():
+import contextlib
+ac = torch.autocast('cuda', dtype=torch.bfloat16) if os.environ.get('AC') == 'bf16' else contextlib.nullcontext()
+with torch.no_grad(), ac:
     for _ in range(3): enc(pts)
     torch.cuda.synchronize()
     _lib.prof_enable(True)
@@ -21,4 +23,4 @@ with torch.no_grad():
     e1.record(); torch.cuda.synchronize()
     _lib.prof_enable(False)
 ms, n = _lib.prof_read("spconv.k_conv")
-print(f"B={B} sweeps={sweeps}: encoder fwd {e0.elapsed_time(e1)/10:.2f} ms; spconv.k_conv total {ms/10:.2f} ms/fwd over {n//10} convs")
+print(f"AC={os.environ.get('AC')} B={B} sweeps={sweeps}: encoder fwd {e0.elapsed_time(e1)/10:.2f} ms; spconv.k_conv total {ms/10:.2f} ms/fwd over {n//10} convs")
