@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from ..dist import reduce_mean, reduce_mean_many
+from ..ops import head_tail
 
 
 # --------------------------------------------------------------------------------------------
@@ -317,6 +318,7 @@ class PackedSepHeads(nn.Module):
         self.c2_weight = nn.Parameter(torch.zeros(G * self.kmax, hc, final_kernel, final_kernel))
         self.c2_bias = nn.Parameter(torch.zeros(G * self.kmax))
         self.bn_eps, self.bn_momentum = 1e-5, 0.1
+        self.fused_tail = True      # HIP tail kernel when the hidden tensor is CUDA bf16
         self.register_buffer("_c2_rows", torch.arange(G * self.kmax), persistent=False)
         self.register_buffer("_c2_grp", torch.arange(G * self.kmax) // self.kmax, persistent=False)
         # initialise exactly like the reference's per-head modules (center_head.py:323-362)
@@ -346,19 +348,30 @@ class PackedSepHeads(nn.Module):
         y = torch.nn.functional.conv2d(x, self.c1_weight, self.c1_bias, padding=pad)
         if self.training:
             self.bn_num_batches_tracked += 1
+        G = len(self.layout)
+        frozen_bn_grad = (not self.training) and torch.is_grad_enabled() and y.requires_grad
+        if self.fused_tail and head_tail.supported(y, self.head_conv, self.kmax, self.k) and not frozen_bn_grad:
+            # bf16 mixed-precision mode on the GPU: BN + ReLU + all 42 second convs in one HBM-bound
+            # kernel (ops/head_tail.py); y is read once instead of 3 r/w passes + a 42x padded conv
+            z = head_tail.head_tail(y, self.bn_weight, self.bn_bias, self.c2_weight, self.c2_bias,
+                                    self.bn_running_mean, self.bn_running_var, self.training,
+                                    self.bn_momentum, self.bn_eps, G, self.kmax)
+            return self._split(z)
         y = torch.nn.functional.batch_norm(y, self.bn_running_mean, self.bn_running_var, self.bn_weight,
                                            self.bn_bias, self.training, self.bn_momentum, self.bn_eps)
         y = torch.relu(y)
         # second layer: ONE dense conv with a block-diagonal weight built from the compact per-head
         # parameters (rows padded to a multiple of 64).  A 42-group conv with 3 outputs per group is
         # ~5x slower in MIOpen/CK than the dense conv despite 42x fewer FLOPs (tools/exp_gconv.py).
-        G = len(self.layout)
         rows = G * self.kmax
         rows_p = (rows + 63) // 64 * 64
         wd = self.c2_weight.new_zeros(rows_p, G, self.head_conv, self.k, self.k)
         wd = wd.index_put((self._c2_rows, self._c2_grp), self.c2_weight)
         bd = torch.nn.functional.pad(self.c2_bias, (0, rows_p - rows))
         z = torch.nn.functional.conv2d(y, wd.view(rows_p, G * self.head_conv, self.k, self.k), bd, padding=pad)
+        return self._split(z)
+
+    def _split(self, z):
         outs = [dict() for _ in range(self.num_tasks)]
         for g, (t, name, kout) in enumerate(self.layout):
             outs[t][name] = z[:, g * self.kmax:g * self.kmax + kout]

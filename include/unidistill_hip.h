@@ -308,6 +308,33 @@ int ud_distill_resp_bwd(const float* const* s_hm, const float* const* t_hm, floa
                         float clamp_hi, const float* gscale_cls, const float* gscale_reg,
                         ud_stream_t stream);
 
+/* ---- Detection-head tail: BatchNorm -> ReLU -> per-head 3x3 conv (64 -> k) --------------------------
+ * Replaces modules 1..3 of every SepHead stack (reference unidistill/layers/head/det3d/
+ * center_head.py:311-362: nn.Sequential(Conv 64->64, BatchNorm2d, ReLU, Conv 64->k)) for all
+ * G = tasks x heads packed heads at once, on the hidden tensor produced by the packed first conv.
+ *   y, dy : [B][H][W][G*64] bf16, channels-last.          z, dz : [B][G*kmax][H][W] fp32.
+ *   w2, dw2 : [G][kmax][9][64] fp32 (tap = ky*3 + kx), rows j >= a head's real k are zero.
+ *   per-channel vectors (gamma, beta, mean, var, invstd, scale, shift, dgamma, dbeta): fp32 [G*64].
+ * kmax <= 3 (UD_ERR_UNSUPPORTED otherwise).  BN + ReLU are applied while tiles are staged, the conv
+ * multiplies bf16 operands with fp32 accumulation (same arithmetic as the bf16 autocast library path).
+ *   ud_head_tail_stats : training-mode batch statistics of y -> mean, biased var, invstd and the
+ *                        folded scale = gamma*invstd, shift = beta - mean*scale.
+ *   ud_head_tail_fwd   : z = conv(relu(y*scale + shift), w2) + b2   (any scale/shift: batch or running).
+ *   ud_head_tail_bwd   : training-mode backward through conv, ReLU and BatchNorm: dy, dw2, dgamma,
+ *                        dbeta (db2 = sum of dz is left to the caller).  Deterministic. */
+size_t ud_head_tail_workspace_bytes(int G);
+int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* gamma,
+                       const float* beta, float eps, float* mean, float* var, float* invstd,
+                       float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                       ud_stream_t stream);
+int ud_head_tail_fwd(const void* y, const float* scale, const float* shift, const float* w2,
+                     const float* b2, float* z, int B, int H, int W, int G, int kmax,
+                     ud_stream_t stream);
+int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, void* dy,
+                     float* dw2, float* dgamma, float* dbeta, int B, int H, int W, int G, int kmax,
+                     void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

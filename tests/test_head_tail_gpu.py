@@ -1,0 +1,109 @@
+"""Detection-head tail (BN -> ReLU -> per-head conv) on the GPU vs a plain PyTorch fp32 composition
+of the reference's modules (center_head.py:311-362: BatchNorm2d, ReLU, Conv2d per head)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    return t.bfloat16().float()
+
+
+def _reference(y, gamma, beta, w2, b2, G, kmax, training, rm, rv, eps=1e-5, round_act=True):
+    """fp32 torch: grouped conv over relu(bn(y)); activations/weights rounded to bf16 like the kernel."""
+    a = F.relu(F.batch_norm(y, rm, rv, gamma, beta, training, 0.1, eps))
+    if round_act:
+        a = a + (_bf16(a) - a).detach()          # straight-through rounding
+        w = w2 + (_bf16(w2) - w2).detach()
+    else:
+        w = w2
+    return F.conv2d(a, w, b2, padding=1, groups=G)
+
+
+def _case(B, H, W, G, kmax, seed):
+    g = torch.Generator().manual_seed(seed)
+    y = (torch.randn(B, G * 64, H, W, generator=g) * 1.5 + 0.3).bfloat16()
+    gamma = torch.rand(G * 64, generator=g) + 0.5
+    beta = torch.randn(G * 64, generator=g) * 0.2
+    w2 = torch.randn(G * kmax, 64, 3, 3, generator=g) * 0.05
+    if G * kmax > 1:
+        w2[1] = 0                                     # a head narrower than kmax keeps zero rows
+    b2 = torch.randn(G * kmax, generator=g)
+    return y, gamma, beta, w2, b2
+
+
+@pytest.mark.parametrize("B,H,W,G,kmax", [(2, 20, 36, 3, 3), (1, 16, 16, 2, 2), (3, 33, 17, 1, 1)])
+@pytest.mark.parametrize("training", [True, False])
+def test_head_tail_forward(hip_lib, B, H, W, G, kmax, training):
+    from unidistill_amd.ops import head_tail as ht
+    y, gamma, beta, w2, b2 = _case(B, H, W, G, kmax, 5)
+    rm, rv = torch.randn(G * 64) * 0.1, torch.rand(G * 64) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = _reference(y.float(), gamma, beta, w2, b2, G, kmax, training, rm_ref, rv_ref)
+    dev = torch.device("cuda:0")
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    yd = y.to(dev).contiguous(memory_format=torch.channels_last)
+    z = ht.head_tail(yd, gamma.to(dev), beta.to(dev), w2.to(dev), b2.to(dev), rm_d, rv_d, training,
+                     0.1, 1e-5, G, kmax)
+    assert z.dtype == torch.float32 and z.shape == ref.shape
+    # fp32 accumulation of bf16 products; a bf16 ulp flip of an activation moves z by ~1e-3
+    np.testing.assert_allclose(z.cpu().numpy(), ref.numpy(), rtol=0, atol=4e-3 * float(ref.abs().max()))
+    if training:   # nn.BatchNorm2d running-statistics bookkeeping
+        np.testing.assert_allclose(rm_d.cpu().numpy(), rm_ref.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rv_d.cpu().numpy(), rv_ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,G,kmax", [(2, 20, 36, 3, 3), (1, 35, 18, 2, 2)])
+def test_head_tail_backward(hip_lib, B, H, W, G, kmax):
+    from unidistill_amd.ops import head_tail as ht
+    y, gamma, beta, w2, b2 = _case(B, H, W, G, kmax, 9)
+    leaves = [t.clone().requires_grad_(True) for t in (y.float(), gamma, beta, w2, b2)]
+    ref = _reference(*leaves, G, kmax, True, None, None, round_act=False)
+    gz = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    ref.backward(gz)
+    dev = torch.device("cuda:0")
+    yd = y.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    prm = [t.to(dev).requires_grad_(True) for t in (gamma, beta, w2, b2)]
+    z = ht.head_tail(yd, prm[0], prm[1], prm[2], prm[3], None, None, True, 0.1, 1e-5, G, kmax)
+    z.backward(gz.to(dev))
+    assert yd.grad.dtype == torch.bfloat16 and yd.grad.is_contiguous(memory_format=torch.channels_last)
+    got = [yd.grad.float()] + [p.grad for p in prm]
+    for name, a, r in zip(("dy", "dgamma", "dbeta", "dw2", "db2"), got, [l.grad for l in leaves]):
+        tol = 2e-2 * float(r.abs().max())       # bf16 operands (dz, w2, activations) + bf16 dy
+        np.testing.assert_allclose(a.cpu().numpy(), r.numpy(), rtol=0, atol=tol, err_msg=name)
+    # deterministic: a second backward gives the same bits
+    yd.grad = None
+    for p in prm:
+        p.grad = None
+    z2 = ht.head_tail(yd, prm[0], prm[1], prm[2], prm[3], None, None, True, 0.1, 1e-5, G, kmax)
+    z2.backward(gz.to(dev))
+    assert torch.equal(z2, z) and torch.equal(yd.grad.float(), got[0]) and torch.equal(prm[2].grad, got[3])
+
+
+def test_packed_heads_fused_tail_matches_library_path(hip_lib):
+    """PackedSepHeads with the HIP tail == the same module on the MIOpen path (bf16 autocast)."""
+    from unidistill_amd.layers.center_head import PackedSepHeads
+    torch.manual_seed(0)
+    heads = [{"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "hm": (2, 2)}, {"reg": (2, 2), "hm": (1, 2)}]
+    m = PackedSepHeads(64, heads).cuda()
+    with torch.no_grad():
+        m.c2_weight.mul_(0).add_(torch.randn_like(m.c2_weight) * 0.05 * (m.c2_weight != 0).any(dim=(1, 2, 3), keepdim=True))
+    x = torch.randn(2, 64, 24, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for fused in (True, False):
+        m.fused_tail = fused
+        m.zero_grad()
+        xs = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            o = m(xs)
+        loss = sum((v.float() ** 2).mean() for d in o for v in d.values())
+        loss.backward()
+        outs[fused] = ([v.float() for d in o for v in d.values()], xs.grad.float(), m.c1_weight.grad.clone(),
+                       m.bn_weight.grad.clone(), m.c2_weight.grad.clone())
+    for a, b in zip(outs[True][0], outs[False][0]):
+        assert torch.allclose(a, b, rtol=0, atol=2e-2 * float(b.detach().abs().max()) + 1e-3)
+    for a, b in zip(outs[True][1:], outs[False][1:]):
+        assert torch.allclose(a, b, rtol=0, atol=4e-2 * float(b.detach().abs().max()) + 1e-6)
