@@ -30,8 +30,8 @@ constexpr int kQ = kHalo * kHalo;    // 324 staged pixels
 constexpr int kPix = kHC + 8;        // bf16 elements per staged pixel: 144 B rows keep b128 reads spread
 constexpr int kMaxOut = 3;           // outputs per head handled by the MFMA packing (27 <= 32)
 constexpr int kA2 = 40;              // bf16 elements per pixel of the (j,tap) image (32 + pad)
-constexpr int kWgradSlices = 16;
-constexpr int kBwdSlices = 32;
+constexpr int kWgradSlices = 12;   // 42 heads x 12 = 504 persistent blocks <= 2 per CU
+constexpr int kBwdSlices = 96;
 constexpr int kStatSlices = 64;
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -44,12 +44,7 @@ struct TailGeom {
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua += 0x7FFFu + ((ua >> 16) & 1u);
-  ub += 0x7FFFu + ((ub >> 16) & 1u);
-  return (ua >> 16) | (ub & 0xFFFF0000u);
-}
+__device__ __forceinline__ unsigned pack2(float a, float b) { return ud_pack_bf16x2(a, b); }
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   union { unsigned u[4]; bf16x8 h; } r;
   r.u[0] = pack2(v[0], v[1]); r.u[1] = pack2(v[2], v[3]);
@@ -57,40 +52,90 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   return r.h;
 }
 
-// Stage ReLU(y*scale+shift) of one 18x18 halo tile of head g into LDS as bf16 [q][kPix].
-// Pixels outside the image are the conv's zero padding (applied AFTER BN+ReLU, as in the reference).
-__device__ __forceinline__ void stage_activation_tile(const unsigned short* __restrict__ y,
-                                                      const float* __restrict__ scale,
-                                                      const float* __restrict__ shift,
-                                                      const TailGeom& gm, int b, int g, int ty0,
-                                                      int tx0, unsigned short* img) {
+// Stage ReLU(y*scale+shift) of one 18x18 halo tile of head g into LDS as bf16: [q][kPix] rows
+// (TRANSPOSED = false, A operand of the forward conv) or [c][kRS] columns (TRANSPOSED = true, the
+// pixel-contiguous operand of the weight-gradient GEMM).  All global loads are issued before the
+// first use so a block pays one HBM latency per tile, not eleven.  Pixels outside the image are the
+// conv's zero padding (applied AFTER BN+ReLU, as in the reference).
+constexpr int kStageIters = (kQ * 8 + 255) / 256;   // 11
+constexpr int kRS = 360;                            // bf16 elements per row of the transposed images
+
+struct TileLoads {
+  uint4 raw[kStageIters];
+  unsigned inside;
+};
+
+__device__ __forceinline__ void issue_tile_loads(const unsigned short* __restrict__ y,
+                                                 const TailGeom& gm, int b, int g, int ty0, int tx0,
+                                                 TileLoads& ld) {
   const int tid = threadIdx.x, chunk = tid & 7;
-  float s[8], t[8];
+  ld.inside = 0u;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    s[e] = scale[g * kHC + chunk * 8 + e];
-    t[e] = shift[g * kHC + chunk * 8 + e];
-  }
-  for (int idx = tid; idx < kQ * 8; idx += 256) {
-    const int q = idx >> 3;
+  for (int it = 0; it < kStageIters; ++it) {
+    const int q = (tid + 256 * it) >> 3;
     const int qy = q / kHalo, qx = q - qy * kHalo;
     const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
-    uint4 o = make_uint4(0u, 0u, 0u, 0u);
-    if (gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(
+    ld.raw[it] = make_uint4(0u, 0u, 0u, 0u);
+    if (q < kQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W) {
+      ld.inside |= 1u << it;
+      ld.raw[it] = *reinterpret_cast<const uint4*>(
           y + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.C + g * kHC + chunk * 8);
-      const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-      unsigned r[4];
+    }
+  }
+}
+
+template <bool TRANSPOSED>
+__device__ __forceinline__ void commit_tile(const TileLoads& ld, const float* s, const float* t,
+                                            unsigned short* img) {
+  const int tid = threadIdx.x, chunk = tid & 7;
+#pragma unroll
+  for (int it = 0; it < kStageIters; ++it) {
+    const int q = (tid + 256 * it) >> 3;
+    if (q >= kQ) break;
+    const unsigned w[4] = {ld.raw[it].x, ld.raw[it].y, ld.raw[it].z, ld.raw[it].w};
+    unsigned r[4] = {0u, 0u, 0u, 0u};
+    if ((ld.inside >> it) & 1u) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float lo = fmaxf(fmaf(bf_lo(w[i]), s[2 * i], t[2 * i]), 0.f);
         const float hi = fmaxf(fmaf(bf_hi(w[i]), s[2 * i + 1], t[2 * i + 1]), 0.f);
         r[i] = pack2(lo, hi);
       }
-      o = make_uint4(r[0], r[1], r[2], r[3]);
     }
-    *reinterpret_cast<uint4*>(img + q * kPix + chunk * 8) = o;
+    if (TRANSPOSED) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        img[(chunk * 8 + 2 * i) * kRS + q] = (unsigned short)(r[i] & 0xFFFFu);
+        img[(chunk * 8 + 2 * i + 1) * kRS + q] = (unsigned short)(r[i] >> 16);
+      }
+    } else {
+      *reinterpret_cast<uint4*>(img + q * kPix + chunk * 8) = make_uint4(r[0], r[1], r[2], r[3]);
+    }
   }
+}
+
+__device__ __forceinline__ void load_chunk_constants(const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int g,
+                                                     float* s, float* t) {
+  const int chunk = threadIdx.x & 7;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s[e] = scale[g * kHC + chunk * 8 + e];
+    t[e] = shift[g * kHC + chunk * 8 + e];
+  }
+}
+
+template <bool TRANSPOSED>
+__device__ __forceinline__ void stage_activation_tile(const unsigned short* __restrict__ y,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift,
+                                                      const TailGeom& gm, int b, int g, int ty0,
+                                                      int tx0, unsigned short* img) {
+  TileLoads ld;
+  issue_tile_loads(y, gm, b, g, ty0, tx0, ld);
+  float s[8], t[8];
+  load_chunk_constants(scale, shift, g, s, t);
+  commit_tile<TRANSPOSED>(ld, s, t, img);
 }
 
 // ---- forward -------------------------------------------------------------------------------------
@@ -101,27 +146,17 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const unsigned short* __restri
                                                   const float* __restrict__ b2,
                                                   float* __restrict__ z, TailGeom gm) {
   __shared__ __attribute__((aligned(16))) unsigned short img[kQ * kPix];
+  __shared__ __attribute__((aligned(16))) unsigned short wl[kMaxOut * 9 * kHC];
   const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
   const int ty0 = (tile / gm.tiles_x) * kT, tx0 = (tile % gm.tiles_x) * kT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kg = lane >> 4;
-  // weight fragments: B operand, column n = output j, k = 8*kg+e within the (tap, half) slice
-  bf16x8 wf[9][2];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (n < gm.kmax) {
-        const float* src = w2 + ((size_t)(g * gm.kmax + n) * 9 + tap) * kHC + 32 * h + 8 * kg;
-        const float4 a = *reinterpret_cast<const float4*>(src);
-        const float4 c = *reinterpret_cast<const float4*>(src + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-      }
-      wf[tap][h] = pack8(v);
-    }
-  stage_activation_tile(y, scale, shift, gm, b, g, ty0, tx0, img);
+  stage_activation_tile<false>(y, scale, shift, gm, b, g, ty0, tx0, img);
+  // weights of the (<= 3) real outputs as bf16 in LDS; MFMA columns n >= kmax multiply zeros
+  for (int idx = threadIdx.x; idx < gm.kmax * 9 * kHC / 2; idx += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(w2 + (size_t)g * gm.kmax * 9 * kHC + 2 * idx);
+    reinterpret_cast<unsigned*>(wl)[idx] = pack2(v.x, v.y);
+  }
   __syncthreads();
   const float bias = (n < gm.kmax) ? b2[g * gm.kmax + n] : 0.f;
   const int Cz = gm.G * gm.kmax;
@@ -136,7 +171,9 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const unsigned short* __restri
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + q * kPix + 32 * h + 8 * kg);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[tap][h], acc, 0, 0, 0);
+        bf16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n < gm.kmax) w = *reinterpret_cast<const bf16x8*>(wl + (n * 9 + tap) * kHC + 32 * h + 8 * kg);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
       }
     }
     if (n < gm.kmax) {
@@ -211,70 +248,82 @@ __global__ void k_stats_final(const unsigned short* __restrict__ y, const float*
 }
 
 // ---- weight gradient of the per-head conv --------------------------------------------------------
-// dW2[g][j][tap][c] = sum_p dz[j][p] * a[p + tap][c]; persistent blocks (slice, g) walk the tiles
-// and keep all 27 x 64 sums in registers (thread = channel pair x pixel group).
+// dW2[g][j][tap][c] = sum_p dz[j][p] * a[p + tap][c] as one GEMM per tile with the staged pixels q as
+// the reduction index:  D[c][(j,tap)] += sum_q aT[c][q] * dT[(j,tap)][q],  dT[(j,tap)][q] = dz[j][q - tap]
+// (zero unless q - tap is a pixel of this tile).  Both operands are pixel-contiguous bf16 images in
+// LDS; wave w owns channels 16w..16w+15 and keeps its 16 x 32 accumulators across all tiles of the
+// persistent block (slice, g).
+constexpr int kKSteps = (kQ + 31) / 32;             // 11 (q padded to 352 <= kRS)
+
 __global__ __launch_bounds__(256) void k_tail_wgrad(const unsigned short* __restrict__ y,
                                                     const float* __restrict__ scale,
                                                     const float* __restrict__ shift,
                                                     const float* __restrict__ dz,
                                                     float* __restrict__ partial, TailGeom gm) {
-  __shared__ __attribute__((aligned(16))) unsigned short img[kQ * kPix];
-  __shared__ __attribute__((aligned(16))) float dzs[kT * kT][4];
-  const int g = blockIdx.y, tid = threadIdx.x;
-  const int cp = tid & 31, pg = tid >> 5;
+  __shared__ __attribute__((aligned(16))) unsigned short aT[kHC * kRS];
+  __shared__ __attribute__((aligned(16))) unsigned short dT[32 * kRS];
+  __shared__ float dzs[kMaxOut][kT * kT];
+  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kg = lane >> 4;
   const int Cz = gm.G * gm.kmax;
-  float acc[9][3][2];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc[t][j][0] = acc[t][j][1] = 0.f;
+  for (int idx = tid; idx < kHC * (kRS - kQ); idx += 256)          // K padding columns stay zero
+    aT[(idx / (kRS - kQ)) * kRS + kQ + idx % (kRS - kQ)] = 0;
+  for (int idx = tid; idx < 32 * kRS; idx += 256) dT[idx] = 0;      // padding columns and rows 27..31
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const int total = gm.B * gm.tiles();
-  for (int it = blockIdx.x; it < total; it += gridDim.x) {
+  float cs[8], ct[8];
+  load_chunk_constants(scale, shift, g, cs, ct);
+  TileLoads ld;
+  float dzr[kMaxOut];
+  // loads of tile `it` (y pieces + this thread's dz pixel) -> registers
+  auto issue = [&](int it) {
     const int b = it / gm.tiles(), tile = it - b * gm.tiles();
     const int ty0 = (tile / gm.tiles_x) * kT, tx0 = (tile % gm.tiles_x) * kT;
+    issue_tile_loads(y, gm, b, g, ty0, tx0, ld);
+    const int gy = ty0 + (tid >> 4), gx = tx0 + (tid & 15);
+    const bool in = gy < gm.H && gx < gm.W;
+#pragma unroll
+    for (int j = 0; j < kMaxOut; ++j)
+      dzr[j] = (in && j < gm.kmax)
+                   ? dz[((size_t)(b * Cz + g * gm.kmax + j) * gm.H + gy) * gm.W + gx] : 0.f;
+  };
+  if ((int)blockIdx.x < total) issue(blockIdx.x);
+  for (int it = blockIdx.x; it < total; it += gridDim.x) {
     __syncthreads();                                   // previous tile fully consumed
-    stage_activation_tile(y, scale, shift, gm, b, g, ty0, tx0, img);
-    {
-      const int ly = tid >> 4, lx = tid & 15, gy = ty0 + ly, gx = tx0 + lx;
-      float v[3] = {0.f, 0.f, 0.f};
-      if (gy < gm.H && gx < gm.W)
-        for (int j = 0; j < gm.kmax; ++j)
-          v[j] = dz[((size_t)(b * Cz + g * gm.kmax + j) * gm.H + gy) * gm.W + gx];
-      *reinterpret_cast<float4*>(dzs[tid]) = make_float4(v[0], v[1], v[2], 0.f);
+#pragma unroll
+    for (int j = 0; j < kMaxOut; ++j) dzs[j][tid] = dzr[j];
+    commit_tile<true>(ld, cs, ct, aT);
+    if (it + (int)gridDim.x < total) issue(it + gridDim.x);   // next tile's HBM latency hides below
+    __syncthreads();
+    for (int idx = tid; idx < 27 * kQ; idx += 256) {
+      const int k = idx / kQ, q = idx - k * kQ;
+      const int j = k / 9, tap = k - j * 9;
+      const int qy = q / kHalo, qx = q - qy * kHalo;
+      const int py = qy - tap / 3, px = qx - tap % 3;  // tile pixel whose (tap)-neighbour is q
+      float v = 0.f;
+      if (py >= 0 && py < kT && px >= 0 && px < kT) v = dzs[j][py * kT + px];
+      dT[k * kRS + q] = (unsigned short)(pack2(v, 0.f) & 0xFFFFu);
     }
     __syncthreads();
-#pragma unroll 2
-    for (int i = 0; i < 32; ++i) {
-      const int p = pg * 32 + i, ly = p >> 4, lx = p & 15;
-      const float4 d = *reinterpret_cast<const float4*>(dzs[p]);
-      const unsigned short* base = img + (ly * kHalo + lx) * kPix + 2 * cp;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const unsigned u = *reinterpret_cast<const unsigned*>(base + ((tap / 3) * kHalo + tap % 3) * kPix);
-        const float a0 = bf_lo(u), a1 = bf_hi(u);
-        acc[tap][0][0] += d.x * a0; acc[tap][0][1] += d.x * a1;
-        acc[tap][1][0] += d.y * a0; acc[tap][1][1] += d.y * a1;
-        acc[tap][2][0] += d.z * a0; acc[tap][2][1] += d.z * a1;
+    for (int ks = 0; ks < kKSteps; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(aT + (16 * wave + n) * kRS + 32 * ks + 8 * kg);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(dT + (16 * nt + n) * kRS + 32 * ks + 8 * kg);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nt], 0, 0, 0);
       }
     }
   }
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(img);          // [4 waves][27][64]
-  const int wave = tid >> 6;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int nt = 0; nt < 2; ++nt) {
+    const int k = 16 * nt + n, j = k / 9, tap = k - j * 9;
+    if (k < 27 && j < gm.kmax) {
+      float* dst = partial + ((((size_t)blockIdx.x * gm.G + g) * gm.kmax + j) * 9 + tap) * kHC +
+                   16 * wave + 4 * kg;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float v = acc[tap][j][e];
-        v += __shfl_xor(v, 32);
-        if ((tid & 63) < 32) red[(wave * 27 + j * 9 + tap) * kHC + 2 * cp + e] = v;
-      }
-  __syncthreads();
-  for (int idx = tid; idx < gm.kmax * 9 * kHC; idx += 256) {
-    const float v = (red[idx] + red[27 * kHC + idx]) + (red[2 * 27 * kHC + idx] + red[3 * 27 * kHC + idx]);
-    partial[((size_t)blockIdx.x * gm.G + g) * gm.kmax * 9 * kHC + idx] = v;
+      for (int r = 0; r < 4; ++r) dst[r] = acc[nt][r];
+    }
   }
 }
 
@@ -317,17 +366,28 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const unsigned short* __restri
     }
     wfr[t] = pack8(v);
   }
+  // per-channel constants of this head, staged once: [scale, shift, mean|k0, k2][64]
+  __shared__ __attribute__((aligned(16))) float cst_s[4][kHC];
+  if (tid < kHC) {
+    const int c = g * kHC + tid;
+    cst_s[0][tid] = cst.scale[c];
+    cst_s[1][tid] = cst.shift[c];
+    cst_s[2][tid] = WRITE_DY ? cst.k0[c] : cst.mean[c];
+    cst_s[3][tid] = WRITE_DY ? cst.k2[c] : 0.f;
+  }
+  // WRITE_DY keeps both channel halves of a pixel together (full 128-byte lines are written at once),
+  // so its constants live in registers; the reduction variant walks one half at a time from LDS.
   // per-lane channel constants: channels 32*u + 8*gq + e  (index u*8+e)
-  float cs[16], ct[16], c3[16], c4[16];
+  float rcs[16], rct[16], rc3[16], rc4[16];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = g * kHC + 32 * u + 8 * gq + e;
-      cs[u * 8 + e] = cst.scale[c];
-      ct[u * 8 + e] = cst.shift[c];
-      c3[u * 8 + e] = WRITE_DY ? cst.k0[c] : cst.mean[c];
-      c4[u * 8 + e] = WRITE_DY ? cst.k2[c] : 0.f;
+      rcs[u * 8 + e] = cst.scale[c];
+      rct[u * 8 + e] = cst.shift[c];
+      rc3[u * 8 + e] = WRITE_DY ? cst.k0[c] : cst.mean[c];
+      rc4[u * 8 + e] = WRITE_DY ? cst.k2[c] : 0.f;
     }
   float s1[16], s2[16];
 #pragma unroll
@@ -361,6 +421,7 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const unsigned short* __restri
         *reinterpret_cast<bf16x8*>(a2 + tid * kA2 + 8 * c) = pack8(v + 8 * c);
     }
     __syncthreads();
+    if constexpr (WRITE_DY) {
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       const int ly = wave * 4 + rr, gy = ty0 + ly, gx = tx0 + n;
@@ -384,12 +445,12 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const unsigned short* __restri
             const float yv = (e & 1) ? bf_hi(w[e >> 1]) : bf_lo(w[e >> 1]);
             const float da = d[2 * u + (e >> 2)][e & 3];
             const int i = u * 8 + e;
-            const float dr = (fmaf(yv, cs[i], ct[i]) > 0.f) ? da : 0.f;
+            const float dr = (fmaf(yv, rcs[i], rct[i]) > 0.f) ? da : 0.f;
             if (WRITE_DY) {
-              out[e] = fmaf(cs[i], dr, fmaf(c4[i], yv, c3[i]));
+              out[e] = fmaf(rcs[i], dr, fmaf(rc4[i], yv, rc3[i]));
             } else {
               s1[i] += dr;
-              s2[i] += dr * (yv - c3[i]);
+              s2[i] += dr * (yv - rc3[i]);
             }
           }
           if (WRITE_DY) {
@@ -399,6 +460,65 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const unsigned short* __restri
           }
         }
       }
+    }
+    } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                      // channels 32u + 8gq .. +7 of this lane
+      uint4 raw[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {                 // the wave's four rows in flight together
+        const int gy = ty0 + wave * 4 + rr, gx = tx0 + n;
+        raw[rr] = make_uint4(0u, 0u, 0u, 0u);
+        if (gy < gm.H && gx < gm.W)
+          raw[rr] = *reinterpret_cast<const uint4*>(
+              y + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.C + g * kHC + 32 * u + 8 * gq);
+      }
+      float cs[8], ct[8], c3[8], c4[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c0 = 32 * u + 8 * gq + 4 * h;
+        const float4 a0 = *reinterpret_cast<const float4*>(&cst_s[0][c0]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&cst_s[1][c0]);
+        const float4 a2v = *reinterpret_cast<const float4*>(&cst_s[2][c0]);
+        const float4 a3 = *reinterpret_cast<const float4*>(&cst_s[3][c0]);
+        cs[4 * h] = a0.x; cs[4 * h + 1] = a0.y; cs[4 * h + 2] = a0.z; cs[4 * h + 3] = a0.w;
+        ct[4 * h] = a1.x; ct[4 * h + 1] = a1.y; ct[4 * h + 2] = a1.z; ct[4 * h + 3] = a1.w;
+        c3[4 * h] = a2v.x; c3[4 * h + 1] = a2v.y; c3[4 * h + 2] = a2v.z; c3[4 * h + 3] = a2v.w;
+        c4[4 * h] = a3.x; c4[4 * h + 1] = a3.y; c4[4 * h + 2] = a3.z; c4[4 * h + 3] = a3.w;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int ly = wave * 4 + rr, gy = ty0 + ly, gx = tx0 + n;
+        if (gy >= gm.H) break;
+        const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(a2 + (ly * kT + n) * kA2 + 8 * gq);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 d[2];
+        d[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[2 * u], bfrag, zero, 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[2 * u + 1], bfrag, zero, 0, 0, 0);
+        if (gx < gm.W) {
+          const unsigned w[4] = {raw[rr].x, raw[rr].y, raw[rr].z, raw[rr].w};
+          float out[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float yv = (e & 1) ? bf_hi(w[e >> 1]) : bf_lo(w[e >> 1]);
+            const float da = d[e >> 2][e & 3];
+            const float dr = (fmaf(yv, cs[e], ct[e]) > 0.f) ? da : 0.f;
+            if (WRITE_DY) {
+              out[e] = fmaf(cs[e], dr, fmaf(c4[e], yv, c3[e]));
+            } else {
+              s1[u * 8 + e] += dr;
+              s2[u * 8 + e] += dr * (yv - c3[e]);
+            }
+          }
+          if (WRITE_DY) {
+            const uint4 o = make_uint4(pack2(out[0], out[1]), pack2(out[2], out[3]),
+                                       pack2(out[4], out[5]), pack2(out[6], out[7]));
+            *reinterpret_cast<uint4*>(dy + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.C + g * kHC +
+                                      32 * u + 8 * gq) = o;
+          }
+        }
+      }
+    }
     }
   }
   if (!WRITE_DY) {
@@ -554,7 +674,7 @@ int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const floa
   }
   {
     UdProfScope prof("head_tail.k_dy", stream);
-    k_tail_bwd<true><<<dim3(kBwdSlices * 4, G), 256, 0, stream>>>((const unsigned short*)y, dz, w2, cst,
+    k_tail_bwd<true><<<dim3(128, G), 256, 0, stream>>>((const unsigned short*)y, dz, w2, cst,
                                                                   (unsigned short*)dy, nullptr, gm);
     UD_LAUNCH_CHECK();
   }

@@ -322,12 +322,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
 // stay fp32.  Used when the caller runs under bf16 autocast; NOT bit-compatible with the fp32 path.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua += 0x7FFFu + ((ua >> 16) & 1u);   // round to nearest even
-  ub += 0x7FFFu + ((ub >> 16) & 1u);
-  return (ua >> 16) | (ub & 0xFFFF0000u);
-}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) { return ud_pack_bf16x2(a, b); }
 
 template <int CIN_P, int COUT_P>   // CIN_P multiple of 32
 __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict__ in, int cin,
@@ -434,11 +429,8 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict_
           for (int q = 0; q < 4; ++q)
             if (n4 + q < cout) v[q] = src[(n4 + q) * ws.sn];
         }
-        for (int q = 0; q < 4; ++q) {
-          unsigned u32 = __float_as_uint(v[q]);
-          u32 += 0x7FFFu + ((u32 >> 16) & 1u);
-          Bs[(n4 + q) * LDB + c] = (unsigned short)(u32 >> 16);
-        }
+        for (int q = 0; q < 4; ++q)
+          Bs[(n4 + q) * LDB + c] = (unsigned short)(ud_pack_bf16x2(v[q], 0.f) & 0xFFFFu);
       }
     }
   };

@@ -58,6 +58,14 @@ __device__ __forceinline__ void ud_stg_stream(float* p, const float4& v) {
   __builtin_nontemporal_store(t, reinterpret_cast<ud_vf4*>(p));
 }
 
+// Two floats -> packed bf16 pair (round to nearest even) in ONE v_cvt_pk_bf16_f32; a in the low half.
+typedef float ud_vf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ud_vbf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ud_pack_bf16x2(float a, float b) {
+  const ud_vf2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ud_vbf2));
+}
+
 __device__ __forceinline__ int ud_wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
