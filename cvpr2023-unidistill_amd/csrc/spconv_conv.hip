@@ -331,7 +331,11 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict_
                                                         WStrides ws, const float* __restrict__ bias,
                                                         float* __restrict__ out, int cout, int Mout,
                                                         const int32_t* __restrict__ order,
-                                                        ConvEpilogue ep) {
+                                                        ConvEpilogue ep, int io) {
+  // io bit 0: `in` holds bf16 rows; bit 1: `out` and ep.residual hold bf16; bit 2: W holds bf16
+  const bool in_bf = io & 1, out_bf = io & 2, w_bf = io & 4;
+  const unsigned short* in_h = reinterpret_cast<const unsigned short*>(in);
+  const unsigned short* W_h = reinterpret_cast<const unsigned short*>(W);
   constexpr int LDB = CIN_P + 8;                                 // bf16 elements per LDS row
   constexpr int NT = COUT_P / 16;
   constexpr int A4 = kTM2 * (CIN_P / 4) / 512;
@@ -384,7 +388,13 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict_
       const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
       const int rr = s_nbr[k * kTM2 + row];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rr >= 0) {
+      if (rr >= 0 && in_bf) {          // bf16 rows (cin % 4 == 0): 8 bytes carry the 4 channels
+        if (c4 < cin) {
+          const uint2 h = *reinterpret_cast<const uint2*>(in_h + (size_t)rr * cin + c4);
+          v.x = __uint_as_float(h.x);
+          v.y = __uint_as_float(h.y);
+        }
+      } else if (rr >= 0) {
         const float* src = in + (size_t)rr * cin + c4;
         if (vecA) {
           if (c4 < cin) v = *reinterpret_cast<const float4*>(src);
@@ -404,7 +414,8 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict_
       const int u = tid + 512 * j;
       const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
       *reinterpret_cast<uint2*>(As + row * LDB + c4) =
-          make_uint2(pack_bf16x2(ra[j].x, ra[j].y), pack_bf16x2(ra[j].z, ra[j].w));
+          in_bf ? make_uint2(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y))
+                : make_uint2(pack_bf16x2(ra[j].x, ra[j].y), pack_bf16x2(ra[j].z, ra[j].w));
     }
     if (vecB) {
 #pragma unroll
@@ -412,10 +423,16 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict_
         const int u = tid + 512 * j;
         if (u >= BU) break;
         const int n = u / (CIN_P / 4), c4 = (u - n * (CIN_P / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < cout && c4 < cin) v = *reinterpret_cast<const float4*>(W + n * ws.sn + k * ws.sk + c4);
-        *reinterpret_cast<uint2*>(Bs + n * LDB + c4) =
-            make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        uint2 o = make_uint2(0u, 0u);
+        if (n < cout && c4 < cin) {
+          if (w_bf) {
+            o = *reinterpret_cast<const uint2*>(W_h + n * ws.sn + k * ws.sk + c4);
+          } else {
+            const float4 v = *reinterpret_cast<const float4*>(W + n * ws.sn + k * ws.sk + c4);
+            o = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+          }
+        }
+        *reinterpret_cast<uint2*>(Bs + n * LDB + c4) = o;
       }
     } else {
 #pragma unroll
@@ -471,11 +488,184 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict_
       if (row >= 0) {
         float v = acc[t][r] + bv;
         if (ep.scale) v = v * sc + sh;
-        if (ep.residual) v += ep.residual[(size_t)row * cout + col];
+        if (ep.residual)
+          v += out_bf ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(
+                                            ep.residual)[(size_t)row * cout + col] << 16)
+                      : ep.residual[(size_t)row * cout + col];
         if (ep.relu) v = fmaxf(v, 0.f);
-        out[(size_t)row * cout + col] = v;
+        if (out_bf)
+          reinterpret_cast<unsigned short*>(out)[(size_t)row * cout + col] =
+              (unsigned short)(ud_pack_bf16x2(v, 0.f) & 0xFFFFu);
+        else
+          out[(size_t)row * cout + col] = v;
       }
     }
+  }
+}
+
+// ---- all-bf16 inference kernel (bf16 rows, bf16 weights, bf16 output) ------------------------------
+// Same tile / mask scheme as k_conv_mfma_bf16, with everything the mixed-precision teacher path
+// allows: 16-byte gathers of bf16 rows, the next offset's A rows AND weight slice prefetched in
+// registers while the current one is multiplied (the weight slice was a synchronous L2 round trip
+// per offset before -- the dominant cost once the products run on the bf16 pipe), and the output tile
+// staged through LDS as fp32 so residual rows are read and results written as 16-byte pieces.
+// bytes of the region shared by the operand tiles (K loop) and the staged fp32 output tile (epilogue)
+__host__ __device__ constexpr size_t fast_front_bytes(int cin_p, int cout_p) {
+  const size_t a = (size_t)(kTM2 + cout_p) * (cin_p + 8) * 2, o = (size_t)kTM2 * (cout_p + 4) * 4;
+  return ((a > o ? a : o) + 15) / 16 * 16;
+}
+
+template <int CIN_P, int COUT_P>   // CIN_P multiple of 32; cin, cout multiples of 8
+__global__ __launch_bounds__(512) void k_conv_mfma_bf16_fast(
+    const unsigned short* __restrict__ in, int cin, const int32_t* __restrict__ nbr, int K, int mirror,
+    const unsigned short* __restrict__ W, WStrides ws, const float* __restrict__ bias,
+    unsigned short* __restrict__ out, int cout, int Mout, const int32_t* __restrict__ order,
+    ConvEpilogue ep) {
+  constexpr int LDB = CIN_P + 8;
+  constexpr int NT = COUT_P / 16;
+  constexpr int AU = kTM2 * (CIN_P / 8);            // 16-byte units of the A tile
+  constexpr int BU = COUT_P * (CIN_P / 8);
+  constexpr int A8 = (AU + 511) / 512, B8 = (BU + 511) / 512;
+  constexpr int LDO = COUT_P + 4;                   // fp32 elements per staged output row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bs = As + kTM2 * LDB;
+  int* s_nbr = reinterpret_cast<int*>(smem + fast_front_bytes(CIN_P, COUT_P));
+  unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
+  int* s_row = s_nbr + K * kTM2 + 4;
+  float* Os = reinterpret_cast<float*>(smem);       // [kTM2][LDO], aliases As/Bs after the K loop
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int row0 = blockIdx.x * kTM2;
+  if (tid == 0) s_active = 0u;
+  if (tid < kTM2) {
+    const int p = row0 + tid;
+    s_row[tid] = (p < Mout) ? (order ? order[p] : p) : -1;
+  }
+  __syncthreads();
+  unsigned mine = 0u;
+  for (int idx = tid; idx < kTM2 * K; idx += 512) {
+    const int r = idx / K, k = idx - r * K;
+    int v = -1;
+    const int orow = s_row[r];
+    if (orow >= 0) v = nbr[(size_t)orow * K + (mirror ? K - 1 - k : k)];
+    s_nbr[k * kTM2 + r] = v;
+    if (v >= 0) mine |= 1u << k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor((int)mine, o);
+  if (lane == 0 && mine) atomicOr(&s_active, mine);
+  __syncthreads();
+  const unsigned active = s_active;
+  unsigned wmask = 0u;
+  for (int k = 0; k < K; ++k) {
+    const int v = (lane < 16) ? s_nbr[k * kTM2 + wave * 16 + lane] : -1;
+    if (__any(v >= 0)) wmask |= 1u << k;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 ra[A8], rb[B8];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < A8; ++j) {
+      const int u = tid + 512 * j;
+      ra[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < AU) {
+        const int row = u / (CIN_P / 8), c8 = (u - row * (CIN_P / 8)) * 8;
+        const int rr = s_nbr[k * kTM2 + row];
+        if (rr >= 0 && c8 < cin) ra[j] = *reinterpret_cast<const uint4*>(in + (size_t)rr * cin + c8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B8; ++j) {
+      const int u = tid + 512 * j;
+      rb[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < BU) {
+        const int n = u / (CIN_P / 8), c8 = (u - n * (CIN_P / 8)) * 8;
+        if (n < cout && c8 < cin) rb[j] = *reinterpret_cast<const uint4*>(W + n * ws.sn + k * ws.sk + c8);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < A8; ++j) {
+      const int u = tid + 512 * j;
+      if (u < AU) {
+        const int row = u / (CIN_P / 8), c8 = (u - row * (CIN_P / 8)) * 8;
+        *reinterpret_cast<uint4*>(As + row * LDB + c8) = ra[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B8; ++j) {
+      const int u = tid + 512 * j;
+      if (u < BU) {
+        const int n = u / (CIN_P / 8), c8 = (u - n * (CIN_P / 8)) * 8;
+        *reinterpret_cast<uint4*>(Bs + n * LDB + c8) = rb[j];
+      }
+    }
+  };
+  unsigned todo = active;
+  int k = todo ? (__ffs((int)todo) - 1) : -1;
+  if (k >= 0) fetch(k);
+  while (k >= 0) {
+    todo &= todo - 1;
+    commit();
+    __syncthreads();
+    const int knext = todo ? (__ffs((int)todo) - 1) : -1;
+    if (knext >= 0) fetch(knext);
+    if ((wmask >> k) & 1u) {
+      const unsigned short* arow = As + (wave * 16 + li) * LDB + 8 * g;
+#pragma unroll
+      for (int cb = 0; cb < CIN_P / 32; ++cb) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + cb * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (t * 16 + li) * LDB + cb * 32 + 8 * g);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    k = knext;
+  }
+  // epilogue 1: bias + folded BatchNorm in registers, fp32 tile -> LDS
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = t * 16 + li;
+    const bool cv = col < cout;
+    const float bv = (cv && bias) ? bias[col] : 0.f;
+    const float sc = (cv && ep.scale) ? ep.scale[col] : 1.f;
+    const float sh = (cv && ep.shift) ? ep.shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Os[(wave * 16 + 4 * g + r) * LDO + col] = (acc[t][r] + bv) * sc + sh;
+  }
+  __syncthreads();
+  // epilogue 2: + residual, ReLU, bf16, 16-byte rows
+  const unsigned short* res = reinterpret_cast<const unsigned short*>(ep.residual);
+  for (int u = tid; u < kTM2 * (COUT_P / 8); u += 512) {
+    const int r = u / (COUT_P / 8), c8 = (u - r * (COUT_P / 8)) * 8;
+    const int row = s_row[r];
+    if (row < 0 || c8 >= cout) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(Os + r * LDO + c8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Os + r * LDO + c8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (res) {
+      const uint4 h = *reinterpret_cast<const uint4*>(res + (size_t)row * cout + c8);
+      const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[2 * q] += __uint_as_float(hw[q] << 16);
+        v[2 * q + 1] += __uint_as_float(hw[q] & 0xFFFF0000u);
+      }
+    }
+    if (ep.relu) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)row * cout + c8) =
+        make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]), ud_pack_bf16x2(v[4], v[5]),
+                   ud_pack_bf16x2(v[6], v[7]));
   }
 }
 
@@ -628,8 +818,26 @@ int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirr
 template <int CIN_P, int COUT_P>
 int launch_conv_bf16(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
                      WStrides ws, const float* bias, float* out, int cout, int Mout,
-                     const int32_t* order, ConvEpilogue ep, hipStream_t stream) {
+                     const int32_t* order, ConvEpilogue ep, int io, hipStream_t stream) {
   constexpr int CP = CIN_P < 32 ? 32 : CIN_P;
+  if ((io & 1) && (cin & 3)) return UD_ERR_UNSUPPORTED;          // bf16 rows are read 4 channels at a time
+  if ((io & 4) && !(ws.sc == 1 && (cin & 3) == 0)) return UD_ERR_UNSUPPORTED;
+  if (io == 7 && (cin & 7) == 0 && (cout & 7) == 0 && (ws.sn & 7) == 0 && (ws.sk & 7) == 0) {
+    const size_t lds_f = fast_front_bytes(CP, COUT_P) + (size_t)K * kTM2 * sizeof(int) + 16 +
+                         kTM2 * sizeof(int);
+    static bool fast_attr_set = false;
+    if (!fast_attr_set && lds_f > 64 * 1024) {
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_bf16_fast<CP, COUT_P>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      fast_attr_set = true;
+    }
+    k_conv_mfma_bf16_fast<CP, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds_f, stream>>>(
+        reinterpret_cast<const unsigned short*>(in), cin, nbr, K, mirror,
+        reinterpret_cast<const unsigned short*>(W), ws, bias, reinterpret_cast<unsigned short*>(out), cout,
+        Mout, order, ep);
+    UD_LAUNCH_CHECK();
+    return UD_OK;
+  }
   const size_t lds = (size_t)(kTM2 + COUT_P) * (CP + 8) * sizeof(unsigned short) +
                      (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
   static bool attr_set = false;
@@ -639,7 +847,7 @@ int launch_conv_bf16(const float* in, int cin, const int32_t* nbr, int K, int mi
     attr_set = true;
   }
   k_conv_mfma_bf16<CP, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(
-      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep);
+      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, io);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -649,7 +857,7 @@ int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror,
                 WStrides ws, const float* bias, float* out, int cout, int Mout,
                 const int32_t* order, ConvEpilogue ep, int algo, hipStream_t stream) {
   if (K <= 32 && algo == 3)
-    return launch_conv_bf16<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, stream);
+    return launch_conv_bf16<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, 0, stream);
   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles
   if (K <= 32 && algo != 2)
     return launch_conv_v2<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, stream);
@@ -734,6 +942,34 @@ extern "C" int ud_spconv_conv(const float* in, const int32_t* nbr, const float* 
       in, Cin, nbr, K, mirror, W, ws, bias, out, Cout, Mout);
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+// Mixed-precision inference variant of ud_spconv_conv: the bf16 MFMA kernel with bf16 tensors in HBM.
+// io_flags bit 0: in is bf16 [*, Cin]; bit 1: out and ep_residual are bf16 [Mout, Cout]; bit 2: W is bf16.
+extern "C" int ud_spconv_conv_bf16io(const void* in, const int32_t* nbr, const void* W, int64_t w_sn,
+                                     int64_t w_sk, int64_t w_sc, int mirror, const float* bias,
+                                     void* out, int Mout, int K, int Cin, int Cout, int io_flags,
+                                     const int32_t* row_order, const float* ep_scale,
+                                     const float* ep_shift, const void* ep_residual, int ep_relu,
+                                     ud_stream_t stream_) {
+  if (Mout < 0 || K <= 0 || K > 32 || Cin <= 0 || Cout <= 0 || (io_flags & ~7)) return UD_ERR_INVALID_ARG;
+  if (Mout == 0) return UD_OK;
+  if (!in || !nbr || !W || !out) return UD_ERR_INVALID_ARG;
+  if ((ep_scale == nullptr) != (ep_shift == nullptr)) return UD_ERR_INVALID_ARG;
+  ConvEpilogue ep{ep_scale, ep_shift, reinterpret_cast<const float*>(ep_residual), ep_relu};
+  hipStream_t stream = (hipStream_t)stream_;
+  WStrides ws{w_sn, w_sk, w_sc};
+  const int cp = pad16(Cin), np = pad16(Cout);
+  UdProfScope prof("spconv.k_conv", stream);
+#define X(A, B)             \
+  if (cp == A && np == B)   \
+    return launch_conv_bf16<A, B>(reinterpret_cast<const float*>(in), Cin, nbr, K, mirror,           \
+                                  reinterpret_cast<const float*>(W), ws, bias,                        \
+                                  reinterpret_cast<float*>(out), Cout, Mout, row_order, ep, io_flags, \
+                                  stream);
+  UD_CONV_CASES(X)
+#undef X
+  return UD_ERR_UNSUPPORTED;
 }
 
 extern "C" size_t ud_spconv_wgrad_workspace_bytes(int Mout, int K, int Cin, int Cout) {

@@ -46,6 +46,8 @@ _SIGS = {
                                 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ud_spconv_conv": (c_int, [c_void_p] * 3 + [c_i64] * 3 + [c_int, c_void_p, c_void_p]
                        + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ud_spconv_conv_bf16io": (c_int, [c_void_p] * 3 + [c_i64] * 3 + [c_int, c_void_p, c_void_p]
+                              + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ud_spconv_wgrad_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_spconv_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),

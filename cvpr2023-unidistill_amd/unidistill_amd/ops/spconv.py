@@ -157,6 +157,41 @@ def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0, scale=N
     return out
 
 
+def _conv_bf16io(feat, nbr, weight, bias, cin, cout, scale=None, shift=None, residual=None, relu=False):
+    """Inference conv with bf16 tensors in HBM (ud_spconv_conv_bf16io): feat fp32 or bf16 [*, cin],
+    weight [cout, K, cin] bf16 (or fp32 when cin % 4 != 0), output (and residual) bf16 [Mout, cout]."""
+    Mout, K = nbr.shape
+    io = 2 | (4 if weight.dtype == torch.bfloat16 else 0)
+    if feat.dtype == torch.bfloat16 and cin % 4 == 0:
+        io |= 1
+    elif feat.dtype != torch.float32:
+        feat = feat.float()
+    if residual is not None and residual.dtype != torch.bfloat16:
+        residual = residual.to(torch.bfloat16)
+    out = torch.empty((Mout, cout), dtype=torch.bfloat16, device=feat.device)
+    order = mask_order(nbr, False)
+    _lib.check(_lib.load().ud_spconv_conv_bf16io(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(weight),
+                                                 K * cin, cin, 1, 0, _lib.ptr(bias), _lib.ptr(out),
+                                                 Mout, K, cin, cout, io, _lib.ptr(order),
+                                                 _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual),
+                                                 1 if relu else 0, _lib.stream_of(feat)),
+               "ud_spconv_conv_bf16io")
+    return out
+
+
+def bf16_weight(conv):
+    """[cout, K, cin] bf16 copy of a sparse conv's weight for the mixed-precision inference path;
+    cached on the module, refreshed when the parameter changes (version counter)."""
+    w = conv.weight
+    ver = (w._version, w.device, w.data_ptr())
+    hit = getattr(conv, "_ud_w_bf16", None)
+    if hit is None or hit[0] != ver:
+        with torch.no_grad():
+            hit = (ver, w.detach().reshape(w.shape[0], -1, w.shape[-1]).to(torch.bfloat16).contiguous())
+        conv._ud_w_bf16 = hit
+    return hit[1]
+
+
 def folded_batchnorm(bn):
     """(scale, shift) of an eval-mode BatchNorm1d: y = x * scale + shift.  Cached on the module
     and refreshed when any of its tensors changed (version counters)."""
@@ -289,7 +324,8 @@ class SparseConvTensor:
 
     def dense(self, channels_first=True):
         grid = (self.batch_size,) + tuple(self._sites.spatial_shape)
-        out = _DenseFn.apply(self.features, self.indices, grid)
+        feats = self.features if self.features.dtype == torch.float32 else self.features.float()
+        out = _DenseFn.apply(feats, self.indices, grid)
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
 
@@ -398,10 +434,17 @@ class _SparseConvBase(SparseModule):
         if bn is not None:
             scale, shift = folded_batchnorm(bn)
         with torch.no_grad():
-            feats = _conv(x.features.detach().contiguous().float(), nbr, w, (K * cin, cin, 1), False,
-                          None if self.bias is None else self.bias.detach().contiguous().float(),
-                          cin, cout, effective_algo(0), scale, shift,
-                          None if residual is None else residual.detach().contiguous().float(), relu)
+            bias = None if self.bias is None else self.bias.detach().contiguous().float()
+            if effective_algo(0) == 3 and K <= 32:
+                # bf16 autocast: activations stay bf16 between the fused layers (half the gather bytes)
+                feats = _conv_bf16io(x.features.detach().contiguous(), nbr,
+                                     bf16_weight(self) if cin % 4 == 0 else w.view(cout, K, cin), bias, cin,
+                                     cout, scale, shift,
+                                     None if residual is None else residual.detach().contiguous(), relu)
+            else:
+                feats = _conv(x.features.detach().contiguous().float(), nbr, w, (K * cin, cin, 1), False,
+                              bias, cin, cout, 0, scale, shift,
+                              None if residual is None else residual.detach().contiguous().float(), relu)
         return SparseConvTensor(feats, None, None, None, _sites=out_sites, _indice_dict=x.indice_dict)
 
 

@@ -240,6 +240,14 @@ int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t 
                    const float* ep_shift, const float* ep_residual, int ep_relu, ud_stream_t stream);
 
 /* gW f32[Cout,K,Cin] = sum_o gout[o,n] * in[nbr[o][k], c]  (ordered partial sums, deterministic). */
+/* Mixed-precision inference variant: the bf16-operand MFMA kernel (algo 3 above) with bf16 tensors in
+ * HBM so the gather moves half the bytes.  io_flags bit 0: `in` is bf16 [*, Cin] (Cin % 4 == 0);
+ * bit 1: `out` and `ep_residual` are bf16 [Mout, Cout]; bit 2: `W` is bf16 (w_sc == 1).  K <= 32. */
+int ud_spconv_conv_bf16io(const void* in, const int32_t* nbr, const void* W, int64_t w_sn,
+                          int64_t w_sk, int64_t w_sc, int mirror, const float* bias, void* out,
+                          int Mout, int K, int Cin, int Cout, int io_flags, const int32_t* row_order,
+                          const float* ep_scale, const float* ep_shift, const void* ep_residual,
+                          int ep_relu, ud_stream_t stream);
 size_t ud_spconv_wgrad_workspace_bytes(int Mout, int K, int Cin, int Cout);
 int ud_spconv_wgrad(const float* in, const int32_t* nbr, const float* gout, float* gW, int Mout,
                     int K, int Cin, int Cout, int algo, void* workspace, size_t workspace_bytes,

@@ -222,3 +222,10 @@ def test_fused_inference_epilogue_matches_module_chain():
         ref = seq(blk(xr)).features
         assert ref.requires_grad and not fused.requires_grad
         np.testing.assert_allclose(fused.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+        # mixed precision: under bf16 autocast the fused chain keeps bf16 activations in HBM
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            mixed = seq(blk(_tensor(coords, feat, shape)))
+        assert mixed.features.dtype == torch.bfloat16
+        err = (mixed.features.float() - ref.detach()).abs().max().item()
+        assert err < 3e-2 * max(1.0, ref.detach().abs().max().item()), err
+        assert mixed.dense().dtype == torch.float32
