@@ -372,9 +372,22 @@ class PackedSepHeads(nn.Module):
         return self._split(z)
 
     def _split(self, z):
+        # ONE split node: its backward is a single concatenation of the 42 head gradients, where 42
+        # independent slices would each zero-pad to the full [B, 126, H, W] tensor and add (1.5 ms/step)
+        sizes = []
+        for _t, _name, kout in self.layout:
+            sizes.append(kout)
+            if self.kmax > kout:
+                sizes.append(self.kmax - kout)
+        rest = z.shape[1] - sum(sizes)
+        if rest:
+            sizes.append(rest)
+        parts = iter(z.split_with_sizes(sizes, dim=1))
         outs = [dict() for _ in range(self.num_tasks)]
-        for g, (t, name, kout) in enumerate(self.layout):
-            outs[t][name] = z[:, g * self.kmax:g * self.kmax + kout]
+        for t, name, kout in self.layout:
+            outs[t][name] = next(parts)
+            if self.kmax > kout:
+                next(parts)
         return outs
 
     # ---- reference-compatible (de)serialisation ------------------------------------------------

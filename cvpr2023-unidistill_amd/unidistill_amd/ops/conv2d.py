@@ -1,0 +1,86 @@
+"""3x3 / stride 1 / pad 1 convolution on channels-last bf16 tensors (ud_conv3x3_nhwc_bf16).
+
+Stands in for nn.Conv2d(k=3, s=1, p=1) in the BEV trunk and the detection head of the reference
+(unidistill/layers/blocks_2d/det3d/base_bev_backbone.py:30-110, layers/head/det3d/center_head.py:408-420)
+in the bf16 mixed-precision mode.  Forward and data gradient run on the hand-written MFMA kernel; the
+weight gradient stays with the library (aten.convolution_backward).
+"""
+import torch
+
+from .. import _lib
+
+
+def supported(x, weight, stride=1, padding=1, dilation=1, groups=1):
+    def one(v):
+        return v[0] if isinstance(v, (tuple, list)) else v
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and weight.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and one(stride) == 1 and one(padding) == 1
+            and one(dilation) == 1 and groups == 1 and weight.shape[1] % 64 == 0
+            and weight.shape[0] % 64 == 0)
+
+
+def _nhwc(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else \
+        t.contiguous(memory_format=torch.channels_last)
+
+
+def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, relu=False):
+    """x: [B, Cin, H, W] bf16 channels-last; w_tap: [Cout, 3, 3, Cin] bf16 contiguous."""
+    B, cin, H, W = x.shape
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    _lib.check(_lib.load().ud_conv3x3_nhwc_bf16(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin,
+                                                cout, _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
+                                                _lib.ptr(residual), 1 if relu else 0,
+                                                _lib.stream_of(x)), "ud_conv3x3_nhwc_bf16")
+    return y
+
+
+def tap_major(weight):
+    """[Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] bf16 contiguous (the kernel's weight layout)."""
+    return weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+
+
+def tap_major_transposed(weight):
+    """Weights of the data-gradient convolution: [Cin, 3, 3, Cout], spatially flipped."""
+    return weight.detach().flip(2, 3).permute(1, 2, 3, 0).to(torch.bfloat16).contiguous()
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_gpu(x, weight)
+        x = _nhwc(x)
+        y = _launch(x, tap_major(weight), weight.shape[0],
+                    None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _nhwc(gy.to(torch.bfloat16))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _launch(gy, tap_major_transposed(weight), weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gw = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False,
+                                                     [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.float().sum((0, 2, 3))
+        return gx, gw, gb
+
+
+def conv3x3(x, weight, bias=None):
+    """y = conv2d(x, weight, bias, stride=1, padding=1) for bf16 channels-last x (autograd-aware)."""
+    return _Conv3x3Fn.apply(x, weight, bias)
+
+
+def conv3x3_inference(x, weight, bias=None, scale=None, shift=None, residual=None, relu=False):
+    """Inference conv with the fused epilogue: (+bias) (*scale+shift) (+residual) (ReLU)."""
+    with torch.no_grad():
+        return _launch(_nhwc(x), tap_major(weight), weight.shape[0],
+                       None if bias is None else bias.float().contiguous(), scale, shift,
+                       None if residual is None else _nhwc(residual), relu)

@@ -343,6 +343,18 @@ int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const floa
                      float* dw2, float* dgamma, float* dbeta, int B, int H, int W, int G, int kmax,
                      void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
+/* ---- Dense 3x3 / stride 1 / pad 1 convolution, channels-last bf16 (BEV trunk + head convs) ----------
+ * Replaces nn.Conv2d(k=3, s=1, p=1) of BaseBEVBackbone (reference unidistill/layers/blocks_2d/det3d/
+ * base_bev_backbone.py:30-110) and CenterHead.shared_conv (layers/head/det3d/center_head.py:408-420)
+ * when tensors are bf16 channels-last: x [B][H][W][Cin], w [Cout][9][Cin] (tap = ky*3+kx),
+ * y [B][H][W][Cout]; fp32 accumulation on the MFMA pipe.  Optional fused epilogue, in this order:
+ * + bias[Cout], * scale + shift (folded eval BatchNorm), + residual (bf16, y's layout), ReLU.
+ * Cin % 64 == 0 and Cout % 8 == 0, else UD_ERR_UNSUPPORTED.  The data gradient of the convolution is
+ * the same call on dy with w' [Cin][9][Cout], w'[c][8 - tap][n] = w[n][tap][c]. */
+int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
+                         const float* bias, const float* scale, const float* shift,
+                         const void* residual, int relu, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

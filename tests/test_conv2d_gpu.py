@@ -1,0 +1,59 @@
+"""Hand-written MFMA 3x3 convolution (channels-last bf16) vs torch.nn.functional.conv2d in fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(B, Cin, H, W, Cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).bfloat16().float()
+    b = torch.randn(Cout, generator=g)
+    return x, w, b
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(1, 64, 8, 16, 64), (2, 64, 19, 21, 128), (1, 128, 30, 37, 192),
+                                            (2, 256, 9, 5, 64), (1, 128, 180, 180, 128)])
+def test_conv3x3_forward_backward(hip_lib, B, Cin, H, W, Cout):
+    from unidistill_amd.ops import conv2d as c2
+    x, w, b = _mk(B, Cin, H, W, Cout, Cin + Cout + H)
+    dev = torch.device("cuda:0")
+    xr = x.float().to(dev).requires_grad_(True)
+    wr = w.to(dev).requires_grad_(True)
+    br = b.to(dev).requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, 1, 1)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3)).bfloat16().float().to(dev)
+    ref.backward(gy)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    assert c2.supported(xd, wd)
+    y = c2.conv3x3(xd, wd, bd)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    # bf16 operands are exact here; the only rounding is the bf16 store of y (2^-9 relative)
+    tol = 6e-3 * float(ref.detach().abs().max())
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0, atol=tol)
+    y.backward(gy.to(torch.bfloat16))
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=0,
+                               atol=6e-3 * float(xr.grad.abs().max()))
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=0,
+                               atol=2e-2 * float(wr.grad.abs().max()))
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.cpu().numpy(), rtol=1e-3,
+                               atol=1e-3 * float(br.grad.abs().max()))
+
+
+def test_conv3x3_fused_epilogue(hip_lib):
+    from unidistill_amd.ops import conv2d as c2
+    x, w, b = _mk(2, 64, 20, 23, 128, 11)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    res = torch.randn(2, 128, 20, 23, generator=g).bfloat16()
+    ref = F.relu((F.conv2d(x.float(), w, b, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None])
+                 + res.float())
+    y = c2.conv3x3_inference(x.to(dev).contiguous(memory_format=torch.channels_last), w.to(dev), b.to(dev),
+                             scale.to(dev), shift.to(dev), res.to(dev), relu=True)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=0, atol=6e-3 * float(ref.abs().max()))
