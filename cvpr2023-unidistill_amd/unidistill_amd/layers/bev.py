@@ -4,11 +4,14 @@ State_dict-compatible mirror of BaseBEVBackbone
 (unidistill/layers/blocks_2d/det3d/base_bev_backbone.py:10-174) for the configuration the
 experiments use (no SC-Conv, base_nuscenes_cfg.py:166-174).  The module layout keeps the reference's
 Sequential indices (ZeroPad2d at 0, conv at 1, BN at 2, ...) so checkpoints load unchanged.
-The dense convs run through PyTorch-ROCm (MIOpen); channels-last inputs are passed through as is.
+In the bf16 mixed-precision mode the 3x3 stride-1 convs run on the hand-written MFMA kernel
+(layers/dense.py, ops/conv2d.py); strided / transposed convs and the fp32 mode use PyTorch-ROCm.
 """
 import numpy as np
 import torch
 from torch import nn
+
+from .dense import Conv2d, FusedSequential
 
 
 def _bn(c):
@@ -33,11 +36,11 @@ class BaseBEVBackbone(nn.Module):
         self.blocks = nn.ModuleList()
         self.deblocks = nn.ModuleList()
         for lvl, (n, s, c) in enumerate(zip(layer_nums, layer_strides, num_filters)):
-            seq = [nn.ZeroPad2d(1), nn.Conv2d(c_in[lvl], c, 3, stride=s, padding=0, bias=False),
+            seq = [nn.ZeroPad2d(1), Conv2d(c_in[lvl], c, 3, stride=s, padding=0, bias=False),
                    _bn(c), nn.ReLU()]
             for _ in range(n):
-                seq += [nn.Conv2d(c, c, 3, padding=1, bias=False), _bn(c), nn.ReLU()]
-            self.blocks.append(nn.Sequential(*seq))
+                seq += [Conv2d(c, c, 3, padding=1, bias=False), _bn(c), nn.ReLU()]
+            self.blocks.append(FusedSequential(*seq))
             if upsample_strides:
                 us, uc = upsample_strides[lvl], num_upsample_filters[lvl]
                 if us >= 1:
@@ -100,7 +103,7 @@ class FusionEncoder(nn.Module):
         if not use_elementwise:
             self.att = nn.Sequential(nn.AdaptiveAvgPool2d(1),
                                      nn.Conv2d(input_channel, input_channel, 1), nn.Sigmoid())
-            self.reduce_conv = nn.Sequential(nn.Conv2d(input_channel, output_channel, 3, padding=1, bias=False),
+            self.reduce_conv = FusedSequential(Conv2d(input_channel, output_channel, 3, padding=1, bias=False),
                                              nn.BatchNorm2d(output_channel), nn.ReLU(True))
 
     def forward(self, x1, x2):

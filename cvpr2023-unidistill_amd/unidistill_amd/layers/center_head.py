@@ -20,7 +20,8 @@ import torch
 from torch import nn
 
 from ..dist import reduce_mean, reduce_mean_many
-from ..ops import head_tail
+from ..ops import conv2d as hipconv, head_tail
+from .dense import Conv2d, FusedSequential
 
 
 # --------------------------------------------------------------------------------------------
@@ -345,7 +346,11 @@ class PackedSepHeads(nn.Module):
     def forward(self, x):
         """-> list (per task) of {head: [B, k, H, W]} like [SepHead(x) for each task]."""
         pad = self.k // 2
-        y = torch.nn.functional.conv2d(x, self.c1_weight, self.c1_bias, padding=pad)
+        if Conv2d.hip_enabled and self.k == 3 and x.is_cuda and x.dtype == torch.bfloat16 \
+                and hipconv.supported(x, self.c1_weight):
+            y = hipconv.conv3x3(x, self.c1_weight, self.c1_bias)      # 64 -> 42*64 on the MFMA kernel
+        else:
+            y = torch.nn.functional.conv2d(x, self.c1_weight, self.c1_bias, padding=pad)
         if self.training:
             self.bn_num_batches_tracked += 1
         G = len(self.layout)
@@ -461,8 +466,8 @@ class CenterHead(nn.Module):
         self.dataset = dataset_name
         self.box_n_dim = 9 if dataset_name == "nuscenes" else 7
         self.distill = distill
-        self.shared_conv = nn.Sequential(
-            nn.Conv2d(input_channels, share_conv_channel, 3, padding=1, bias=True),
+        self.shared_conv = FusedSequential(
+            Conv2d(input_channels, share_conv_channel, 3, padding=1, bias=True),
             nn.BatchNorm2d(share_conv_channel), nn.ReLU(inplace=True))
         self.upsample_for_pedestrian = upsample_for_pedestrian
         if upsample_for_pedestrian:

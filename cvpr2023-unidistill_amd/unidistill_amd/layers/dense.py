@@ -1,0 +1,74 @@
+"""Dense 2-D building blocks that route 3x3 convolutions to the hand-written MFMA kernel.
+
+``Conv2d`` is nn.Conv2d (same parameters, same state_dict keys); in the bf16 mixed-precision mode on
+the GPU its 3x3 / stride-1 / pad-1 case runs ops/conv2d.py (ud_conv3x3_nhwc_bf16) for the forward
+and the data gradient.  ``FusedSequential`` is nn.Sequential that additionally
+  * folds ``ZeroPad2d(1)`` + unpadded 3x3 conv (the first conv of every BaseBEVBackbone level,
+    reference base_bev_backbone.py:48-58) into the kernel's implicit padding, and
+  * in inference (no autograd, BatchNorm in eval) runs conv + BatchNorm2d + ReLU as ONE kernel
+    through the fused epilogue -- the frozen distillation teacher's trunk.
+Anything else (fp32 mode, CPU, other kernel sizes / strides) is the plain PyTorch module.
+"""
+import torch
+from torch import nn
+
+from ..ops import conv2d as hipconv
+from ..ops.spconv import folded_batchnorm
+
+
+def _mixed_precision(x):
+    return x.is_cuda and (x.dtype == torch.bfloat16 or (
+        torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16))
+
+
+def _is3x3(conv, padding):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (padding, padding) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros" and conv.in_channels % 64 == 0
+            and conv.out_channels % 64 == 0)
+
+
+class Conv2d(nn.Conv2d):
+    hip_enabled = True          # class-wide switch (tests / A-B timing)
+
+    def forward(self, x):
+        if Conv2d.hip_enabled and _is3x3(self, 1) and x.dim() == 4 and _mixed_precision(x):
+            return hipconv.conv3x3(x.to(torch.bfloat16), self.weight, self.bias)
+        return super().forward(x)
+
+
+def _can_fuse_inference(x, bn):
+    return (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.affine and bn.track_running_stats
+            and not (torch.is_grad_enabled() and x.requires_grad))
+
+
+class FusedSequential(nn.Sequential):
+    def forward(self, x):
+        mods = list(self)
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            conv, skip = None, 0
+            if Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x):
+                if isinstance(m, nn.ZeroPad2d) and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < n \
+                        and _is3x3(mods[i + 1], 0):
+                    conv, skip = mods[i + 1], 2
+                elif _is3x3(m, 1):
+                    conv, skip = m, 1
+            if conv is None:
+                x = m(x)
+                i += 1
+                continue
+            j = i + skip
+            bn = mods[j] if j < n else None
+            if bn is not None and _can_fuse_inference(x, bn) and not (torch.is_grad_enabled() and (
+                    conv.weight.requires_grad and x.requires_grad)):
+                relu = j + 1 < n and isinstance(mods[j + 1], nn.ReLU)
+                scale, shift = folded_batchnorm(bn)
+                x = hipconv.conv3x3_inference(x.to(torch.bfloat16), conv.weight, conv.bias, scale, shift,
+                                              None, relu)
+                i = j + (2 if relu else 1)
+            else:
+                x = hipconv.conv3x3(x.to(torch.bfloat16), conv.weight, conv.bias)
+                i = j
+        return x

@@ -12,6 +12,8 @@ import numpy as np
 import torch
 from torch import nn
 
+from .dense import Conv2d
+
 
 class Bottleneck(nn.Module):
     expansion = 4
@@ -20,7 +22,7 @@ class Bottleneck(nn.Module):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)   # "pytorch" style
+        self.conv2 = Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)   # "pytorch" style
         self.bn2 = nn.BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)

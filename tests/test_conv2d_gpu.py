@@ -57,3 +57,38 @@ def test_conv3x3_fused_epilogue(hip_lib):
     y = c2.conv3x3_inference(x.to(dev).contiguous(memory_format=torch.channels_last), w.to(dev), b.to(dev),
                              scale.to(dev), shift.to(dev), res.to(dev), relu=True)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=0, atol=6e-3 * float(ref.abs().max()))
+
+
+def test_trunk_on_mfma_kernel_matches_library_path(hip_lib):
+    """BaseBEVBackbone in bf16 autocast: hand-written conv path == MIOpen path (train and fused eval)."""
+    from unidistill_amd.layers.bev import BaseBEVBackbone
+    from unidistill_amd.layers import dense
+    torch.manual_seed(0)
+    net = BaseBEVBackbone([1, 1], [1, 2], [64, 128], [1, 2], [64, 64], 64).cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 64, 36, 28, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    for hip in (True, False):
+        dense.Conv2d.hip_enabled = hip
+        try:
+            net.train(); net.zero_grad()
+            xs = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y, _ = net(xs)
+            y.float().square().mean().backward()
+            g = [p.grad.clone() for p in net.parameters()]
+            net.eval()
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                ye, _ = net(x)
+            res[hip] = (y.detach().float(), xs.grad.float(), g, ye.float())
+        finally:
+            dense.Conv2d.hip_enabled = True
+    def close(a, b, f):
+        return torch.allclose(a, b, rtol=0, atol=f * float(b.abs().max()) + 1e-6)
+    assert close(res[True][0], res[False][0], 3e-2)
+    assert close(res[True][1], res[False][1], 5e-2)
+    for a, b in zip(res[True][2], res[False][2]):
+        assert close(a, b, 5e-2)
+    assert close(res[True][3], res[False][3], 3e-2)
