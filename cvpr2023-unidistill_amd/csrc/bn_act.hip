@@ -1,0 +1,256 @@
+// BatchNorm2d (+ residual) (+ ReLU) on channels-last bf16 activations as streaming kernels.
+//
+// The reference's dense layers are Conv2d -> BatchNorm2d -> ReLU chains (BaseBEVBackbone,
+// base_bev_backbone.py:48-66; ResNet bottlenecks via mmdet; CenterHead.shared_conv, center_head.py:
+// 408-420).  Run as separate library ops each chain link is its own read+write pass over the
+// activation (BN statistics, BN normalise, ReLU, residual add; and three more in backward).  These
+// kernels are the HBM-bound formulation: statistics are one read (ud_head_tail_stats, any
+// [pixels][C % 64 == 0] bf16 tensor), normalise + residual + ReLU one read/write, and the backward is
+// one reduction pass + one pass that writes dx -- the ReLU mask is recomputed from x, never stored.
+//   y  = act(x * scale + shift (+ residual)),  scale = gamma * invstd, shift = beta - mean * scale
+//   dr = dy * [y > 0];  dbeta = sum dr;  dgamma = invstd * sum dr (x - mean)
+//   dx = scale * dr + k2 * x + k0,  k2 = -scale * dgamma / P * invstd,  k0 = -scale * dbeta / P - k2 * mean
+#include "ud_common.h"
+#include "ud_prof.h"
+
+namespace {
+
+constexpr int kMaxSlices = 1024;
+// pixel slices per 64-channel group: enough workgroups (~2048) to fill 256 CUs whatever C is
+int slices_for(long long P, int C) {
+  long long s = 2048 / (C / 64 > 0 ? C / 64 : 1);
+  const long long cap = (P + 31) / 32;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  if (s > kMaxSlices) s = kMaxSlices;
+  return (int)s;
+}
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+__device__ __forceinline__ void unpack8(const uint4& r, float* v) {
+  v[0] = bf_lo(r.x); v[1] = bf_hi(r.x); v[2] = bf_lo(r.y); v[3] = bf_hi(r.y);
+  v[4] = bf_lo(r.z); v[5] = bf_hi(r.z); v[6] = bf_lo(r.w); v[7] = bf_hi(r.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  return make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]),
+                    ud_pack_bf16x2(v[4], v[5]), ud_pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void load8(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const unsigned short* __restrict__ x,
+                                                    const unsigned short* __restrict__ res,
+                                                    const float* __restrict__ scale,
+                                                    const float* __restrict__ shift,
+                                                    unsigned short* __restrict__ y, long long units,
+                                                    int c_units, int relu) {
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int c = (int)(u % c_units) * 8;
+    float v[8], s[8], t[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + u * 8), v);
+    load8(scale + c, s);
+    load8(shift + c, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], s[e], t[e]);
+    if (res) {
+      float r[8];
+      unpack8(*reinterpret_cast<const uint4*>(res + u * 8), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + u * 8) = pack8(v);
+  }
+}
+
+// mask source: y (the saved output) when a residual took part, else recomputed from x.
+__device__ __forceinline__ void masked_grad(const float* xv, const uint4* yraw, const float* dyv,
+                                            const float* s, const float* t, int relu, float* dr) {
+  if (!relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dr[e] = dyv[e];
+    return;
+  }
+  if (yraw) {
+    float yv[8];
+    unpack8(*yraw, yv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dr[e] = yv[e] > 0.f ? dyv[e] : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dr[e] = fmaf(xv[e], s[e], t[e]) > 0.f ? dyv[e] : 0.f;
+  }
+}
+
+// grid (kSlices, C/64): partial[slice][C][2] = sum dr, sum dr * (x - mean)
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ y,
+                                                       const unsigned short* __restrict__ dy,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ mean, long long P,
+                                                       int C, int relu, float* __restrict__ partial) {
+  __shared__ float red[32][65][2];
+  const int cg = blockIdx.y, tid = threadIdx.x, chunk = tid & 7, pl = tid >> 3;
+  const int c0 = cg * 64 + chunk * 8;
+  float s[8], t[8], mu[8], s1[8], s2[8];
+  load8(scale + c0, s);
+  load8(shift + c0, t);
+  load8(mean + c0, mu);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  for (long long p = (long long)blockIdx.x * 32 + pl; p < P; p += (long long)gridDim.x * 32) {
+    const size_t off = (size_t)p * C + c0;
+    float xv[8], dyv[8], dr[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+    unpack8(*reinterpret_cast<const uint4*>(dy + off), dyv);
+    uint4 yr;
+    if (y) yr = *reinterpret_cast<const uint4*>(y + off);
+    masked_grad(xv, y ? &yr : nullptr, dyv, s, t, relu, dr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += dr[e];
+      s2[e] += dr[e] * (xv[e] - mu[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[pl][chunk * 8 + e][0] = s1[e]; red[pl][chunk * 8 + e][1] = s2[e]; }
+  __syncthreads();
+  if (tid < 128) {
+    const int c = tid >> 1, w = tid & 1;
+    float a = 0.f;
+    for (int i = 0; i < 32; ++i) a += red[i][c][w];
+    partial[((size_t)blockIdx.x * C + cg * 64 + c) * 2 + w] = a;
+  }
+}
+
+__global__ void k_bn_bwd_final(const float* __restrict__ partial, int slices, int C, long long P,
+                               const float* __restrict__ scale, const float* __restrict__ mean,
+                               const float* __restrict__ invstd, float* __restrict__ dgamma,
+                               float* __restrict__ dbeta, float* __restrict__ k0, float* __restrict__ k2) {
+  const int c = blockIdx.x, lane = threadIdx.x;      // one wave per channel, fixed-order reduction
+  float a = 0.f, q = 0.f;
+  for (int s = lane; s < slices; s += 64) {
+    a += partial[((size_t)s * C + c) * 2];
+    q += partial[((size_t)s * C + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane != 0) return;
+  const float is = invstd[c], dg = q * is, inv_p = 1.0f / (float)P;
+  dbeta[c] = a;
+  dgamma[c] = dg;
+  const float kk2 = -scale[c] * (dg * inv_p) * is;
+  k2[c] = kk2;
+  k0[c] = -scale[c] * (a * inv_p) - kk2 * mean[c];
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_dx(const unsigned short* __restrict__ x,
+                                                   const unsigned short* __restrict__ y,
+                                                   const unsigned short* __restrict__ dy,
+                                                   const float* __restrict__ scale,
+                                                   const float* __restrict__ shift,
+                                                   const float* __restrict__ k0,
+                                                   const float* __restrict__ k2,
+                                                   unsigned short* __restrict__ dx,
+                                                   unsigned short* __restrict__ dres, long long units,
+                                                   int c_units, int relu) {
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int c = (int)(u % c_units) * 8;
+    float xv[8], dyv[8], dr[8], s[8], t[8], a0[8], a2[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + u * 8), xv);
+    unpack8(*reinterpret_cast<const uint4*>(dy + u * 8), dyv);
+    load8(scale + c, s);
+    load8(shift + c, t);
+    load8(k0 + c, a0);
+    load8(k2 + c, a2);
+    uint4 yr;
+    if (y) yr = *reinterpret_cast<const uint4*>(y + u * 8);
+    masked_grad(xv, y ? &yr : nullptr, dyv, s, t, relu, dr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(s[e], dr[e], fmaf(a2[e], xv[e], a0[e]));
+    *reinterpret_cast<uint4*>(dx + u * 8) = pack8(o);
+    if (dres) *reinterpret_cast<uint4*>(dres + u * 8) = pack8(dr);
+  }
+}
+
+struct BnWs { float *partial, *k0, *k2; };
+size_t carve(UdArena& ar, int C, BnWs* w) {
+  w->partial = ar.take<float>((size_t)kMaxSlices * C * 2);
+  w->k0 = ar.take<float>(C);
+  w->k2 = ar.take<float>(C);
+  return ar.used;
+}
+int stream_blocks(long long units) {
+  const long long b = (units + 255) / 256;
+  return (int)(b < 8192 ? b : 8192);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ud_bn_act_workspace_bytes(int C) {
+  if (C <= 0) return 0;
+  UdArena ar(nullptr, 0);
+  BnWs w;
+  return carve(ar, C, &w);
+}
+
+int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,
+                  long long P, int C, int relu, ud_stream_t stream_) {
+  if (!x || !scale || !shift || !y || P <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
+  if (C % 8) return UD_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long units = P * (C / 8);
+  UdProfScope prof("bn_act.k_fwd", stream);
+  k_bn_act_fwd<<<stream_blocks(units), 256, 0, stream>>>(
+      (const unsigned short*)x, (const unsigned short*)residual, scale, shift, (unsigned short*)y, units,
+      C / 8, relu);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* scale, const float* shift,
+                  const float* mean, const float* invstd, void* dx, void* dresidual, float* dgamma,
+                  float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
+                  ud_stream_t stream_) {
+  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || P <= 0 || C <= 0)
+    return UD_ERR_INVALID_ARG;
+  if (C % 64) return UD_ERR_UNSUPPORTED;
+  UdArena ar(workspace, workspace_bytes);
+  BnWs w;
+  carve(ar, C, &w);
+  if (!ar.ok()) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  {
+    UdProfScope prof("bn_act.k_bwd_reduce", stream);
+    const int slices = slices_for(P, C);
+    k_bn_bwd_reduce<<<dim3(slices, C / 64), 256, 0, stream>>>(
+        (const unsigned short*)x, (const unsigned short*)y, (const unsigned short*)dy, scale, shift, mean, P,
+        C, relu, w.partial);
+    UD_LAUNCH_CHECK();
+    k_bn_bwd_final<<<C, 64, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd,
+                                                           dgamma, dbeta, w.k0, w.k2);
+    UD_LAUNCH_CHECK();
+  }
+  const long long units = P * (C / 8);
+  UdProfScope prof("bn_act.k_bwd_dx", stream);
+  k_bn_bwd_dx<<<stream_blocks(units), 256, 0, stream>>>(
+      (const unsigned short*)x, (const unsigned short*)y, (const unsigned short*)dy, scale, shift, w.k0, w.k2,
+      (unsigned short*)dx, (unsigned short*)dresidual, units, C / 8, relu);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+}  // extern "C"

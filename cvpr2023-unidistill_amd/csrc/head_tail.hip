@@ -32,7 +32,7 @@ constexpr int kMaxOut = 3;           // outputs per head handled by the MFMA pac
 constexpr int kA2 = 40;              // bf16 elements per pixel of the (j,tap) image (32 + pad)
 constexpr int kWgradSlices = 12;   // 42 heads x 12 = 504 persistent blocks <= 2 per CU
 constexpr int kBwdSlices = 96;
-constexpr int kStatSlices = 64;
+constexpr int kStatSlices = 1024;   // upper bound; the launch picks ~2048 / G pixel slices
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -227,13 +227,19 @@ __global__ void k_stats_final(const unsigned short* __restrict__ y, const float*
                               const float* __restrict__ beta, float eps, float* __restrict__ mean,
                               float* __restrict__ var, float* __restrict__ invstd,
                               float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // one wave per channel: lanes stride over the slices, then a fixed-order butterfly (deterministic)
+  const int c = blockIdx.x, lane = threadIdx.x;
   double a = 0.0, q = 0.0;
-  for (int s = 0; s < slices; ++s) {
+  for (int s = lane; s < slices; s += 64) {
     a += partial[((size_t)s * C + c) * 2];
     q += partial[((size_t)s * C + c) * 2 + 1];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane != 0) return;
   const double piv = __uint_as_float((unsigned)y[c] << 16);
   const double m = a / (double)P;
   double v = q / (double)P - m * m;
@@ -548,13 +554,18 @@ __global__ void k_bn_bwd_final(const float* __restrict__ partial, int slices, in
                                const float* __restrict__ invstd, float* __restrict__ dgamma,
                                float* __restrict__ dbeta, float* __restrict__ k0,
                                float* __restrict__ k2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;      // one wave per channel, fixed-order reduction
   float a = 0.f, q = 0.f;
-  for (int s = 0; s < slices; ++s) {
+  for (int s = lane; s < slices; s += 64) {
     a += partial[((size_t)s * C + c) * 2];
     q += partial[((size_t)s * C + c) * 2 + 1];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane != 0) return;
   const float is = invstd[c], dg = q * is;
   dbeta[c] = a;
   dgamma[c] = dg;
@@ -616,10 +627,14 @@ int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* g
   UdProfScope prof("head_tail.stats", stream);
   const long long P = (long long)B * H * W;
   const int C = G * kHC;
-  k_stats_partial<<<dim3(kStatSlices, G), 256, 0, stream>>>((const unsigned short*)y, P, C, w.stat_partial);
+  long long slices = 2048 / G;
+  if (slices > (P + 31) / 32) slices = (P + 31) / 32;
+  if (slices < 1) slices = 1;
+  if (slices > kStatSlices) slices = kStatSlices;
+  k_stats_partial<<<dim3((int)slices, G), 256, 0, stream>>>((const unsigned short*)y, P, C, w.stat_partial);
   UD_LAUNCH_CHECK();
-  k_stats_final<<<ud_div_up(C, 256), 256, 0, stream>>>((const unsigned short*)y, w.stat_partial,
-                                                        kStatSlices, P, C, gamma, beta, eps, mean, var,
+  k_stats_final<<<C, 64, 0, stream>>>((const unsigned short*)y, w.stat_partial,
+                                                        (int)slices, P, C, gamma, beta, eps, mean, var,
                                                         invstd, scale, shift);
   UD_LAUNCH_CHECK();
   return UD_OK;
@@ -668,7 +683,7 @@ int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const floa
     k_tail_bwd<false><<<dim3(kBwdSlices, G), 256, 0, stream>>>((const unsigned short*)y, dz, w2, cst,
                                                                nullptr, w.bwd_partial, gm);
     UD_LAUNCH_CHECK();
-    k_bn_bwd_final<<<ud_div_up(C, 256), 256, 0, stream>>>(w.bwd_partial, kBwdSlices, C, P, scale, mean,
+    k_bn_bwd_final<<<C, 64, 0, stream>>>(w.bwd_partial, kBwdSlices, C, P, scale, mean,
                                                            invstd, dgamma, dbeta, w.k0, w.k2);
     UD_LAUNCH_CHECK();
   }

@@ -48,7 +48,7 @@ class BaseBEVBackbone(nn.Module):
                 else:
                     k = int(np.round(1 / us))
                     up = nn.Conv2d(c, uc, k, stride=k, bias=False)
-                self.deblocks.append(nn.Sequential(up, _bn(uc), nn.ReLU()))
+                self.deblocks.append(FusedSequential(up, _bn(uc), nn.ReLU()))
         c_out = sum(num_upsample_filters)
         if len(upsample_strides) > len(layer_nums):
             us = upsample_strides[-1]

@@ -9,10 +9,12 @@ and the data gradient.  ``FusedSequential`` is nn.Sequential that additionally
     through the fused epilogue -- the frozen distillation teacher's trunk.
 Anything else (fp32 mode, CPU, other kernel sizes / strides) is the plain PyTorch module.
 """
+import os
+
 import torch
 from torch import nn
 
-from ..ops import conv2d as hipconv
+from ..ops import bn_act as hipbn, conv2d as hipconv
 from ..ops.spconv import folded_batchnorm
 
 
@@ -42,6 +44,23 @@ def _can_fuse_inference(x, bn):
             and not (torch.is_grad_enabled() and x.requires_grad))
 
 
+_HIP_BN = os.environ.get("UD_HIP_BN", "1") != "0"      # A/B switch for the streaming BatchNorm kernels
+
+
+def batchnorm_act(bn, x, residual=None, relu=True):
+    """relu(bn(x) (+ residual)): the streaming HIP kernels in bf16 channels-last mode (training-mode
+    statistics with autograd, or eval-mode without), the PyTorch ops otherwise."""
+    frozen_grad = (not bn.training) and torch.is_grad_enabled() and (
+        x.requires_grad or (residual is not None and residual.requires_grad))
+    if Conv2d.hip_enabled and _HIP_BN and isinstance(bn, nn.BatchNorm2d) and not frozen_grad \
+            and hipbn.supported(x, bn):
+        return hipbn.bn_act(bn, x, residual, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
+
+
 class FusedSequential(nn.Sequential):
     def forward(self, x):
         mods = list(self)
@@ -56,6 +75,11 @@ class FusedSequential(nn.Sequential):
                 elif _is3x3(m, 1):
                     conv, skip = m, 1
             if conv is None:
+                if isinstance(m, nn.BatchNorm2d) and x.dim() == 4:
+                    relu = i + 1 < n and isinstance(mods[i + 1], nn.ReLU)
+                    x = batchnorm_act(m, x, None, relu)
+                    i += 2 if relu else 1
+                    continue
                 x = m(x)
                 i += 1
                 continue

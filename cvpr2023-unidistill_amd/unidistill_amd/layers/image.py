@@ -12,7 +12,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .dense import Conv2d
+from .dense import Conv2d, FusedSequential, batchnorm_act
 
 
 class Bottleneck(nn.Module):
@@ -31,10 +31,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + idt)
+        y = batchnorm_act(self.bn1, self.conv1(x))
+        y = batchnorm_act(self.bn2, self.conv2(y))
+        return batchnorm_act(self.bn3, self.conv3(y), residual=idt)
 
 
 class ResNet(nn.Module):
@@ -52,8 +51,8 @@ class ResNet(nn.Module):
         inplanes = 64
         for i, n in enumerate(self.arch[depth]):
             planes, stride = 64 * 2 ** i, (1 if i == 0 else 2)
-            down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
-                                 nn.BatchNorm2d(planes * 4))
+            down = FusedSequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                   nn.BatchNorm2d(planes * 4))
             blocks = [Bottleneck(inplanes, planes, stride, down)]
             inplanes = planes * 4
             blocks += [Bottleneck(inplanes, planes) for _ in range(1, n)]
@@ -68,7 +67,7 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(batchnorm_act(self.bn1, self.conv1(x)))
         outs = []
         for i in range(4):
             x = getattr(self, f"layer{i + 1}")(x)
@@ -99,8 +98,8 @@ class SECONDFPN(nn.Module):
             else:
                 k = int(np.round(1 / s))
                 op = nn.Conv2d(cin, cout, k, stride=k, bias=False)
-            self.deblocks.append(nn.Sequential(op, nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01),
-                                               nn.ReLU(inplace=True)))
+            self.deblocks.append(FusedSequential(op, nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01),
+                                                 nn.ReLU(inplace=True)))
 
     def init_weights(self):
         for m in self.modules():

@@ -36,14 +36,39 @@ def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, re
     return y
 
 
+def _cached(weight, key, make):
+    """bf16 re-layouts of a FROZEN weight (requires_grad False: the distillation teacher) are cached on
+    the tensor and rebuilt when its version counter moves.  Trainable weights are converted on every
+    call: fused optimizers update parameters without touching the version counter."""
+    if weight.requires_grad or torch.cuda.is_current_stream_capturing():
+        return make(weight.detach())
+    ver = (weight._version, weight.data_ptr())
+    hit = getattr(weight, key, None)
+    if hit is None or hit[0] != ver:
+        with torch.no_grad():
+            hit = (ver, make(weight.detach()))
+        try:
+            setattr(weight, key, hit)
+        except AttributeError:          # non-leaf views etc.: just do not cache
+            pass
+    return hit[1]
+
+
 def tap_major(weight):
     """[Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] bf16 contiguous (the kernel's weight layout)."""
-    return weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+    return _cached(weight, "_ud_tap", lambda w: w.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous())
 
 
 def tap_major_transposed(weight):
     """Weights of the data-gradient convolution: [Cin, 3, 3, Cout], spatially flipped."""
-    return weight.detach().flip(2, 3).permute(1, 2, 3, 0).to(torch.bfloat16).contiguous()
+    return _cached(weight, "_ud_tap_t",
+                   lambda w: w.flip(2, 3).permute(1, 2, 3, 0).to(torch.bfloat16).contiguous())
+
+
+def library_layout(weight):
+    """bf16 channels-last copy for aten.convolution_backward (weight gradient)."""
+    return _cached(weight, "_ud_cl",
+                   lambda w: w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
 
 
 class _Conv3x3Fn(torch.autograd.Function):
@@ -65,7 +90,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _launch(gy, tap_major_transposed(weight), weight.shape[1])
         if ctx.needs_input_grad[1]:
-            wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            wb = library_layout(weight)
             gw = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False,
                                                      [0, 0], 1, [False, True, False])[1].to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -185,7 +185,7 @@ def bf16_weight(conv):
     w = conv.weight
     ver = (w._version, w.device, w.data_ptr())
     hit = getattr(conv, "_ud_w_bf16", None)
-    if hit is None or hit[0] != ver:
+    if hit is None or hit[0] != ver or w.requires_grad:
         with torch.no_grad():
             hit = (ver, w.detach().reshape(w.shape[0], -1, w.shape[-1]).to(torch.bfloat16).contiguous())
         conv._ud_w_bf16 = hit
@@ -198,7 +198,8 @@ def folded_batchnorm(bn):
     ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.device)
     hit = getattr(bn, "_ud_folded", None)
-    if hit is None or hit[0] != ver:
+    # trainable parameters are never cached: fused optimizers step them without a version bump
+    if hit is None or hit[0] != ver or bn.weight.requires_grad or bn.bias.requires_grad:
         with torch.no_grad():
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
             shift = (bn.bias - bn.running_mean * scale).float().contiguous()

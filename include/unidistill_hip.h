@@ -355,6 +355,24 @@ int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, in
                          const float* bias, const float* scale, const float* shift,
                          const void* residual, int relu, ud_stream_t stream);
 
+/* ---- BatchNorm2d (+ residual) (+ ReLU), channels-last bf16 ------------------------------------------
+ * The Conv2d -> BatchNorm2d -> ReLU links of the reference's dense layers (base_bev_backbone.py:48-66,
+ * center_head.py:408-420, the mmdet ResNet bottlenecks) as HBM-bound streaming kernels over
+ * x [P pixels][C] bf16.  Batch statistics: ud_head_tail_stats (any C % 64 == 0 tensor, G = C / 64).
+ *   ud_bn_act_fwd : y = act(x * scale + shift (+ residual)), scale = gamma*invstd, shift = beta - mean*scale
+ *                   (batch statistics in training, running statistics in eval).  C % 8 == 0.
+ *   ud_bn_act_bwd : training-mode backward: dx (bf16), dgamma, dbeta [C] and, when `dresidual` is given,
+ *                   the masked gradient for the residual branch.  Pass `y` (the saved output) when a
+ *                   residual took part in the forward, NULL otherwise (the ReLU mask is then recomputed
+ *                   from x).  C % 64 == 0.  Deterministic two-stage reductions. */
+size_t ud_bn_act_workspace_bytes(int C);
+int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,
+                  long long P, int C, int relu, ud_stream_t stream);
+int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* scale, const float* shift,
+                  const float* mean, const float* invstd, void* dx, void* dresidual, float* dgamma,
+                  float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
+                  ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

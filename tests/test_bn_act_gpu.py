@@ -1,0 +1,63 @@
+"""Streaming BatchNorm(+residual)(+ReLU) kernels vs torch.nn.BatchNorm2d in fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, f, name=""):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), rtol=0,
+                               atol=f * float(b.detach().abs().max()) + 1e-6, err_msg=name)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 9, 13), (3, 128, 16, 20), (1, 256, 5, 7)])
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_act_training(hip_lib, B, C, H, W, residual, relu):
+    from unidistill_amd.layers.dense import batchnorm_act
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 2 + 0.5).bfloat16()
+    r = torch.randn(B, C, H, W, generator=g).bfloat16() if residual else None
+    gy = torch.randn(B, C, H, W, generator=g).bfloat16()
+    bn_ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.normal_(0, 0.3)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).cuda()
+    bn.load_state_dict(bn_ref.state_dict())
+    xr = x.float().requires_grad_(True)
+    rr = r.float().requires_grad_(True) if residual else None
+    yr = bn_ref(xr)
+    if residual:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(gy.float())
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rd = r.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if residual else None
+    y = batchnorm_act(bn, xd, rd, relu)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.cuda())
+    _close(y, yr, 8e-3, "y")
+    _close(xd.grad, xr.grad, 2e-2, "dx")
+    _close(bn.weight.grad, bn_ref.weight.grad, 1e-2, "dgamma")
+    _close(bn.bias.grad, bn_ref.bias.grad, 1e-2, "dbeta")
+    if residual:
+        _close(rd.grad, rr.grad, 8e-3, "dres")
+    _close(bn.running_mean, bn_ref.running_mean, 1e-3, "running_mean")
+    _close(bn.running_var, bn_ref.running_var, 1e-3, "running_var")
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_bn_act_eval(hip_lib):
+    from unidistill_amd.layers.dense import batchnorm_act
+    bn = torch.nn.BatchNorm2d(128).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2); bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    x = torch.randn(2, 128, 11, 7, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = batchnorm_act(bn, x)
+        ref = F.relu(bn(x.float()))
+    _close(y, ref, 8e-3)

@@ -60,7 +60,8 @@ def test_conv3x3_fused_epilogue(hip_lib):
 
 
 def test_trunk_on_mfma_kernel_matches_library_path(hip_lib):
-    """BaseBEVBackbone in bf16 autocast: hand-written conv path == MIOpen path (train and fused eval)."""
+    """BaseBEVBackbone under bf16 autocast: the hand-written conv/BN path is as close to the fp32
+    result as the library's bf16 path is (train forward/backward and fused eval)."""
     from unidistill_amd.layers.bev import BaseBEVBackbone
     from unidistill_amd.layers import dense
     torch.manual_seed(0)
@@ -68,27 +69,30 @@ def test_trunk_on_mfma_kernel_matches_library_path(hip_lib):
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
     x = torch.randn(2, 64, 36, 28, device="cuda").contiguous(memory_format=torch.channels_last)
-    res = {}
-    for hip in (True, False):
+
+    def run(hip, autocast):
         dense.Conv2d.hip_enabled = hip
         try:
+            net.load_state_dict(state)
             net.train(); net.zero_grad()
             xs = x.clone().requires_grad_(True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
                 y, _ = net(xs)
             y.float().square().mean().backward()
             g = [p.grad.clone() for p in net.parameters()]
             net.eval()
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
                 ye, _ = net(x)
-            res[hip] = (y.detach().float(), xs.grad.float(), g, ye.float())
+            return [y.detach().float(), xs.grad.float(), torch.cat([t.flatten() for t in g]), ye.float()]
         finally:
             dense.Conv2d.hip_enabled = True
-    def close(a, b, f):
-        return torch.allclose(a, b, rtol=0, atol=f * float(b.abs().max()) + 1e-6)
-    assert close(res[True][0], res[False][0], 3e-2)
-    assert close(res[True][1], res[False][1], 5e-2)
-    for a, b in zip(res[True][2], res[False][2]):
-        assert close(a, b, 5e-2)
-    assert close(res[True][3], res[False][3], 3e-2)
+
+    ref, lib, ours = run(False, False), run(False, True), run(True, True)
+
+    def rel(a, b):
+        return float((a - b).norm()) / (float(b.norm()) + 1e-12)
+    for name, r, l, o in zip(("train output", "input grad", "parameter grads", "eval output"), ref, lib, ours):
+        e_lib, e_ours = rel(l, r), rel(o, r)
+        assert e_ours < 1.5 * e_lib + 5e-3, (name, e_ours, e_lib)

@@ -16,12 +16,14 @@ else:
     batch = train.synthetic_batch(dev, B, sweeps=int(os.environ.get("SWEEPS", 1)))
 ac = {"bf16": torch.bfloat16, "": None}[os.environ.get("AC", "")]
 tr = train.Trainer(step, device=dev, autocast_dtype=ac, channels_last=os.environ.get("CL", "0") == "1")
-for _ in range(3):
+for i in range(3):
     out = tr.step(batch)
+    if os.environ.get('LOSSES'): print('warm', i, float(out['loss']))
 torch.cuda._sleep(1000); torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(steps):
+for i in range(steps):
     out = tr.step(batch)
+    if os.environ.get('LOSSES'): print('step', i, float(out['loss']))
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 torch.cuda._sleep(1000); torch.cuda.synchronize()
