@@ -226,7 +226,9 @@ __global__ void k_stats_final(const unsigned short* __restrict__ y, const float*
                               int slices, long long P, int C, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float eps, float* __restrict__ mean,
                               float* __restrict__ var, float* __restrict__ invstd,
-                              float* __restrict__ scale, float* __restrict__ shift) {
+                              float* __restrict__ scale, float* __restrict__ shift,
+                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                              float momentum) {
   // one wave per channel: lanes stride over the slices, then a fixed-order butterfly (deterministic)
   const int c = blockIdx.x, lane = threadIdx.x;
   double a = 0.0, q = 0.0;
@@ -251,6 +253,11 @@ __global__ void k_stats_final(const unsigned short* __restrict__ y, const float*
   const float sc = gamma[c] * is;
   scale[c] = sc;
   shift[c] = beta[c] - mu * sc;
+  if (running_mean) {   // nn.BatchNorm2d bookkeeping: unbiased variance goes into the buffer
+    const double unbiased = v * ((double)P / (double)(P > 1 ? P - 1 : 1));
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
 }
 
 // ---- weight gradient of the per-head conv --------------------------------------------------------
@@ -615,10 +622,11 @@ size_t ud_head_tail_workspace_bytes(int G) {
 
 int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* gamma,
                        const float* beta, float eps, float* mean, float* var, float* invstd,
-                       float* scale, float* shift, void* workspace, size_t workspace_bytes,
-                       ud_stream_t stream_) {
+                       float* scale, float* shift, float* running_mean, float* running_var,
+                       float momentum, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!y || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || !geom_ok(B, H, W, G, 1))
+  if (!y || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || !geom_ok(B, H, W, G, 1) ||
+      ((running_mean == nullptr) != (running_var == nullptr)))
     return UD_ERR_INVALID_ARG;
   UdArena ar(workspace, workspace_bytes);
   TailWs w;
@@ -635,7 +643,8 @@ int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* g
   UD_LAUNCH_CHECK();
   k_stats_final<<<C, 64, 0, stream>>>((const unsigned short*)y, w.stat_partial,
                                                         (int)slices, P, C, gamma, beta, eps, mean, var,
-                                                        invstd, scale, shift);
+                                                        invstd, scale, shift, running_mean,
+                                                        running_var, momentum);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

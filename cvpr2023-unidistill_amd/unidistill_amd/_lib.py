@@ -77,7 +77,7 @@ _SIGS = {
     "ud_bn_act_bwd": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_workspace_bytes": (c_size_t, [c_int]),
     "ud_head_tail_stats": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_float]
-                           + [c_void_p] * 5 + [c_void_p, c_size_t, c_void_p]),
+                           + [c_void_p] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_fwd": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "ud_head_tail_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
 }

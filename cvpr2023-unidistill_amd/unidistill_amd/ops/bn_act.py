@@ -23,19 +23,24 @@ class _BnActFn(torch.autograd.Function):
         B, C, H, W = x.shape
         P = B * H * W
         dev = x.device
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
+        b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
         stream = _lib.stream_of(x)
         if training:
             vec = torch.empty((5, C), dtype=torch.float32, device=dev)
             mean, var, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3], vec[4]
             ws = _lib.workspace(dev, lib.ud_head_tail_workspace_bytes(C // 64), "head_tail")
+            fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
+            rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
             _lib.check(lib.ud_head_tail_stats(_lib.ptr(x), B, H, W, C // 64, _lib.ptr(g32), _lib.ptr(b32),
                                               float(eps), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(invstd),
-                                              _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(ws), ws.numel(),
+                                              _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
+                                              _lib.ptr(ws), ws.numel(),
                                               stream), "ud_head_tail_stats")
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var, alpha=momentum * P / max(P - 1, 1))
+            if running_mean is not None and not fp32_buffers:
+                with torch.no_grad():
+                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(var, alpha=momentum * P / max(P - 1, 1))
         else:
             invstd = torch.rsqrt(running_var.float() + eps)
             mean = running_mean.float()

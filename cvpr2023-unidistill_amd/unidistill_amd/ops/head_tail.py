@@ -45,11 +45,13 @@ class _HeadTailFn(torch.autograd.Function):
         if training:
             vec = torch.empty((5, C), dtype=torch.float32, device=dev)
             mean, var, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3], vec[4]
+            fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
+            rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
             _lib.check(lib.ud_head_tail_stats(_lib.ptr(y), B, H, W, G, _lib.ptr(g32), _lib.ptr(b32),
                                               float(eps), _lib.ptr(mean), _lib.ptr(var),
-                                              _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift),
-                                              _lib.ptr(ws), ws.numel(), stream), "ud_head_tail_stats")
-            if running_mean is not None:
+                                              _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv),
+                                              float(momentum or 0.0), _lib.ptr(ws), ws.numel(), stream), "ud_head_tail_stats")
+            if running_mean is not None and not fp32_buffers:
                 n = B * H * W
                 with torch.no_grad():     # nn.BatchNorm2d bookkeeping: unbiased variance in the buffers
                     running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)

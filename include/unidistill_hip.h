@@ -326,15 +326,17 @@ int ud_distill_resp_bwd(const float* const* s_hm, const float* const* t_hm, floa
  * kmax <= 3 (UD_ERR_UNSUPPORTED otherwise).  BN + ReLU are applied while tiles are staged, the conv
  * multiplies bf16 operands with fp32 accumulation (same arithmetic as the bf16 autocast library path).
  *   ud_head_tail_stats : training-mode batch statistics of y -> mean, biased var, invstd and the
- *                        folded scale = gamma*invstd, shift = beta - mean*scale.
+ *                        folded scale = gamma*invstd, shift = beta - mean*scale.  When running_mean /
+ *                        running_var are given (both or neither) they are updated in place like
+ *                        nn.BatchNorm2d does: r = (1-momentum)*r + momentum*{mean, unbiased var}.
  *   ud_head_tail_fwd   : z = conv(relu(y*scale + shift), w2) + b2   (any scale/shift: batch or running).
  *   ud_head_tail_bwd   : training-mode backward through conv, ReLU and BatchNorm: dy, dw2, dgamma,
  *                        dbeta (db2 = sum of dz is left to the caller).  Deterministic. */
 size_t ud_head_tail_workspace_bytes(int G);
 int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* gamma,
                        const float* beta, float eps, float* mean, float* var, float* invstd,
-                       float* scale, float* shift, void* workspace, size_t workspace_bytes,
-                       ud_stream_t stream);
+                       float* scale, float* shift, float* running_mean, float* running_var,
+                       float momentum, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 int ud_head_tail_fwd(const void* y, const float* scale, const float* shift, const float* w2,
                      const float* b2, float* z, int B, int H, int W, int G, int kmax,
                      ud_stream_t stream);
