@@ -97,7 +97,10 @@ def roofline_leg(device, batch):
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "avg_kernel_us": k_us, "launches": k_calls, "algorithmic_bytes_per_launch": alg,
             "op_avg_us": op_ms / reps * 1e3, "op_GBps": alg / (op_ms / reps * 1e-3) / 1e9,
-            "traffic": None,
+            # HBM bytes per launch from the PMC passes of the same op at the same shape
+            # (profiles/r01_pmc_k_pool.md: FETCH_SIZE 182401 KB x2 (gfx950) + WRITE_SIZE 32400 KB);
+            # counters cannot be read from inside this process, so the committed figure is reported.
+            "traffic": 406.8e6 if (C, nx, ny, N) == (256, 180, 180, 473088) else None,
             "note": "measured after the timed region; the training step itself uses the fused "
                     "lift+splat (no [B,N,C] tensor), see DESIGN.md"}
 
@@ -199,7 +202,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": loss,
                        "precision": "fp32 everywhere" if ac is None else
-                       "bf16 autocast on dense convs, fp32 HIP ops (voxelize/spconv/splat/losses), fp32 master weights",
+                       "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the teacher's sparse convs (HIP MFMA kernels + MIOpen wgrad); fp32 voxelize/splat/losses; fp32 master weights",
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
                        "executor": "hipGraph" if isinstance(trainer, train.GraphTrainer) else "eager+DDP"},
         }
