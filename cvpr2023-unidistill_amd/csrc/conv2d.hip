@@ -7,10 +7,12 @@
 //
 // One workgroup (4 waves, each a 64 x 64 sub-tile) owns 8 x 16 output pixels x 128 output channels.
 // Per 64-channel slice of Cin the 10 x 18 input halo is staged ONCE in LDS and serves all nine
-// taps (the gather a library implicit GEMM repeats per tap); the [128 x 64] weight slice of the next
-// (tap, slice) is prefetched into registers while the current one is multiplied and lands in the
-// other half of a double-buffered LDS tile, so there is one barrier per 32 MFMAs per wave.
-// 144-byte LDS rows keep the ds_read_b128 fragment loads conflict-free; the fp32 result tile is
+// taps (the gather a library implicit GEMM repeats per tap).  Halo and weight slices travel
+// HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write -- the register
+// staged version spent 31 % of its time in the weight ds_writes); both are double-buffered, the next
+// (tap, slice) weight tile flies while the current one is multiplied: one barrier per 32 MFMAs per
+// wave.  Tiles are unpadded 128-byte rows whose 16-byte slots are XOR-swizzled with the row index on
+// the source address, which keeps every ds_read_b128 fragment load conflict-free; the fp32 result tile is
 // staged through LDS so that bias / folded BatchNorm / residual / ReLU are applied on, and stored as,
 // 16-byte channel pieces.  The data gradient is the same kernel on the flipped, transposed weights.
 #include "ud_common.h"
@@ -21,13 +23,13 @@ namespace {
 constexpr int kTW = 16, kTH = 8;             // output pixel tile
 constexpr int kTM = kTW * kTH;               // 128 GEMM rows
 constexpr int kTN = 128;                     // output channels per workgroup
-constexpr int kKC = 64;                      // input channels per staged slice
+constexpr int kKC = 64;                      // input channels per staged slice (one 128-byte LDS row)
 constexpr int kHW = kTW + 2, kHH = kTH + 2;  // halo
 constexpr int kHQ = kHW * kHH;               // 180 staged pixels
-constexpr int kLD = kKC + 8;                 // bf16 elements per LDS row (144 B)
+constexpr int kHQP = (kHQ + 7) / 8 * 8;      // 184: rows are staged 8 at a time
 constexpr int kLDO = kTN + 4;                // fp32 elements per staged output row
-constexpr int kAIters = (kHQ * 8 + 255) / 256;   // 16-byte units of the halo per thread (6)
-constexpr int kBIters = kTN * 8 / 256;           // 16-byte units of a weight slice per thread (4)
+constexpr int kAInstr = kHQP / 8;            // 1-KiB direct-to-LDS pieces of a halo slice (23)
+constexpr int kBInstr = kTN / 8;             // ... of a weight slice (16)
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -43,17 +45,31 @@ struct ConvEp {
   int relu;
 };
 
-constexpr size_t kOperandBytes = (size_t)(kHQ + 2 * kTN) * kLD * 2;
+// LDS: two halo slices, two weight slices; the fp32 output tile reuses the space after the K loop.
+constexpr size_t kABytes = (size_t)kHQP * kKC * 2, kBBytes = (size_t)kTN * kKC * 2;
+constexpr size_t kOperandBytes = 2 * kABytes + 2 * kBBytes;
 constexpr size_t kOutBytes = (size_t)kTM * kLDO * 4;
 constexpr size_t kSmemBytes = kOperandBytes > kOutBytes ? kOperandBytes : kOutBytes;
+
+// Out-of-image halo pixels and output channels past Cout are loaded from here (LDS-DMA cannot
+// write a constant).
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+
+// One wave-wide 1 KiB piece: lane l lands at lds + 16*l (the DMA's fixed pattern) = row l>>3, 16-byte
+// slot l&7 of an unpadded 8 x 128 B block.  Slot s of row r holds channel group s ^ (r & 7): the XOR
+// swizzle is applied on the SOURCE address, which keeps every later ds_read_b128 conflict-free.
+__device__ __forceinline__ void dma16(const unsigned short* src, unsigned short* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __restrict__ x,
                                                       const unsigned short* __restrict__ w,
                                                       unsigned short* __restrict__ y, ConvGeom gm,
                                                       ConvEp ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned short* As = reinterpret_cast<unsigned short*>(smem);          // [kHQ][kLD]
-  unsigned short* Bs = As + kHQ * kLD;                                     // [2][kTN][kLD]
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);          // [2][kHQP][64]
+  unsigned short* Bs = As + 2 * kHQP * kKC;                                // [2][kTN][64]
   float* Os = reinterpret_cast<float*>(smem);                              // [kTM][kLDO] after the K loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -68,6 +84,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
   tile -= b * gm.tiles_x * gm.tiles_y;
   const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
   const int n0 = blockIdx.y * kTN;
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -75,81 +92,61 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[kAIters], rb[kBIters];
-  auto fetch_a = [&](int chunk) {
-#pragma unroll
-    for (int j = 0; j < kAIters; ++j) {
-      const int u = tid + 256 * j;
-      const int q = u >> 3, c8 = (u & 7) * 8;
+  const int r8 = lane >> 3, slot = lane & 7;      // this lane's row / 16-byte slot inside a 1 KiB piece
+  auto stage_a = [&](int chunk, int buf) {
+    for (int piece = wave; piece < kAInstr; piece += 4) {
+      const int q = piece * 8 + r8;
       const int qy = q / kHW, qx = q - qy * kHW;
       const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
-      ra[j] = make_uint4(0u, 0u, 0u, 0u);
+      const unsigned short* src = zero;
       if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W)
-        ra[j] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin +
-                                                chunk * kKC + c8);
+        src = x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + chunk * kKC + ((slot ^ (q & 7)) << 3);
+      dma16(src, As + (buf * kHQP + piece * 8) * kKC);
     }
   };
-  auto commit_a = [&]() {
+  auto stage_b = [&](int chunk, int tap, int buf) {
 #pragma unroll
-    for (int j = 0; j < kAIters; ++j) {
-      const int u = tid + 256 * j;
-      if (u < kHQ * 8) *reinterpret_cast<uint4*>(As + (u >> 3) * kLD + (u & 7) * 8) = ra[j];
-    }
-  };
-  auto fetch_b = [&](int chunk, int tap) {
-#pragma unroll
-    for (int j = 0; j < kBIters; ++j) {
-      const int u = tid + 256 * j;
-      const int n = u >> 3, c8 = (u & 7) * 8;
-      rb[j] = make_uint4(0u, 0u, 0u, 0u);
+    for (int j = 0; j < kBInstr / 4; ++j) {
+      const int piece = wave + 4 * j;
+      const int n = piece * 8 + r8;
+      const unsigned short* src = zero;
       if (n0 + n < gm.Cout)
-        rb[j] = *reinterpret_cast<const uint4*>(w + ((size_t)(n0 + n) * 9 + tap) * gm.Cin + chunk * kKC + c8);
-    }
-  };
-  auto commit_b = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < kBIters; ++j) {
-      const int u = tid + 256 * j;
-      *reinterpret_cast<uint4*>(Bs + (buf * kTN + (u >> 3)) * kLD + (u & 7) * 8) = rb[j];
+        src = w + ((size_t)(n0 + n) * 9 + tap) * gm.Cin + chunk * kKC + ((slot ^ (n & 7)) << 3);
+      dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
     }
   };
 
   const int nchunks = gm.Cin / kKC, total = nchunks * 9;
-  fetch_a(0);
-  fetch_b(0, 0);
-  commit_a();
-  commit_b(0);
-  __syncthreads();
+  stage_a(0, 0);
+  stage_b(0, 0, 0);
+  __syncthreads();                 // drains the DMAs (vmcnt(0)) and publishes the tiles
   for (int it = 0; it < total; ++it) {
     const int chunk = it / 9, tap = it - chunk * 9;
-    const bool more = it + 1 < total;
-    const bool new_chunk = more && tap == 8;
-    if (more) fetch_b(new_chunk ? chunk + 1 : chunk, new_chunk ? 0 : tap + 1);
-    if (tap == 0 && chunk + 1 < nchunks) fetch_a(chunk + 1);
+    // next weight slice (and, at the start of a slice, the next halo) fly while this one is multiplied
+    if (it + 1 < total) stage_b(tap == 8 ? chunk + 1 : chunk, tap == 8 ? 0 : tap + 1, (it + 1) & 1);
+    if (tap == 0 && chunk + 1 < nchunks) stage_a(chunk + 1, (chunk + 1) & 1);
     {
-      const unsigned short* bbase = Bs + ((it & 1) * kTN + 64 * wn + li) * kLD + 8 * g;
-      const unsigned short* abase = As + ((4 * wm + tap / 3) * kHW + li + tap % 3) * kLD + 8 * g;
+      const unsigned short* bbuf = Bs + (it & 1) * kTN * kKC;
+      const unsigned short* abuf = As + (chunk & 1) * kHQP * kKC;
+      const int q0 = (4 * wm + tap / 3) * kHW + li + tap % 3;   // halo pixel of row tile 0 for this lane
 #pragma unroll
       for (int ks = 0; ks < kKC / 32; ++ks) {
+        const int cg = 4 * ks + g;                              // logical 16-byte channel group
         bf16x8 a[4];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-          a[ti] = *reinterpret_cast<const bf16x8*>(abase + ti * kHW * kLD + 32 * ks);
+        for (int ti = 0; ti < 4; ++ti) {
+          const int q = q0 + ti * kHW;
+          a[ti] = *reinterpret_cast<const bf16x8*>(abuf + q * kKC + ((cg ^ (q & 7)) << 3));
+        }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
-          const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bbase + tj * 16 * kLD + 32 * ks);
+          const int n = 64 * wn + 16 * tj + li;
+          const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bbuf + n * kKC + ((cg ^ (n & 7)) << 3));
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti)
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
         }
       }
-    }
-    if (more) {
-      if (new_chunk) {
-        __syncthreads();           // every wave is done with this slice's halo
-        commit_a();
-      }
-      commit_b((it + 1) & 1);
     }
     __syncthreads();
   }

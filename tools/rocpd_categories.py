@@ -1,5 +1,5 @@
 """Group a rocprofv3 rocpd .db kernel trace into categories; print ms per category (total / per step)."""
-import re, sqlite3, sys
+import os, re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 # steady-state window: between the last two marker kernels (torch.cuda._sleep -> "spin_kernel")
 marks = [r[0] for r in db.execute("select start from kernels where name like '%spin_kernel%' order by start").fetchall()]
@@ -10,7 +10,7 @@ if len(marks) >= 2:
     print(f"window between markers: {span:.1f} ms wall, {span/steps:.2f} ms/step")
 rows = db.execute(f"select name, count(*), sum(duration) from kernels{where} group by name").fetchall()
 if "--top" in sys.argv:
-    for name, n, dur in sorted(rows, key=lambda r: -r[2])[:25]:
+    for name, n, dur in sorted(rows, key=lambda r: -r[2])[:int(os.environ.get("TOP", 25))]:
         print(f"  {dur/1e6/steps:8.3f} ms/step  {n/steps:7.1f} x  {name[:110]}")
 cats = [("ours:conv3x3 (MFMA)", r"k_conv3x3_bf16"),
         ("ours:head_tail", r"k_tail_|k_stats_|k_sum_slices|k_bn_bwd_final"),
