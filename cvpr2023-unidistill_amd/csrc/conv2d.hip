@@ -196,6 +196,158 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
   }
 }
 
+// ---- weight gradient -----------------------------------------------------------------------------
+//   dW[n][tap][c] = sum_p dy[p][n] * x[p + tap][c]           (p over all B*H*W output pixels)
+// A GEMM whose reduction index is the pixel, i.e. both operands are K-STRIDED in their channels-last
+// tensors.  Tiles are staged row-major ([pixel][channel], rows padded by 32 B) and the MFMA operand
+// fragments are read with ds_read_b64_tr_b16: inside each 16-lane group, lane j points at the 8-byte
+// piece [pixel k0 + (j>>2)][channel c0 + 4*(j&3)], and the hardware hands lane i the four values
+// [k0 .. k0+3][c0 + i] -- the transpose costs no extra LDS pass.  A workgroup owns one
+// (tap, 128 x CT output tile) and a slice of the pixels (64 per step, next step prefetched in
+// registers, double-buffered LDS); the slices' partial sums are reduced in a fixed order by
+// k_wgrad_sum (deterministic, no atomics).
+typedef short v4s __attribute__((ext_vector_type(4)));
+constexpr int kWP = 64;                      // pixels per step
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* p_lo, const unsigned short* p_hi) {
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p_lo);
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p_hi);
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int CT>   // channels of x per workgroup: 64 or 128
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ dy,
+                                                       float* __restrict__ partial, ConvGeom gm,
+                                                       int c_tiles, int n_tiles) {
+  constexpr int LDN = 128 + 16, LDC = CT + 16;        // bf16 elements per LDS row (+32 B pad)
+  constexpr int NU = kWP * 16 / 256;                  // 16-byte units per thread, dy tile (4)
+  constexpr int CU = kWP * (CT / 8) / 256;            // ... x tile (2 or 4)
+  constexpr int TJ = CT / 32;                         // 16-wide c tiles per wave (2 or 4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* Ns = reinterpret_cast<unsigned short*>(smem);        // [2][kWP][LDN]  dy
+  unsigned short* Cs = Ns + 2 * kWP * LDN;                               // [2][kWP][LDC]  shifted x
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  int combo = blockIdx.y;
+  const int ct = combo % c_tiles; combo /= c_tiles;
+  const int nt = combo % n_tiles;
+  const int tap = combo / n_tiles;
+  const int sy = tap / 3 - 1, sx = tap % 3 - 1;
+  const int n0 = nt * 128, c0 = ct * CT;
+  const long long P = (long long)gm.B * gm.H * gm.W;
+  const int steps = (int)((P + kWP - 1) / kWP);
+
+  f32x4 acc[4][TJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 rn[NU], rc[CU];
+  auto fetch = [&](int step) {
+    const long long p0 = (long long)step * kWP;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int u = tid + 256 * j, r = u >> 4, n8 = (u & 15) * 8;
+      const long long p = p0 + r;
+      rn[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (p < P && n0 + n8 < gm.Cout) rn[j] = *reinterpret_cast<const uint4*>(dy + (size_t)p * gm.Cout + n0 + n8);
+    }
+#pragma unroll
+    for (int j = 0; j < CU; ++j) {
+      const int u = tid + 256 * j, r = u / (CT / 8), c8 = (u - r * (CT / 8)) * 8;
+      const long long p = p0 + r;
+      rc[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (p < P && c0 + c8 < gm.Cin) {
+        const int px = (int)(p % gm.W), py = (int)((p / gm.W) % gm.H);
+        if (px + sx >= 0 && px + sx < gm.W && py + sy >= 0 && py + sy < gm.H)
+          rc[j] = *reinterpret_cast<const uint4*>(x + (size_t)(p + (long long)sy * gm.W + sx) * gm.Cin + c0 + c8);
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int u = tid + 256 * j;
+      *reinterpret_cast<uint4*>(Ns + (buf * kWP + (u >> 4)) * LDN + (u & 15) * 8) = rn[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CU; ++j) {
+      const int u = tid + 256 * j, r = u / (CT / 8);
+      *reinterpret_cast<uint4*>(Cs + (buf * kWP + r) * LDC + (u - r * (CT / 8)) * 8) = rc[j];
+    }
+  };
+
+  int step = blockIdx.x;
+  if (step < steps) {
+    fetch(step);
+    commit(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; step < steps; step += gridDim.x) {
+    const bool more = step + (int)gridDim.x < steps;
+    if (more) fetch(step + gridDim.x);
+    {
+      // lane j of a 16-lane group addresses pixel row (j>>2), 8-byte piece 4*(j&3) of a 16-wide tile
+      const unsigned short* nb = Ns + (buf * kWP + 8 * g + (li >> 2)) * LDN + 64 * wm + 4 * (li & 3);
+      const unsigned short* cb = Cs + (buf * kWP + 8 * g + (li >> 2)) * LDC + (CT / 2) * wn + 4 * (li & 3);
+#pragma unroll
+      for (int ks = 0; ks < kWP / 32; ++ks) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          a[ti] = tr_frag(nb + 32 * ks * LDN + 16 * ti, nb + (32 * ks + 4) * LDN + 16 * ti);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          const bf16x8 bb = tr_frag(cb + 32 * ks * LDC + 16 * tj, cb + (32 * ks + 4) * LDC + 16 * tj);
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
+        }
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial[slice][n][tap][c]; D layout: lane holds column c = li, rows n = 4g + r
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int c = c0 + (CT / 2) * wn + 16 * tj + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 64 * wm + 16 * ti + 4 * g + r;
+        if (n < gm.Cout && c < gm.Cin)
+          partial[(((size_t)blockIdx.x * gm.Cout + n) * 9 + tap) * gm.Cin + c] = acc[ti][tj][r];
+      }
+    }
+}
+
+__global__ void k_wgrad_sum(const float* __restrict__ partial, int slices, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < slices; ++s) a += partial[(size_t)s * n + i];
+  out[i] = a;
+}
+
+// pixel slices so that (slices x taps x output tiles) is ~600 workgroups
+int wgrad_slices(int Cin, int Cout, long long P, int* ct_width) {
+  const int CT = (Cin % 128 == 0) ? 128 : 64;
+  *ct_width = CT;
+  const int combos = 9 * ud_div_up(Cout, 128) * ud_div_up(Cin, CT);
+  long long s = (600 + combos - 1) / combos;
+  const long long steps = (P + kWP - 1) / kWP;
+  if (s > steps) s = steps;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 }  // namespace
 
 extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin,
@@ -220,6 +372,46 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   k_conv3x3_bf16<<<dim3(gx, ud_div_up(Cout, kTN)), 256, kSmemBytes, stream>>>(
       reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
       reinterpret_cast<unsigned short*>(y), gm, ep);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+extern "C" size_t ud_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  int ctw;
+  const int S = wgrad_slices(Cin, Cout, (long long)B * H * W, &ctw);
+  return ud_align_up((size_t)S * Cout * 9 * Cin * sizeof(float));
+}
+
+extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W,
+                                          int Cin, int Cout, void* workspace, size_t workspace_bytes,
+                                          ud_stream_t stream_) {
+  if (!x || !dy || !dw || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if (Cin % 64 != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ud_conv3x3_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvGeom gm{B, H, W, Cin, Cout, 0, 0};
+  int CT;
+  const int S = wgrad_slices(Cin, Cout, (long long)B * H * W, &CT);
+  const int c_tiles = ud_div_up(Cin, CT), n_tiles = ud_div_up(Cout, 128);
+  float* partial = reinterpret_cast<float*>(workspace);
+  UdProfScope prof("conv2d.k_wgrad", stream);
+  const dim3 grid(S, 9 * n_tiles * c_tiles);
+  if (CT == 128) {
+    const size_t lds = (size_t)2 * kWP * (144 + 144) * 2;
+    static bool set128 = false;
+    if (!set128) {
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set128 = true;
+    }
+    k_conv3x3_wgrad<128><<<grid, 256, lds, stream>>>((const unsigned short*)x, (const unsigned short*)dy, partial, gm, c_tiles, n_tiles);
+  } else {
+    const size_t lds = (size_t)2 * kWP * (144 + 80) * 2;
+    k_conv3x3_wgrad<64><<<grid, 256, lds, stream>>>((const unsigned short*)x, (const unsigned short*)dy, partial, gm, c_tiles, n_tiles);
+  }
+  UD_LAUNCH_CHECK();
+  const size_t n = (size_t)Cout * 9 * Cin;
+  k_wgrad_sum<<<ud_div_up((long long)n, 256), 256, 0, stream>>>(partial, S, n, dw);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

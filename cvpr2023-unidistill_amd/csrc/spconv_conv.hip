@@ -764,6 +764,178 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in
   }
 }
 
+// ---- weight gradient, bf16 operands (mixed-precision training) --------------------------------------
+// Same decomposition (one workgroup per (offset k, row chunk g), ordered reduction of the chunks), but
+// the products run on v_mfma_f32_16x16x32_bf16 -- 16x the rate of the fp32 matrix instruction the exact
+// path uses.  The reduction index of this GEMM is the sparse ROW, i.e. both operands (gout[row][n] and
+// the gathered in[nbr[row][k]][c]) are K-strided in memory: tiles of 64 rows are staged row-major as
+// bf16 and the fragments are read with ds_read_b64_tr_b16 (see csrc/conv2d.hip: inside a 16-lane group
+// lane j points at [row k0 + (j>>2)][channel 4*(j&3)..+3] and lane i receives [k0..k0+3][channel i]).
+// Row tiles follow the mask-sorted row order of the forward kernel; a per-tile 27-bit activity mask
+// (k_tile_masks) lets a workgroup skip the tiles that have no pair for its offset.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+constexpr int kWR = 64;                              // rows per step
+
+__global__ __launch_bounds__(256) void k_tile_masks(const int32_t* __restrict__ nbr, int K,
+                                                    const int32_t* __restrict__ order, int Mout,
+                                                    unsigned* __restrict__ masks, int ntiles) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (tile >= ntiles) return;
+  const int p = tile * kWR + lane;
+  unsigned m = 0u;
+  if (p < Mout) {
+    const int row = order ? order[p] : p;
+    for (int k = 0; k < K; ++k)
+      if (nbr[(size_t)row * K + k] >= 0) m |= 1u << k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor((int)m, o);
+  if (lane == 0) masks[tile] = m;
+}
+
+__device__ __forceinline__ bf16x8 tr_frag8(const unsigned short* lo_p, const unsigned short* hi_p) {
+  const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)lo_p);
+  const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)hi_p);
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int CIN_P, int COUT_P>
+__global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in, int cin,
+                                                    const int32_t* __restrict__ nbr, int K,
+                                                    const float* __restrict__ gout, int cout,
+                                                    float* __restrict__ partial, int Mout,
+                                                    const int32_t* __restrict__ order,
+                                                    const unsigned* __restrict__ masks, int ntiles,
+                                                    int tiles_per_chunk) {
+  constexpr int LDN = COUT_P + 16, LDC = CIN_P + 16;          // bf16 elements per LDS row
+  constexpr int NT = COUT_P / 16, CTT = CIN_P / 16;
+  constexpr int WM = NT >= 2 ? 2 : 1, WN = 4 / WM;
+  constexpr int TI = NT / WM, TJ = (CTT / WN) > 0 ? (CTT / WN) : 1;
+  constexpr int NU = (kWR * (COUT_P / 4) + 255) / 256;        // float4 units per thread
+  constexpr int CU = (kWR * (CIN_P / 4) + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* Ns = reinterpret_cast<unsigned short*>(smem);      // [2][kWR][LDN]
+  unsigned short* Cs = Ns + 2 * kWR * LDN;                             // [2][kWR][LDC]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = wave / WN, wn = wave % WN;
+  const bool wave_on = wn * TJ < CTT;
+  const int k = blockIdx.x, chunk = blockIdx.y;
+  const int t_end = min(ntiles, (chunk + 1) * tiles_per_chunk);
+  auto next_active = [&](int t) {
+    while (t < t_end && !((masks[t] >> k) & 1u)) ++t;
+    return t;
+  };
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 rn[NU], rc[CU];
+  const bool vec_n = (cout & 3) == 0, vec_c = (cin & 3) == 0;
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int u = tid + 256 * j, r = u / (COUT_P / 4), n4 = (u - r * (COUT_P / 4)) * 4;
+      const int p = t * kWR + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < kWR && p < Mout) {
+        const float* src = gout + (size_t)(order ? order[p] : p) * cout + n4;
+        if (vec_n) {
+          if (n4 < cout) v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (n4 + 0 < cout) v.x = src[0];
+          if (n4 + 1 < cout) v.y = src[1];
+          if (n4 + 2 < cout) v.z = src[2];
+          if (n4 + 3 < cout) v.w = src[3];
+        }
+      }
+      rn[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < CU; ++j) {
+      const int u = tid + 256 * j, r = u / (CIN_P / 4), c4 = (u - r * (CIN_P / 4)) * 4;
+      const int p = t * kWR + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < kWR && p < Mout) {
+        const int rr = nbr[(size_t)(order ? order[p] : p) * K + k];
+        if (rr >= 0) {
+          const float* src = in + (size_t)rr * cin + c4;
+          if (vec_c) {
+            if (c4 < cin) v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (c4 + 0 < cin) v.x = src[0];
+            if (c4 + 1 < cin) v.y = src[1];
+            if (c4 + 2 < cin) v.z = src[2];
+            if (c4 + 3 < cin) v.w = src[3];
+          }
+        }
+      }
+      rc[j] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int u = tid + 256 * j, r = u / (COUT_P / 4), n4 = (u - r * (COUT_P / 4)) * 4;
+      if (r < kWR)
+        *reinterpret_cast<uint2*>(Ns + (buf * kWR + r) * LDN + n4) =
+            make_uint2(ud_pack_bf16x2(rn[j].x, rn[j].y), ud_pack_bf16x2(rn[j].z, rn[j].w));
+    }
+#pragma unroll
+    for (int j = 0; j < CU; ++j) {
+      const int u = tid + 256 * j, r = u / (CIN_P / 4), c4 = (u - r * (CIN_P / 4)) * 4;
+      if (r < kWR)
+        *reinterpret_cast<uint2*>(Cs + (buf * kWR + r) * LDC + c4) =
+            make_uint2(ud_pack_bf16x2(rc[j].x, rc[j].y), ud_pack_bf16x2(rc[j].z, rc[j].w));
+    }
+  };
+  int t = next_active(chunk * tiles_per_chunk);
+  if (t < t_end) {
+    fetch(t);
+    commit(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  while (t < t_end) {
+    const int tn = next_active(t + 1);
+    if (tn < t_end) fetch(tn);
+    if (wave_on) {
+      const unsigned short* nb = Ns + (buf * kWR + 8 * g + (li >> 2)) * LDN + 16 * TI * wm + 4 * (li & 3);
+      const unsigned short* cb = Cs + (buf * kWR + 8 * g + (li >> 2)) * LDC + 16 * TJ * wn + 4 * (li & 3);
+#pragma unroll
+      for (int ks = 0; ks < kWR / 32; ++ks) {
+        bf16x8 a[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+          a[ti] = tr_frag8(nb + 32 * ks * LDN + 16 * ti, nb + (32 * ks + 4) * LDN + 16 * ti);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          const bf16x8 bb = tr_frag8(cb + 32 * ks * LDC + 16 * tj, cb + (32 * ks + 4) * LDC + 16 * tj);
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
+        }
+      }
+    }
+    if (tn < t_end) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    t = tn;
+  }
+  // partial[chunk][k][n][c] (padded sizes); D layout: column c = li, rows n = 4g + r
+  if (wave_on) {
+    float* pbase = partial + ((size_t)chunk * K + k) * COUT_P * CIN_P;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pbase[(size_t)(16 * (TI * wm + ti) + 4 * g + r) * CIN_P + 16 * (TJ * wn + tj) + li] = acc[ti][tj][r];
+  }
+}
+
 // gW[n][k][c] (KRSC, dense) = sum over chunks in order of partial[g][k][n][c]
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int G,
                                                       int K, int cinp, int coutp, int cin, int cout,
@@ -977,6 +1149,76 @@ extern "C" size_t ud_spconv_wgrad_workspace_bytes(int Mout, int K, int Cin, int 
   int rpc;
   const int G = wgrad_chunks(Mout > 0 ? Mout : 1, &rpc);
   return ud_align_up((size_t)G * K * pad16(Cin) * pad16(Cout) * sizeof(float));
+}
+
+namespace {
+int wgrad_bf16_chunks(int ntiles, int K, int* tiles_per_chunk) {
+  int G = 768 / (K > 0 ? K : 1);              // ~768 workgroups
+  if (G > 32) G = 32;
+  if (G > ntiles) G = ntiles;
+  if (G < 1) G = 1;
+  *tiles_per_chunk = (ntiles + G - 1) / G;
+  return (ntiles + *tiles_per_chunk - 1) / *tiles_per_chunk;
+}
+
+template <int CIN_P, int COUT_P>
+int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const float* gout, int cout,
+                      float* gW, int Mout, const int32_t* order, float* partial, unsigned* masks,
+                      hipStream_t stream) {
+  const int ntiles = ud_div_up(Mout, kWR);
+  int tpc;
+  const int G = wgrad_bf16_chunks(ntiles, K, &tpc);
+  k_tile_masks<<<ud_div_up(ntiles, 4), 256, 0, stream>>>(nbr, K, order, Mout, masks, ntiles);
+  UD_LAUNCH_CHECK();
+  const size_t lds = (size_t)2 * kWR * (CIN_P + COUT_P + 32) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16<CIN_P, COUT_P>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  k_wgrad_bf16<CIN_P, COUT_P><<<dim3(K, G), 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial, Mout,
+                                                                order, masks, ntiles, tpc);
+  UD_LAUNCH_CHECK();
+  k_wgrad_reduce<<<ud_div_up((long long)cout * K * cin, 256), 256, 0, stream>>>(
+      partial, G, K, CIN_P, COUT_P, cin, cout, gW);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+}  // namespace
+
+extern "C" size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin, int Cout) {
+  if (Mout < 0 || K <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const int ntiles = ud_div_up(Mout > 0 ? Mout : 1, kWR);
+  return ud_align_up((size_t)32 * K * pad16(Cin) * pad16(Cout) * sizeof(float)) +
+         ud_align_up((size_t)ntiles * sizeof(unsigned));
+}
+
+// Mixed-precision weight gradient: bf16 operands (rounded when the row tiles are staged), fp32
+// accumulation, ordered reduction.  row_order (optional) = the forward's mask-sorted row permutation.
+extern "C" int ud_spconv_wgrad_bf16(const float* in, const int32_t* nbr, const float* gout, float* gW,
+                                    int Mout, int K, int Cin, int Cout, const int32_t* row_order,
+                                    void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  if (Mout < 0 || K <= 0 || K > 32 || Cin <= 0 || Cout <= 0 || !gW) return UD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (Mout == 0) {
+    UD_HIP_TRY(hipMemsetAsync(gW, 0, (size_t)Cout * K * Cin * sizeof(float), stream));
+    return UD_OK;
+  }
+  if (!in || !nbr || !gout) return UD_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < ud_spconv_wgrad_bf16_workspace_bytes(Mout, K, Cin, Cout))
+    return UD_ERR_WORKSPACE;
+  const int cp = pad16(Cin), np = pad16(Cout);
+  float* partial = reinterpret_cast<float*>(workspace);
+  unsigned* masks = reinterpret_cast<unsigned*>(
+      reinterpret_cast<char*>(workspace) + ud_align_up((size_t)32 * K * cp * np * sizeof(float)));
+  UdProfScope prof("spconv.k_wgrad", stream);
+#define X(A, B) \
+  if (cp == A && np == B) \
+    return launch_wgrad_bf16<A, B>(in, Cin, nbr, K, gout, Cout, gW, Mout, row_order, partial, masks, stream);
+  UD_CONV_CASES(X)
+#undef X
+  return UD_ERR_UNSUPPORTED;
 }
 
 // gW f32[Cout,K,Cin] (dense KRSC) = sum_o gout[o,:]^T (x) in[nbr[o][k], :]

@@ -71,6 +71,28 @@ def library_layout(weight):
                    lambda w: w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
 
 
+USE_HIP_WGRAD = "auto"     # True / False / "auto": hand-written weight-gradient kernel vs aten.convolution_backward
+                           # (auto: ours on small feature maps where it measured faster, tools/time_conv2d.py)
+
+
+def weight_grad(x, gy, weight):
+    """dL/dweight [Cout, Cin, 3, 3] from channels-last bf16 x and gy."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if USE_HIP_WGRAD is True or (USE_HIP_WGRAD == "auto" and x.shape[2] * x.shape[3] <= 1024):
+        lib = _lib.load()
+        B, _, H, W = x.shape
+        need = lib.ud_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
+        ws = _lib.workspace(x.device, need, "conv_wgrad")
+        dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ud_conv3x3_wgrad_nhwc_bf16(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), B, H, W, cin, cout,
+                                                  _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+                   "ud_conv3x3_wgrad_nhwc_bf16")
+        return dw.permute(0, 3, 1, 2).to(weight.dtype)
+    wb = library_layout(weight)
+    return torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                               [False, True, False])[1].to(weight.dtype)
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -90,9 +112,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _launch(gy, tap_major_transposed(weight), weight.shape[1])
         if ctx.needs_input_grad[1]:
-            wb = library_layout(weight)
-            gw = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False,
-                                                     [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+            gw = weight_grad(x, gy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.float().sum((0, 2, 3))
         return gx, gw, gb

@@ -257,11 +257,19 @@ class _SparseConvFn(torch.autograd.Function):
             lib = _lib.load()
             Mout = nbr.shape[0]
             gw = torch.empty(wshape, dtype=torch.float32, device=w.device)
-            need = lib.ud_spconv_wgrad_workspace_bytes(Mout, K, cin, cout)
-            ws = _lib.workspace(w.device, need, "spconv_wgrad")
-            _lib.check(lib.ud_spconv_wgrad(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
-                                           _lib.ptr(gw), Mout, K, cin, cout, algo, _lib.ptr(ws),
-                                           ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad")
+            if algo == 3 and K <= 32:       # bf16 operands, fp32 accumulate (mixed-precision training)
+                need = lib.ud_spconv_wgrad_bf16_workspace_bytes(Mout, K, cin, cout)
+                ws = _lib.workspace(w.device, need, "spconv_wgrad")
+                _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
+                                                    _lib.ptr(gw), Mout, K, cin, cout,
+                                                    _lib.ptr(mask_order(nbr, False)), _lib.ptr(ws),
+                                                    ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
+            else:
+                need = lib.ud_spconv_wgrad_workspace_bytes(Mout, K, cin, cout)
+                ws = _lib.workspace(w.device, need, "spconv_wgrad")
+                _lib.check(lib.ud_spconv_wgrad(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
+                                               _lib.ptr(gw), Mout, K, cin, cout, algo, _lib.ptr(ws),
+                                               ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(0)
         return gin, gw, gb, None, None, None, None

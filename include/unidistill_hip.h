@@ -240,6 +240,14 @@ int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t 
                    const float* ep_shift, const float* ep_residual, int ep_relu, ud_stream_t stream);
 
 /* gW f32[Cout,K,Cin] = sum_o gout[o,n] * in[nbr[o][k], c]  (ordered partial sums, deterministic). */
+/* Mixed-precision weight gradient (training under bf16 autocast): operands rounded to bf16 when the
+ * 64-row tiles are staged, fp32 accumulation on v_mfma_f32_16x16x32_bf16, ordered reduction of the row
+ * chunks (deterministic).  row_order (optional) is the forward kernel's row permutation; tiles that
+ * have no pair for an offset are skipped.  K <= 32.  gW f32[Cout,K,Cin]. */
+size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin, int Cout);
+int ud_spconv_wgrad_bf16(const float* in, const int32_t* nbr, const float* gout, float* gW, int Mout,
+                         int K, int Cin, int Cout, const int32_t* row_order, void* workspace,
+                         size_t workspace_bytes, ud_stream_t stream);
 /* Mixed-precision inference variant: the bf16-operand MFMA kernel (algo 3 above) with bf16 tensors in
  * HBM so the gather moves half the bytes.  io_flags bit 0: `in` is bf16 [*, Cin] (Cin % 4 == 0);
  * bit 1: `out` and `ep_residual` are bf16 [Mout, Cout]; bit 2: `W` is bf16 (w_sc == 1).  K <= 32. */
@@ -356,6 +364,12 @@ int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const floa
 int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
                          const float* bias, const float* scale, const float* shift,
                          const void* residual, int relu, ud_stream_t stream);
+/* Weight gradient of the same convolution: dw [Cout][9][Cin] fp32 = sum over pixels of
+ * dy [B][H][W][Cout] (bf16) x shifted x [B][H][W][Cin] (bf16); fp32 accumulation, fixed-order
+ * reduction of pixel slices (deterministic).  Cin % 64 == 0, Cout % 8 == 0. */
+size_t ud_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
+                               int Cout, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* ---- BatchNorm2d (+ residual) (+ ReLU), channels-last bf16 ------------------------------------------
  * The Conv2d -> BatchNorm2d -> ReLU links of the reference's dense layers (base_bev_backbone.py:48-66,

@@ -103,7 +103,7 @@ def _bf16(a):
 def test_bf16_mfma_conv_equals_oracle_on_bf16_rounded_operands(cin, cout):
     """algo 3 rounds activations and weights to bf16 and accumulates in fp32: it must match the
     oracle fed the same rounded operands to fp32-accumulation accuracy (a far tighter check than
-    a bf16-sized tolerance against the unrounded result).  wgrad stays fp32."""
+    a bf16-sized tolerance against the unrounded result).  Forward, data gradient and weight gradient."""
     from unidistill_amd.ops import spconv as sp
     rng = np.random.default_rng(cin * 77 + cout)
     shape = (2, 7, 18, 20)
@@ -131,7 +131,7 @@ def test_bf16_mfma_conv_equals_oracle_on_bf16_rounded_operands(cin, cout):
     y.features.backward(torch.from_numpy(gout).cuda())
     ref_gin = oracle.spconv_conv(_bf16(gout), nbr, _bf16(W), mirror=True, transpose=True)
     np.testing.assert_allclose(x.features.grad.cpu().numpy(), ref_gin, **_tol(ref_gin))
-    ref_gw = oracle.spconv_wgrad(feat, nbr, gout, cout)
+    ref_gw = oracle.spconv_wgrad(_bf16(feat), nbr, _bf16(gout), cout)
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(cout, 27, cin), ref_gw, **_tol(ref_gw))
 
 

@@ -28,3 +28,13 @@ for name, N, Cin, H, W, Cout in SHAPES:
     t_our = timeit(lambda: c2._launch(x, wt, Cout))
     err = (c2._launch(x, wt, Cout).float() - F.conv2d(x, wb, None, 1, 1).float()).abs().max().item()
     print(f"{name:22s} MIOpen {t_lib:7.1f} us ({flop/t_lib/1e6:5.0f} TF)   ours {t_our:7.1f} us ({flop/t_our/1e6:5.0f} TF)   x{t_lib/t_our:4.2f}  maxdiff {err:.3g}")
+print("--- weight gradient ---")
+for name, N, Cin, H, W, Cout in SHAPES:
+    x = torch.randn(N, Cin, H, W, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, Cout, H, W, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02)
+    flop = 2 * N * H * W * Cout * Cin * 9
+    c2.USE_HIP_WGRAD = False; t_lib = timeit(lambda: c2.weight_grad(x, gy, w)); ref = c2.weight_grad(x, gy, w)
+    c2.USE_HIP_WGRAD = True; t_our = timeit(lambda: c2.weight_grad(x, gy, w)); got = c2.weight_grad(x, gy, w)
+    err = ((got - ref).norm() / ref.norm()).item()
+    print(f"{name:22s} MIOpen {t_lib:7.1f} us ({flop/t_lib/1e6:5.0f} TF)   ours {t_our:7.1f} us ({flop/t_our/1e6:5.0f} TF)   x{t_lib/t_our:4.2f}  rel diff {err:.3g}")
