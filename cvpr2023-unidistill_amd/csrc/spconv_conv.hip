@@ -799,7 +799,7 @@ __device__ __forceinline__ bf16x8 tr_frag8(const unsigned short* lo_p, const uns
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int CIN_P, int COUT_P>
+template <int CIN_P, int COUT_P, bool BF_IO>   // BF_IO: `in` and `gout` already hold bf16 (cin, cout % 8 == 0)
 __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in, int cin,
                                                     const int32_t* __restrict__ nbr, int K,
                                                     const float* __restrict__ gout, int cout,
@@ -831,63 +831,101 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 rn[NU], rc[CU];
+  constexpr int NU8 = (kWR * (COUT_P / 8) + 255) / 256, CU8 = (kWR * (CIN_P / 8) + 255) / 256;
+  float4 rn[BF_IO ? 1 : NU], rc[BF_IO ? 1 : CU];
+  uint4 hn[BF_IO ? NU8 : 1], hc[BF_IO ? CU8 : 1];
+  const unsigned short* in_h = reinterpret_cast<const unsigned short*>(in);
+  const unsigned short* gout_h = reinterpret_cast<const unsigned short*>(gout);
   const bool vec_n = (cout & 3) == 0, vec_c = (cin & 3) == 0;
   auto fetch = [&](int t) {
+    if constexpr (BF_IO) {
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      const int u = tid + 256 * j, r = u / (COUT_P / 4), n4 = (u - r * (COUT_P / 4)) * 4;
-      const int p = t * kWR + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < kWR && p < Mout) {
-        const float* src = gout + (size_t)(order ? order[p] : p) * cout + n4;
-        if (vec_n) {
-          if (n4 < cout) v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (n4 + 0 < cout) v.x = src[0];
-          if (n4 + 1 < cout) v.y = src[1];
-          if (n4 + 2 < cout) v.z = src[2];
-          if (n4 + 3 < cout) v.w = src[3];
+      for (int j = 0; j < NU8; ++j) {
+        const int u = tid + 256 * j, r = u / (COUT_P / 8), n8 = (u - r * (COUT_P / 8)) * 8;
+        const int p = t * kWR + r;
+        hn[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < kWR && p < Mout && n8 < cout)
+          hn[j] = *reinterpret_cast<const uint4*>(gout_h + (size_t)(order ? order[p] : p) * cout + n8);
+      }
+#pragma unroll
+      for (int j = 0; j < CU8; ++j) {
+        const int u = tid + 256 * j, r = u / (CIN_P / 8), c8 = (u - r * (CIN_P / 8)) * 8;
+        const int p = t * kWR + r;
+        hc[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < kWR && p < Mout && c8 < cin) {
+          const int rr = nbr[(size_t)(order ? order[p] : p) * K + k];
+          if (rr >= 0) hc[j] = *reinterpret_cast<const uint4*>(in_h + (size_t)rr * cin + c8);
         }
       }
-      rn[j] = v;
-    }
+    } else {
 #pragma unroll
-    for (int j = 0; j < CU; ++j) {
-      const int u = tid + 256 * j, r = u / (CIN_P / 4), c4 = (u - r * (CIN_P / 4)) * 4;
-      const int p = t * kWR + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < kWR && p < Mout) {
-        const int rr = nbr[(size_t)(order ? order[p] : p) * K + k];
-        if (rr >= 0) {
-          const float* src = in + (size_t)rr * cin + c4;
-          if (vec_c) {
-            if (c4 < cin) v = *reinterpret_cast<const float4*>(src);
+      for (int j = 0; j < NU; ++j) {
+        const int u = tid + 256 * j, r = u / (COUT_P / 4), n4 = (u - r * (COUT_P / 4)) * 4;
+        const int p = t * kWR + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < kWR && p < Mout) {
+          const float* src = gout + (size_t)(order ? order[p] : p) * cout + n4;
+          if (vec_n) {
+            if (n4 < cout) v = *reinterpret_cast<const float4*>(src);
           } else {
-            if (c4 + 0 < cin) v.x = src[0];
-            if (c4 + 1 < cin) v.y = src[1];
-            if (c4 + 2 < cin) v.z = src[2];
-            if (c4 + 3 < cin) v.w = src[3];
+            if (n4 + 0 < cout) v.x = src[0];
+            if (n4 + 1 < cout) v.y = src[1];
+            if (n4 + 2 < cout) v.z = src[2];
+            if (n4 + 3 < cout) v.w = src[3];
           }
         }
+        rn[j] = v;
       }
-      rc[j] = v;
+#pragma unroll
+      for (int j = 0; j < CU; ++j) {
+        const int u = tid + 256 * j, r = u / (CIN_P / 4), c4 = (u - r * (CIN_P / 4)) * 4;
+        const int p = t * kWR + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < kWR && p < Mout) {
+          const int rr = nbr[(size_t)(order ? order[p] : p) * K + k];
+          if (rr >= 0) {
+            const float* src = in + (size_t)rr * cin + c4;
+            if (vec_c) {
+              if (c4 < cin) v = *reinterpret_cast<const float4*>(src);
+            } else {
+              if (c4 + 0 < cin) v.x = src[0];
+              if (c4 + 1 < cin) v.y = src[1];
+              if (c4 + 2 < cin) v.z = src[2];
+              if (c4 + 3 < cin) v.w = src[3];
+            }
+          }
+        }
+        rc[j] = v;
+      }
     }
   };
   auto commit = [&](int buf) {
+    if constexpr (BF_IO) {
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      const int u = tid + 256 * j, r = u / (COUT_P / 4), n4 = (u - r * (COUT_P / 4)) * 4;
-      if (r < kWR)
-        *reinterpret_cast<uint2*>(Ns + (buf * kWR + r) * LDN + n4) =
-            make_uint2(ud_pack_bf16x2(rn[j].x, rn[j].y), ud_pack_bf16x2(rn[j].z, rn[j].w));
-    }
+      for (int j = 0; j < NU8; ++j) {
+        const int u = tid + 256 * j, r = u / (COUT_P / 8), n8 = (u - r * (COUT_P / 8)) * 8;
+        if (r < kWR) *reinterpret_cast<uint4*>(Ns + (buf * kWR + r) * LDN + n8) = hn[j];
+      }
 #pragma unroll
-    for (int j = 0; j < CU; ++j) {
-      const int u = tid + 256 * j, r = u / (CIN_P / 4), c4 = (u - r * (CIN_P / 4)) * 4;
-      if (r < kWR)
-        *reinterpret_cast<uint2*>(Cs + (buf * kWR + r) * LDC + c4) =
-            make_uint2(ud_pack_bf16x2(rc[j].x, rc[j].y), ud_pack_bf16x2(rc[j].z, rc[j].w));
+      for (int j = 0; j < CU8; ++j) {
+        const int u = tid + 256 * j, r = u / (CIN_P / 8), c8 = (u - r * (CIN_P / 8)) * 8;
+        if (r < kWR) *reinterpret_cast<uint4*>(Cs + (buf * kWR + r) * LDC + c8) = hc[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        const int u = tid + 256 * j, r = u / (COUT_P / 4), n4 = (u - r * (COUT_P / 4)) * 4;
+        if (r < kWR)
+          *reinterpret_cast<uint2*>(Ns + (buf * kWR + r) * LDN + n4) =
+              make_uint2(ud_pack_bf16x2(rn[j].x, rn[j].y), ud_pack_bf16x2(rn[j].z, rn[j].w));
+      }
+#pragma unroll
+      for (int j = 0; j < CU; ++j) {
+        const int u = tid + 256 * j, r = u / (CIN_P / 4), c4 = (u - r * (CIN_P / 4)) * 4;
+        if (r < kWR)
+          *reinterpret_cast<uint2*>(Cs + (buf * kWR + r) * LDC + c4) =
+              make_uint2(ud_pack_bf16x2(rc[j].x, rc[j].y), ud_pack_bf16x2(rc[j].z, rc[j].w));
+      }
     }
   };
   int t = next_active(chunk * tiles_per_chunk);
@@ -1164,7 +1202,7 @@ int wgrad_bf16_chunks(int ntiles, int K, int* tiles_per_chunk) {
 template <int CIN_P, int COUT_P>
 int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const float* gout, int cout,
                       float* gW, int Mout, const int32_t* order, float* partial, unsigned* masks,
-                      hipStream_t stream) {
+                      int io_bf16, hipStream_t stream) {
   const int ntiles = ud_div_up(Mout, kWR);
   int tpc;
   const int G = wgrad_bf16_chunks(ntiles, K, &tpc);
@@ -1173,12 +1211,18 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
   const size_t lds = (size_t)2 * kWR * (CIN_P + COUT_P + 32) * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16<CIN_P, COUT_P>,
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16<CIN_P, COUT_P, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16<CIN_P, COUT_P, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  k_wgrad_bf16<CIN_P, COUT_P><<<dim3(K, G), 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial, Mout,
-                                                                order, masks, ntiles, tpc);
+  if (io_bf16)
+    k_wgrad_bf16<CIN_P, COUT_P, true><<<dim3(K, G), 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
+                                                                        Mout, order, masks, ntiles, tpc);
+  else
+    k_wgrad_bf16<CIN_P, COUT_P, false><<<dim3(K, G), 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
+                                                                         Mout, order, masks, ntiles, tpc);
   UD_LAUNCH_CHECK();
   k_wgrad_reduce<<<ud_div_up((long long)cout * K * cin, 256), 256, 0, stream>>>(
       partial, G, K, CIN_P, COUT_P, cin, cout, gW);
@@ -1196,10 +1240,14 @@ extern "C" size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin,
 
 // Mixed-precision weight gradient: bf16 operands (rounded when the row tiles are staged), fp32
 // accumulation, ordered reduction.  row_order (optional) = the forward's mask-sorted row permutation.
-extern "C" int ud_spconv_wgrad_bf16(const float* in, const int32_t* nbr, const float* gout, float* gW,
-                                    int Mout, int K, int Cin, int Cout, const int32_t* row_order,
-                                    void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+extern "C" int ud_spconv_wgrad_bf16(const void* in_, const int32_t* nbr, const void* gout_, float* gW,
+                                    int Mout, int K, int Cin, int Cout, int io_bf16,
+                                    const int32_t* row_order, void* workspace, size_t workspace_bytes,
+                                    ud_stream_t stream_) {
+  const float* in = reinterpret_cast<const float*>(in_);
+  const float* gout = reinterpret_cast<const float*>(gout_);
   if (Mout < 0 || K <= 0 || K > 32 || Cin <= 0 || Cout <= 0 || !gW) return UD_ERR_INVALID_ARG;
+  if (io_bf16 && ((Cin & 7) || (Cout & 7))) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   if (Mout == 0) {
     UD_HIP_TRY(hipMemsetAsync(gW, 0, (size_t)Cout * K * Cin * sizeof(float), stream));
@@ -1215,7 +1263,7 @@ extern "C" int ud_spconv_wgrad_bf16(const float* in, const int32_t* nbr, const f
   UdProfScope prof("spconv.k_wgrad", stream);
 #define X(A, B) \
   if (cp == A && np == B) \
-    return launch_wgrad_bf16<A, B>(in, Cin, nbr, K, gout, Cout, gW, Mout, row_order, partial, masks, stream);
+    return launch_wgrad_bf16<A, B>(in, Cin, nbr, K, gout, Cout, gW, Mout, row_order, partial, masks, io_bf16, stream);
   UD_CONV_CASES(X)
 #undef X
   return UD_ERR_UNSUPPORTED;

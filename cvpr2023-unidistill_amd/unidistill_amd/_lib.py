@@ -51,7 +51,7 @@ _SIGS = {
     "ud_spconv_wgrad_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_spconv_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_spconv_wgrad_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
-    "ud_spconv_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_spconv_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "ud_dense_to_sparse": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "ud_distill_box_corners": (c_int, [c_void_p, c_int, c_int, c_int] + [ctypes.c_double] * 4

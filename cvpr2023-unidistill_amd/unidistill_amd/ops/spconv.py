@@ -157,9 +157,11 @@ def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0, scale=N
     return out
 
 
-def _conv_bf16io(feat, nbr, weight, bias, cin, cout, scale=None, shift=None, residual=None, relu=False):
-    """Inference conv with bf16 tensors in HBM (ud_spconv_conv_bf16io): feat fp32 or bf16 [*, cin],
-    weight [cout, K, cin] bf16 (or fp32 when cin % 4 != 0), output (and residual) bf16 [Mout, cout]."""
+def _conv_bf16io(feat, nbr, weight, bias, cin, cout, scale=None, shift=None, residual=None, relu=False,
+                 mirror=False):
+    """Conv with bf16 tensors in HBM (ud_spconv_conv_bf16io): feat fp32 or bf16 [*, cin], weight
+    [cout, K, cin] bf16 (or fp32 when cin % 4 != 0), output (and residual) bf16 [Mout, cout].
+    ``mirror`` reads rulebook column K-1-k for weight offset k (submanifold data gradient)."""
     Mout, K = nbr.shape
     io = 2 | (4 if weight.dtype == torch.bfloat16 else 0)
     if feat.dtype == torch.bfloat16 and cin % 4 == 0:
@@ -169,9 +171,10 @@ def _conv_bf16io(feat, nbr, weight, bias, cin, cout, scale=None, shift=None, res
     if residual is not None and residual.dtype != torch.bfloat16:
         residual = residual.to(torch.bfloat16)
     out = torch.empty((Mout, cout), dtype=torch.bfloat16, device=feat.device)
-    order = mask_order(nbr, False)
+    order = mask_order(nbr, mirror)
     _lib.check(_lib.load().ud_spconv_conv_bf16io(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(weight),
-                                                 K * cin, cin, 1, 0, _lib.ptr(bias), _lib.ptr(out),
+                                                 K * cin, cin, 1, 1 if mirror else 0, _lib.ptr(bias),
+                                                 _lib.ptr(out),
                                                  Mout, K, cin, cout, io, _lib.ptr(order),
                                                  _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual),
                                                  1 if relu else 0, _lib.stream_of(feat)),
@@ -225,43 +228,71 @@ def effective_algo(algo):
 
 
 class _SparseConvFn(torch.autograd.Function):
-    """out = conv(features; nbr, W, bias).  nbr_t / mirror describe the transposed rulebook."""
+    """out = conv(features; nbr, W, bias).  nbr_t / mirror describe the transposed rulebook.
+
+    fp32 mode: exact fp32 MFMA kernels, fp32 tensors.  Under bf16 autocast (algo 3) the activations
+    are bf16 in HBM end to end -- forward and data gradient on the all-bf16 kernel, weight gradient on
+    the bf16 transposing-read kernel -- with fp32 accumulation and fp32 master weights."""
 
     @staticmethod
     def forward(ctx, features, weight, bias, nbr, nbr_t, mirror_t, algo):
         _lib.require_gpu(features, weight, nbr)
+        cout, cin = weight.shape[0], weight.shape[-1]
+        K = nbr.shape[1]
+        assert weight.numel() == cout * K * cin and features.shape[1] == cin
+        algo = effective_algo(algo)
+        b32 = None if bias is None else bias.detach().contiguous().float()
+        if algo == 3 and K <= 32 and cin % 8 == 0 and cout % 8 == 0:
+            xb = features.detach().to(torch.bfloat16).contiguous()
+            wb = weight.detach().reshape(cout, K, cin).to(torch.bfloat16).contiguous()
+            out = _conv_bf16io(xb, nbr, wb, b32, cin, cout)
+            ctx.save_for_backward(xb, wb, nbr, nbr_t)
+            ctx.cfg = (mirror_t, "bf16io", bias is not None, weight.shape, features.dtype)
+            return out
         features = features.contiguous().float()
         w = weight.contiguous().float()
-        cout, cin = w.shape[0], w.shape[-1]
-        K = nbr.shape[1]
-        assert w.numel() == cout * K * cin and features.shape[1] == cin
-        algo = effective_algo(algo)
-        out = _conv(features, nbr, w, (K * cin, cin, 1), False,
-                    None if bias is None else bias.contiguous().float(), cin, cout, algo)
+        out = _conv(features, nbr, w, (K * cin, cin, 1), False, b32, cin, cout, algo)
         ctx.save_for_backward(features, w, nbr, nbr_t)
-        ctx.cfg = (mirror_t, algo, bias is not None, weight.shape)
+        ctx.cfg = (mirror_t, algo, bias is not None, weight.shape, torch.float32)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         features, w, nbr, nbr_t = ctx.saved_tensors
-        mirror_t, algo, has_bias, wshape = ctx.cfg
-        gout = gout.contiguous().float()
-        cout, cin = w.shape[0], w.shape[-1]
+        mirror_t, algo, has_bias, wshape, in_dtype = ctx.cfg
+        cout, cin = wshape[0], wshape[-1]
         K = nbr.shape[1]
+        lib = _lib.load()
+        Mout = nbr.shape[0]
         gin = gw = gb = None
+        if algo == "bf16io":
+            gout = gout.to(torch.bfloat16).contiguous()
+            if ctx.needs_input_grad[0]:
+                # transposed conv: reduce over cout with W^T laid out [cin, K, cout]
+                wt = w.permute(2, 1, 0).contiguous()
+                gin = _conv_bf16io(gout, nbr_t, wt, None, cout, cin, mirror=mirror_t).to(in_dtype)
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty(wshape, dtype=torch.float32, device=w.device)
+                need = lib.ud_spconv_wgrad_bf16_workspace_bytes(Mout, K, cin, cout)
+                ws = _lib.workspace(w.device, need, "spconv_wgrad")
+                _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
+                                                    _lib.ptr(gw), Mout, K, cin, cout, 1,
+                                                    _lib.ptr(mask_order(nbr, False)), _lib.ptr(ws),
+                                                    ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = gout.float().sum(0)
+            return gin, gw, gb, None, None, None, None
+        gout = gout.contiguous().float()
         if ctx.needs_input_grad[0]:
             # transposed conv: reduce over cout; W element (n'=c, k, c'=n) at c + k*cin + n*K*cin
             gin = _conv(gout, nbr_t, w, (1, cin, K * cin), mirror_t, None, cout, cin, algo)
         if ctx.needs_input_grad[1]:
-            lib = _lib.load()
-            Mout = nbr.shape[0]
             gw = torch.empty(wshape, dtype=torch.float32, device=w.device)
-            if algo == 3 and K <= 32:       # bf16 operands, fp32 accumulate (mixed-precision training)
+            if algo == 3 and K <= 32:       # bf16 operands staged from fp32 tensors
                 need = lib.ud_spconv_wgrad_bf16_workspace_bytes(Mout, K, cin, cout)
                 ws = _lib.workspace(w.device, need, "spconv_wgrad")
                 _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
-                                                    _lib.ptr(gw), Mout, K, cin, cout,
+                                                    _lib.ptr(gw), Mout, K, cin, cout, 0,
                                                     _lib.ptr(mask_order(nbr, False)), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
             else:

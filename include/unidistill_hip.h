@@ -243,11 +243,12 @@ int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t 
 /* Mixed-precision weight gradient (training under bf16 autocast): operands rounded to bf16 when the
  * 64-row tiles are staged, fp32 accumulation on v_mfma_f32_16x16x32_bf16, ordered reduction of the row
  * chunks (deterministic).  row_order (optional) is the forward kernel's row permutation; tiles that
- * have no pair for an offset are skipped.  K <= 32.  gW f32[Cout,K,Cin]. */
+ * have no pair for an offset are skipped.  K <= 32.  gW f32[Cout,K,Cin].  io_bf16 != 0: `in` and `gout`
+ * already hold bf16 rows (Cin, Cout % 8 == 0); otherwise they are fp32. */
 size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin, int Cout);
-int ud_spconv_wgrad_bf16(const float* in, const int32_t* nbr, const float* gout, float* gW, int Mout,
-                         int K, int Cin, int Cout, const int32_t* row_order, void* workspace,
-                         size_t workspace_bytes, ud_stream_t stream);
+int ud_spconv_wgrad_bf16(const void* in, const int32_t* nbr, const void* gout, float* gW, int Mout,
+                         int K, int Cin, int Cout, int io_bf16, const int32_t* row_order,
+                         void* workspace, size_t workspace_bytes, ud_stream_t stream);
 /* Mixed-precision inference variant: the bf16-operand MFMA kernel (algo 3 above) with bf16 tensors in
  * HBM so the gather moves half the bytes.  io_flags bit 0: `in` is bf16 [*, Cin] (Cin % 4 == 0);
  * bit 1: `out` and `ep_residual` are bf16 [Mout, Cout]; bit 2: `W` is bf16 (w_sc == 1).  K <= 32. */

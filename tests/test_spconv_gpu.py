@@ -122,15 +122,18 @@ def test_bf16_mfma_conv_equals_oracle_on_bf16_rounded_operands(cin, cout):
     with torch.autocast("cuda", dtype=torch.bfloat16):     # default algo 0 -> 3 under autocast
         assert sp.effective_algo(0) == 3
         y = conv(x)
-    assert y.features.dtype == torch.float32
+    bf_io = cin % 8 == 0 and cout % 8 == 0          # activations stay bf16 in HBM on this path
+    assert y.features.dtype == (torch.bfloat16 if bf_io else torch.float32)
+    def tol(r):                                      # + one bf16 rounding of the stored result
+        return dict(rtol=0, atol=6e-3 * max(1.0, float(np.abs(r).max()))) if bf_io else _tol(r)
     ref = oracle.spconv_conv(_bf16(feat), nbr, _bf16(W), bias)
-    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, **_tol(ref))
+    np.testing.assert_allclose(y.features.detach().float().cpu().numpy(), ref, **tol(ref))
     full = oracle.spconv_conv(feat, nbr, W, bias)
-    assert np.abs(y.features.detach().cpu().numpy() - full).max() < 3e-2 * max(1.0, np.abs(full).max())
+    assert np.abs(y.features.detach().float().cpu().numpy() - full).max() < 3e-2 * max(1.0, np.abs(full).max())
     gout = rng.standard_normal(ref.shape).astype(np.float32)
     y.features.backward(torch.from_numpy(gout).cuda())
     ref_gin = oracle.spconv_conv(_bf16(gout), nbr, _bf16(W), mirror=True, transpose=True)
-    np.testing.assert_allclose(x.features.grad.cpu().numpy(), ref_gin, **_tol(ref_gin))
+    np.testing.assert_allclose(x.features.grad.float().cpu().numpy(), ref_gin, **tol(ref_gin))
     ref_gw = oracle.spconv_wgrad(_bf16(feat), nbr, _bf16(gout), cout)
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(cout, 27, cin), ref_gw, **_tol(ref_gw))
 
