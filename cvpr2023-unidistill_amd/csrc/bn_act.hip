@@ -17,9 +17,11 @@ namespace {
 
 constexpr int kMaxSlices = 1024;
 // pixel slices per 64-channel group: enough workgroups (~2048) to fill 256 CUs whatever C is
+int group_width(int C) { return C % 64 == 0 ? 64 : (C % 32 == 0 ? 32 : 16); }
 int slices_for(long long P, int C) {
-  long long s = 2048 / (C / 64 > 0 ? C / 64 : 1);
-  const long long cap = (P + 31) / 32;
+  const int gw = group_width(C), groups = C / gw;
+  long long s = 2048 / (groups > 0 ? groups : 1);
+  const long long cap = (P + 256 / (gw / 8) - 1) / (256 / (gw / 8));
   if (s > cap) s = cap;
   if (s < 1) s = 1;
   if (s > kMaxSlices) s = kMaxSlices;
@@ -89,7 +91,85 @@ __device__ __forceinline__ void masked_grad(const float* xv, const uint4* yraw, 
   }
 }
 
-// grid (kSlices, C/64): partial[slice][C][2] = sum dr, sum dr * (x - mean)
+// One workgroup = (pixel slice, group of GW channels); thread = (8-channel chunk, pixel lane).
+template <int GW>
+struct GroupMap {
+  static constexpr int kChunks = GW / 8, kLanes = 256 / kChunks;
+};
+
+// grid (slices, C/GW): partial[slice][C][2] = sum (x - pivot), sum (x - pivot)^2, pivot = x[row 0][c]
+template <int GW>
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const unsigned short* __restrict__ x, long long P,
+                                                          int C, float* __restrict__ partial) {
+  using M = GroupMap<GW>;
+  __shared__ float red[M::kLanes][GW + 1][2];
+  const int cg = blockIdx.y, tid = threadIdx.x, chunk = tid % M::kChunks, pl = tid / M::kChunks;
+  const int c0 = cg * GW + chunk * 8;
+  float piv[8], s1[8], s2[8];
+  unpack8(*reinterpret_cast<const uint4*>(x + c0), piv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  for (long long p = (long long)blockIdx.x * M::kLanes + pl; p < P; p += (long long)gridDim.x * M::kLanes) {
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)p * C + c0), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[e] - piv[e];
+      s1[e] += d;
+      s2[e] += d * d;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[pl][chunk * 8 + e][0] = s1[e]; red[pl][chunk * 8 + e][1] = s2[e]; }
+  __syncthreads();
+  if (tid < 2 * GW) {
+    const int c = tid >> 1, w = tid & 1;
+    float a = 0.f;
+    for (int i = 0; i < M::kLanes; ++i) a += red[i][c][w];
+    partial[((size_t)blockIdx.x * C + cg * GW + c) * 2 + w] = a;
+  }
+}
+
+// one wave per channel: mean / biased variance / invstd, folded scale+shift, running statistics
+__global__ void k_bn_stats_final(const unsigned short* __restrict__ x, const float* __restrict__ partial,
+                                 int slices, long long P, int C, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, float* __restrict__ mean,
+                                 float* __restrict__ var, float* __restrict__ invstd,
+                                 float* __restrict__ scale, float* __restrict__ shift,
+                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                 float momentum) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double a = 0.0, q = 0.0;
+  for (int s = lane; s < slices; s += 64) {
+    a += partial[((size_t)s * C + c) * 2];
+    q += partial[((size_t)s * C + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane != 0) return;
+  const double piv = __uint_as_float((unsigned)x[c] << 16);
+  const double m = a / (double)P;
+  double v = q / (double)P - m * m;
+  if (v < 0.0) v = 0.0;
+  const float mu = (float)(piv + m), is = (float)(1.0 / sqrt(v + (double)eps));
+  mean[c] = mu;
+  var[c] = (float)v;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - mu * sc;
+  if (running_mean) {
+    const double unbiased = v * ((double)P / (double)(P > 1 ? P - 1 : 1));
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// grid (slices, C/GW): partial[slice][C][2] = sum dr, sum dr * (x - mean)
+template <int GW>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ y,
                                                        const unsigned short* __restrict__ dy,
@@ -97,16 +177,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const unsigned short* __r
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ mean, long long P,
                                                        int C, int relu, float* __restrict__ partial) {
-  __shared__ float red[32][65][2];
-  const int cg = blockIdx.y, tid = threadIdx.x, chunk = tid & 7, pl = tid >> 3;
-  const int c0 = cg * 64 + chunk * 8;
+  using M = GroupMap<GW>;
+  __shared__ float red[M::kLanes][GW + 1][2];
+  const int cg = blockIdx.y, tid = threadIdx.x, chunk = tid % M::kChunks, pl = tid / M::kChunks;
+  const int c0 = cg * GW + chunk * 8;
   float s[8], t[8], mu[8], s1[8], s2[8];
   load8(scale + c0, s);
   load8(shift + c0, t);
   load8(mean + c0, mu);
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-  for (long long p = (long long)blockIdx.x * 32 + pl; p < P; p += (long long)gridDim.x * 32) {
+  for (long long p = (long long)blockIdx.x * M::kLanes + pl; p < P; p += (long long)gridDim.x * M::kLanes) {
     const size_t off = (size_t)p * C + c0;
     float xv[8], dyv[8], dr[8];
     unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
@@ -123,11 +204,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const unsigned short* __r
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[pl][chunk * 8 + e][0] = s1[e]; red[pl][chunk * 8 + e][1] = s2[e]; }
   __syncthreads();
-  if (tid < 128) {
+  if (tid < 2 * GW) {
     const int c = tid >> 1, w = tid & 1;
     float a = 0.f;
-    for (int i = 0; i < 32; ++i) a += red[i][c][w];
-    partial[((size_t)blockIdx.x * C + cg * 64 + c) * 2 + w] = a;
+    for (int i = 0; i < M::kLanes; ++i) a += red[i][c][w];
+    partial[((size_t)blockIdx.x * C + cg * GW + c) * 2 + w] = a;
   }
 }
 
@@ -207,6 +288,34 @@ size_t ud_bn_act_workspace_bytes(int C) {
   return carve(ar, C, &w);
 }
 
+int ud_bn_stats(const void* x, long long P, int C, const float* gamma, const float* beta, float eps,
+                float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
+                float* running_var, float momentum, void* workspace, size_t workspace_bytes,
+                ud_stream_t stream_) {
+  if (!x || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || P <= 0 || C <= 0 ||
+      ((running_mean == nullptr) != (running_var == nullptr)))
+    return UD_ERR_INVALID_ARG;
+  if (C % 16) return UD_ERR_UNSUPPORTED;
+  UdArena ar(workspace, workspace_bytes);
+  BnWs w;
+  carve(ar, C, &w);
+  if (!ar.ok()) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  UdProfScope prof("bn_act.stats", stream);
+  const int slices = slices_for(P, C), gw = group_width(C);
+  if (gw == 64)
+    k_bn_stats_partial<64><<<dim3(slices, C / 64), 256, 0, stream>>>((const unsigned short*)x, P, C, w.partial);
+  else if (gw == 32)
+    k_bn_stats_partial<32><<<dim3(slices, C / 32), 256, 0, stream>>>((const unsigned short*)x, P, C, w.partial);
+  else
+    k_bn_stats_partial<16><<<dim3(slices, C / 16), 256, 0, stream>>>((const unsigned short*)x, P, C, w.partial);
+  UD_LAUNCH_CHECK();
+  k_bn_stats_final<<<C, 64, 0, stream>>>((const unsigned short*)x, w.partial, slices, P, C, gamma, beta, eps,
+                                         mean, var, invstd, scale, shift, running_mean, running_var, momentum);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
 int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,
                   long long P, int C, int relu, ud_stream_t stream_) {
   if (!x || !scale || !shift || !y || P <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
@@ -227,7 +336,7 @@ int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* sca
                   ud_stream_t stream_) {
   if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || P <= 0 || C <= 0)
     return UD_ERR_INVALID_ARG;
-  if (C % 64) return UD_ERR_UNSUPPORTED;
+  if (C % 16) return UD_ERR_UNSUPPORTED;
   UdArena ar(workspace, workspace_bytes);
   BnWs w;
   carve(ar, C, &w);
@@ -235,10 +344,13 @@ int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* sca
   hipStream_t stream = (hipStream_t)stream_;
   {
     UdProfScope prof("bn_act.k_bwd_reduce", stream);
-    const int slices = slices_for(P, C);
-    k_bn_bwd_reduce<<<dim3(slices, C / 64), 256, 0, stream>>>(
-        (const unsigned short*)x, (const unsigned short*)y, (const unsigned short*)dy, scale, shift, mean, P,
-        C, relu, w.partial);
+    const int slices = slices_for(P, C), gw = group_width(C);
+#define UD_BN_REDUCE(GW)                                                                                   \
+  k_bn_bwd_reduce<GW><<<dim3(slices, C / GW), 256, 0, stream>>>(                                           \
+      (const unsigned short*)x, (const unsigned short*)y, (const unsigned short*)dy, scale, shift, mean, P, \
+      C, relu, w.partial)
+    if (gw == 64) UD_BN_REDUCE(64); else if (gw == 32) UD_BN_REDUCE(32); else UD_BN_REDUCE(16);
+#undef UD_BN_REDUCE
     UD_LAUNCH_CHECK();
     k_bn_bwd_final<<<C, 64, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd,
                                                            dgamma, dbeta, w.k0, w.k2);

@@ -1202,12 +1202,16 @@ int wgrad_bf16_chunks(int ntiles, int K, int* tiles_per_chunk) {
 template <int CIN_P, int COUT_P>
 int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const float* gout, int cout,
                       float* gW, int Mout, const int32_t* order, float* partial, unsigned* masks,
-                      int io_bf16, hipStream_t stream) {
+                      const unsigned* given_masks, int io_bf16, hipStream_t stream) {
   const int ntiles = ud_div_up(Mout, kWR);
   int tpc;
   const int G = wgrad_bf16_chunks(ntiles, K, &tpc);
-  k_tile_masks<<<ud_div_up(ntiles, 4), 256, 0, stream>>>(nbr, K, order, Mout, masks, ntiles);
-  UD_LAUNCH_CHECK();
+  if (given_masks) {
+    masks = const_cast<unsigned*>(given_masks);
+  } else {
+    k_tile_masks<<<ud_div_up(ntiles, 4), 256, 0, stream>>>(nbr, K, order, Mout, masks, ntiles);
+    UD_LAUNCH_CHECK();
+  }
   const size_t lds = (size_t)2 * kWR * (CIN_P + COUT_P + 32) * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
@@ -1238,12 +1242,25 @@ extern "C" size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin,
          ud_align_up((size_t)ntiles * sizeof(unsigned));
 }
 
+// Per-64-row-tile activity masks (bit k: some row of the tile has a pair at offset k) of a rulebook in
+// the given row order; depends on the rulebook only, so callers may compute it once and reuse it.
+extern "C" int ud_spconv_tile_masks(const int32_t* nbr, int Mout, int K, const int32_t* row_order,
+                                    unsigned* masks, ud_stream_t stream_) {
+  if (Mout < 0 || K <= 0 || K > 32) return UD_ERR_INVALID_ARG;
+  if (Mout == 0) return UD_OK;
+  if (!nbr || !masks) return UD_ERR_INVALID_ARG;
+  const int ntiles = ud_div_up(Mout, kWR);
+  k_tile_masks<<<ud_div_up(ntiles, 4), 256, 0, (hipStream_t)stream_>>>(nbr, K, row_order, Mout, masks, ntiles);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
 // Mixed-precision weight gradient: bf16 operands (rounded when the row tiles are staged), fp32
 // accumulation, ordered reduction.  row_order (optional) = the forward's mask-sorted row permutation.
 extern "C" int ud_spconv_wgrad_bf16(const void* in_, const int32_t* nbr, const void* gout_, float* gW,
                                     int Mout, int K, int Cin, int Cout, int io_bf16,
-                                    const int32_t* row_order, void* workspace, size_t workspace_bytes,
-                                    ud_stream_t stream_) {
+                                    const int32_t* row_order, const unsigned* tile_masks,
+                                    void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
   const float* in = reinterpret_cast<const float*>(in_);
   const float* gout = reinterpret_cast<const float*>(gout_);
   if (Mout < 0 || K <= 0 || K > 32 || Cin <= 0 || Cout <= 0 || !gW) return UD_ERR_INVALID_ARG;
@@ -1263,7 +1280,7 @@ extern "C" int ud_spconv_wgrad_bf16(const void* in_, const int32_t* nbr, const v
   UdProfScope prof("spconv.k_wgrad", stream);
 #define X(A, B) \
   if (cp == A && np == B) \
-    return launch_wgrad_bf16<A, B>(in, Cin, nbr, K, gout, Cout, gW, Mout, row_order, partial, masks, io_bf16, stream);
+    return launch_wgrad_bf16<A, B>(in, Cin, nbr, K, gout, Cout, gW, Mout, row_order, partial, masks, tile_masks, io_bf16, stream);
   UD_CONV_CASES(X)
 #undef X
   return UD_ERR_UNSUPPORTED;

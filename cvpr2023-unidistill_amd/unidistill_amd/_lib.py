@@ -51,7 +51,9 @@ _SIGS = {
     "ud_spconv_wgrad_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_spconv_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_spconv_wgrad_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
-    "ud_spconv_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_spconv_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t,
+                                                                   c_void_p]),
+    "ud_spconv_tile_masks": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "ud_dense_to_sparse": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "ud_distill_box_corners": (c_int, [c_void_p, c_int, c_int, c_int] + [ctypes.c_double] * 4
@@ -77,6 +79,8 @@ _SIGS = {
     "ud_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_conv3x3_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_bn_act_workspace_bytes": (c_size_t, [c_int]),
+    "ud_bn_stats": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7
+                    + [c_float, c_void_p, c_size_t, c_void_p]),
     "ud_bn_act_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_int, c_void_p]),
     "ud_bn_act_bwd": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_workspace_bytes": (c_size_t, [c_int]),

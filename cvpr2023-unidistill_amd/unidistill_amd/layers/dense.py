@@ -52,8 +52,8 @@ def batchnorm_act(bn, x, residual=None, relu=True):
     statistics with autograd, or eval-mode without), the PyTorch ops otherwise."""
     frozen_grad = (not bn.training) and torch.is_grad_enabled() and (
         x.requires_grad or (residual is not None and residual.requires_grad))
-    if Conv2d.hip_enabled and _HIP_BN and isinstance(bn, nn.BatchNorm2d) and not frozen_grad \
-            and hipbn.supported(x, bn):
+    if Conv2d.hip_enabled and _HIP_BN and isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm1d)) \
+            and not frozen_grad and hipbn.supported(x, bn):
         return hipbn.bn_act(bn, x, residual, relu)
     y = bn(x)
     if residual is not None:

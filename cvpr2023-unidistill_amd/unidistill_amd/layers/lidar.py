@@ -56,10 +56,11 @@ class SparseBasicBlock(sp.SparseModule):
             # inference: two kernels for the whole block (BN folded, residual + ReLU in the epilogue)
             y = self.conv1.forward_fused(x, self.bn1, relu=True)
             return self.conv2.forward_fused(y, self.bn2, relu=True, residual=skip.features)
+        from .dense import batchnorm_act      # BN (+ residual) + ReLU as one streaming pass in bf16 mode
         y = self.conv1(x)
-        y = y.replace_feature(self.relu(self.bn1(y.features)))
+        y = y.replace_feature(batchnorm_act(self.bn1, y.features))
         y = self.conv2(y)
-        y = y.replace_feature(self.relu(self.bn2(y.features) + skip.features))
+        y = y.replace_feature(batchnorm_act(self.bn2, y.features, residual=skip.features))
         return y
 
 

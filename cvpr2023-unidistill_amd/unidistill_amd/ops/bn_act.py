@@ -10,9 +10,17 @@ from .. import _lib
 
 
 def supported(x, bn):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 64 == 0
-            and bn.affine and bn.track_running_stats and bn.momentum is not None
-            and x.is_contiguous(memory_format=torch.channels_last))
+    """4-D channels-last maps [B, C, H, W] or 2-D row tensors [M, C] (sparse voxel features), bf16."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() in (2, 4) and x.shape[1] % 16 == 0
+            and x.shape[0] > 0 and bn.affine and bn.track_running_stats and bn.momentum is not None):
+        return False
+    return x.is_contiguous() if x.dim() == 2 else x.is_contiguous(memory_format=torch.channels_last)
+
+
+def _like(t, ref):
+    """t in ref's dtype/layout (bf16; contiguous rows or channels-last map)."""
+    t = t.to(torch.bfloat16)
+    return t.contiguous() if ref.dim() == 2 else t.contiguous(memory_format=torch.channels_last)
 
 
 class _BnActFn(torch.autograd.Function):
@@ -20,8 +28,8 @@ class _BnActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu):
         lib = _lib.load()
         _lib.require_gpu(x, gamma, beta)
-        B, C, H, W = x.shape
-        P = B * H * W
+        C = x.shape[1]
+        P = x.numel() // C
         dev = x.device
         g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
         b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
@@ -29,14 +37,13 @@ class _BnActFn(torch.autograd.Function):
         if training:
             vec = torch.empty((5, C), dtype=torch.float32, device=dev)
             mean, var, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3], vec[4]
-            ws = _lib.workspace(dev, lib.ud_head_tail_workspace_bytes(C // 64), "head_tail")
+            ws = _lib.workspace(dev, lib.ud_bn_act_workspace_bytes(C), "bn_act")
             fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
             rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
-            _lib.check(lib.ud_head_tail_stats(_lib.ptr(x), B, H, W, C // 64, _lib.ptr(g32), _lib.ptr(b32),
-                                              float(eps), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(invstd),
-                                              _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
-                                              _lib.ptr(ws), ws.numel(),
-                                              stream), "ud_head_tail_stats")
+            _lib.check(lib.ud_bn_stats(_lib.ptr(x), P, C, _lib.ptr(g32), _lib.ptr(b32), float(eps),
+                                       _lib.ptr(mean), _lib.ptr(var), _lib.ptr(invstd), _lib.ptr(scale),
+                                       _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
+                                       _lib.ptr(ws), ws.numel(), stream), "ud_bn_stats")
             if running_mean is not None and not fp32_buffers:
                 with torch.no_grad():
                     running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
@@ -47,7 +54,7 @@ class _BnActFn(torch.autograd.Function):
             scale = (g32 * invstd).contiguous()
             shift = (b32 - mean * scale).contiguous()
         if residual is not None:
-            residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            residual = _like(residual, x)
         y = torch.empty_like(x)
         _lib.check(lib.ud_bn_act_fwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(scale), _lib.ptr(shift),
                                      _lib.ptr(y), P, C, 1 if relu else 0, stream), "ud_bn_act_fwd")
@@ -62,8 +69,9 @@ class _BnActFn(torch.autograd.Function):
         if not training:
             raise NotImplementedError("fused BatchNorm backward covers training-mode statistics only")
         lib = _lib.load()
-        B, C, H, W = x.shape
-        dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        C = x.shape[1]
+        P = x.numel() // C
+        dy = _like(dy, x)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
         if dres is not None and not relu:
@@ -72,7 +80,7 @@ class _BnActFn(torch.autograd.Function):
         ws = _lib.workspace(x.device, lib.ud_bn_act_workspace_bytes(C), "bn_act")
         _lib.check(lib.ud_bn_act_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(scale), _lib.ptr(shift),
                                      _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(dres),
-                                     _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), B * H * W, C, 1 if relu else 0,
+                                     _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), P, C, 1 if relu else 0,
                                      _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd")
         if has_res and ctx.needs_input_grad[3] and dres is None:
             dres = dy

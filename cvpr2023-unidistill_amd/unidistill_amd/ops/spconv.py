@@ -127,7 +127,9 @@ def mask_order(nbr, mirror=False):
     """Permutation of the rulebook rows sorted by their neighbour bit mask (cached on the rulebook
     tensor).  Rows with equal / similar masks become neighbours, so a 128-row tile activates only a
     few of the K kernel offsets instead of nearly all of them."""
-    key = _ORDER_CACHE_ATTR + ("_m" if mirror else "")
+    # ``mirror`` only permutes the bits of every mask: rows with equal masks are neighbours either way,
+    # so the forward order also serves the mirrored (submanifold data-gradient) pass.
+    key = _ORDER_CACHE_ATTR
     order = getattr(nbr, key, None)
     if order is None:
         K = nbr.shape[1]
@@ -135,8 +137,6 @@ def mask_order(nbr, mirror=False):
             order = False
         else:
             bits = (1 << torch.arange(K, device=nbr.device, dtype=torch.int32))
-            if mirror:
-                bits = bits.flip(0)
             mask = ((nbr >= 0).int() * bits[None, :]).sum(1, dtype=torch.int32)
             order = torch.argsort(mask).int().contiguous()
         setattr(nbr, key, order)
@@ -155,6 +155,19 @@ def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0, scale=N
                                           _lib.ptr(shift), _lib.ptr(residual), 1 if relu else 0,
                                           _lib.stream_of(feat)), "ud_spconv_conv")
     return out
+
+
+def tile_masks(nbr):
+    """u32 activity mask per 64-row tile of ``nbr`` in its mask-sorted row order; cached on the rulebook
+    tensor like the row order itself (both depend on the rulebook only)."""
+    hit = getattr(nbr, "_ud_tile_masks", None)
+    if hit is None:
+        Mout, K = nbr.shape
+        hit = torch.empty(((Mout + 63) // 64,), dtype=torch.int32, device=nbr.device)
+        _lib.check(_lib.load().ud_spconv_tile_masks(_lib.ptr(nbr), Mout, K, _lib.ptr(mask_order(nbr, False)),
+                                                    _lib.ptr(hit), _lib.stream_of(nbr)), "ud_spconv_tile_masks")
+        nbr._ud_tile_masks = hit
+    return hit
 
 
 def _conv_bf16io(feat, nbr, weight, bias, cin, cout, scale=None, shift=None, residual=None, relu=False,
@@ -277,7 +290,8 @@ class _SparseConvFn(torch.autograd.Function):
                 ws = _lib.workspace(w.device, need, "spconv_wgrad")
                 _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
                                                     _lib.ptr(gw), Mout, K, cin, cout, 1,
-                                                    _lib.ptr(mask_order(nbr, False)), _lib.ptr(ws),
+                                                    _lib.ptr(mask_order(nbr, False)),
+                                                    _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
             if has_bias and ctx.needs_input_grad[2]:
                 gb = gout.float().sum(0)
@@ -293,7 +307,8 @@ class _SparseConvFn(torch.autograd.Function):
                 ws = _lib.workspace(w.device, need, "spconv_wgrad")
                 _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
                                                     _lib.ptr(gw), Mout, K, cin, cout, 0,
-                                                    _lib.ptr(mask_order(nbr, False)), _lib.ptr(ws),
+                                                    _lib.ptr(mask_order(nbr, False)),
+                                                    _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
             else:
                 need = lib.ud_spconv_wgrad_workspace_bytes(Mout, K, cin, cout)
@@ -406,6 +421,13 @@ class SparseSequential(SparseModule):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
                 if x.indices.shape[0] != 0:
+                    if isinstance(m, nn.BatchNorm1d):
+                        # BatchNorm1d (+ ReLU) over the voxel rows: streaming HIP kernels in bf16 mode
+                        from ..layers.dense import batchnorm_act
+                        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                        x = x.replace_feature(batchnorm_act(m, x.features, None, relu))
+                        i += 2 if relu else 1
+                        continue
                     x = x.replace_feature(m(x.features))
             else:
                 x = m(x)

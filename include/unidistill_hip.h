@@ -248,7 +248,12 @@ int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t 
 size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin, int Cout);
 int ud_spconv_wgrad_bf16(const void* in, const int32_t* nbr, const void* gout, float* gW, int Mout,
                          int K, int Cin, int Cout, int io_bf16, const int32_t* row_order,
-                         void* workspace, size_t workspace_bytes, ud_stream_t stream);
+                         const unsigned* tile_masks, void* workspace, size_t workspace_bytes,
+                         ud_stream_t stream);
+/* tile_masks (optional, u32[ceil(Mout/64)]): bit k set iff some row of the 64-row tile (in row_order) has
+ * a pair at offset k; computed internally when NULL.  It depends on the rulebook only. */
+int ud_spconv_tile_masks(const int32_t* nbr, int Mout, int K, const int32_t* row_order, unsigned* masks,
+                         ud_stream_t stream);
 /* Mixed-precision inference variant: the bf16-operand MFMA kernel (algo 3 above) with bf16 tensors in
  * HBM so the gather moves half the bytes.  io_flags bit 0: `in` is bf16 [*, Cin] (Cin % 4 == 0);
  * bit 1: `out` and `ep_residual` are bf16 [Mout, Cout]; bit 2: `W` is bf16 (w_sc == 1).  K <= 32. */
@@ -375,14 +380,22 @@ int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, 
 /* ---- BatchNorm2d (+ residual) (+ ReLU), channels-last bf16 ------------------------------------------
  * The Conv2d -> BatchNorm2d -> ReLU links of the reference's dense layers (base_bev_backbone.py:48-66,
  * center_head.py:408-420, the mmdet ResNet bottlenecks) as HBM-bound streaming kernels over
- * x [P pixels][C] bf16.  Batch statistics: ud_head_tail_stats (any C % 64 == 0 tensor, G = C / 64).
+ * x [P rows][C] bf16 -- P = B*H*W pixels of a channels-last map, or the active voxels of a sparse tensor
+ * (the BatchNorm1d of the reference's sparse blocks, spconv_backbone.py:10-113).
+ *   ud_bn_stats   : training-mode batch statistics -> mean, biased var, invstd, folded scale/shift;
+ *                   running_mean / running_var (optional, both or neither) are updated in place like
+ *                   nn.BatchNorm does (unbiased variance).  C % 16 == 0.
  *   ud_bn_act_fwd : y = act(x * scale + shift (+ residual)), scale = gamma*invstd, shift = beta - mean*scale
  *                   (batch statistics in training, running statistics in eval).  C % 8 == 0.
  *   ud_bn_act_bwd : training-mode backward: dx (bf16), dgamma, dbeta [C] and, when `dresidual` is given,
  *                   the masked gradient for the residual branch.  Pass `y` (the saved output) when a
  *                   residual took part in the forward, NULL otherwise (the ReLU mask is then recomputed
- *                   from x).  C % 64 == 0.  Deterministic two-stage reductions. */
+ *                   from x).  C % 16 == 0.  Deterministic two-stage reductions. */
 size_t ud_bn_act_workspace_bytes(int C);
+int ud_bn_stats(const void* x, long long P, int C, const float* gamma, const float* beta, float eps,
+                float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
+                float* running_var, float momentum, void* workspace, size_t workspace_bytes,
+                ud_stream_t stream);
 int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,
                   long long P, int C, int relu, ud_stream_t stream);
 int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* scale, const float* shift,

@@ -61,3 +61,36 @@ def test_bn_act_eval(hip_lib):
         y = batchnorm_act(bn, x)
         ref = F.relu(bn(x.float()))
     _close(y, ref, 8e-3)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 16), (777, 32), (300, 128), (5, 48)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_bn_act_voxel_rows(hip_lib, M, C, residual):
+    """BatchNorm1d (+ residual) + ReLU over sparse voxel rows [M, C] (spconv_backbone.py blocks)."""
+    from unidistill_amd.layers.dense import batchnorm_act
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 1.5 - 0.2).bfloat16()
+    r = torch.randn(M, C, generator=g).bfloat16() if residual else None
+    gy = torch.randn(M, C, generator=g).bfloat16()
+    bn_ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.normal_(0, 0.3)
+    bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).cuda()
+    bn.load_state_dict(bn_ref.state_dict())
+    xr = x.float().requires_grad_(True)
+    rr = r.float().requires_grad_(True) if residual else None
+    yr = F.relu(bn_ref(xr) + rr if residual else bn_ref(xr))
+    yr.backward(gy.float())
+    xd = x.cuda().requires_grad_(True)
+    rd = r.cuda().requires_grad_(True) if residual else None
+    y = batchnorm_act(bn, xd, rd, True)
+    assert y.dtype == torch.bfloat16 and y.shape == (M, C)
+    y.backward(gy.cuda())
+    _close(y, yr, 8e-3, "y")
+    _close(xd.grad, xr.grad, 2e-2, "dx")
+    _close(bn.weight.grad, bn_ref.weight.grad, 1e-2, "dgamma")
+    _close(bn.bias.grad, bn_ref.bias.grad, 1e-2, "dbeta")
+    if residual:
+        _close(rd.grad, rr.grad, 8e-3, "dres")
+    _close(bn.running_mean, bn_ref.running_mean, 1e-3, "running_mean")
+    _close(bn.running_var, bn_ref.running_var, 1e-3, "running_var")
