@@ -137,8 +137,9 @@ __global__ void k_bn_stats_final(const unsigned short* __restrict__ x, const flo
                                  float* __restrict__ var, float* __restrict__ invstd,
                                  float* __restrict__ scale, float* __restrict__ shift,
                                  float* __restrict__ running_mean, float* __restrict__ running_var,
-                                 float momentum) {
+                                 float momentum, long long* __restrict__ batches_tracked) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (batches_tracked && c == 0 && lane == 0) *batches_tracked += 1;   // nn.BatchNorm's step counter
   double a = 0.0, q = 0.0;
   for (int s = lane; s < slices; s += 64) {
     a += partial[((size_t)s * C + c) * 2];
@@ -290,8 +291,8 @@ size_t ud_bn_act_workspace_bytes(int C) {
 
 int ud_bn_stats(const void* x, long long P, int C, const float* gamma, const float* beta, float eps,
                 float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
-                float* running_var, float momentum, void* workspace, size_t workspace_bytes,
-                ud_stream_t stream_) {
+                float* running_var, float momentum, long long* batches_tracked, void* workspace,
+                size_t workspace_bytes, ud_stream_t stream_) {
   if (!x || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || P <= 0 || C <= 0 ||
       ((running_mean == nullptr) != (running_var == nullptr)))
     return UD_ERR_INVALID_ARG;
@@ -311,7 +312,8 @@ int ud_bn_stats(const void* x, long long P, int C, const float* gamma, const flo
     k_bn_stats_partial<16><<<dim3(slices, C / 16), 256, 0, stream>>>((const unsigned short*)x, P, C, w.partial);
   UD_LAUNCH_CHECK();
   k_bn_stats_final<<<C, 64, 0, stream>>>((const unsigned short*)x, w.partial, slices, P, C, gamma, beta, eps,
-                                         mean, var, invstd, scale, shift, running_mean, running_var, momentum);
+                                         mean, var, invstd, scale, shift, running_mean, running_var, momentum,
+                                         batches_tracked);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

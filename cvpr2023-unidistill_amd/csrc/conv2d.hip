@@ -43,6 +43,7 @@ struct ConvEp {
   const float* shift;
   const unsigned short* residual;
   int relu;
+  int reverse_taps;   // weights are addressed with tap 8 - t (data gradient on un-flipped weights)
 };
 
 // LDS: two halo slices, two weight slices; the fp32 output tile reuses the space after the K loop.
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
       const int n = piece * 8 + r8;
       const unsigned short* src = zero;
       if (n0 + n < gm.Cout)
-        src = w + ((size_t)(n0 + n) * 9 + tap) * gm.Cin + chunk * kKC + ((slot ^ (n & 7)) << 3);
+        src = w + ((size_t)(n0 + n) * 9 + (ep.reverse_taps ? 8 - tap : tap)) * gm.Cin + chunk * kKC +
+              ((slot ^ (n & 7)) << 3);
       dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
     }
   };
@@ -359,7 +361,7 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   if (Cin % kKC != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH)};
-  ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu};
+  ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
   static bool attr_set = false;
   if (!attr_set) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -228,9 +228,10 @@ __global__ void k_stats_final(const unsigned short* __restrict__ y, const float*
                               float* __restrict__ var, float* __restrict__ invstd,
                               float* __restrict__ scale, float* __restrict__ shift,
                               float* __restrict__ running_mean, float* __restrict__ running_var,
-                              float momentum) {
+                              float momentum, long long* __restrict__ batches_tracked) {
   // one wave per channel: lanes stride over the slices, then a fixed-order butterfly (deterministic)
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (batches_tracked && c == 0 && lane == 0) *batches_tracked += 1;   // nn.BatchNorm's step counter
   double a = 0.0, q = 0.0;
   for (int s = lane; s < slices; s += 64) {
     a += partial[((size_t)s * C + c) * 2];
@@ -623,7 +624,8 @@ size_t ud_head_tail_workspace_bytes(int G) {
 int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* gamma,
                        const float* beta, float eps, float* mean, float* var, float* invstd,
                        float* scale, float* shift, float* running_mean, float* running_var,
-                       float momentum, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+                       float momentum, long long* batches_tracked, void* workspace,
+                       size_t workspace_bytes, ud_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!y || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || !geom_ok(B, H, W, G, 1) ||
       ((running_mean == nullptr) != (running_var == nullptr)))
@@ -644,7 +646,7 @@ int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* g
   k_stats_final<<<C, 64, 0, stream>>>((const unsigned short*)y, w.stat_partial,
                                                         (int)slices, P, C, gamma, beta, eps, mean, var,
                                                         invstd, scale, shift, running_mean,
-                                                        running_var, momentum);
+                                                        running_var, momentum, batches_tracked);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

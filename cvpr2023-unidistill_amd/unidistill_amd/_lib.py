@@ -80,12 +80,12 @@ _SIGS = {
     "ud_conv3x3_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_bn_act_workspace_bytes": (c_size_t, [c_int]),
     "ud_bn_stats": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7
-                    + [c_float, c_void_p, c_size_t, c_void_p]),
+                    + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_bn_act_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_int, c_void_p]),
     "ud_bn_act_bwd": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_workspace_bytes": (c_size_t, [c_int]),
     "ud_head_tail_stats": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_float]
-                           + [c_void_p] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
+                           + [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_fwd": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "ud_head_tail_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
 }

@@ -25,7 +25,8 @@ def _like(t, ref):
 
 class _BnActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu,
+                tracked=None):
         lib = _lib.load()
         _lib.require_gpu(x, gamma, beta)
         C = x.shape[1]
@@ -43,7 +44,7 @@ class _BnActFn(torch.autograd.Function):
             _lib.check(lib.ud_bn_stats(_lib.ptr(x), P, C, _lib.ptr(g32), _lib.ptr(b32), float(eps),
                                        _lib.ptr(mean), _lib.ptr(var), _lib.ptr(invstd), _lib.ptr(scale),
                                        _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
-                                       _lib.ptr(ws), ws.numel(), stream), "ud_bn_stats")
+                                       _lib.ptr(tracked), _lib.ptr(ws), ws.numel(), stream), "ud_bn_stats")
             if running_mean is not None and not fp32_buffers:
                 with torch.no_grad():
                     running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
@@ -84,12 +85,17 @@ class _BnActFn(torch.autograd.Function):
                                      _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd")
         if has_res and ctx.needs_input_grad[3] and dres is None:
             dres = dy
-        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
 
 
 def bn_act(bn, x, residual=None, relu=True):
     """relu(bn(x) + residual) with nn.BatchNorm2d ``bn``'s parameters, buffers and train/eval mode."""
+    tracked = None
     if bn.training:
-        bn.num_batches_tracked.add_(1)
+        nbt = bn.num_batches_tracked
+        if nbt.is_cuda and nbt.dtype == torch.int64 and bn.running_mean.dtype == torch.float32:
+            tracked = nbt                     # incremented by the statistics kernel (no extra launch)
+        else:
+            nbt.add_(1)
     return _BnActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.training,
-                          bn.momentum, bn.eps, relu)
+                          bn.momentum, bn.eps, relu, tracked)

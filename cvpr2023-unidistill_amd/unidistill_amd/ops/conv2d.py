@@ -24,14 +24,14 @@ def _nhwc(t):
         t.contiguous(memory_format=torch.channels_last)
 
 
-def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, relu=False):
+def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, relu=False, reverse_taps=False):
     """x: [B, Cin, H, W] bf16 channels-last; w_tap: [Cout, 3, 3, Cin] bf16 contiguous."""
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
     _lib.check(_lib.load().ud_conv3x3_nhwc_bf16(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin,
                                                 cout, _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
-                                                _lib.ptr(residual), 1 if relu else 0,
+                                                _lib.ptr(residual), (1 if relu else 0) | (2 if reverse_taps else 0),
                                                 _lib.stream_of(x)), "ud_conv3x3_nhwc_bf16")
     return y
 
@@ -56,13 +56,19 @@ def _cached(weight, key, make):
 
 def tap_major(weight):
     """[Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] bf16 contiguous (the kernel's weight layout)."""
-    return _cached(weight, "_ud_tap", lambda w: w.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous())
+    def make(w):      # permute + cast in ONE copy kernel
+        return torch.empty((w.shape[0], 3, 3, w.shape[1]), dtype=torch.bfloat16, device=w.device).copy_(
+            w.permute(0, 2, 3, 1))
+    return _cached(weight, "_ud_tap", make)
 
 
 def tap_major_transposed(weight):
-    """Weights of the data-gradient convolution: [Cin, 3, 3, Cout], spatially flipped."""
-    return _cached(weight, "_ud_tap_t",
-                   lambda w: w.flip(2, 3).permute(1, 2, 3, 0).to(torch.bfloat16).contiguous())
+    """Weights of the data-gradient convolution, [Cin, 3, 3, Cout] (NOT flipped: the kernel walks the
+    taps in reverse, ``reverse_taps``)."""
+    def make(w):
+        return torch.empty((w.shape[1], 3, 3, w.shape[0]), dtype=torch.bfloat16, device=w.device).copy_(
+            w.permute(1, 2, 3, 0))
+    return _cached(weight, "_ud_tap_t", make)
 
 
 def library_layout(weight):
@@ -110,11 +116,11 @@ class _Conv3x3Fn(torch.autograd.Function):
         gy = _nhwc(gy.to(torch.bfloat16))
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _launch(gy, tap_major_transposed(weight), weight.shape[1])
+            gx = _launch(gy, tap_major_transposed(weight), weight.shape[1], reverse_taps=True)
         if ctx.needs_input_grad[1]:
             gw = weight_grad(x, gy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.float().sum((0, 2, 3))
+            gb = gy.sum((0, 2, 3), dtype=torch.float32)
         return gx, gw, gb
 
 

@@ -50,7 +50,7 @@ class _HeadTailFn(torch.autograd.Function):
             _lib.check(lib.ud_head_tail_stats(_lib.ptr(y), B, H, W, G, _lib.ptr(g32), _lib.ptr(b32),
                                               float(eps), _lib.ptr(mean), _lib.ptr(var),
                                               _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv),
-                                              float(momentum or 0.0), _lib.ptr(ws), ws.numel(), stream), "ud_head_tail_stats")
+                                              float(momentum or 0.0), None, _lib.ptr(ws), ws.numel(), stream), "ud_head_tail_stats")
             if running_mean is not None and not fp32_buffers:
                 n = B * H * W
                 with torch.no_grad():     # nn.BatchNorm2d bookkeeping: unbiased variance in the buffers

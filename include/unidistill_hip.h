@@ -342,7 +342,8 @@ int ud_distill_resp_bwd(const float* const* s_hm, const float* const* t_hm, floa
  *   ud_head_tail_stats : training-mode batch statistics of y -> mean, biased var, invstd and the
  *                        folded scale = gamma*invstd, shift = beta - mean*scale.  When running_mean /
  *                        running_var are given (both or neither) they are updated in place like
- *                        nn.BatchNorm2d does: r = (1-momentum)*r + momentum*{mean, unbiased var}.
+ *                        nn.BatchNorm2d does: r = (1-momentum)*r + momentum*{mean, unbiased var};
+ *                        batches_tracked (optional, int64 on the device) is incremented by one.
  *   ud_head_tail_fwd   : z = conv(relu(y*scale + shift), w2) + b2   (any scale/shift: batch or running).
  *   ud_head_tail_bwd   : training-mode backward through conv, ReLU and BatchNorm: dy, dw2, dgamma,
  *                        dbeta (db2 = sum of dz is left to the caller).  Deterministic. */
@@ -350,7 +351,8 @@ size_t ud_head_tail_workspace_bytes(int G);
 int ud_head_tail_stats(const void* y, int B, int H, int W, int G, const float* gamma,
                        const float* beta, float eps, float* mean, float* var, float* invstd,
                        float* scale, float* shift, float* running_mean, float* running_var,
-                       float momentum, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+                       float momentum, long long* batches_tracked, void* workspace,
+                       size_t workspace_bytes, ud_stream_t stream);
 int ud_head_tail_fwd(const void* y, const float* scale, const float* shift, const float* w2,
                      const float* b2, float* z, int B, int H, int W, int G, int kmax,
                      ud_stream_t stream);
@@ -366,7 +368,8 @@ int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const floa
  * y [B][H][W][Cout]; fp32 accumulation on the MFMA pipe.  Optional fused epilogue, in this order:
  * + bias[Cout], * scale + shift (folded eval BatchNorm), + residual (bf16, y's layout), ReLU.
  * Cin % 64 == 0 and Cout % 8 == 0, else UD_ERR_UNSUPPORTED.  The data gradient of the convolution is
- * the same call on dy with w' [Cin][9][Cout], w'[c][8 - tap][n] = w[n][tap][c]. */
+ * the same call on dy with w' [Cin][9][Cout], w'[c][8 - tap][n] = w[n][tap][c] -- or with the un-flipped
+ * w'[c][tap][n] = w[n][tap][c] and bit 1 of `relu` set (walk the taps in reverse).  `relu`: bit 0 = ReLU. */
 int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
                          const float* bias, const float* scale, const float* shift,
                          const void* residual, int relu, ud_stream_t stream);
@@ -384,7 +387,8 @@ int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, 
  * (the BatchNorm1d of the reference's sparse blocks, spconv_backbone.py:10-113).
  *   ud_bn_stats   : training-mode batch statistics -> mean, biased var, invstd, folded scale/shift;
  *                   running_mean / running_var (optional, both or neither) are updated in place like
- *                   nn.BatchNorm does (unbiased variance).  C % 16 == 0.
+ *                   nn.BatchNorm does (unbiased variance); batches_tracked (optional device int64) += 1.
+ *                   C % 16 == 0.
  *   ud_bn_act_fwd : y = act(x * scale + shift (+ residual)), scale = gamma*invstd, shift = beta - mean*scale
  *                   (batch statistics in training, running statistics in eval).  C % 8 == 0.
  *   ud_bn_act_bwd : training-mode backward: dx (bf16), dgamma, dbeta [C] and, when `dresidual` is given,
@@ -394,8 +398,8 @@ int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, 
 size_t ud_bn_act_workspace_bytes(int C);
 int ud_bn_stats(const void* x, long long P, int C, const float* gamma, const float* beta, float eps,
                 float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
-                float* running_var, float momentum, void* workspace, size_t workspace_bytes,
-                ud_stream_t stream);
+                float* running_var, float momentum, long long* batches_tracked, void* workspace,
+                size_t workspace_bytes, ud_stream_t stream);
 int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,
                   long long P, int C, int relu, ud_stream_t stream);
 int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* scale, const float* shift,
