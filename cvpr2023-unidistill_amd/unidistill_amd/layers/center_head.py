@@ -160,6 +160,69 @@ class FCOSAssigner:
             self._tabs[device] = tabs
         return tabs
 
+    windowed = True     # candidate anchors from a 9x9 window around each box centre (see _assign_windowed)
+
+    def _assign_dense(self, anchors, pcx, pcy, mem, K, topk):
+        """Reference formulation: all [TB, M, A] squared centre distances, top-k per box, argmin per anchor."""
+        dev = anchors.device
+        TB, M = pcx.shape
+        A = anchors.shape[0]
+        d = (anchors[None, None, :, 0] - pcx[:, :, None]) ** 2 + (anchors[None, None, :, 1] - pcy[:, :, None]) ** 2
+        d = torch.where(mem[:, :, None], d, torch.full_like(d, float("inf")))
+        tk = torch.topk(d, topk, dim=2, largest=False).indices                           # [TB,M,topk]
+        hits = torch.zeros((TB, A), device=dev)
+        hits.scatter_add_(1, tk.reshape(TB, -1), mem[:, :, None].expand(TB, M, topk).reshape(TB, -1).float())
+        pos = hits > 0                                                                   # [TB,A]
+        gid = d.argmin(1)                                                                # nearest GT (task order)
+        rank = pos.long().cumsum(1) - 1
+        slot = torch.where(pos & (rank < K), rank, torch.full_like(rank, K))
+        aidx = torch.arange(A, device=dev)[None, :].expand(TB, A)
+        ind = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, aidx)[:, :K]
+        sgt = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, gid)[:, :K]
+        mask = torch.zeros((TB, K + 1), dtype=torch.bool, device=dev).scatter_(1, slot, pos)[:, :K]
+        return ind, sgt, mask, pos, gid
+
+    def _assign_windowed(self, anchors, pcx, pcy, mem, w, h, K, topk):
+        """Same result without the [TB, M, A] distance tensor (124 MB at B=4): the k <= 9 anchors nearest
+        to a point lie within +-4 cells of the (clamped) nearest cell of the regular anchor grid, so the
+        top-k runs over 81 candidates per box; positives are the <= M*k selected anchors, sorted and
+        de-duplicated; the nearest box is searched only at those positives."""
+        dev = anchors.device
+        TB, M = pcx.shape
+        s = float(self.out_size_factor)
+        inf = float("inf")
+        cxi = torch.round(pcx / s).clamp(0, w - 1).long()
+        cyi = torch.round(pcy / s).clamp(0, h - 1).long()
+        off = torch.arange(-4, 5, device=dev)
+        ix = cxi[:, :, None, None] + off[None, None, None, :]                            # [TB,M,1,9]
+        iy = cyi[:, :, None, None] + off[None, None, :, None]                            # [TB,M,9,1]
+        ok = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h) & mem[:, :, None, None]
+        d = (ix.float() * s - pcx[:, :, None, None]) ** 2 + (iy.float() * s - pcy[:, :, None, None]) ** 2
+        d = torch.where(ok, d, torch.full_like(d, inf)).reshape(TB, M, 81)
+        aid = (iy * w + ix).reshape(TB, M, 81)
+        dk, sel = torch.topk(d, topk, dim=2, largest=False)
+        cand = aid.gather(2, sel).reshape(TB, M * topk)                                  # anchor ids
+        cok = torch.isfinite(dk).reshape(TB, M * topk)
+        A = w * h
+        key = torch.where(cok, cand, torch.full_like(cand, A))
+        key, _ = torch.sort(key, dim=1)                                                  # ascending anchors
+        first = torch.ones_like(key, dtype=torch.bool)
+        first[:, 1:] = key[:, 1:] != key[:, :-1]
+        pos_ok = first & (key < A)                                                       # unique positives
+        pos_ids = torch.where(pos_ok, key, torch.zeros_like(key))
+        # nearest box (task order, first on ties) at every positive anchor
+        ax = (pos_ids % w).float() * s
+        ay = (pos_ids // w).float() * s
+        dg = (ax[:, None, :] - pcx[:, :, None]) ** 2 + (ay[:, None, :] - pcy[:, :, None]) ** 2   # [TB,M,P]
+        dg = torch.where(mem[:, :, None], dg, torch.full_like(dg, inf))
+        pos_gid = dg.argmin(1)                                                           # [TB,P]
+        rank = pos_ok.long().cumsum(1) - 1
+        slot = torch.where(pos_ok & (rank < K), rank, torch.full_like(rank, K))
+        ind = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, pos_ids)[:, :K]
+        sgt = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, pos_gid)[:, :K]
+        mask = torch.zeros((TB, K + 1), dtype=torch.bool, device=dev).scatter_(1, slot, pos_ok)[:, :K]
+        return ind, sgt, mask, pos_ids, pos_gid, pos_ok
+
     @torch.no_grad()
     def assign_targets(self, gt_boxes):
         """gt_boxes f32[B,M,C+1] (last column = 1-based class) -> dict of per-task targets.
@@ -199,29 +262,30 @@ class FCOSAssigner:
         perm = key.argsort(1)
         mem = member.gather(1, perm)
         pcx, pcy = rep(cx).gather(1, perm), rep(cy).gather(1, perm)
-        # squared centre distances, laid out [TB, M, A] so that topk runs on a CONTIGUOUS tensor
-        # (topk on a transposed view keeps hidden state that breaks hipGraph replays on ROCm)
-        d = (anchors[None, None, :, 0] - pcx[:, :, None]) ** 2 + (anchors[None, None, :, 1] - pcy[:, :, None]) ** 2
-        d = torch.where(mem[:, :, None], d, torch.full_like(d, float("inf")))
         topk = min(self.assign_topk, A)
-        tk = torch.topk(d, topk, dim=2, largest=False).indices                           # [TB,M,topk]
-        hits = torch.zeros((TB, A), device=dev)
-        hits.scatter_add_(1, tk.reshape(TB, -1), mem[:, :, None].expand(TB, M, topk).reshape(TB, -1).float())
-        pos = hits > 0                                                                   # [TB,A]
-        gid = d.argmin(1)                                                                # nearest GT (task order)
-        # compact the positive anchors, ascending, into K slots
-        rank = pos.long().cumsum(1) - 1
-        slot = torch.where(pos & (rank < K), rank, torch.full_like(rank, K))
-        aidx = torch.arange(A, device=dev)[None, :].expand(TB, A)
-        ind = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, aidx)[:, :K]
-        sgt = torch.zeros((TB, K + 1), dtype=torch.long, device=dev).scatter_(1, slot, gid)[:, :K]
-        mask = torch.zeros((TB, K + 1), dtype=torch.bool, device=dev).scatter_(1, slot, pos)[:, :K]
+        if self.windowed and topk <= 9 and w >= 9 and h >= 9:
+            ind, sgt, mask, pos_ids, pos_gid, pos_ok = self._assign_windowed(anchors, pcx, pcy, mem, w, h, K, topk)
+            cat_src = (pos_ids, pos_gid, pos_ok)
+        else:
+            ind, sgt, mask, pos, gid = self._assign_dense(anchors, pcx, pcy, mem, K, topk)
+            cat_src = None
         sperm = perm.gather(1, sgt)                                                      # original box row
         cat = torch.where(mask, coff.gather(1, sperm), torch.zeros_like(sgt))
         # heat map: one-hot of the assigned class at every positive anchor
-        cat_anchor = coff.gather(1, perm.gather(1, gid)).clamp_min(0)
-        hm = torch.zeros((TB, ncmax, A), device=dev)
-        hm.scatter_(1, cat_anchor[:, None, :], pos[:, None, :].float())
+        if cat_src is None:
+            hm = torch.zeros((TB, ncmax, A), device=dev)
+            cat_anchor = coff.gather(1, perm.gather(1, gid)).clamp_min(0)
+            hm.scatter_(1, cat_anchor[:, None, :], pos[:, None, :].float())
+        else:
+            pos_ids, pos_gid, pos_ok = cat_src                                         # [TB, M*topk]
+            cls_of = coff.gather(1, perm.gather(1, pos_gid)).clamp_min(0)
+            flat = cls_of * A + pos_ids                                                # index into [ncmax*A]
+            # invalid candidates write a 0 at (class 0, anchor 0 ...): harmless only if nothing valid
+            # writes there too, so route them to a scratch column instead
+            hm_flat = torch.zeros((TB, ncmax * A + 1), device=dev)
+            hm_flat.scatter_(1, torch.where(pos_ok, flat, torch.full_like(flat, ncmax * A)),
+                             pos_ok.float())
+            hm = hm_flat[:, :ncmax * A].reshape(TB, ncmax, A)
         # box encoding of the assigned GT relative to its anchor point
         g = lambda v: rep(v).gather(1, sperm)
         ax, ay = anchors[:, 0][ind], anchors[:, 1][ind]

@@ -129,3 +129,36 @@ def test_param_counts_match_survey():
     """BEV trunk 4.58 M, head 1.90 M params at the real widths."""
     trunk = BaseBEVBackbone([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256)
     assert abs(sum(p.numel() for p in trunk.parameters()) - 4.58e6) < 0.02e6
+
+
+def test_windowed_assignment_equals_dense_formulation():
+    """The 9x9-window target assignment == the all-anchors formulation, incl. boxes at / beyond the
+    range border, many boxes per task and empty tasks (bit-exact integer targets, equal encodings)."""
+    import torch
+    head = _head()
+    asg = head.target_assigner
+    g = torch.Generator().manual_seed(11)
+    names = [n for t in TASKS for n in t["class_names"]]
+    for trial in range(4):
+        B, M = 3, 30
+        gt = torch.zeros(B, M, 10)
+        n_valid = [M, 7, 0][:B]
+        for b in range(B):
+            n = n_valid[b]
+            xy = (torch.rand(n, 2, generator=g) * 2 - 1) * (33.5 if trial % 2 else 31.0)   # some outside
+            if trial == 3 and n:
+                xy[: n // 2] = xy[0] + torch.randn(n // 2, 2, generator=g) * 0.6           # crowded
+            gt[b, :n, 0:2] = xy
+            gt[b, :n, 2] = torch.randn(n, generator=g)
+            gt[b, :n, 3:6] = torch.rand(n, 3, generator=g) * 3 + 0.5
+            gt[b, :n, 6] = (torch.rand(n, generator=g) * 2 - 1) * 3.1
+            gt[b, :n, 7:9] = torch.randn(n, 2, generator=g)
+            gt[b, :n, 9] = torch.randint(1, len(names) + 1, (n,), generator=g).float()
+        asg.windowed = True
+        a = asg.assign_targets(gt)
+        asg.windowed = False
+        b_ = asg.assign_targets(gt)
+        asg.windowed = True
+        for key in ("heatmap", "ind", "mask", "cat", "box_encoding"):
+            for t in a[key]:
+                assert torch.equal(a[key][t], b_[key][t]), (trial, key, t)
