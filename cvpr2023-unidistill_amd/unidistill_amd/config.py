@@ -52,7 +52,12 @@ DET_HEAD = dict(
     share_conv_channel=64,
     common_heads={"iou": [1, 2], "reg": [2, 2], "height": [1, 2], "dim": [3, 2], "rot": [2, 2],
                   "vel": [2, 2]},
-    init_bias=-2.19, focal_alpha=0.25, focal_gamma=2)
+    init_bias=-2.19, focal_alpha=0.25, focal_gamma=2,
+    # proposal layer (base_nuscenes_cfg.py:239-255): eval-time decode + rotated NMS
+    proposal=dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.1,
+                  no_log=False, iou_aware_list=[0.65] * 10,
+                  nms_iou_threshold_train=0.8, nms_pre_max_size_train=1500, nms_post_max_size_train=80,
+                  nms_iou_threshold_test=0.1, nms_pre_max_size_test=1500, nms_post_max_size_test=100))
 
 
 def model_cfg(lidar=True, camera=True):

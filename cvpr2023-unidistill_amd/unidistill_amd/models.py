@@ -11,6 +11,7 @@ from torch import nn
 
 from .layers.bev import BevEncoder, FusionEncoder
 from .layers.center_head import CenterHeadIouAware, FCOSAssigner
+from .layers.gen_proposals import IouAwareGenProposals
 from .layers.lidar import LidarEncoder
 from .layers.lss_fpn import LSSFPN
 
@@ -36,8 +37,22 @@ class DetHead(nn.Module):
             grid_size=cfg["grid_size"], pc_range=cfg["point_cloud_range"][0:2],
             voxel_size=cfg["voxel_size"][0:2], assign_topk=cfg["assign_topk"],
             with_velocity=cfg["with_velocity"])
+        prop = cfg.get("proposal")
+        proposal_layer = None
+        if prop is not None:      # BEVFusion_nuscenes_centerhead_fusion_exp.py:67-84
+            proposal_layer = IouAwareGenProposals(
+                dataset_name="nuscenes", class_names=[t["class_names"] for t in cfg["tasks"]],
+                post_center_limit_range=prop["post_center_limit_range"], score_threshold=prop["score_threshold"],
+                pc_range=cfg["point_cloud_range"][0:2], out_size_factor=cfg["out_size_factor"],
+                voxel_size=cfg["voxel_size"][0:2], no_log=prop["no_log"], iou_aware_list=prop["iou_aware_list"],
+                nms_iou_threshold_train=prop["nms_iou_threshold_train"],
+                nms_pre_max_size_train=prop["nms_pre_max_size_train"],
+                nms_post_max_size_train=prop["nms_post_max_size_train"],
+                nms_iou_threshold_test=prop["nms_iou_threshold_test"],
+                nms_pre_max_size_test=prop["nms_pre_max_size_test"],
+                nms_post_max_size_test=prop["nms_post_max_size_test"])
         self.dense_head = CenterHeadIouAware(
-            dataset_name="nuscenes", tasks=cfg["tasks"], target_assigner=assigner, proposal_layer=None,
+            dataset_name="nuscenes", tasks=cfg["tasks"], target_assigner=assigner, proposal_layer=proposal_layer,
             out_size_factor=cfg["out_size_factor"], input_channels=cfg["input_channels"],
             grid_size=cfg["grid_size"], point_cloud_range=cfg["point_cloud_range"],
             code_weights=cfg["code_weights"], loc_weight=cfg["loc_weight"], iou_weight=cfg["iou_weight"],
@@ -58,7 +73,8 @@ class BEVFusionCenterHead(nn.Module):
 
     training:            (ret_dict{'loss'}, tb_dict, bev_feat, trunk_out, multi_head_features, {})
     return_feature=True: (bev_feat, trunk_out, multi_head_features)
-    eval:                the head's dict (multi_head_features; proposal decoding is SURVEY 8f.1)
+    eval:                the proposal layer's dict: pred_dicts (boxes / scores / labels per sample), rois,
+                         roi_scores, roi_labels (layers/gen_proposals.py, rotated NMS on the HIP library)
     """
 
     def __init__(self, model_cfg, camera_kwargs=None):

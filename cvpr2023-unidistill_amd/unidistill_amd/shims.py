@@ -9,8 +9,8 @@ height_compression.py, the BEVFusion_*_exp files) import and run on this library
   spconv.pytorch / spconv.pytorch.utils / spconv.core     -> ops.spconv, ops.voxelize.PointToVoxel, ConvAlgo
   mmdet.models.build_backbone / mmdet3d.models.build_neck -> layers.image (ResNet-50, SECONDFPN)
   mmcv.Config                                             -> attribute dict
-  iou3d_nms_cuda / roiaware_pool3d_cuda                   -> import-time stubs (eval-only / unused paths;
-                                                             calling them raises NotImplementedError)
+  iou3d_nms_cuda.nms_gpu                                  -> ops.nms.nms_gpu (rotated-BEV NMS, ud_nms_rotated_bev)
+  roiaware_pool3d_cuda                                    -> import-time stub (unused path; calling raises)
 Registry-style mmdet.core.* names the reference merely imports are provided as inert placeholders.
 """
 import sys
@@ -79,8 +79,10 @@ def install():
     # --- the reference's three missing pybind extensions (relative imports fall back to sys.modules)
     _leaf("unidistill.layers.blocks_3d.mmdet3d.voxel_pooling_ext",
           voxel_pooling_forward_wrapper=bev_pool.voxel_pooling_forward_wrapper)
+    from .ops import nms
     _leaf("unidistill.layers.head.det3d.generate_proposals.iou3d_nms_cuda",
-          nms_gpu=_unavailable("iou3d_nms_cuda.nms_gpu"), nms_normal_gpu=_unavailable("nms_normal_gpu"))
+          nms_gpu=nms.nms_gpu, boxes_iou_bev_gpu=nms.boxes_iou_bev_gpu,
+          nms_normal_gpu=_unavailable("nms_normal_gpu"))
     _leaf("unidistill.utils.det3d_utils.roiaware_pool3d_cuda",
           **{n: _unavailable("roiaware_pool3d_cuda." + n) for n in (
               "points_in_boxes_cpu", "points_in_boxes_gpu", "bev_in_boxes_cpu", "bev_in_boxes_gpu",

@@ -407,6 +407,17 @@ int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* sca
                   float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
                   ud_stream_t stream);
 
+/* ---- Proposal layer: rotated-BEV IoU + greedy NMS -----------------------------------------------------
+ * Replaces `iou3d_nms_cuda.nms_gpu(boxes, keep, thresh)` (reference layers/head/det3d/generate_proposals/
+ * centerpoint_gen_proposals.py:85-105; OpenPCDet iou3d_nms, binary absent from the tree).
+ * boxes f32[N,7] = (x, y, z, dx, dy, dz, heading) sorted by descending score.  keep i64[N] receives the
+ * kept indices in order (rest = -1), *num_keep (device int) their count; nothing synchronises with the
+ * host.  N <= 16384.  ud_boxes_iou_bev: iou f32[Na,Nb] of the BEV footprints. */
+size_t ud_nms_bev_workspace_bytes(int N);
+int ud_nms_rotated_bev(const float* boxes, int N, float thresh, long long* keep, int* num_keep,
+                       void* workspace, size_t workspace_bytes, ud_stream_t stream);
+int ud_boxes_iou_bev(const float* a, int Na, const float* b, int Nb, float* iou, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

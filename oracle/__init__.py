@@ -218,3 +218,36 @@ def sparse_to_dense(feat, coords, shape):
     dense = np.empty((B, C, Dz, Hy, Wx), np.float32)
     lib().oracle_sparse_to_dense(_p(feat, F), _p(coords, I), M, C, B, Dz, Hy, Wx, _p(dense, F))
     return dense
+
+
+def iou_bev(a, b):
+    """f32[Na,Nb] BEV IoU of boxes (x,y,z,dx,dy,dz,heading); same float algorithm as the HIP kernel."""
+    a, b = _f32(a).reshape(-1, 7), _f32(b).reshape(-1, 7)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    lib().oracle_iou_bev_matrix(_p(a, F), a.shape[0], _p(b, F), b.shape[0], _p(out, F))
+    return out
+
+
+def iou_bev_f64(a, b):
+    """Independent double-precision overlap (chord integration) for checking the restatement."""
+    import ctypes
+    L = lib()
+    L.oracle_iou_bev_f64.restype = ctypes.c_double
+    a, b = _f32(a).reshape(-1, 7), _f32(b).reshape(-1, 7)
+    out = np.empty((a.shape[0], b.shape[0]), np.float64)
+    for i in range(a.shape[0]):
+        for j in range(b.shape[0]):
+            out[i, j] = L.oracle_iou_bev_f64(_p(np.ascontiguousarray(a[i]), F), _p(np.ascontiguousarray(b[j]), F))
+    return out
+
+
+def nms_bev(boxes, thresh):
+    """Greedy NMS over score-sorted boxes f32[N,7] -> kept indices (int64), in order."""
+    import ctypes
+    boxes = _f32(boxes).reshape(-1, 7)
+    keep = np.empty((max(boxes.shape[0], 1),), np.int64)
+    L = lib()
+    L.oracle_nms_bev.restype = ctypes.c_int
+    n = L.oracle_nms_bev(_p(boxes, F), boxes.shape[0], ctypes.c_float(thresh),
+                         keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    return keep[:n].copy()

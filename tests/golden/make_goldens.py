@@ -352,6 +352,53 @@ def gold_dense_head():
 
 ALL["dense_head"] = gold_dense_head
 
+
+def gold_proposals():
+    """IouAwareGenProposals.generate_predicted_boxes (iou_aware_gen_proposals.py:43-139,
+    centerpoint_gen_proposals.py:85-340): top-K decode, range/score filter, NMS, roi padding.  The
+    reference's NMS binary is missing from its tree; the harness binds `iou3d_nms_cuda.nms_gpu` to the
+    CPU oracle (oracle.nms_bev), so this golden pins everything AROUND the NMS against the reference's own
+    code and the NMS itself against the oracle."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import oracle
+    from unidistill.layers.head.det3d.generate_proposals import iou3d_nms_cuda, IouAwareGenProposals
+
+    def nms_gpu(boxes, keep, thresh):
+        kept = oracle.nms_bev(boxes.detach().cpu().numpy(), float(thresh))
+        keep[:len(kept)] = torch.from_numpy(kept)
+        return len(kept)
+    iou3d_nms_cuda.nms_gpu = nms_gpu
+    g = torch.Generator().manual_seed(105)
+    tasks = [["car"], ["truck", "bus"], ["barrier"]]
+    prop = IouAwareGenProposals(
+        dataset_name="nuscenes", class_names=tasks, post_center_limit_range=[-30.0, -30.0, -6.0, 30.0, 30.0, 6.0],
+        score_threshold=0.1, pc_range=[-32.0, -32.0], out_size_factor=8, voxel_size=[0.25, 0.25], no_log=False,
+        iou_aware_list=[0.65] * 3, nms_iou_threshold_train=0.8, nms_pre_max_size_train=60,
+        nms_post_max_size_train=20, nms_iou_threshold_test=0.2, nms_pre_max_size_test=50,
+        nms_post_max_size_test=12)
+    B, H, W = 2, 32, 32
+    out, heads = {}, []
+    for t, names in enumerate(tasks):
+        d = {"hm": torch.randn(B, len(names), H, W, generator=g) * 2.0 - 1.0,
+             "reg": torch.rand(B, 2, H, W, generator=g), "height": torch.randn(B, 1, H, W, generator=g),
+             "dim": torch.randn(B, 3, H, W, generator=g) * 0.4 + 0.8, "rot": torch.randn(B, 2, H, W, generator=g),
+             "vel": torch.randn(B, 2, H, W, generator=g), "iou": torch.randn(B, 1, H, W, generator=g)}
+        heads.append(d)
+        for k, v in d.items():
+            out[f"in{t}_{k}"] = v
+    for phase in ("train", "test"):
+        prop.training = phase == "train"
+        res = prop.generate_predicted_boxes({"multi_head_features": [dict(d) for d in heads]}, {})
+        out[f"{phase}_rois"] = res["rois"]
+        out[f"{phase}_roi_scores"] = res["roi_scores"]
+        out[f"{phase}_roi_labels"] = res["roi_labels"]
+        for b, pd in enumerate(res["pred_dicts"]):
+            out[f"{phase}_n{b}"] = np.array([pd["pred_boxes"].shape[0]])
+    _save("proposals", **out)
+
+
+ALL["proposals"] = gold_proposals
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)
     for n in names:
