@@ -13,7 +13,9 @@ rm -rf /tmp/p_bench; rocprofv3 --kernel-trace --stats -d /tmp/p_bench -- python 
 DB=$(ls /tmp/p_bench/*/*.db | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo;
   echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt; echo '```'; echo; echo "## Kernels by total time (whole run incl. warm-up, MIOpen find and the roofline leg)"; echo;
-  python $T/rocpd_summary.py $DB | head -60; } > $OUT/${R}_bench_kernel_stats.md
+  python $T/rocpd_summary.py $DB | head -60;
+  echo; echo "## Roofline kernel (bench.py roofline leg: 2 warm-up + 10 timed launches of bev_pool forward, cache scrubbed)"; echo;
+  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4"; } > $OUT/${R}_bench_kernel_stats.md
 # 2. steady-state training step by category (marker-delimited window)
 rm -rf /tmp/p_step; B=4 CL=1 AC=bf16 STEPS=6 rocprofv3 --kernel-trace -d /tmp/p_step -- python $T/profile_step.py > $OUT/step_stdout.txt 2>&1
 { echo "# Steady-state distillation step, B=4, bf16 + channels-last (6 steps between marker kernels) ($R)"; echo; echo '```'; grep "samples/s" $OUT/step_stdout.txt; echo '```'; echo;
