@@ -78,6 +78,15 @@ _SIGS = {
     "ud_conv3x3_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
     "ud_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_conv3x3_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "ud_det_loss_workspace_bytes": (c_size_t, [c_int]),
+    "ud_det_focal_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                                                c_void_p, c_size_t, c_void_p]),
+    "ud_det_focal_bwd": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p] * 5 + [c_float, c_float, c_void_p,
+                                                                              c_void_p]),
+    "ud_det_reg_fwd": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_int,
+                                                                     c_void_p, c_float, c_float, c_void_p,
+                                                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_det_reg_bwd": (c_int, [c_int] * 5 + [c_void_p] * 8),
     "ud_nms_bev_workspace_bytes": (c_size_t, [c_int]),
     "ud_nms_rotated_bev": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from ..dist import reduce_mean, reduce_mean_many
-from ..ops import conv2d as hipconv, head_tail
+from ..ops import conv2d as hipconv, det_loss as hiploss, head_tail
 from .dense import Conv2d, FusedSequential
 
 
@@ -647,38 +647,24 @@ class CenterHeadIouAware(CenterHead):
         gt_hm, ind, mask, tgt_all = st["heatmap"], st["ind"], st["mask"], st["box_encoding"]
         ncm = gt_hm.shape[2]
         B, K = ind.shape[1], ind.shape[2]
-        # ---- heat maps: pad every task to ncm classes; padded channels are "ignore" (gt = -1)
-        logits = torch.stack([torch.nn.functional.pad(pd["hm"], (0, 0, 0, 0, 0, ncm - pd["hm"].shape[1]))
-                              for pd in preds])                                      # [T,B,ncm,H,W]
-        prob = self._sigmoid(logits)
-        for t, pd in enumerate(preds):
-            pd["hm"] = prob[t, :, :self.num_classes[t]]
-        cls_valid = (torch.arange(ncm, device=prob.device)[None, :]
-                     < torch.tensor(self.num_classes, device=prob.device)[:, None]) \
-            if not hasattr(self, "_cls_valid") or self._cls_valid.device != prob.device else self._cls_valid
-        self._cls_valid = cls_valid
-        cv = cls_valid[:, None, :, None, None]
-        pos = gt_hm.eq(1) & cv
-        neg = gt_hm.eq(0) & cv
-        a, gm = self.crit.alpha, self.crit.gamma
-        pos_l = (torch.log(prob) * torch.pow(1 - prob, gm) * pos.long() * a).sum(dim=(1, 2, 3, 4))
-        neg_l = (torch.log(1 - prob + 1e-4) * torch.pow(prob, gm) * neg.long() * (1 - a)).sum(dim=(1, 2, 3, 4))
-        safe = torch.where(num_pos_f == 0, torch.ones_like(num_pos_f), num_pos_f)
-        hm_loss = torch.where(num_pos_f == 0, -neg_l, -(pos_l + neg_l) / safe)          # [T]
-        # ---- regression / IoU terms on the gathered predictions
         if self.dataset == "nuscenes":
             heads, nb = ("reg", "height", "dim", "rot", "vel", "iou"), 10
         else:
             heads, nb = ("reg", "height", "dim", "rot", "iou"), 8
-        enc = torch.cat([torch.stack([pd[hn] for pd in preds]) for hn in heads], 2)    # [T,B,nb+1,H,W]
-        forward_ret_dict["pred_box_encoding"] = {t: enc[t] for t in range(T)}
-        g = _transpose_and_gather_feat(enc.reshape(T * B, nb + 1, *enc.shape[3:]), ind.reshape(T * B, K))
-        g = g.reshape(T, B, K, nb + 1)
-        tgt = tgt_all[..., :nb]
+        a, gm = self.crit.alpha, self.crit.gamma
         stride, vs = self.out_size_factor, self._voxel_xy()
-        iou_loss, iou_aware = self._iou_losses(g, tgt, mask, num_obj, stride, vs)        # [T], [T]
-        m = mask.unsqueeze(3).float() * (~torch.isnan(tgt)).float()
-        box_loss = torch.abs(g[..., :nb] * m - tgt * m).sum(dim=(1, 2)) / (num_obj[:, None] + 1e-4)   # [T,nb]
+        if self.fused_loss and hiploss.supported(preds, nb):
+            # ---- HIP path: focal term over all heat maps + gathered regression / IoU terms, 2 kernels
+            prob, pos_l, neg_l = hiploss.focal_terms([pd["hm"] for pd in preds], gt_hm, a, gm)
+            for t, pd in enumerate(preds):
+                pd["hm"] = prob[t, :, :self.num_classes[t]]
+            box_loss, iou_loss, iou_aware = hiploss.reg_terms(preds, ind, mask, tgt_all, num_obj,
+                                                              stride * vs[0], stride * vs[1], nb)
+        else:
+            pos_l, neg_l, box_loss, iou_loss, iou_aware = self._loss_terms_torch(
+                preds, gt_hm, ind, mask, tgt_all, num_obj, ncm, heads, nb, a, gm, stride, vs, forward_ret_dict)
+        safe = torch.where(num_pos_f == 0, torch.ones_like(num_pos_f), num_pos_f)
+        hm_loss = torch.where(num_pos_f == 0, -neg_l, -(pos_l + neg_l) / safe)          # [T]
         loc_loss = (box_loss * self._code_weights(box_loss)[None, :]).sum(1)                         # [T]
         p2 = self.auto_loss.params[:3] ** 2
         loss = (0.5 / p2[0] * hm_loss + 0.5 / p2[1] * loc_loss + 0.5 / p2[2] * iou_aware) \
@@ -693,6 +679,39 @@ class CenterHeadIouAware(CenterHead):
                        key + "loc_loss": loc_loss[t].detach(), key + "box_loss": box_loss[t].detach(),
                        key + "num_positive": npos[t]})
         return loss.sum(), tb
+
+    fused_loss = True      # HIP detection-loss kernels for fp32 CUDA heads (ops/det_loss.py)
+
+    def _loss_terms_torch(self, preds, gt_hm, ind, mask, tgt_all, num_obj, ncm, heads, nb, a, gm, stride, vs,
+                          forward_ret_dict):
+        """Tensor-op formulation (CPU / fallback / parity reference of the HIP kernels)."""
+        T = len(preds)
+        B, K = ind.shape[1], ind.shape[2]
+        # ---- heat maps: pad every task to ncm classes; padded channels are "ignore" (gt = -1)
+        logits = torch.stack([torch.nn.functional.pad(pd["hm"], (0, 0, 0, 0, 0, ncm - pd["hm"].shape[1]))
+                              for pd in preds])                                      # [T,B,ncm,H,W]
+        prob = self._sigmoid(logits)
+        for t, pd in enumerate(preds):
+            pd["hm"] = prob[t, :, :self.num_classes[t]]
+        cls_valid = (torch.arange(ncm, device=prob.device)[None, :]
+                     < torch.tensor(self.num_classes, device=prob.device)[:, None]) \
+            if not hasattr(self, "_cls_valid") or self._cls_valid.device != prob.device else self._cls_valid
+        self._cls_valid = cls_valid
+        cv = cls_valid[:, None, :, None, None]
+        pos = gt_hm.eq(1) & cv
+        neg = gt_hm.eq(0) & cv
+        pos_l = (torch.log(prob) * torch.pow(1 - prob, gm) * pos.long() * a).sum(dim=(1, 2, 3, 4))
+        neg_l = (torch.log(1 - prob + 1e-4) * torch.pow(prob, gm) * neg.long() * (1 - a)).sum(dim=(1, 2, 3, 4))
+        # ---- regression / IoU terms on the gathered predictions
+        enc = torch.cat([torch.stack([pd[hn] for pd in preds]) for hn in heads], 2)    # [T,B,nb+1,H,W]
+        forward_ret_dict["pred_box_encoding"] = {t: enc[t] for t in range(T)}
+        g = _transpose_and_gather_feat(enc.reshape(T * B, nb + 1, *enc.shape[3:]), ind.reshape(T * B, K))
+        g = g.reshape(T, B, K, nb + 1)
+        tgt = tgt_all[..., :nb]
+        iou_loss, iou_aware = self._iou_losses(g, tgt, mask, num_obj, stride, vs)        # [T], [T]
+        m = mask.unsqueeze(3).float() * (~torch.isnan(tgt)).float()
+        box_loss = torch.abs(g[..., :nb] * m - tgt * m).sum(dim=(1, 2)) / (num_obj[:, None] + 1e-4)   # [T,nb]
+        return pos_l, neg_l, box_loss, iou_loss, iou_aware
 
     def _iou_losses(self, pred, tgt, mask, num_pos, stride, vs):
         """pred [T,B,K,nb+1] gathered predictions (last = iou head), tgt [T,B,K,nb], mask [T,B,K],

@@ -418,6 +418,34 @@ int ud_nms_rotated_bev(const float* boxes, int N, float thresh, long long* keep,
                        void* workspace, size_t workspace_bytes, ud_stream_t stream);
 int ud_boxes_iou_bev(const float* a, int Na, const float* b, int Nb, float* iou, ud_stream_t stream);
 
+/* ---- Detection loss of the CenterPoint heads (focal + gathered regression / IoU terms) ------------------
+ * CenterHeadIouAware.get_loss (reference layers/head/det3d/center_head_iou_aware.py:55-298, losses/det3d.py:
+ * 287-421) for all T <= 8 tasks at once.  Head tensors are given as device-pointer tables (any
+ * [B, c, H, W] fp32 tensors with contiguous H*W planes; *_bstride = elements between batch entries).
+ *   ud_det_focal_fwd : prob [T,B,ncm,HW] = clamp(sigmoid(hm), 1e-4, 1-1e-4) (0 in padded channels),
+ *                      pos_neg [T,2] = (sum log(p)(1-p)^g a [gt==1], sum log(1-p+1e-4) p^g (1-a) [gt==0]).
+ *   ud_det_focal_bwd : dlogit [T,B,ncm,HW] from g_prob (optional), g_pos [T], g_neg [T].
+ *   ud_det_reg_fwd   : head[t*11+j] = plane of gathered value j (reg.x reg.y height dim0..2 rot.sin rot.cos
+ *                      vel.x vel.y iou); ind i64 / mask u8 / tgt f32 [T,B,K(,tgt_dim)], num_obj f32 [T];
+ *                      losses [T,12] = box L1 per code dim (10), IoU loss, IoU-aware L1, all normalised;
+ *                      loc [T,B,K,17] = local derivatives kept for the backward.  nb = 10 (nuScenes codes).
+ *   ud_det_reg_bwd   : dhead [T,B,11,HW] (caller zero-fills) += scaled local derivatives at the slots.
+ * Ordered two-stage reductions; no host synchronisation. */
+size_t ud_det_loss_workspace_bytes(int T);
+int ud_det_focal_fwd(const float* const* hm, const long long* hm_bstride, const int* ncls, int T, int B,
+                     int ncm, int HW, const float* gt, float alpha, float gamma, float* prob,
+                     float* pos_neg, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+int ud_det_focal_bwd(const int* ncls, int T, int B, int ncm, int HW, const float* gt, const float* prob,
+                     const float* g_prob, const float* g_pos, const float* g_neg, float alpha,
+                     float gamma, float* dlogit, ud_stream_t stream);
+int ud_det_reg_fwd(const float* const* head, const long long* head_bstride, int T, int B, int K, int HW,
+                   int nb, const long long* ind, const unsigned char* mask, const float* tgt, int tgt_dim,
+                   const float* num_obj, float sx, float sy, float* losses, float* loc, void* workspace,
+                   size_t workspace_bytes, ud_stream_t stream);
+int ud_det_reg_bwd(int T, int B, int K, int HW, int nb, const long long* ind, const unsigned char* mask,
+                   const float* loc, const float* g_box, const float* g_iou, const float* g_aw,
+                   float* dhead, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
