@@ -160,6 +160,49 @@ class FCOSAssigner:
             self._tabs[device] = tabs
         return tabs
 
+    fused = True        # one HIP kernel per step on the GPU (csrc/assign.hip); tensor ops otherwise
+
+    def _assign_hip(self, gt_boxes, T, B, M, K, w, h):
+        """ud_assign_targets: the whole assignment in one launch.  Returns None when the configuration is
+        outside the kernel's limits (the tensor-op path then runs)."""
+        import ctypes
+        from .. import _lib
+        cols = gt_boxes.shape[2]
+        ncls = max(self.class_to_idx.values()) + 1
+        topk = min(self.assign_topk, w * h)
+        if M > 512 or cols > 12 or cols < 8 or ncls > 64 or topk > 9 or w < 9 or h < 9 or w * h > 180 * 180:
+            return None
+        tabs = getattr(self, "_host_tabs", None)
+        if tabs is None:
+            task_of, off_of = [-1] * ncls, [0] * ncls
+            for t, names in enumerate(self.task_classes):
+                for o, name in enumerate(names):
+                    task_of[self.class_to_idx[name]] = t
+                    off_of[self.class_to_idx[name]] = o
+            tabs = self._host_tabs = ((ctypes.c_byte * ncls)(*task_of), (ctypes.c_byte * ncls)(*off_of))
+        ncmax = max(len(c) for c in self.task_classes)
+        enc_dim = max(8 + max(cols - 1 - 7, 0), self.default_box_dims)
+        dev = gt_boxes.device
+        gt = gt_boxes.contiguous()
+        hm = torch.empty((T, B, ncmax, h, w), dtype=torch.float32, device=dev)
+        ind = torch.empty((T, B, K), dtype=torch.long, device=dev)
+        mask = torch.empty((T, B, K), dtype=torch.bool, device=dev)
+        cat = torch.empty((T, B, K), dtype=torch.long, device=dev)
+        enc = torch.empty((T, B, K, enc_dim), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.ud_assign_targets(_lib.ptr(gt), B, M, cols, tabs[0], tabs[1], ncls, T, ncmax, w, h, K, topk,
+                                         enc_dim, float(self.out_size_factor), float(self.pc_range[0]),
+                                         float(self.pc_range[1]), float(self.voxel_size[0]),
+                                         float(self.voxel_size[1]), _lib.ptr(hm), _lib.ptr(ind), _lib.ptr(mask),
+                                         _lib.ptr(cat), _lib.ptr(enc), _lib.stream_of(gt)), "ud_assign_targets")
+        out = {k: {} for k in ("heatmap", "ind", "mask", "cat", "box_encoding")}
+        for t, names in enumerate(self.task_classes):
+            out["heatmap"][t] = hm[t, :, :len(names)].contiguous() if len(names) != ncmax else hm[t]
+            out["ind"][t], out["mask"][t], out["cat"][t] = ind[t], mask[t], cat[t]
+            out["box_encoding"][t] = enc[t]
+        out["_stacked"] = {"heatmap": hm, "ind": ind, "mask": mask, "box_encoding": enc}
+        return out
+
     windowed = True     # candidate anchors from a 9x9 window around each box centre (see _assign_windowed)
 
     def _assign_dense(self, anchors, pcx, pcy, mem, K, topk):
@@ -233,6 +276,10 @@ class FCOSAssigner:
         T = len(self.task_classes)
         K = self._max_objs * self.dense_reg
         w, h = self.grid_size[0] // self.out_size_factor, self.grid_size[1] // self.out_size_factor
+        if self.fused and gt_boxes.is_cuda and gt_boxes.dtype == torch.float32:
+            out = self._assign_hip(gt_boxes, T, B, M, K, w, h)
+            if out is not None:
+                return out
         anchors = self.anchor_points(dev)
         A = anchors.shape[0]
         ncmax = max(len(c) for c in self.task_classes)

@@ -446,6 +446,20 @@ int ud_det_reg_bwd(int T, int B, int K, int HW, int nb, const long long* ind, co
                    const float* loc, const float* g_box, const float* g_iou, const float* g_aw,
                    float* dhead, ud_stream_t stream);
 
+/* ---- FCOS-style target assignment of the CenterPoint heads -----------------------------------
+ * FCOSAssigner.assign_targets (reference layers/head/det3d/target_assigner/fcos_assigner.py:73-285) for all
+ * T tasks and B samples in one launch.  gt f32[B,M,cols] (x y z dx dy dz yaw [extra...] class(1-based));
+ * task_of / off_of: HOST int8 tables indexed by class id (task of the class or -1, offset inside the task).
+ * Outputs: hm f32[T,B,ncm,h*w] one-hot class map of the positive anchors, ind i64 / mask u8 / cat i64
+ * [T,B,K] (positives in ascending anchor order), enc f32[T,B,K,enc_dim] box encoding relative to the
+ * anchor (log sizes, sin/cos yaw; +-inf for zero-size boxes like the reference).  topk <= 9, M <= 512,
+ * grid <= 180 x 180, else UD_ERR_UNSUPPORTED. */
+int ud_assign_targets(const float* gt, int B, int M, int cols, const signed char* task_of,
+                      const signed char* off_of, int n_classes, int T, int ncm, int w, int h, int K,
+                      int topk, int enc_dim, float osf, float pc0, float pc1, float vs0, float vs1,
+                      float* hm, long long* ind, unsigned char* mask, long long* cat, float* enc,
+                      ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
