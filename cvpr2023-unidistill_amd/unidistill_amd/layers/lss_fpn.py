@@ -13,6 +13,8 @@ arguments, buffers (voxel_size / voxel_coord / voxel_num / frustum), sub-module 
 import torch
 from torch import nn
 
+from .dense import Conv2d
+
 from ..ops import bev_pool as _bp
 from ..ops import lss as _lss
 from .image import build_backbone, build_neck
@@ -48,7 +50,7 @@ class LSSFPN(nn.Module):
         out_ch = self.depth_channels + self.output_channels
         if conf.get("num_res_layer", 0) != 0:
             raise NotImplementedError("depth_net with residual layers is not used by any experiment")
-        return nn.Sequential(nn.Conv2d(conf["in_channels"], out_ch, kernel_size=1))
+        return nn.Sequential(Conv2d(conf["in_channels"], out_ch, kernel_size=1))
 
     def create_frustum(self):
         """[D, fH, fW, 4] = (u, v, d, 1) in image pixels / metres (lss_fpn.py:173-198)."""
