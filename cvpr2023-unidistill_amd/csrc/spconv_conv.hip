@@ -669,6 +669,175 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16_fast(
   }
 }
 
+// Out-of-rulebook rows and output channels past cout are DMA'd from here (LDS-DMA cannot write a constant).
+__device__ __attribute__((aligned(16))) unsigned int g_sp_zero16[4];
+
+// bytes of the LDS region shared by the double-buffered operand tiles and the staged fp32 output tile
+__host__ __device__ constexpr size_t dma_front_bytes(int cin_p, int cout_p) {
+  const int rpp = 64 / (cin_p / 8);
+  const size_t a = (size_t)2 * (kTM2 + (cout_p + rpp - 1) / rpp * rpp) * cin_p * 2;
+  const size_t o = (size_t)kTM2 * (cout_p + 4) * 4;
+  return ((a > o ? a : o) + 15) / 16 * 16;
+}
+
+// ---- all-bf16 kernel with LDS-DMA staging -----------------------------------------------------------
+// k_conv_mfma_bf16_fast with the gathered rows and the weight slice moved L2 -> LDS by
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write), double-buffered so the next offset's
+// operands fly while the current offset is multiplied: one barrier per offset instead of two.
+template <int CIN_P, int COUT_P>   // cin == CIN_P in {32, 64, 128}; cout multiple of 8
+__global__ __launch_bounds__(512) void k_conv_mfma_bf16_dma(
+    const unsigned short* __restrict__ in, int cin, const int32_t* __restrict__ nbr, int K, int mirror,
+    const unsigned short* __restrict__ W, WStrides ws, const float* __restrict__ bias,
+    unsigned short* __restrict__ out, int cout, int Mout, const int32_t* __restrict__ order,
+    ConvEpilogue ep) {
+  constexpr int NT = COUT_P / 16;
+  constexpr int S = CIN_P / 8;                      // 16-byte slots per (unpadded) LDS row
+  constexpr int RPP = 64 / S;                       // rows per 1-KiB DMA piece
+  constexpr int APIECES = kTM2 / RPP, BPIECES = (COUT_P + RPP - 1) / RPP;
+  constexpr int LDO = COUT_P + 4;                   // fp32 elements per staged output row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);            // [2][kTM2][CIN_P]
+  unsigned short* Bs = As + 2 * kTM2 * CIN_P;                                // [2][BPIECES*RPP][CIN_P]
+  int* s_nbr = reinterpret_cast<int*>(smem + dma_front_bytes(CIN_P, COUT_P));
+  unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
+  int* s_row = s_nbr + K * kTM2 + 4;
+  float* Os = reinterpret_cast<float*>(smem);       // [kTM2][LDO], aliases As/Bs after the K loop
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int row0 = blockIdx.x * kTM2;
+  if (tid == 0) s_active = 0u;
+  if (tid < kTM2) {
+    const int p = row0 + tid;
+    s_row[tid] = (p < Mout) ? (order ? order[p] : p) : -1;
+  }
+  __syncthreads();
+  unsigned mine = 0u;
+  for (int idx = tid; idx < kTM2 * K; idx += 512) {
+    const int r = idx / K, k = idx - r * K;
+    int v = -1;
+    const int orow = s_row[r];
+    if (orow >= 0) v = nbr[(size_t)orow * K + (mirror ? K - 1 - k : k)];
+    s_nbr[k * kTM2 + r] = v;
+    if (v >= 0) mine |= 1u << k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor((int)mine, o);
+  if (lane == 0 && mine) atomicOr(&s_active, mine);
+  __syncthreads();
+  const unsigned active = s_active;
+  unsigned wmask = 0u;
+  for (int k = 0; k < K; ++k) {
+    const int v = (lane < 16) ? s_nbr[k * kTM2 + wave * 16 + lane] : -1;
+    if (__any(v >= 0)) wmask |= 1u << k;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Row r of a tile keeps its 16-byte slot t at position t ^ swz(r): the swizzle is applied to the SOURCE
+  // address (the DMA's LDS pattern is fixed: lane l lands at piece base + 16 l) and makes every
+  // ds_read_b128 fragment load below conflict-free on the unpadded rows.
+  auto swz = [](int r) -> int {
+    if (S == 16) return r & 15;
+    if (S == 8) return (r >> 1) & 7;
+    const int q = (r >> 2) & 3;                      // S == 4
+    return q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 3 : 1));
+  };
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_sp_zero16);
+  const int prow = lane / S, pslot = lane % S;
+  auto stage = [&](int k, int buf) {
+#pragma unroll
+    for (int j = 0; j < (APIECES + 7) / 8; ++j) {
+      const int piece = wave + 8 * j;
+      if (piece < APIECES) {
+        const int r = piece * RPP + prow;
+        const int rr = s_nbr[k * kTM2 + r];
+        const unsigned short* src = rr >= 0 ? in + (size_t)rr * cin + ((pslot ^ swz(r)) << 3) : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + (buf * kTM2 + piece * RPP) * CIN_P),
+                                         16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < (BPIECES + 7) / 8; ++j) {
+      const int piece = wave + 8 * j;
+      if (piece < BPIECES) {
+        const int n = piece * RPP + prow;
+        const unsigned short* src = n < cout ? W + n * ws.sn + k * ws.sk + ((pslot ^ swz(n)) << 3) : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Bs + (buf * BPIECES * RPP + piece * RPP) * CIN_P),
+                                         16, 0, 0);
+      }
+    }
+  };
+  unsigned todo = active;
+  int k = todo ? (__ffs((int)todo) - 1) : -1;
+  int buf = 0;
+  if (k >= 0) stage(k, 0);
+  __syncthreads();                                   // drains the DMAs (vmcnt(0)) and publishes the tiles
+  while (k >= 0) {
+    todo &= todo - 1;
+    const int knext = todo ? (__ffs((int)todo) - 1) : -1;
+    if (knext >= 0) stage(knext, buf ^ 1);           // flies while this offset is multiplied
+    if ((wmask >> k) & 1u) {
+      const int ar = wave * 16 + li;
+      const unsigned short* arow = As + (buf * kTM2 + ar) * CIN_P;
+      const int asw = swz(ar);
+#pragma unroll
+      for (int cb = 0; cb < CIN_P / 32; ++cb) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + (((4 * cb + g) ^ asw) << 3));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int n = t * 16 + li;
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (buf * BPIECES * RPP + n) * CIN_P +
+                                                             (((4 * cb + g) ^ swz(n)) << 3));
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+    k = knext;
+  }
+  // epilogue 1: bias + folded BatchNorm in registers, fp32 tile -> LDS
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = t * 16 + li;
+    const bool cv = col < cout;
+    const float bv = (cv && bias) ? bias[col] : 0.f;
+    const float sc = (cv && ep.scale) ? ep.scale[col] : 1.f;
+    const float sh = (cv && ep.shift) ? ep.shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Os[(wave * 16 + 4 * g + r) * LDO + col] = (acc[t][r] + bv) * sc + sh;
+  }
+  __syncthreads();
+  // epilogue 2: + residual, ReLU, bf16, 16-byte rows
+  const unsigned short* res = reinterpret_cast<const unsigned short*>(ep.residual);
+  for (int u = tid; u < kTM2 * (COUT_P / 8); u += 512) {
+    const int r = u / (COUT_P / 8), c8 = (u - r * (COUT_P / 8)) * 8;
+    const int row = s_row[r];
+    if (row < 0 || c8 >= cout) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(Os + r * LDO + c8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Os + r * LDO + c8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (res) {
+      const uint4 h = *reinterpret_cast<const uint4*>(res + (size_t)row * cout + c8);
+      const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[2 * q] += __uint_as_float(hw[q] << 16);
+        v[2 * q + 1] += __uint_as_float(hw[q] & 0xFFFF0000u);
+      }
+    }
+    if (ep.relu) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)row * cout + c8) =
+        make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]), ud_pack_bf16x2(v[4], v[5]),
+                   ud_pack_bf16x2(v[6], v[7]));
+  }
+}
+
 // Any-size fallback (and the cross-check in tests): one thread per (row, n), sequential k, c.
 __global__ __launch_bounds__(256) void k_conv_generic(const float* __restrict__ in, int cin,
                                                       const int32_t* __restrict__ nbr, int K,
@@ -1032,6 +1201,23 @@ int launch_conv_bf16(const float* in, int cin, const int32_t* nbr, int K, int mi
   constexpr int CP = CIN_P < 32 ? 32 : CIN_P;
   if ((io & 1) && (cin & 3)) return UD_ERR_UNSUPPORTED;          // bf16 rows are read 4 channels at a time
   if ((io & 4) && !(ws.sc == 1 && (cin & 3) == 0)) return UD_ERR_UNSUPPORTED;
+  if (io == 7 && cin == CP && (cout & 7) == 0 && (ws.sn & 7) == 0 && (ws.sk & 7) == 0) {
+    const size_t lds_d = dma_front_bytes(CP, COUT_P) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
+    if (lds_d <= 160 * 1024) {
+      static bool dma_attr_set = false;
+      if (!dma_attr_set && lds_d > 64 * 1024) {
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_bf16_dma<CP, COUT_P>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+        dma_attr_set = true;
+      }
+      k_conv_mfma_bf16_dma<CP, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds_d, stream>>>(
+          reinterpret_cast<const unsigned short*>(in), cin, nbr, K, mirror,
+          reinterpret_cast<const unsigned short*>(W), ws, bias, reinterpret_cast<unsigned short*>(out), cout,
+          Mout, order, ep);
+      UD_LAUNCH_CHECK();
+      return UD_OK;
+    }
+  }
   if (io == 7 && (cin & 7) == 0 && (cout & 7) == 0 && (ws.sn & 7) == 0 && (ws.sk & 7) == 0) {
     const size_t lds_f = fast_front_bytes(CP, COUT_P) + (size_t)K * kTM2 * sizeof(int) + 16 +
                          kTM2 * sizeof(int);
