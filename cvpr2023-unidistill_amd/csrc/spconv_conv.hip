@@ -968,6 +968,28 @@ __device__ __forceinline__ bf16x8 tr_frag8(const unsigned short* lo_p, const uns
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// Compact the ids of this workgroup's tiles that have a pair for offset k into LDS (one wave, ordered).
+// Scanning the tile masks in global memory one dependent load at a time cost more than the MFMAs.
+constexpr int kMaxTilesPerChunk = 2048;
+__device__ __forceinline__ int build_active_list(const unsigned* __restrict__ masks, int k, int t_begin,
+                                                 int t_end, short* list) {
+  __shared__ int s_count;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int count = 0;
+    for (int base = t_begin; base < t_end; base += 64) {
+      const int t = base + lane;
+      const bool on = t < t_end && ((masks[t] >> k) & 1u);
+      const unsigned long long b = __ballot(on);
+      if (on) list[count + __popcll(b & ((1ull << lane) - 1ull))] = (short)(t - t_begin);
+      count += __popcll(b);
+    }
+    if (lane == 0) s_count = count;
+  }
+  __syncthreads();
+  return s_count;
+}
+
 template <int CIN_P, int COUT_P, bool BF_IO>   // BF_IO: `in` and `gout` already hold bf16 (cin, cout % 8 == 0)
 __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in, int cin,
                                                     const int32_t* __restrict__ nbr, int K,
@@ -990,11 +1012,9 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in
   const int wm = wave / WN, wn = wave % WN;
   const bool wave_on = wn * TJ < CTT;
   const int k = blockIdx.x, chunk = blockIdx.y;
-  const int t_end = min(ntiles, (chunk + 1) * tiles_per_chunk);
-  auto next_active = [&](int t) {
-    while (t < t_end && !((masks[t] >> k) & 1u)) ++t;
-    return t;
-  };
+  const int t_begin = chunk * tiles_per_chunk, t_end = min(ntiles, (chunk + 1) * tiles_per_chunk);
+  __shared__ short s_list[kMaxTilesPerChunk];
+  const int n_active = build_active_list(masks, k, t_begin, t_end, s_list);
   f32x4 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -1097,16 +1117,15 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in
       }
     }
   };
-  int t = next_active(chunk * tiles_per_chunk);
-  if (t < t_end) {
-    fetch(t);
+  if (n_active > 0) {
+    fetch(t_begin + s_list[0]);
     commit(0);
   }
   __syncthreads();
   int buf = 0;
-  while (t < t_end) {
-    const int tn = next_active(t + 1);
-    if (tn < t_end) fetch(tn);
+  for (int ai = 0; ai < n_active; ++ai) {
+    const bool more = ai + 1 < n_active;
+    if (more) fetch(t_begin + s_list[ai + 1]);
     if (wave_on) {
       const unsigned short* nb = Ns + (buf * kWR + 8 * g + (li >> 2)) * LDN + 16 * TI * wm + 4 * (li & 3);
       const unsigned short* cb = Cs + (buf * kWR + 8 * g + (li >> 2)) * LDC + 16 * TJ * wn + 4 * (li & 3);
@@ -1125,10 +1144,9 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in
         }
       }
     }
-    if (tn < t_end) commit(buf ^ 1);
+    if (more) commit(buf ^ 1);
     __syncthreads();
     buf ^= 1;
-    t = tn;
   }
   // partial[chunk][k][n][c] (padded sizes); D layout: column c = li, rows n = 4g + r
   if (wave_on) {
@@ -1141,6 +1159,114 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in
         for (int r = 0; r < 4; ++r)
           pbase[(size_t)(16 * (TI * wm + ti) + 4 * g + r) * CIN_P + 16 * (TJ * wn + tj) + li] = acc[ti][tj][r];
   }
+}
+
+// bf16-IO weight gradient with LDS-DMA staging (cin == CIN_P, cout == COUT_P in {64, 128}): the 64-row
+// gout / gathered-input tiles go L2 -> LDS by global_load_lds_dwordx4 into unpadded rows whose 32-byte
+// pieces are XOR-swizzled on the source address so that the transposing fragment reads
+// (ds_read_b64_tr_b16: 8 rows x 32 B per 32 lanes) hit 8 different pieces; double-buffered, one barrier
+// per tile.  Removes the ds_write pass that made the register-staged kernel LDS-bound.
+template <int CIN_P, int COUT_P>
+__global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __restrict__ in,
+                                                        const int32_t* __restrict__ nbr, int K,
+                                                        const unsigned short* __restrict__ gout,
+                                                        float* __restrict__ partial, int Mout,
+                                                        const int32_t* __restrict__ order,
+                                                        const unsigned* __restrict__ masks, int ntiles,
+                                                        int tiles_per_chunk) {
+  constexpr int SN = COUT_P / 8, SC = CIN_P / 8;             // 16-byte slots per row
+  constexpr int RN = 64 / SN, RC = 64 / SC;                   // rows per 1-KiB piece
+  constexpr int PN = kWR / RN, PC = kWR / RC;                 // pieces per tile
+  constexpr int NT = COUT_P / 16, CTT = CIN_P / 16;
+  constexpr int TI = NT / 2, TJ = CTT / 2;                    // 2 x 2 waves
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* Ns = reinterpret_cast<unsigned short*>(smem);       // [2][kWR][COUT_P]
+  unsigned short* Cs = Ns + 2 * kWR * COUT_P;                           // [2][kWR][CIN_P]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k = blockIdx.x, chunk = blockIdx.y;
+  const int t_begin = chunk * tiles_per_chunk, t_end = min(ntiles, (chunk + 1) * tiles_per_chunk);
+  __shared__ short s_list[kMaxTilesPerChunk];
+  const int n_active = build_active_list(masks, k, t_begin, t_end, s_list);
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_sp_zero16);
+  // swizzle of the 32-byte piece index by the row (see the header comment); in 16-byte slot units << 1
+  auto fsw = [](int r, int slots) -> int {
+    return slots == 16 ? (((r & 3) | ((r >> 1) & 4)) << 1) : ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
+  };
+  auto stage = [&](int t, int buf) {
+#pragma unroll
+    for (int j = 0; j < PN / 4; ++j) {
+      const int piece = wave + 4 * j, r = piece * RN + lane / SN, slot = lane % SN;
+      const int p = t * kWR + r;
+      const unsigned short* src = zero;
+      if (p < Mout) src = gout + (size_t)(order ? order[p] : p) * COUT_P + ((slot ^ fsw(r, SN)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Ns + (buf * kWR + piece * RN) * COUT_P),
+                                       16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PC / 4; ++j) {
+      const int piece = wave + 4 * j, r = piece * RC + lane / SC, slot = lane % SC;
+      const int p = t * kWR + r;
+      const unsigned short* src = zero;
+      if (p < Mout) {
+        const int rr = nbr[(size_t)(order ? order[p] : p) * K + k];
+        if (rr >= 0) src = in + (size_t)rr * CIN_P + ((slot ^ fsw(r, SC)) << 3);
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Cs + (buf * kWR + piece * RC) * CIN_P),
+                                       16, 0, 0);
+    }
+  };
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (n_active > 0) stage(t_begin + s_list[0], 0);
+  __syncthreads();
+  int buf = 0;
+  for (int ai = 0; ai < n_active; ++ai) {
+    if (ai + 1 < n_active) stage(t_begin + s_list[ai + 1], buf ^ 1);
+    {
+      // transposing fragment read: lane li of a 16-lane group points at [row k0 + (li>>2)][channels c0 + 4*(li&3) ..+3]
+      const unsigned short* nbuf = Ns + buf * kWR * COUT_P;
+      const unsigned short* cbuf = Cs + buf * kWR * CIN_P;
+#pragma unroll
+      for (int ks = 0; ks < kWR / 32; ++ks) {
+        const int r0 = 32 * ks + 8 * g + (li >> 2), r1 = r0 + 4;
+        bf16x8 a[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+          const int c0 = 16 * (TI * wm + ti);
+          const int slot = (c0 >> 3) + ((li & 3) >> 1), half = (li & 1) << 2;
+          a[ti] = tr_frag8(nbuf + r0 * COUT_P + ((slot ^ fsw(r0, SN)) << 3) + half,
+                           nbuf + r1 * COUT_P + ((slot ^ fsw(r1, SN)) << 3) + half);
+        }
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          const int c0 = 16 * (TJ * wn + tj);
+          const int slot = (c0 >> 3) + ((li & 3) >> 1), half = (li & 1) << 2;
+          const bf16x8 bb = tr_frag8(cbuf + r0 * CIN_P + ((slot ^ fsw(r0, SC)) << 3) + half,
+                                     cbuf + r1 * CIN_P + ((slot ^ fsw(r1, SC)) << 3) + half);
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* pbase = partial + ((size_t)chunk * K + k) * COUT_P * CIN_P;
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pbase[(size_t)(16 * (TI * wm + ti) + 4 * g + r) * CIN_P + 16 * (TJ * wn + tj) + li] = acc[ti][tj][r];
 }
 
 // gW[n][k][c] (KRSC, dense) = sum over chunks in order of partial[g][k][n][c]
@@ -1376,12 +1502,22 @@ extern "C" size_t ud_spconv_wgrad_workspace_bytes(int Mout, int K, int Cin, int 
 }
 
 namespace {
-int wgrad_bf16_chunks(int ntiles, int K, int* tiles_per_chunk) {
-  int G = 768 / (K > 0 ? K : 1);              // ~768 workgroups
-  if (G > 32) G = 32;
+// Row chunks per offset: many small (offset, chunk) units balance the very different number of active
+// tiles per offset (the centre offset touches every tile, corner offsets a third of them); bounded by
+// the size of the ordered partial-sum buffer (<= 128 MiB).
+int wgrad_bf16_max_chunks(int K, int cin_p, int cout_p) {
+  const long long per = (long long)K * cin_p * cout_p * (long long)sizeof(float);
+  long long g = (128ll << 20) / (per > 0 ? per : 1);
+  if (g > 64) g = 64;
+  if (g < 8) g = 8;
+  return (int)g;
+}
+int wgrad_bf16_chunks(int ntiles, int K, int cin_p, int cout_p, int* tiles_per_chunk) {
+  int G = wgrad_bf16_max_chunks(K, cin_p, cout_p);
   if (G > ntiles) G = ntiles;
   if (G < 1) G = 1;
   *tiles_per_chunk = (ntiles + G - 1) / G;
+  if (*tiles_per_chunk > kMaxTilesPerChunk) return -1;      // caller falls back (never at real sizes)
   return (ntiles + *tiles_per_chunk - 1) / *tiles_per_chunk;
 }
 
@@ -1391,7 +1527,8 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
                       const unsigned* given_masks, int io_bf16, hipStream_t stream) {
   const int ntiles = ud_div_up(Mout, kWR);
   int tpc;
-  const int G = wgrad_bf16_chunks(ntiles, K, &tpc);
+  const int G = wgrad_bf16_chunks(ntiles, K, CIN_P, COUT_P, &tpc);
+  if (G < 0) return UD_ERR_UNSUPPORTED;
   if (given_masks) {
     masks = const_cast<unsigned*>(given_masks);
   } else {
@@ -1406,6 +1543,25 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16<CIN_P, COUT_P, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
+  }
+  if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128)) {
+    if (io_bf16 && cin == CIN_P && cout == COUT_P) {
+      const size_t lds_d = (size_t)2 * kWR * (CIN_P + COUT_P) * sizeof(unsigned short);
+      static bool dma_set = false;
+      if (!dma_set && lds_d > 64 * 1024) {
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16_dma<CIN_P, COUT_P>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+        dma_set = true;
+      }
+      k_wgrad_bf16_dma<CIN_P, COUT_P><<<dim3(K, G), 256, lds_d, stream>>>(
+          reinterpret_cast<const unsigned short*>(in), nbr, K, reinterpret_cast<const unsigned short*>(gout),
+          partial, Mout, order, masks, ntiles, tpc);
+      UD_LAUNCH_CHECK();
+      k_wgrad_reduce<<<ud_div_up((long long)cout * K * cin, 256), 256, 0, stream>>>(
+          partial, G, K, CIN_P, COUT_P, cin, cout, gW);
+      UD_LAUNCH_CHECK();
+      return UD_OK;
+    }
   }
   if (io_bf16)
     k_wgrad_bf16<CIN_P, COUT_P, true><<<dim3(K, G), 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
@@ -1424,7 +1580,8 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
 extern "C" size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin, int Cout) {
   if (Mout < 0 || K <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const int ntiles = ud_div_up(Mout > 0 ? Mout : 1, kWR);
-  return ud_align_up((size_t)32 * K * pad16(Cin) * pad16(Cout) * sizeof(float)) +
+  const size_t G = (size_t)wgrad_bf16_max_chunks(K, pad16(Cin), pad16(Cout));
+  return ud_align_up(G * K * pad16(Cin) * pad16(Cout) * sizeof(float)) +
          ud_align_up((size_t)ntiles * sizeof(unsigned));
 }
 
@@ -1462,7 +1619,8 @@ extern "C" int ud_spconv_wgrad_bf16(const void* in_, const int32_t* nbr, const v
   const int cp = pad16(Cin), np = pad16(Cout);
   float* partial = reinterpret_cast<float*>(workspace);
   unsigned* masks = reinterpret_cast<unsigned*>(
-      reinterpret_cast<char*>(workspace) + ud_align_up((size_t)32 * K * cp * np * sizeof(float)));
+      reinterpret_cast<char*>(workspace) +
+      ud_align_up((size_t)wgrad_bf16_max_chunks(K, cp, np) * K * cp * np * sizeof(float)));
   UdProfScope prof("spconv.k_wgrad", stream);
 #define X(A, B) \
   if (cp == A && np == B) \

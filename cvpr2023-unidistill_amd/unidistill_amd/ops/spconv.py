@@ -170,6 +170,17 @@ def tile_masks(nbr):
     return hit
 
 
+def sorted_rulebook(nbr):
+    """nbr rows in mask-sorted order (cached on the rulebook): the weight-gradient kernel then walks
+    contiguous tiles of the (equally re-ordered) output gradient instead of chasing ``order``."""
+    hit = getattr(nbr, "_ud_sorted", None)
+    if hit is None:
+        order = mask_order(nbr, False)
+        hit = nbr if order is None else nbr.index_select(0, order.long()).contiguous()
+        nbr._ud_sorted = hit
+    return hit
+
+
 def _conv_bf16io(feat, nbr, weight, bias, cin, cout, scale=None, shift=None, residual=None, relu=False,
                  mirror=False):
     """Conv with bf16 tensors in HBM (ud_spconv_conv_bf16io): feat fp32 or bf16 [*, cin], weight
@@ -288,10 +299,11 @@ class _SparseConvFn(torch.autograd.Function):
                 gw = torch.empty(wshape, dtype=torch.float32, device=w.device)
                 need = lib.ud_spconv_wgrad_bf16_workspace_bytes(Mout, K, cin, cout)
                 ws = _lib.workspace(w.device, need, "spconv_wgrad")
-                _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(nbr), _lib.ptr(gout),
-                                                    _lib.ptr(gw), Mout, K, cin, cout, 1,
-                                                    _lib.ptr(mask_order(nbr, False)),
-                                                    _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
+                order = mask_order(nbr, False)
+                g_sorted = gout if order is None else gout.index_select(0, order.long())
+                _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(sorted_rulebook(nbr)),
+                                                    _lib.ptr(g_sorted), _lib.ptr(gw), Mout, K, cin, cout, 1,
+                                                    None, _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
             if has_bias and ctx.needs_input_grad[2]:
                 gb = gout.float().sum(0)
