@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void k_mark_outputs(const int32_t* __restrict_
         const int ox = tx / c.s[2];
         if (ox >= gout.Wx) continue;
         const long long lin = gout.lin(b, oz, oy, ox);
-        atomicOr(&words[lin >> 6], 1ull << (lin & 63));
+        const unsigned long long bit = 1ull << (lin & 63);
+        // an output cell is reached by several inputs: only the first arrival needs the atomic
+        if (!(__builtin_nontemporal_load(&words[lin >> 6]) & bit)) atomicOr(&words[lin >> 6], bit);
       }
     }
   }
