@@ -424,6 +424,99 @@ extern "C" int ud_sparse_to_dense(const float* feat, const int32_t* coords, int 
   return UD_OK;
 }
 
+// ---- HeightCompression for the mixed-precision path ----------------------------------------------------
+// bev[b][y][x][c * Dz + z] = feat[row(b,z,y,x)][c] (0 where no voxel) as a channels-last bf16 map: what
+// `dense()` + `view(N, C*D, H, W)` (reference height_compression.py:19-22) + the trunk's bf16 cast produce,
+// written once (no fp32 NCDHW tensor, no memset of it, no cast pass).  A small row map (cell -> row)
+// turns the scatter into a per-pixel gather with fully coalesced stores.
+__global__ __launch_bounds__(256) void k_fill_rowmap(const int32_t* __restrict__ coords, int M, GridShape g,
+                                                     int32_t* __restrict__ rowmap) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int b = coords[i * 4 + 0], z = coords[i * 4 + 1], y = coords[i * 4 + 2], x = coords[i * 4 + 3];
+  if ((unsigned)b < (unsigned)g.B && g.inside(z, y, x)) rowmap[g.lin(b, z, y, x)] = i;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bev_nhwc(unsigned short* __restrict__ feat,
+                                                  const int32_t* __restrict__ rowmap, int C, GridShape g,
+                                                  unsigned short* __restrict__ bev) {
+  const int CO = C * g.Dz, pieces = CO / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)g.B * g.Hy * g.Wx * pieces;
+  if (t >= total) return;
+  const int piece = (int)(t % pieces);
+  const long long pix = t / pieces;
+  const int x = (int)(pix % g.Wx), y = (int)((pix / g.Wx) % g.Hy), b = (int)(pix / ((long long)g.Wx * g.Hy));
+  unsigned short v[4] = {0, 0, 0, 0};
+  unsigned short* dst = bev + pix * CO + piece * 4;
+  if (BWD) {
+    const uint2 gpk = *reinterpret_cast<const uint2*>(dst);
+    v[0] = gpk.x & 0xFFFFu; v[1] = gpk.x >> 16; v[2] = gpk.y & 0xFFFFu; v[3] = gpk.y >> 16;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int o = piece * 4 + e, c = o / g.Dz, z = o - c * g.Dz;
+    const int row = rowmap[g.lin(b, z, y, x)];
+    if (row >= 0) {
+      if (BWD) feat[(size_t)row * C + c] = v[e];
+      else v[e] = feat[(size_t)row * C + c];
+    }
+  }
+  if (!BWD) *reinterpret_cast<uint2*>(dst) = make_uint2(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16));
+}
+
+extern "C" size_t ud_sparse_bev_workspace_bytes(int B, int Dz, int Hy, int Wx) {
+  GridShape g{B, Dz, Hy, Wx};
+  if (!shape_ok(g)) return 0;
+  return ud_align_up((size_t)g.cells() * sizeof(int32_t));
+}
+
+// feat bf16[M,C], coords i32[M,4] -> bev bf16[B,Hy,Wx,C*Dz].  (C * Dz) % 4 == 0.
+extern "C" int ud_sparse_to_bev_bf16(const void* feat, const int32_t* coords, int M, int C, int B, int Dz,
+                                     int Hy, int Wx, void* bev, void* workspace, size_t workspace_bytes,
+                                     ud_stream_t stream_) {
+  GridShape g{B, Dz, Hy, Wx};
+  if (!shape_ok(g) || C <= 0 || M < 0 || !bev) return UD_ERR_INVALID_ARG;
+  if ((C * Dz) % 4) return UD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx)) return UD_ERR_WORKSPACE;
+  if (M > 0 && (!feat || !coords)) return UD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int32_t* rowmap = reinterpret_cast<int32_t*>(workspace);
+  UD_HIP_TRY(hipMemsetAsync(rowmap, 0xFF, (size_t)g.cells() * sizeof(int32_t), stream));
+  if (M > 0) {
+    k_fill_rowmap<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, rowmap);
+    UD_LAUNCH_CHECK();
+  }
+  const long long total = (long long)B * Hy * Wx * (C * Dz / 4);
+  k_bev_nhwc<false><<<ud_div_up(total, 256), 256, 0, stream>>>((unsigned short*)feat, rowmap, C, g,
+                                                               (unsigned short*)bev);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+// Backward: gfeat bf16[M,C] (every row of an active voxel is written) from gbev bf16[B,Hy,Wx,C*Dz].
+extern "C" int ud_bev_to_sparse_bf16(const void* gbev, const int32_t* coords, int M, int C, int B, int Dz,
+                                     int Hy, int Wx, void* gfeat, void* workspace, size_t workspace_bytes,
+                                     ud_stream_t stream_) {
+  GridShape g{B, Dz, Hy, Wx};
+  if (!shape_ok(g) || C <= 0 || M < 0) return UD_ERR_INVALID_ARG;
+  if ((C * Dz) % 4) return UD_ERR_UNSUPPORTED;
+  if (M == 0) return UD_OK;
+  if (!gbev || !coords || !gfeat) return UD_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx)) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int32_t* rowmap = reinterpret_cast<int32_t*>(workspace);
+  UD_HIP_TRY(hipMemsetAsync(rowmap, 0xFF, (size_t)g.cells() * sizeof(int32_t), stream));
+  k_fill_rowmap<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, rowmap);
+  UD_LAUNCH_CHECK();
+  const long long total = (long long)B * Hy * Wx * (C * Dz / 4);
+  k_bev_nhwc<true><<<ud_div_up(total, 256), 256, 0, stream>>>((unsigned short*)gfeat, rowmap, C, g,
+                                                              (unsigned short*)gbev);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
 // Backward of dense(): gfeat[row, :] = gdense[b, :, z, y, x].
 extern "C" int ud_dense_to_sparse(const float* gdense, const int32_t* coords, int M, int C, int B,
                                   int Dz, int Hy, int Wx, float* gfeat, ud_stream_t stream_) {

@@ -109,9 +109,7 @@ class HeightCompression(nn.Module):
         self.num_bev_features = num_bev_features
 
     def forward(self, encoded_spconv_tensor, encoded_spconv_tensor_stride):
-        d = encoded_spconv_tensor.dense()
-        n, c, dz, h, w = d.shape
-        return d.view(n, c * dz, h, w), encoded_spconv_tensor_stride
+        return encoded_spconv_tensor.bev(), encoded_spconv_tensor_stride
 
 
 class LidarEncoder(nn.Module):

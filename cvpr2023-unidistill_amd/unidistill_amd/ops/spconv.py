@@ -361,6 +361,38 @@ class _DenseFn(torch.autograd.Function):
         return g, None, None
 
 
+class _BevFn(torch.autograd.Function):
+    """bf16 features [M, C] -> channels-last bf16 BEV map [B, C*Dz, Hy, Wx] (ud_sparse_to_bev_bf16)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, grid):
+        lib = _lib.load()
+        features = features.contiguous()
+        B, Dz, Hy, Wx = grid
+        M, C = features.shape
+        bev = torch.empty((B, Hy, Wx, C * Dz), dtype=torch.bfloat16, device=features.device)
+        ws = _lib.workspace(features.device, lib.ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx), "sparse_bev")
+        _lib.check(lib.ud_sparse_to_bev_bf16(_lib.ptr(features), _lib.ptr(indices), M, C, B, Dz, Hy, Wx,
+                                             _lib.ptr(bev), _lib.ptr(ws), ws.numel(), _lib.stream_of(bev)),
+                   "ud_sparse_to_bev_bf16")
+        ctx.save_for_backward(indices)
+        ctx.cfg = (grid, M, C)
+        return bev.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gbev):
+        (indices,) = ctx.saved_tensors
+        (B, Dz, Hy, Wx), M, C = ctx.cfg
+        lib = _lib.load()
+        g = gbev.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+        gfeat = torch.zeros((M, C), dtype=torch.bfloat16, device=g.device)
+        ws = _lib.workspace(g.device, lib.ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx), "sparse_bev")
+        _lib.check(lib.ud_bev_to_sparse_bf16(_lib.ptr(g), _lib.ptr(indices), M, C, B, Dz, Hy, Wx,
+                                             _lib.ptr(gfeat), _lib.ptr(ws), ws.numel(), _lib.stream_of(g)),
+                   "ud_bev_to_sparse_bf16")
+        return gfeat, None, None
+
+
 class SparseConvTensor:
     """features f32[M,C] + indices i32[M,4] (b,z,y,x) on a (spatial_shape, batch_size) grid."""
 
@@ -388,6 +420,17 @@ class SparseConvTensor:
     def replace_feature(self, feature):
         return SparseConvTensor(feature, None, None, None, _sites=self._sites,
                                 _indice_dict=self.indice_dict)
+
+    def bev(self):
+        """[B, C*Dz, Hy, Wx]: z folded into channels (channel = c*Dz + z) -- HeightCompression.  bf16
+        features give a channels-last bf16 map in one kernel; otherwise dense().view(...)."""
+        grid = (self.batch_size,) + tuple(self._sites.spatial_shape)
+        C = self.features.shape[1]
+        if self.features.dtype == torch.bfloat16 and (C * grid[1]) % 4 == 0 and self.indices.shape[0] > 0:
+            return _BevFn.apply(self.features, self.indices, grid)
+        d = self.dense()
+        n, c, dz, h, w = d.shape
+        return d.view(n, c * dz, h, w)
 
     def dense(self, channels_first=True):
         grid = (self.batch_size,) + tuple(self._sites.spatial_shape)

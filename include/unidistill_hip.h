@@ -273,6 +273,14 @@ int ud_sparse_to_dense(const float* feat, const int32_t* coords, int M, int C, i
                        int Hy, int Wx, float* dense, ud_stream_t stream);
 int ud_dense_to_sparse(const float* gdense, const int32_t* coords, int M, int C, int B, int Dz,
                        int Hy, int Wx, float* gfeat, ud_stream_t stream);
+/* HeightCompression in the mixed-precision path (reference layers/blocks_2d/det3d/map_to_bev/
+ * height_compression.py:19-22: dense() then view(N, C*D, H, W)): bev bf16[B,Hy,Wx,C*Dz] (channels-last,
+ * channel = c*Dz + z) straight from feat bf16[M,C], zeros where no voxel; and its backward. (C*Dz) % 4 == 0. */
+size_t ud_sparse_bev_workspace_bytes(int B, int Dz, int Hy, int Wx);
+int ud_sparse_to_bev_bf16(const void* feat, const int32_t* coords, int M, int C, int B, int Dz, int Hy,
+                          int Wx, void* bev, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+int ud_bev_to_sparse_bf16(const void* gbev, const int32_t* coords, int M, int C, int B, int Dz, int Hy,
+                          int Wx, void* gfeat, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Distillation losses (feature / relation / response) + gaussian box mask   */

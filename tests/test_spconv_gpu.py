@@ -232,3 +232,25 @@ def test_fused_inference_epilogue_matches_module_chain():
         err = (mixed.features.float() - ref.detach()).abs().max().item()
         assert err < 3e-2 * max(1.0, ref.detach().abs().max().item()), err
         assert mixed.dense().dtype == torch.float32
+
+
+def test_bev_nhwc_bf16_equals_dense_view():
+    """SparseConvTensor.bev() on bf16 features == dense().view(N, C*D, H, W) (pure data movement), fwd and bwd."""
+    rng = np.random.default_rng(8)
+    shape = (2, 2, 18, 20)
+    coords = _sites(rng, *shape, 0.3)
+    feat = rng.standard_normal((len(coords), 24)).astype(np.float32)
+    x = _tensor(coords, feat, shape)
+    fb = x.features.to(torch.bfloat16).detach().requires_grad_(True)
+    xb = x.replace_feature(fb)
+    bev = xb.bev()
+    assert bev.dtype == torch.bfloat16 and bev.shape == (2, 48, 18, 20)
+    assert bev.is_contiguous(memory_format=torch.channels_last)
+    ff = fb.detach().float().requires_grad_(True)
+    ref = x.replace_feature(ff).dense()
+    ref = ref.view(2, 48, 18, 20)
+    assert torch.equal(bev.float(), ref)
+    g = torch.randn(2, 48, 18, 20, device="cuda").bfloat16()
+    bev.backward(g)
+    ref.backward(g.float())
+    assert torch.equal(fb.grad.float(), ff.grad)
