@@ -354,6 +354,9 @@ class GraphTrainer:
 
     # ---- one training step ----------------------------------------------------------------
     def step(self, batch):
+        # Back-to-back replays without a host-side join fault on this ROCm ("write access to a read-only
+        # page" inside a replayed graph); one stream join per step avoids it (tools/dbg_graph_b4.py).
+        torch.cuda.current_stream(self.device).synchronize()
         if batch is not self.batch:
             _tree_copy_(self.batch, batch)
         self.g_prep.replay()
