@@ -251,3 +251,21 @@ def nms_bev(boxes, thresh):
     n = L.oracle_nms_bev(_p(boxes, F), boxes.shape[0], ctypes.c_float(thresh),
                          keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
     return keep[:n].copy()
+
+
+def conv3x3_nhwc(x, w, bias=None):
+    """y[b,h,w,n] = sum_{ty,tx,c} x[b,h+ty-1,w+tx-1,c] * w[n,ty,tx,c] (zero padding), float64 accumulate.
+    Plain numpy restatement of nn.Conv2d(k=3, s=1, p=1) on channels-last data (reference
+    base_bev_backbone.py:48-66) for checking the MFMA convolution kernel."""
+    x = np.asarray(x, np.float64)
+    w = np.asarray(w, np.float64)
+    B, H, W, C = x.shape
+    xp = np.zeros((B, H + 2, W + 2, C))
+    xp[:, 1:-1, 1:-1] = x
+    y = np.zeros((B, H, W, w.shape[0]))
+    for ty in range(3):
+        for tx in range(3):
+            y += xp[:, ty:ty + H, tx:tx + W] @ w[:, ty, tx].T
+    if bias is not None:
+        y += np.asarray(bias, np.float64)
+    return y

@@ -96,3 +96,15 @@ def test_trunk_on_mfma_kernel_matches_library_path(hip_lib):
     for name, r, l, o in zip(("train output", "input grad", "parameter grads", "eval output"), ref, lib, ours):
         e_lib, e_ours = rel(l, r), rel(o, r)
         assert e_ours < 1.5 * e_lib + 5e-3, (name, e_ours, e_lib)
+
+
+def test_conv3x3_matches_numpy_oracle(hip_lib):
+    """The CPU oracle's plain-numpy convolution (float64) vs the MFMA kernel on bf16-valued data."""
+    import oracle
+    from unidistill_amd.ops import conv2d as c2
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((2, 11, 19, 128)).astype(np.float32)).cuda().bfloat16()
+    w = torch.from_numpy((rng.standard_normal((64, 3, 3, 128)) * 0.04).astype(np.float32)).cuda().bfloat16()
+    got = c2._launch(x.permute(0, 3, 1, 2), w.contiguous(), 64).permute(0, 2, 3, 1).float().cpu().numpy()
+    ref = oracle.conv3x3_nhwc(x.float().cpu().numpy(), w.float().cpu().numpy())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=6e-3 * np.abs(ref).max())
