@@ -105,6 +105,33 @@ def roofline_leg(device, batch):
                     "lift+splat (no [B,N,C] tensor), see DESIGN.md"}
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+
+
+def mfma_leg(trainer, batch, steps=3):
+    """The dense trunk / head / image-branch 3x3 convolutions (k_conv3x3_bf16, the largest kernel family of
+    the step) over a few extra training steps: algorithmic flops / HIP-event kernel time."""
+    from unidistill_amd import _lib
+    from unidistill_amd.ops import conv2d as c2
+    c2.FLOP_COUNTER = [0]
+    _lib.prof_read("conv2d.k_conv3x3", reset=True)
+    _lib.prof_enable(True)
+    for _ in range(steps):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    ms, calls = _lib.prof_read("conv2d.k_conv3x3")
+    flops, c2.FLOP_COUNTER = c2.FLOP_COUNTER[0], None
+    if not calls or ms <= 0:
+        return None
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv2d.k_conv3x3 (ud_conv3x3_nhwc_bf16: BEV trunk, head, ResNet 3x3 convs; fwd + dgrad)",
+            "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+            "launches": calls, "avg_kernel_us": ms / calls * 1e3, "algorithmic_flops_per_step": flops / steps,
+            "kernel_ms_per_step": ms / steps, "traffic": None,
+            "note": "measured over %d extra steps after the timed region (HIP events around every launch)" % steps}
+
+
 def cpu_baseline_leg():
     """Oracle (scalar C, 1 thread) on a bounded sample: 1 of 6 cameras of lift + bev_pool fwd+bwd,
     a single-sweep voxelize+mean, a 2k-voxel slice of one 64->64 sparse conv, the 3 distill losses'
@@ -208,6 +235,8 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = roofline_leg(device, 1)
+            if ac is not None and not isinstance(trainer, train.GraphTrainer):
+                line["roofline_mfma"] = mfma_leg(trainer, batch)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg()
         print(json.dumps(line))

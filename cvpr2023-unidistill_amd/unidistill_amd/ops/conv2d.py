@@ -24,9 +24,14 @@ def _nhwc(t):
         t.contiguous(memory_format=torch.channels_last)
 
 
+FLOP_COUNTER = None      # set to [0] to accumulate the multiply-add count of every kernel launch (bench.py)
+
+
 def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, relu=False, reverse_taps=False):
     """x: [B, Cin, H, W] bf16 channels-last; w_tap: [Cout, 3, 3, Cin] bf16 contiguous."""
     B, cin, H, W = x.shape
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER[0] += 2 * B * H * W * cout * 9 * cin
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
     _lib.check(_lib.load().ud_conv3x3_nhwc_bf16(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin,
