@@ -22,14 +22,11 @@ namespace {
 
 constexpr int kTW = 16, kTH = 8;             // output pixel tile
 constexpr int kTM = kTW * kTH;               // 128 GEMM rows
-constexpr int kTN = 128;                     // output channels per workgroup
 constexpr int kKC = 64;                      // input channels per staged slice (one 128-byte LDS row)
 constexpr int kHW = kTW + 2, kHH = kTH + 2;  // halo
 constexpr int kHQ = kHW * kHH;               // 180 staged pixels
 constexpr int kHQP = (kHQ + 7) / 8 * 8;      // 184: rows are staged 8 at a time
-constexpr int kLDO = kTN + 4;                // fp32 elements per staged output row
 constexpr int kAInstr = kHQP / 8;            // 1-KiB direct-to-LDS pieces of a halo slice (23)
-constexpr int kBInstr = kTN / 8;             // ... of a weight slice (16)
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -47,10 +44,11 @@ struct ConvEp {
 };
 
 // LDS: two halo slices, two weight slices; the fp32 output tile reuses the space after the K loop.
-constexpr size_t kABytes = (size_t)kHQP * kKC * 2, kBBytes = (size_t)kTN * kKC * 2;
-constexpr size_t kOperandBytes = 2 * kABytes + 2 * kBBytes;
-constexpr size_t kOutBytes = (size_t)kTM * kLDO * 4;
-constexpr size_t kSmemBytes = kOperandBytes > kOutBytes ? kOperandBytes : kOutBytes;
+constexpr size_t conv_smem_bytes(int tn) {
+  const size_t operands = 2 * (size_t)kHQP * kKC * 2 + 2 * (size_t)tn * kKC * 2;
+  const size_t out = (size_t)kTM * (tn + 4) * 4;
+  return operands > out ? operands : out;
+}
 
 // Out-of-image halo pixels and output channels past Cout are loaded from here (LDS-DMA cannot
 // write a constant).
@@ -64,17 +62,24 @@ __device__ __forceinline__ void dma16(const unsigned short* src, unsigned short*
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// TN = output channels per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64; layers
+// with Cout <= 64 -- the head's shared conv, the data gradient of the packed first head convs -- would
+// waste half of a 128-wide tile).
+template <int TN>
 __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __restrict__ x,
                                                       const unsigned short* __restrict__ w,
                                                       unsigned short* __restrict__ y, ConvGeom gm,
                                                       ConvEp ep) {
+  constexpr int kTN = TN, kLDO = TN + 4, kBInstr = TN / 8;
+  constexpr int WM = TN == 128 ? 2 : 4;          // waves along the pixel dimension
+  constexpr int RW = 8 / WM;                     // image rows (of 16 pixels) per wave: 4 or 2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* As = reinterpret_cast<unsigned short*>(smem);          // [2][kHQP][64]
   unsigned short* Bs = As + 2 * kHQP * kKC;                                // [2][kTN][64]
   float* Os = reinterpret_cast<float*>(smem);                              // [kTM][kLDO] after the K loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
   // XCD-aware tile order: the 8 XCDs (workgroups are dealt round-robin) each walk a contiguous band
   // of tiles, so halo rows shared by neighbouring tiles meet in the same L2.
   const int ntiles = gm.B * gm.tiles_x * gm.tiles_y;
@@ -87,9 +92,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
   const int n0 = blockIdx.y * kTN;
   const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
 
-  f32x4 acc[4][4];
+  f32x4 acc[RW][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -130,13 +135,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
     {
       const unsigned short* bbuf = Bs + (it & 1) * kTN * kKC;
       const unsigned short* abuf = As + (chunk & 1) * kHQP * kKC;
-      const int q0 = (4 * wm + tap / 3) * kHW + li + tap % 3;   // halo pixel of row tile 0 for this lane
+      const int q0 = (RW * wm + tap / 3) * kHW + li + tap % 3;  // halo pixel of row tile 0 for this lane
 #pragma unroll
       for (int ks = 0; ks < kKC / 32; ++ks) {
         const int cg = 4 * ks + g;                              // logical 16-byte channel group
-        bf16x8 a[4];
+        bf16x8 a[RW];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
+        for (int ti = 0; ti < RW; ++ti) {
           const int q = q0 + ti * kHW;
           a[ti] = *reinterpret_cast<const bf16x8*>(abuf + q * kKC + ((cg ^ (q & 7)) << 3));
         }
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
           const int n = 64 * wn + 16 * tj + li;
           const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bbuf + n * kKC + ((cg ^ (n & 7)) << 3));
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti)
+          for (int ti = 0; ti < RW; ++ti)
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
         }
       }
@@ -154,16 +159,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
   }
   // epilogue 1: accumulators -> fp32 tile in LDS (aliases the operand tiles; the loop ended on a barrier)
 #pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
+  for (int ti = 0; ti < RW; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        Os[(64 * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
+        Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
   __syncthreads();
   // epilogue 2: 16-byte channel pieces: bias, folded BN, residual, ReLU, bf16 store
   for (int u = tid; u < kTM * (kTN / 8); u += 256) {
-    const int r = u >> 4, c8 = (u & 15) * 8;
+    const int r = u / (kTN / 8), c8 = (u - r * (kTN / 8)) * 8;
     const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
     const int n = n0 + c8;
     if (gy >= gm.H || gx >= gm.W || n >= gm.Cout) continue;
@@ -364,16 +369,23 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
   static bool attr_set = false;
   if (!attr_set) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)kSmemBytes));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(128)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(64)));
     attr_set = true;
   }
   const int ntiles = B * gm.tiles_x * gm.tiles_y;
   const int gx = (ntiles + 7) / 8 * 8;
   UdProfScope prof("conv2d.k_conv3x3", stream);
-  k_conv3x3_bf16<<<dim3(gx, ud_div_up(Cout, kTN)), 256, kSmemBytes, stream>>>(
-      reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
-      reinterpret_cast<unsigned short*>(y), gm, ep);
+  if (Cout <= 64)
+    k_conv3x3_bf16<64><<<dim3(gx, 1), 256, conv_smem_bytes(64), stream>>>(
+        reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
+        reinterpret_cast<unsigned short*>(y), gm, ep);
+  else
+    k_conv3x3_bf16<128><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128), stream>>>(
+        reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
+        reinterpret_cast<unsigned short*>(y), gm, ep);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
