@@ -7,7 +7,7 @@ from unidistill_amd.ops import conv2d as c2
 dev = torch.device("cuda:0"); B = int(os.environ.get("B", 4))
 SHAPES = [("trunk b0 256->128", B, 256, 180, 180, 128), ("trunk b0 128->128", B, 128, 180, 180, 128),
           ("trunk b1 256->256", B, 256, 90, 90, 256), ("head shared 512->64", B, 512, 180, 180, 64),
-          ("head c1 64->2688", B, 64, 180, 180, 2688), ("lss depth 512->512", 6 * B, 512, 16, 44, 512),
+          ("head c1 64->2688", B, 64, 180, 180, 2688), ("head c1 dgrad 2688->64", B, 2688, 180, 180, 64), ("lss depth 512->512", 6 * B, 512, 16, 44, 512),
           ("resnet l1 64->64", 6 * B, 64, 64, 176, 64), ("resnet l2 128->128", 6 * B, 128, 32, 88, 128),
           ("resnet l3 256->256", 6 * B, 256, 16, 44, 256), ("resnet l4 512->512", 6 * B, 512, 8, 22, 512)]
 def timeit(fn, n=20):
