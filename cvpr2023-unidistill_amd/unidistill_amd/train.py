@@ -24,6 +24,18 @@ def build_model(modality, **kw):
     return BEVFusionCenterHead(cfg, **kw)
 
 
+def _tensors_in(obj):
+    """All tensors inside nested lists / tuples / dicts."""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_in(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_in(v)
+
+
 class DistillStep(nn.Module):
     """Holds the trainable student and the frozen teacher; forward(batch) returns the loss dict."""
 
@@ -89,13 +101,15 @@ class DistillStep(nn.Module):
         return self.teacher_model(self._points(batch), batch.get("imgs"), batch.get("mats_dict"),
                                   prep["gt"], return_feature=True)
 
-    def student_loss(self, batch, prep, teacher_out):
+    def student_loss(self, batch, prep, teacher_out, join=None):
         e = self.exp
         norm = prep["norm"]
         nh = norm.numel() - 2
         ret, tb, feat_s, bev_s, resp_s, _ = self.model(
             self._points(batch), batch.get("imgs"), batch.get("mats_dict"), prep["gt"],
             targets=prep["targets"], loss_norm=list(norm[:nh].unbind(0)))
+        if join is not None:                       # teacher stream -> main stream hand-over
+            torch.cuda.current_stream(prep["gt"].device).wait_stream(join)
         feat_t, bev_t, resp_t = teacher_out
         w_box, w_mask = norm[nh], norm[nh + 1]
         loss_feat = D.FeatureDistillLoss(feat_s, feat_t, prep["corners"], prep["valid"], weight=w_box)
@@ -109,9 +123,28 @@ class DistillStep(nn.Module):
                   loss_resp_cls=loss_cls.detach(), loss_resp_reg=loss_reg.detach())
         return {"loss": loss, "tb": tb}
 
+    overlap_teacher = True      # frozen teacher on a second HIP stream, concurrent with the student forward
+
     def forward(self, batch):
         prep = self.reduce(self.prep(batch))
-        return self.student_loss(batch, prep, self.teacher(batch, prep))
+        gt = prep["gt"]
+        if not (self.overlap_teacher and gt.is_cuda) or torch.cuda.is_current_stream_capturing():
+            return self.student_loss(batch, prep, self.teacher(batch, prep))
+        # The teacher and the student forward are independent until the distillation losses, and both
+        # are chains of short dependent kernels: on two streams the GPU fills one chain's gaps with the
+        # other's kernels.  The teacher gets its own scratch buffers (ops on different streams must not
+        # share a workspace) and its outputs are handed to the main stream explicitly.
+        cur = torch.cuda.current_stream(gt.device)
+        side = getattr(self, "_teacher_stream", None)
+        if side is None or side.device != gt.device:
+            side = self._teacher_stream = torch.cuda.Stream(gt.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), _lib.workspace_scope("teacher_stream"):
+            tout = self.teacher(batch, prep)
+        for part in tout:
+            for t in _tensors_in(part):
+                t.record_stream(cur)
+        return self.student_loss(batch, prep, tout, join=side)
 
 
 def to_channels_last(module):
