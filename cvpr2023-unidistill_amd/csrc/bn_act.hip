@@ -44,23 +44,29 @@ __device__ __forceinline__ void load8(const float* p, float* v) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
+// Thread = (8-channel chunk, pixel lane): the chunk's scale / shift live in registers for the whole
+// pixel loop (a flat unit loop re-loaded 4 constant vectors and took a 64-bit modulo per 16 bytes).
+// grid (pixel slices, channel blocks); CH = chunks per workgroup (power of two <= 256).
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const unsigned short* __restrict__ x,
                                                     const unsigned short* __restrict__ res,
                                                     const float* __restrict__ scale,
                                                     const float* __restrict__ shift,
-                                                    unsigned short* __restrict__ y, long long units,
-                                                    int c_units, int relu) {
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-    const int c = (int)(u % c_units) * 8;
-    float v[8], s[8], t[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + u * 8), v);
-    load8(scale + c, s);
-    load8(shift + c, t);
+                                                    unsigned short* __restrict__ y, long long P, int C,
+                                                    int CH, int relu) {
+  const int chunk = blockIdx.y * CH + threadIdx.x % CH, lanes = 256 / CH, pl = threadIdx.x / CH;
+  if (chunk * 8 >= C) return;
+  float s[8], t[8];
+  load8(scale + chunk * 8, s);
+  load8(shift + chunk * 8, t);
+  for (long long p = (long long)blockIdx.x * lanes + pl; p < P; p += (long long)gridDim.x * lanes) {
+    const size_t off = (size_t)p * C + chunk * 8;
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + off), v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], s[e], t[e]);
     if (res) {
       float r[8];
-      unpack8(*reinterpret_cast<const uint4*>(res + u * 8), r);
+      unpack8(*reinterpret_cast<const uint4*>(res + off), r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += r[e];
     }
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const unsigned short* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    *reinterpret_cast<uint4*>(y + u * 8) = pack8(v);
+    *reinterpret_cast<uint4*>(y + off) = pack8(v);
   }
 }
 
@@ -245,24 +251,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const unsigned short* __restr
                                                    const float* __restrict__ k0,
                                                    const float* __restrict__ k2,
                                                    unsigned short* __restrict__ dx,
-                                                   unsigned short* __restrict__ dres, long long units,
-                                                   int c_units, int relu) {
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-    const int c = (int)(u % c_units) * 8;
-    float xv[8], dyv[8], dr[8], s[8], t[8], a0[8], a2[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + u * 8), xv);
-    unpack8(*reinterpret_cast<const uint4*>(dy + u * 8), dyv);
-    load8(scale + c, s);
-    load8(shift + c, t);
-    load8(k0 + c, a0);
-    load8(k2 + c, a2);
+                                                   unsigned short* __restrict__ dres, long long P, int C,
+                                                   int CH, int relu) {
+  const int chunk = blockIdx.y * CH + threadIdx.x % CH, lanes = 256 / CH, pl = threadIdx.x / CH;
+  if (chunk * 8 >= C) return;
+  float s[8], t[8], a0[8], a2[8];
+  load8(scale + chunk * 8, s);
+  load8(shift + chunk * 8, t);
+  load8(k0 + chunk * 8, a0);
+  load8(k2 + chunk * 8, a2);
+  for (long long p = (long long)blockIdx.x * lanes + pl; p < P; p += (long long)gridDim.x * lanes) {
+    const size_t off = (size_t)p * C + chunk * 8;
+    float xv[8], dyv[8], dr[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+    unpack8(*reinterpret_cast<const uint4*>(dy + off), dyv);
     uint4 yr;
-    if (y) yr = *reinterpret_cast<const uint4*>(y + u * 8);
+    if (y) yr = *reinterpret_cast<const uint4*>(y + off);
     masked_grad(xv, y ? &yr : nullptr, dyv, s, t, relu, dr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = fmaf(s[e], dr[e], fmaf(a2[e], xv[e], a0[e]));
-    *reinterpret_cast<uint4*>(dx + u * 8) = pack8(o);
-    if (dres) *reinterpret_cast<uint4*>(dres + u * 8) = pack8(dr);
+    *reinterpret_cast<uint4*>(dx + off) = pack8(o);
+    if (dres) *reinterpret_cast<uint4*>(dres + off) = pack8(dr);
   }
 }
 
@@ -273,9 +282,18 @@ size_t carve(UdArena& ar, int C, BnWs* w) {
   w->k2 = ar.take<float>(C);
   return ar.used;
 }
-int stream_blocks(long long units) {
-  const long long b = (units + 255) / 256;
-  return (int)(b < 8192 ? b : 8192);
+// grid for the streaming kernels: CH channel chunks (of 8) per workgroup, enough pixel slices for ~4096 groups
+void stream_grid(long long P, int C, int* CH, dim3* grid) {
+  const int chunks = C / 8;
+  int ch = 1;
+  while (ch < chunks && ch < 256) ch <<= 1;
+  const int lanes = 256 / ch, cblocks = (chunks + ch - 1) / ch;
+  long long slices = (P + lanes - 1) / lanes;
+  const long long want = 4096 / cblocks > 0 ? 4096 / cblocks : 1;
+  if (slices > want) slices = want;
+  if (slices < 1) slices = 1;
+  *CH = ch;
+  *grid = dim3((unsigned)slices, (unsigned)cblocks);
 }
 
 }  // namespace
@@ -323,11 +341,12 @@ int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const
   if (!x || !scale || !shift || !y || P <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
   if (C % 8) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  const long long units = P * (C / 8);
+  int CH;
+  dim3 grid;
+  stream_grid(P, C, &CH, &grid);
   UdProfScope prof("bn_act.k_fwd", stream);
-  k_bn_act_fwd<<<stream_blocks(units), 256, 0, stream>>>(
-      (const unsigned short*)x, (const unsigned short*)residual, scale, shift, (unsigned short*)y, units,
-      C / 8, relu);
+  k_bn_act_fwd<<<grid, 256, 0, stream>>>((const unsigned short*)x, (const unsigned short*)residual, scale, shift,
+                                         (unsigned short*)y, P, C, CH, relu);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -358,11 +377,13 @@ int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* sca
                                                            dgamma, dbeta, w.k0, w.k2);
     UD_LAUNCH_CHECK();
   }
-  const long long units = P * (C / 8);
+  int CH;
+  dim3 grid;
+  stream_grid(P, C, &CH, &grid);
   UdProfScope prof("bn_act.k_bwd_dx", stream);
-  k_bn_bwd_dx<<<stream_blocks(units), 256, 0, stream>>>(
-      (const unsigned short*)x, (const unsigned short*)y, (const unsigned short*)dy, scale, shift, w.k0, w.k2,
-      (unsigned short*)dx, (unsigned short*)dresidual, units, C / 8, relu);
+  k_bn_bwd_dx<<<grid, 256, 0, stream>>>((const unsigned short*)x, (const unsigned short*)y,
+                                        (const unsigned short*)dy, scale, shift, w.k0, w.k2, (unsigned short*)dx,
+                                        (unsigned short*)dresidual, P, C, CH, relu);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

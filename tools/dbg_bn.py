@@ -23,6 +23,6 @@ for (B, C, H, W, res) in [(24, 64, 64, 176, False), (4, 128, 180, 180, False), (
         y = batchnorm_act(bn, xa, ra, True); y.backward(gy)
     torch.cuda.synchronize(); _lib.prof_enable(False)
     nb = x.numel() * 2
-    for k in ("head_tail.stats", "bn_act.k_fwd", "bn_act.k_bwd_reduce", "bn_act.k_bwd_dx"):
-        ms, n = _lib.prof_read(k); us = ms / max(n, 1) * 1e3
+    for k in ("bn_act.stats", "bn_act.k_fwd", "bn_act.k_bwd_reduce", "bn_act.k_bwd_dx"):
+        ms, n = _lib.prof_read(k); us = max(ms / max(n, 1) * 1e3, 1e-3)
         print(f"   {k:22s} {us:8.1f} us  ({nb/us/1e6:.2f} TB/s per tensor pass)")
