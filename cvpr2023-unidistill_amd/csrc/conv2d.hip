@@ -335,12 +335,179 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const unsigned short* __r
     }
 }
 
-__global__ void k_wgrad_sum(const float* __restrict__ partial, int slices, size_t n, float* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float a = 0.f;
-  for (int s = 0; s < slices; ++s) a += partial[(size_t)s * n + i];
-  out[i] = a;
+// Large feature maps: the tap-shared, LDS-DMA staged variant.  A workgroup owns a 64 (dy channels) x 64
+// (x channels) tile of dW for ALL nine taps and walks a slice of the 8 x 16 pixel tiles: per pixel tile
+// the x halo (10 x 18 pixels) and the dy tile are staged ONCE (global_load_lds_dwordx4, double-buffered,
+// one barrier per tile) and serve the nine shifted GEMMs -- the per-tap kernel above re-stages both
+// operands for every tap through registers.  Rows are unpadded 128 B; their 32-byte pieces are
+// XOR-swizzled with f(row) = bit1 | bit3 << 1 on the SOURCE address, which keeps the transposing fragment
+// reads (8 rows x 32 B per half-wave, rows {a..a+3, a+8..a+11} for ANY a, i.e. any tap shift) conflict
+// free.  Wave w owns x channels 16w..16w+15: per 32-pixel step 4 dy fragments + 9 x fragments feed 36
+// MFMAs (0.36 fragment reads per MFMA; 144 accumulator registers).
+__device__ __forceinline__ int wg_fsw(int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; }
+
+// The compiler makes every ds_read_tr builtin wait for ALL outstanding LDS-DMA (vmcnt(0)), so the next
+// tile's DMAs would never overlap this tile's MFMAs.  The fragment reads are therefore issued as
+// inline asm (invisible to the waitcnt pass) and completed by an explicit lgkmcnt wait that is tied to
+// the fragment registers.
+__device__ __forceinline__ v4s tr_issue(unsigned lds_byte_addr) {
+  v4s r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_byte_addr));
+  return r;
+}
+__device__ __forceinline__ bf16x8 cat8(v4s lo, v4s hi) {
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ dy,
+                                                              float* __restrict__ partial, ConvGeom gm,
+                                                              int c_tiles, int tiles_per_slice) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* Xs = reinterpret_cast<unsigned short*>(smem);        // [2][kHQP][64]  x halo
+  unsigned short* Ds = Xs + 2 * kHQP * kKC;                              // [2][kTM][64]   dy tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int r8 = lane >> 3, slot = lane & 7;
+  const int ct = blockIdx.y % c_tiles, nt = blockIdx.y / c_tiles;
+  const int n0 = nt * 64, c0 = ct * 64;
+  const int per_img = gm.tiles_x * gm.tiles_y, ntiles = gm.B * per_img;
+  const int t_begin = blockIdx.x * tiles_per_slice, t_end = min(ntiles, t_begin + tiles_per_slice);
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
+
+  auto stage = [&](int tile, int buf) {
+    const int b = tile / per_img;
+    const int rem = tile - b * per_img;
+    const int ty0 = (rem / gm.tiles_x) * kTH, tx0 = (rem % gm.tiles_x) * kTW;
+    for (int piece = wave; piece < kAInstr; piece += 4) {
+      const int q = piece * 8 + r8;
+      const int qy = q / kHW, qx = q - qy * kHW;
+      const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
+      const unsigned short* src = zero;
+      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W)
+        src = x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + c0 + ((slot ^ wg_fsw(q)) << 3);
+      dma16(src, Xs + (buf * kHQP + piece * 8) * kKC);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = wave + 4 * j;
+      const int p = piece * 8 + r8;
+      const int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+      const int n = n0 + ((slot ^ wg_fsw(p)) << 3);
+      const unsigned short* src = zero;
+      if (gy < gm.H && gx < gm.W && n < gm.Cout) src = dy + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+      dma16(src, Ds + (buf * kTM + piece * 8) * kKC);
+    }
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (t_begin < t_end) stage(t_begin, 0);
+  __syncthreads();
+  int buf = 0;
+  const int sub = (li & 3) >> 1, half = (li & 1) << 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    if (tile + 1 < t_end) stage(tile + 1, buf ^ 1);
+    const unsigned xb = lds0 + buf * (kHQP * kKC * 2);
+    const unsigned db = lds0 + (2 * kHQP + buf * kTM) * (kKC * 2);
+#pragma unroll 1
+    for (int ks = 0; ks < kTM / 32; ++ks) {
+      const int p0 = 32 * ks + 8 * g + (li >> 2), p1 = p0 + 4;
+      v4s al[4], ah[4], bl[9], bh[9];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        al[ti] = tr_issue(db + 2 * (p0 * kKC + (((2 * ti + sub) ^ wg_fsw(p0)) << 3) + half));
+        ah[ti] = tr_issue(db + 2 * (p1 * kKC + (((2 * ti + sub) ^ wg_fsw(p1)) << 3) + half));
+      }
+      const int qb = (2 * ks + (g >> 1)) * kHW + 8 * (g & 1) + (li >> 2);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int q0 = qb + (tap / 3) * kHW + tap % 3, q1 = q0 + 4;
+        bl[tap] = tr_issue(xb + 2 * (q0 * kKC + (((2 * wave + sub) ^ wg_fsw(q0)) << 3) + half));
+        bh[tap] = tr_issue(xb + 2 * (q1 * kKC + (((2 * wave + sub) ^ wg_fsw(q1)) << 3) + half));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]));
+      asm volatile("" : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]),
+                        "+v"(bh[3]), "+v"(bl[4]), "+v"(bh[4]));
+      asm volatile("" : "+v"(bl[5]), "+v"(bh[5]), "+v"(bl[6]), "+v"(bh[6]), "+v"(bl[7]), "+v"(bh[7]), "+v"(bl[8]),
+                        "+v"(bh[8]));
+      bf16x8 a[4];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) a[ti] = cat8(al[ti], ah[ti]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bf16x8 bb = cat8(bl[tap], bh[tap]);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          acc[tap][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[tap][ti], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial[slice][n][tap][c]; D layout: lane holds column c = li, rows n = 4g + r
+  const int c = c0 + 16 * wave + li;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * ti + 4 * g + r;
+        if (n < gm.Cout) partial[(((size_t)blockIdx.x * gm.Cout + n) * 9 + tap) * gm.Cin + c] = acc[tap][ti][r];
+      }
+}
+constexpr size_t kWgradDmaLds = 2 * ((size_t)kHQP + kTM) * kKC * 2;
+
+// pixel-tile slices of the DMA kernel: <= 2 workgroups per CU over (slices x 64x64 output tiles)
+int wgrad_dma_slices(int B, int H, int W, int Cin, int Cout, int* tiles_per_slice) {
+  const int ntiles = B * ud_div_up(W, kTW) * ud_div_up(H, kTH);
+  const int combos = ud_div_up(Cout, 64) * (Cin / 64);
+  static const int target = getenv("UD_WGRAD_WGS") ? atoi(getenv("UD_WGRAD_WGS")) : 512;
+  int s = target / combos;      // all workgroups resident at once (2 per CU): no second round
+  if (s > ntiles) s = ntiles;
+  if (s < 1) s = 1;
+  const int per = (ntiles + s - 1) / s;
+  *tiles_per_slice = per;
+  return (ntiles + per - 1) / per;
+}
+bool wgrad_use_dma(int B, int H, int W) {
+  static const int force = getenv("UD_WGRAD_DMA") ? atoi(getenv("UD_WGRAD_DMA")) : -1;
+  if (force >= 0) return force != 0;
+  return (long long)B * H * W > 4096;
+}
+
+// out[i] = sum over slices of partial[s][i], i in float4 units: a workgroup owns 64 float4 outputs, its four
+// waves each add a quarter of the slices (ascending), the four sub-sums are combined in wave order.
+__global__ __launch_bounds__(256) void k_wgrad_sum(const float* __restrict__ partial, int slices, size_t n,
+                                                   float* __restrict__ out) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t i4 = (size_t)blockIdx.x * 64 + lane, n4 = n / 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i4 < n4) {
+    const int per = (slices + 3) / 4, s0 = wave * per, s1 = min(slices, s0 + per);
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)s * n + 4 * i4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  part[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && i4 < n4) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 v = part[w][lane];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + 4 * i4) = a;
+  }
 }
 
 // pixel slices so that (slices x taps x output tiles) is ~600 workgroups
@@ -393,7 +560,8 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
 extern "C" size_t ud_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   int ctw;
-  const int S = wgrad_slices(Cin, Cout, (long long)B * H * W, &ctw);
+  const int S = (wgrad_use_dma(B, H, W) && Cin % 64 == 0) ? wgrad_dma_slices(B, H, W, Cin, Cout, &ctw)
+                                                          : wgrad_slices(Cin, Cout, (long long)B * H * W, &ctw);
   return ud_align_up((size_t)S * Cout * 9 * Cin * sizeof(float));
 }
 
@@ -404,11 +572,30 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   if (Cin % 64 != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < ud_conv3x3_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return UD_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
+  float* partial = reinterpret_cast<float*>(workspace);
+  const size_t n = (size_t)Cout * 9 * Cin;
+  if (wgrad_use_dma(B, H, W)) {
+    ConvGeom gd{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH)};
+    int per;
+    const int S = wgrad_dma_slices(B, H, W, Cin, Cout, &per);
+    static bool set_dma = false;
+    if (!set_dma) {
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kWgradDmaLds));
+      set_dma = true;
+    }
+    UdProfScope prof("conv2d.k_wgrad_dma", stream);
+    k_conv3x3_wgrad_dma<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
+        (const unsigned short*)x, (const unsigned short*)dy, partial, gd, Cin / 64, per);
+    UD_LAUNCH_CHECK();
+    k_wgrad_sum<<<ud_div_up((long long)(n / 4), 64), 256, 0, stream>>>(partial, S, n, dw);
+    UD_LAUNCH_CHECK();
+    return UD_OK;
+  }
   ConvGeom gm{B, H, W, Cin, Cout, 0, 0};
   int CT;
   const int S = wgrad_slices(Cin, Cout, (long long)B * H * W, &CT);
   const int c_tiles = ud_div_up(Cin, CT), n_tiles = ud_div_up(Cout, 128);
-  float* partial = reinterpret_cast<float*>(workspace);
   UdProfScope prof("conv2d.k_wgrad", stream);
   const dim3 grid(S, 9 * n_tiles * c_tiles);
   if (CT == 128) {
@@ -424,8 +611,7 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     k_conv3x3_wgrad<64><<<grid, 256, lds, stream>>>((const unsigned short*)x, (const unsigned short*)dy, partial, gm, c_tiles, n_tiles);
   }
   UD_LAUNCH_CHECK();
-  const size_t n = (size_t)Cout * 9 * Cin;
-  k_wgrad_sum<<<ud_div_up((long long)n, 256), 256, 0, stream>>>(partial, S, n, dw);
+  k_wgrad_sum<<<ud_div_up((long long)(n / 4), 64), 256, 0, stream>>>(partial, S, n, dw);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

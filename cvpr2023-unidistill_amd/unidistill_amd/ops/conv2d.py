@@ -83,13 +83,14 @@ def library_layout(weight):
 
 
 USE_HIP_WGRAD = "auto"     # True / False / "auto": hand-written weight-gradient kernel vs aten.convolution_backward
-                           # (auto: ours on small feature maps where it measured faster, tools/time_conv2d.py)
+                           # (auto: ours wherever the kernel applies -- 1.2-1.6x the library on every conv shape
+                           # of the step, tools/time_conv2d.py -- and deterministic, which the library's is not)
 
 
 def weight_grad(x, gy, weight):
     """dL/dweight [Cout, Cin, 3, 3] from channels-last bf16 x and gy."""
     cout, cin = weight.shape[0], weight.shape[1]
-    if USE_HIP_WGRAD is True or (USE_HIP_WGRAD == "auto" and x.shape[2] * x.shape[3] <= 1024):
+    if USE_HIP_WGRAD is True or (USE_HIP_WGRAD == "auto" and cin % 64 == 0 and cout % 8 == 0):
         lib = _lib.load()
         B, _, H, W = x.shape
         need = lib.ud_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
