@@ -962,6 +962,14 @@ __global__ __launch_bounds__(256) void k_tile_masks(const int32_t* __restrict__ 
   if (lane == 0) masks[tile] = m;
 }
 
+__device__ __forceinline__ v4s_t tr_issue(unsigned lds_byte_addr) {
+  v4s_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_byte_addr));
+  return r;
+}
+__device__ __forceinline__ bf16x8 cat8(v4s_t lo, v4s_t hi) {
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 __device__ __forceinline__ bf16x8 tr_frag8(const unsigned short* lo_p, const unsigned short* hi_p) {
   const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)lo_p);
   const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)hi_p);
@@ -1227,32 +1235,44 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
   if (n_active > 0) stage(t_begin + s_list[0], 0);
   __syncthreads();
   int buf = 0;
+  const int sub = (li & 3) >> 1, half = (li & 1) << 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   for (int ai = 0; ai < n_active; ++ai) {
     if (ai + 1 < n_active) stage(t_begin + s_list[ai + 1], buf ^ 1);
     {
-      // transposing fragment read: lane li of a 16-lane group points at [row k0 + (li>>2)][channels c0 + 4*(li&3) ..+3]
-      const unsigned short* nbuf = Ns + buf * kWR * COUT_P;
-      const unsigned short* cbuf = Cs + buf * kWR * CIN_P;
+      // transposing fragment read: lane li of a 16-lane group points at [row k0 + (li>>2)][channels c0 + 4*(li&3) ..+3].
+      // Issued as inline asm + an explicit lgkmcnt wait tied to the fragment registers: the compiler makes
+      // the ds_read_tr builtin wait for ALL outstanding LDS-DMA (vmcnt(0)), which would serialise the next
+      // tile's DMAs behind this tile's MFMAs.
+      const unsigned nbuf = lds0 + buf * (kWR * COUT_P * 2);
+      const unsigned cbuf = lds0 + (2 * kWR * COUT_P + buf * kWR * CIN_P) * 2;
 #pragma unroll
       for (int ks = 0; ks < kWR / 32; ++ks) {
         const int r0 = 32 * ks + 8 * g + (li >> 2), r1 = r0 + 4;
-        bf16x8 a[TI];
+        v4s_t al[TI], ah[TI], bl[TJ], bh[TJ];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
-          const int c0 = 16 * (TI * wm + ti);
-          const int slot = (c0 >> 3) + ((li & 3) >> 1), half = (li & 1) << 2;
-          a[ti] = tr_frag8(nbuf + r0 * COUT_P + ((slot ^ fsw(r0, SN)) << 3) + half,
-                           nbuf + r1 * COUT_P + ((slot ^ fsw(r1, SN)) << 3) + half);
+          const int slot = 2 * (TI * wm + ti) + sub;
+          al[ti] = tr_issue(nbuf + 2 * (r0 * COUT_P + ((slot ^ fsw(r0, SN)) << 3) + half));
+          ah[ti] = tr_issue(nbuf + 2 * (r1 * COUT_P + ((slot ^ fsw(r1, SN)) << 3) + half));
         }
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj) {
-          const int c0 = 16 * (TJ * wn + tj);
-          const int slot = (c0 >> 3) + ((li & 3) >> 1), half = (li & 1) << 2;
-          const bf16x8 bb = tr_frag8(cbuf + r0 * CIN_P + ((slot ^ fsw(r0, SC)) << 3) + half,
-                                     cbuf + r1 * CIN_P + ((slot ^ fsw(r1, SC)) << 3) + half);
+          const int slot = 2 * (TJ * wn + tj) + sub;
+          bl[tj] = tr_issue(cbuf + 2 * (r0 * CIN_P + ((slot ^ fsw(r0, SC)) << 3) + half));
+          bh[tj] = tr_issue(cbuf + 2 * (r1 * CIN_P + ((slot ^ fsw(r1, SC)) << 3) + half));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) asm volatile("" : "+v"(al[ti]), "+v"(ah[ti]));
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) asm volatile("" : "+v"(bl[tj]), "+v"(bh[tj]));
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          const bf16x8 bb = cat8(bl[tj], bh[tj]);
 #pragma unroll
           for (int ti = 0; ti < TI; ++ti)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(al[ti], ah[ti]), bb, acc[ti][tj], 0, 0, 0);
         }
       }
     }
