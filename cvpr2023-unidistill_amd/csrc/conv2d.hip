@@ -510,6 +510,149 @@ __global__ __launch_bounds__(256) void k_wgrad_sum(const float* __restrict__ par
   }
 }
 
+// ---- 1x1 convolutions: weight gradient ---------------------------------------------------------------
+//   dW[n][c] = sum_p dy[p][n] * x[p][c]        (p over all B*H*W pixels; ResNet bottleneck 1x1 convs,
+//   unidistill/layers/blocks_2d/mmdet3d/resnet.py via mmcv's ResNet in the reference)
+// The pixel-reduced GEMM that a BLAS library runs on 16 CUs (M x N = Cout x Cin has few tiles and the
+// library does not split K): here (pixel slice) x (NT x CT output tile) workgroups, 64-pixel steps
+// staged by LDS-DMA (double-buffered, one barrier per step), transposing fragment reads issued as
+// inline asm (see tr_issue), 2 x 2 waves.  Unpadded rows; 32-byte pieces swizzled on the source
+// address: f(r) = (r & 3) | ((r >> 1) & 4) for 256-byte rows, bit1 | bit3 << 1 for 128-byte rows.
+template <int NT, int CT>
+__global__ __launch_bounds__(256) void k_conv1x1_wgrad_dma(const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ dy,
+                                                           float* __restrict__ partial, long long P, int Cin,
+                                                           int Cout, int c_tiles, int steps_per_slice) {
+  constexpr int SN = NT / 8, SC = CT / 8;                 // 16-byte slots per row
+  constexpr int RN = 64 / SN, RC = 64 / SC;               // rows per 1-KiB piece
+  constexpr int PN = 64 / RN, PC = 64 / RC;               // pieces per 64-row tile
+  constexpr int TI = NT / 32, TJ = CT / 32;               // 16-wide tiles per wave (2 x 2 waves)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* Ns = reinterpret_cast<unsigned short*>(smem);        // [2][64][NT]  dy
+  unsigned short* Cs = Ns + 2 * 64 * NT;                                 // [2][64][CT]  x
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ct = blockIdx.y % c_tiles, nt = blockIdx.y / c_tiles;
+  const int n0 = nt * NT, c0 = ct * CT;
+  const int steps = (int)((P + 63) / 64);
+  const int s_begin = blockIdx.x * steps_per_slice, s_end = min(steps, s_begin + steps_per_slice);
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
+  auto fsw = [](int r, int slots) -> int {
+    return slots == 16 ? (((r & 3) | ((r >> 1) & 4)) << 1) : ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
+  };
+  auto stage = [&](int step, int buf) {
+#pragma unroll
+    for (int j = 0; j < PN / 4; ++j) {
+      const int piece = wave + 4 * j, r = piece * RN + lane / SN, slot = lane % SN;
+      const long long p = (long long)step * 64 + r;
+      const int n = n0 + ((slot ^ fsw(r, SN)) << 3);
+      const unsigned short* src = zero;
+      if (p < P && n < Cout) src = dy + (size_t)p * Cout + n;
+      dma16(src, Ns + (buf * 64 + piece * RN) * NT);
+    }
+#pragma unroll
+    for (int j = 0; j < PC / 4; ++j) {
+      const int piece = wave + 4 * j, r = piece * RC + lane / SC, slot = lane % SC;
+      const long long p = (long long)step * 64 + r;
+      const unsigned short* src = zero;
+      if (p < P) src = x + (size_t)p * Cin + c0 + ((slot ^ fsw(r, SC)) << 3);
+      dma16(src, Cs + (buf * 64 + piece * RC) * CT);
+    }
+  };
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (s_begin < s_end) stage(s_begin, 0);
+  __syncthreads();
+  int buf = 0;
+  const int sub = (li & 3) >> 1, half = (li & 1) << 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  for (int step = s_begin; step < s_end; ++step) {
+    if (step + 1 < s_end) stage(step + 1, buf ^ 1);
+    const unsigned nbuf = lds0 + buf * (64 * NT * 2);
+    const unsigned cbuf = lds0 + (2 * 64 * NT + buf * 64 * CT) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = 32 * ks + 8 * g + (li >> 2), r1 = r0 + 4;
+      v4s al[TI], ah[TI], bl[TJ], bh[TJ];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        const int slot = 2 * (TI * wm + ti) + sub;
+        al[ti] = tr_issue(nbuf + 2 * (r0 * NT + ((slot ^ fsw(r0, SN)) << 3) + half));
+        ah[ti] = tr_issue(nbuf + 2 * (r1 * NT + ((slot ^ fsw(r1, SN)) << 3) + half));
+      }
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int slot = 2 * (TJ * wn + tj) + sub;
+        bl[tj] = tr_issue(cbuf + 2 * (r0 * CT + ((slot ^ fsw(r0, SC)) << 3) + half));
+        bh[tj] = tr_issue(cbuf + 2 * (r1 * CT + ((slot ^ fsw(r1, SC)) << 3) + half));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) asm volatile("" : "+v"(al[ti]), "+v"(ah[ti]));
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) asm volatile("" : "+v"(bl[tj]), "+v"(bh[tj]));
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const bf16x8 bb = cat8(bl[tj], bh[tj]);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(al[ti], ah[ti]), bb, acc[ti][tj], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial[slice][n][c]; D layout: lane holds column c = li, rows n = 4g + r
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int c = c0 + 16 * (TJ * wn + tj) + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * (TI * wm + ti) + 4 * g + r;
+        if (n < Cout) partial[((size_t)blockIdx.x * Cout + n) * Cin + c] = acc[ti][tj][r];
+      }
+    }
+}
+
+struct Wgrad1x1Plan {
+  int nt, ct, n_tiles, c_tiles, slices, steps_per_slice;
+};
+Wgrad1x1Plan wgrad1x1_plan(long long P, int Cin, int Cout) {
+  Wgrad1x1Plan pl;
+  pl.nt = Cout >= 128 ? 128 : 64;
+  pl.ct = Cin % 128 == 0 ? 128 : 64;
+  pl.n_tiles = ud_div_up(Cout, pl.nt);
+  pl.c_tiles = Cin / pl.ct;
+  const int steps = (int)((P + 63) / 64);
+  int s = 512 / (pl.n_tiles * pl.c_tiles);          // all workgroups resident at once (2 per CU)
+  if (s > steps) s = steps;
+  if (s < 1) s = 1;
+  pl.steps_per_slice = (steps + s - 1) / s;
+  pl.slices = (steps + pl.steps_per_slice - 1) / pl.steps_per_slice;
+  return pl;
+}
+template <int NT, int CT>
+int launch_wgrad1x1(const void* x, const void* dy, float* partial, long long P, int Cin, int Cout,
+                    const Wgrad1x1Plan& pl, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * 64 * (NT + CT) * 2;
+  static bool set = false;
+  if (!set) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_wgrad_dma<NT, CT>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set = true;
+  }
+  k_conv1x1_wgrad_dma<NT, CT><<<dim3(pl.slices, pl.n_tiles * pl.c_tiles), 256, lds, stream>>>(
+      (const unsigned short*)x, (const unsigned short*)dy, partial, P, Cin, Cout, pl.c_tiles, pl.steps_per_slice);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
 // pixel slices so that (slices x taps x output tiles) is ~600 workgroups
 int wgrad_slices(int Cin, int Cout, long long P, int* ct_width) {
   const int CT = (Cin % 128 == 0) ? 128 : 64;
@@ -545,8 +688,9 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   const int ntiles = B * gm.tiles_x * gm.tiles_y;
   const int gx = (ntiles + 7) / 8 * 8;
   UdProfScope prof("conv2d.k_conv3x3", stream);
-  if (Cout <= 64)
-    k_conv3x3_bf16<64><<<dim3(gx, 1), 256, conv_smem_bytes(64), stream>>>(
+  // 64-wide output tiles when Cout <= 64, and on small maps where 128-wide tiles would leave CUs idle
+  if (Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256)
+    k_conv3x3_bf16<64><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64), stream>>>(
         reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
         reinterpret_cast<unsigned short*>(y), gm, ep);
   else
@@ -612,6 +756,33 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   }
   UD_LAUNCH_CHECK();
   k_wgrad_sum<<<ud_div_up((long long)(n / 4), 64), 256, 0, stream>>>(partial, S, n, dw);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+extern "C" size_t ud_conv1x1_wgrad_workspace_bytes(int64_t P, int Cin, int Cout) {
+  if (P <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 != 0) return 0;
+  const Wgrad1x1Plan pl = wgrad1x1_plan(P, Cin, Cout);
+  return ud_align_up((size_t)pl.slices * Cout * Cin * sizeof(float));
+}
+
+extern "C" int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
+                                          void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  if (!x || !dy || !dw || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if (Cin % 64 != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ud_conv1x1_wgrad_workspace_bytes(P, Cin, Cout)) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const Wgrad1x1Plan pl = wgrad1x1_plan(P, Cin, Cout);
+  float* partial = reinterpret_cast<float*>(workspace);
+  UdProfScope prof("conv2d.k_wgrad_1x1", stream);
+  int rc;
+  if (pl.nt == 128 && pl.ct == 128) rc = launch_wgrad1x1<128, 128>(x, dy, partial, P, Cin, Cout, pl, stream);
+  else if (pl.nt == 128) rc = launch_wgrad1x1<128, 64>(x, dy, partial, P, Cin, Cout, pl, stream);
+  else if (pl.ct == 128) rc = launch_wgrad1x1<64, 128>(x, dy, partial, P, Cin, Cout, pl, stream);
+  else rc = launch_wgrad1x1<64, 64>(x, dy, partial, P, Cin, Cout, pl, stream);
+  if (rc != UD_OK) return rc;
+  const size_t n = (size_t)Cout * Cin;
+  k_wgrad_sum<<<ud_div_up((long long)(n / 4), 64), 256, 0, stream>>>(partial, pl.slices, n, dw);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

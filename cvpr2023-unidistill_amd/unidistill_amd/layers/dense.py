@@ -35,9 +35,6 @@ def _is1x1(conv):
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1)
 
 
-GEMM_1X1_MAX_PIXELS = 1024     # per image; above this MIOpen's 1x1 conv beats the GEMM (tools/exp_conv1x1.py)
-
-
 class Conv2d(nn.Conv2d):
     hip_enabled = True          # class-wide switch (tests / A-B timing)
 
@@ -45,18 +42,10 @@ class Conv2d(nn.Conv2d):
         if Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x):
             if _is3x3(self, 1):
                 return hipconv.conv3x3(x.to(torch.bfloat16), self.weight, self.bias)
-            if _is1x1(self) and x.shape[2] * x.shape[3] <= GEMM_1X1_MAX_PIXELS \
+            if _is1x1(self) and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 \
                     and x.is_contiguous(memory_format=torch.channels_last):
-                # a 1x1 convolution of a channels-last map IS a plain GEMM [pixels, Cin] x [Cin, Cout]:
-                # on the small maps of the deep ResNet stages the library GEMM (hipBLASLt) is 1.2-2.5x
-                # faster than the convolution solver, forward and backward
-                B, cin, H, W = x.shape
-                xb = x.to(torch.bfloat16).permute(0, 2, 3, 1).reshape(B * H * W, cin)
-                wb = self.weight.view(self.out_channels, cin).to(torch.bfloat16)
-                y = xb @ wb.t()
-                if self.bias is not None:
-                    y = y + self.bias.to(torch.bfloat16)
-                return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
+                # library forward / data gradient (GEMM on small maps), hand-written weight gradient
+                return hipconv.conv1x1(x.to(torch.bfloat16), self.weight, self.bias)
         return super().forward(x)
 
 

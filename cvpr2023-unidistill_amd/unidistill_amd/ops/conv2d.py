@@ -2,8 +2,10 @@
 
 Stands in for nn.Conv2d(k=3, s=1, p=1) in the BEV trunk and the detection head of the reference
 (unidistill/layers/blocks_2d/det3d/base_bev_backbone.py:30-110, layers/head/det3d/center_head.py:408-420)
-in the bf16 mixed-precision mode.  Forward and data gradient run on the hand-written MFMA kernel; the
-weight gradient stays with the library (aten.convolution_backward).
+in the bf16 mixed-precision mode.  Forward, data gradient and weight gradient run on the hand-written MFMA
+kernels.  ``conv1x1`` covers the 1x1 / stride-1 convolutions of the ResNet bottlenecks: the library computes
+y and dx (MIOpen on large maps, a plain GEMM on small ones), the weight gradient -- a pixel-reduced GEMM that
+BLAS libraries run on a handful of CUs -- is ud_conv1x1_wgrad_nhwc_bf16.
 """
 import torch
 
@@ -141,3 +143,79 @@ def conv3x3_inference(x, weight, bias=None, scale=None, shift=None, residual=Non
         return _launch(_nhwc(x), tap_major(weight), weight.shape[0],
                        None if bias is None else bias.float().contiguous(), scale, shift,
                        None if residual is None else _nhwc(residual), relu)
+
+
+# ---- 1x1 / stride 1 ------------------------------------------------------------------------------------
+GEMM_1X1_MAX_PIXELS = 1024     # per image; above this MIOpen's 1x1 conv beats the GEMM (tools/exp_conv1x1.py)
+
+
+def supported_1x1(x, weight):
+    return (x.is_cuda and x.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1)
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0)
+
+
+def weight_grad_1x1(x, gy, weight):
+    """dL/dweight [Cout, Cin, 1, 1] (fp32) from channels-last bf16 x [B,Cin,H,W] and gy [B,Cout,H,W]."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    lib = _lib.load()
+    P = x.shape[0] * x.shape[2] * x.shape[3]
+    need = lib.ud_conv1x1_wgrad_workspace_bytes(P, cin, cout)
+    ws = _lib.workspace(x.device, need, "conv_wgrad")
+    dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ud_conv1x1_wgrad_nhwc_bf16(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), P, cin, cout,
+                                              _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+               "ud_conv1x1_wgrad_nhwc_bf16")
+    return dw.to(weight.dtype)
+
+
+def _w1x1(weight):
+    return _cached(weight, "_ud_1x1", lambda w: w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_gpu(x, weight)
+        x = _nhwc(x)
+        wb = _w1x1(weight)
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        ctx.gemm = H * W <= GEMM_1X1_MAX_PIXELS
+        if ctx.gemm:
+            # a 1x1 convolution of a channels-last map IS a plain GEMM [pixels, Cin] x [Cin, Cout]: on the
+            # small maps of the deep ResNet stages the library GEMM is 1.2-2.5x faster than the conv solver
+            y = x.permute(0, 2, 3, 1).reshape(B * H * W, cin) @ wb.view(cout, cin).t()
+            if bias is not None:
+                y = y + bias.to(torch.bfloat16)
+            y = y.view(B, H, W, cout).permute(0, 3, 1, 2)
+        else:
+            y = torch.nn.functional.conv2d(x, wb, None if bias is None else bias.to(torch.bfloat16))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _nhwc(gy.to(torch.bfloat16))
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wb = _w1x1(weight)
+            if ctx.gemm:
+                gx = (gy.permute(0, 2, 3, 1).reshape(B * H * W, cout) @ wb.view(cout, cin)) \
+                    .view(B, H, W, cin).permute(0, 3, 1, 2)
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = weight_grad_1x1(x, gy, weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3), dtype=torch.float32)
+        return gx, gw, gb
+
+
+def conv1x1(x, weight, bias=None):
+    """y = conv2d(x, weight, bias) for a 1x1 / stride-1 convolution of a bf16 channels-last map."""
+    return _Conv1x1Fn.apply(x, weight, bias)

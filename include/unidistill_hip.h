@@ -387,6 +387,13 @@ int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, in
 size_t ud_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
                                int Cout, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+/* Weight gradient of a 1x1 / stride-1 convolution (reference: the ResNet bottleneck and neck 1x1 convs,
+ * nn.Conv2d backward): dw [Cout][Cin] fp32 = sum over the P = B*H*W pixels of dy [P][Cout] (bf16) x
+ * x [P][Cin] (bf16), channels-last rows.  Pixel-sliced MFMA GEMM with a fixed-order reduction of the
+ * slices (deterministic).  Cin % 64 == 0, Cout % 8 == 0, else UD_ERR_UNSUPPORTED. */
+size_t ud_conv1x1_wgrad_workspace_bytes(int64_t P, int Cin, int Cout);
+int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
+                               void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* ---- BatchNorm2d (+ residual) (+ ReLU), channels-last bf16 ------------------------------------------
  * The Conv2d -> BatchNorm2d -> ReLU links of the reference's dense layers (base_bev_backbone.py:48-66,

@@ -1,4 +1,4 @@
-"""Hand-written MFMA 3x3 convolution (channels-last bf16) vs torch.nn.functional.conv2d in fp32."""
+"""Hand-written MFMA convolution kernels (channels-last bf16) vs torch.nn.functional.conv2d in fp32."""
 import numpy as np
 import pytest
 import torch
@@ -108,3 +108,59 @@ def test_conv3x3_matches_numpy_oracle(hip_lib):
     got = c2._launch(x.permute(0, 3, 1, 2), w.contiguous(), 64).permute(0, 2, 3, 1).float().cpu().numpy()
     ref = oracle.conv3x3_nhwc(x.float().cpu().numpy(), w.float().cpu().numpy())
     np.testing.assert_allclose(got, ref, rtol=0, atol=6e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(1, 64, 8, 16, 64), (2, 64, 64, 41, 256), (3, 256, 33, 17, 64),
+                                            (2, 128, 20, 20, 368), (1, 512, 7, 9, 8), (2, 1024, 16, 44, 256)])
+def test_conv1x1_forward_backward(hip_lib, B, Cin, H, W, Cout):
+    """1x1 convolution: library forward / data gradient, hand-written pixel-reduced MFMA weight gradient
+    (ud_conv1x1_wgrad_nhwc_bf16) vs fp32 autograd; the weight gradient is bitwise repeatable."""
+    from unidistill_amd.ops import conv2d as c2
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    dev = torch.device("cuda:0")
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.float().to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    ref = F.conv2d(xr, wr, br)
+    gy = torch.randn(ref.shape, generator=g).bfloat16().float().to(dev)
+    ref.backward(gy)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    assert c2.supported_1x1(xd, wd)
+    y = c2.conv1x1(xd, wd, bd)
+    assert y.dtype == torch.bfloat16
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0,
+                               atol=1e-2 * float(ref.detach().abs().max()))
+    y.backward(gy.to(torch.bfloat16))
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=0,
+                               atol=1e-2 * float(xr.grad.abs().max()))
+    # bf16 operands are exact, products are accumulated in fp32: only the summation order differs
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=0,
+                               atol=1e-4 * float(wr.grad.abs().max()))
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.cpu().numpy(), rtol=1e-3,
+                               atol=1e-3 * float(br.grad.abs().max()))
+    xc, gc = xd.detach(), gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(c2.weight_grad_1x1(xc, gc, wd.detach()), c2.weight_grad_1x1(xc, gc, wd.detach()))
+
+
+def test_conv3x3_weight_gradient_large_map_kernel(hip_lib):
+    """The tap-shared LDS-DMA weight-gradient kernel (maps with more than 4096 pixels) on ragged sizes:
+    image edges that are not multiples of the 8 x 16 pixel tile, Cout that is not a multiple of 64."""
+    from unidistill_amd.ops import conv2d as c2
+    dev = torch.device("cuda:0")
+    for (B, Cin, H, W, Cout) in [(1, 128, 67, 83, 72), (2, 64, 100, 90, 128), (5, 192, 33, 29, 136)]:
+        g = torch.Generator().manual_seed(H + W)
+        x = torch.randn(B, Cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(B, Cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+        w = torch.zeros(Cout, Cin, 3, 3, device=dev, requires_grad=True)
+        F.conv2d(x.float(), w, None, 1, 1).backward(gy.float())
+        c2_prev, c2.USE_HIP_WGRAD = c2.USE_HIP_WGRAD, True
+        try:
+            got = c2.weight_grad(x, gy, w.detach())
+            again = c2.weight_grad(x, gy, w.detach())
+        finally:
+            c2.USE_HIP_WGRAD = c2_prev
+        assert torch.equal(got, again)
+        np.testing.assert_allclose(got.cpu().numpy(), w.grad.cpu().numpy(), rtol=0,
+                                   atol=1e-4 * float(w.grad.abs().max()))
