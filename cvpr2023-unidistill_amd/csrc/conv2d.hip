@@ -469,19 +469,15 @@ constexpr size_t kWgradDmaLds = 2 * ((size_t)kHQP + kTM) * kKC * 2;
 int wgrad_dma_slices(int B, int H, int W, int Cin, int Cout, int* tiles_per_slice) {
   const int ntiles = B * ud_div_up(W, kTW) * ud_div_up(H, kTH);
   const int combos = ud_div_up(Cout, 64) * (Cin / 64);
-  static const int target = getenv("UD_WGRAD_WGS") ? atoi(getenv("UD_WGRAD_WGS")) : 512;
-  int s = target / combos;      // all workgroups resident at once (2 per CU): no second round
+  int s = 512 / combos;         // all workgroups resident at once (2 per CU): no second round
   if (s > ntiles) s = ntiles;
   if (s < 1) s = 1;
   const int per = (ntiles + s - 1) / s;
   *tiles_per_slice = per;
   return (ntiles + per - 1) / per;
 }
-bool wgrad_use_dma(int B, int H, int W) {
-  static const int force = getenv("UD_WGRAD_DMA") ? atoi(getenv("UD_WGRAD_DMA")) : -1;
-  if (force >= 0) return force != 0;
-  return (long long)B * H * W > 4096;
-}
+// the per-tap kernel keeps the tiny maps (<= 4096 pixels in total: too few pixel tiles to slice)
+bool wgrad_use_dma(int B, int H, int W) { return (long long)B * H * W > 4096; }
 
 // out[i] = sum over slices of partial[s][i], i in float4 units: a workgroup owns 64 float4 outputs, its four
 // waves each add a quarter of the slices (ascending), the four sub-sums are combined in wave order.
