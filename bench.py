@@ -229,7 +229,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": loss,
                        "precision": "fp32 everywhere" if ac is None else
-                       "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the teacher's sparse convs (HIP MFMA kernels incl. the 3x3 / 1x1 weight gradients; MIOpen for 1x1 fwd/dgrad and strided convs); fp32 voxelize/splat/losses; fp32 master weights",
+                       "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the teacher's sparse convs (HIP MFMA kernels incl. 1x1 convs and all 3x3 / 1x1 weight gradients; libraries for strided / transposed convs and small-map 1x1 GEMMs); fp32 voxelize/splat/losses; fp32 master weights",
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
                        "executor": "hipGraph" if isinstance(trainer, train.GraphTrainer) else "eager+DDP"},
         }

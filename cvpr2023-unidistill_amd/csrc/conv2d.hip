@@ -33,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvGeom {
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
+  long long npix;     // pixels of the tensor (1x1 convs are launched on a [P/16][16] view: the last row may be short)
 };
 struct ConvEp {
   const float* bias;
@@ -44,8 +45,8 @@ struct ConvEp {
 };
 
 // LDS: two halo slices, two weight slices; the fp32 output tile reuses the space after the K loop.
-constexpr size_t conv_smem_bytes(int tn) {
-  const size_t operands = 2 * (size_t)kHQP * kKC * 2 + 2 * (size_t)tn * kKC * 2;
+constexpr size_t conv_smem_bytes(int tn, int ks = 3) {
+  const size_t operands = 2 * (size_t)(ks == 3 ? kHQP : kTM) * kKC * 2 + 2 * (size_t)tn * kKC * 2;
   const size_t out = (size_t)kTM * (tn + 4) * 4;
   return operands > out ? operands : out;
 }
@@ -65,13 +66,17 @@ __device__ __forceinline__ void dma16(const unsigned short* src, unsigned short*
 // TN = output channels per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64; layers
 // with Cout <= 64 -- the head's shared conv, the data gradient of the packed first head convs -- would
 // waste half of a 128-wide tile).
-template <int TN>
+// KS = 3 (pad 1) or 1 (no halo: the staged tile is the 8 x 16 pixel tile itself, one "tap").
+template <int TN, int KS>
 __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __restrict__ x,
                                                       const unsigned short* __restrict__ w,
                                                       unsigned short* __restrict__ y, ConvGeom gm,
                                                       ConvEp ep) {
   constexpr int kTN = TN, kLDO = TN + 4, kBInstr = TN / 8;
   constexpr int WM = TN == 128 ? 2 : 4;          // waves along the pixel dimension
+  constexpr int kTaps = KS * KS, kPad = KS / 2;
+  constexpr int kHW = kTW + 2 * kPad, kHQ = kHW * (kTH + 2 * kPad);   // staged pixels: 18 x 10 or 16 x 8
+  constexpr int kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
   constexpr int RW = 8 / WM;                     // image rows (of 16 pixels) per wave: 4 or 2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* As = reinterpret_cast<unsigned short*>(smem);          // [2][kHQP][64]
@@ -103,10 +108,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
     for (int piece = wave; piece < kAInstr; piece += 4) {
       const int q = piece * 8 + r8;
       const int qy = q / kHW, qx = q - qy * kHW;
-      const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
+      const int gy = ty0 + qy - kPad, gx = tx0 + qx - kPad;
+      const long long pix = (long long)(b * gm.H + gy) * gm.W + gx;
       const unsigned short* src = zero;
-      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W)
-        src = x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + chunk * kKC + ((slot ^ (q & 7)) << 3);
+      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && pix < gm.npix)
+        src = x + (size_t)pix * gm.Cin + chunk * kKC + ((slot ^ (q & 7)) << 3);
       dma16(src, As + (buf * kHQP + piece * 8) * kKC);
     }
   };
@@ -117,25 +123,26 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
       const int n = piece * 8 + r8;
       const unsigned short* src = zero;
       if (n0 + n < gm.Cout)
-        src = w + ((size_t)(n0 + n) * 9 + (ep.reverse_taps ? 8 - tap : tap)) * gm.Cin + chunk * kKC +
+        src = w + ((size_t)(n0 + n) * kTaps + (ep.reverse_taps ? kTaps - 1 - tap : tap)) * gm.Cin + chunk * kKC +
               ((slot ^ (n & 7)) << 3);
       dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
     }
   };
 
-  const int nchunks = gm.Cin / kKC, total = nchunks * 9;
+  const int nchunks = gm.Cin / kKC, total = nchunks * kTaps;
   stage_a(0, 0);
   stage_b(0, 0, 0);
   __syncthreads();                 // drains the DMAs (vmcnt(0)) and publishes the tiles
   for (int it = 0; it < total; ++it) {
-    const int chunk = it / 9, tap = it - chunk * 9;
+    const int chunk = it / kTaps, tap = it - chunk * kTaps;
     // next weight slice (and, at the start of a slice, the next halo) fly while this one is multiplied
-    if (it + 1 < total) stage_b(tap == 8 ? chunk + 1 : chunk, tap == 8 ? 0 : tap + 1, (it + 1) & 1);
+    if (it + 1 < total)
+      stage_b(tap == kTaps - 1 ? chunk + 1 : chunk, tap == kTaps - 1 ? 0 : tap + 1, (it + 1) & 1);
     if (tap == 0 && chunk + 1 < nchunks) stage_a(chunk + 1, (chunk + 1) & 1);
     {
       const unsigned short* bbuf = Bs + (it & 1) * kTN * kKC;
       const unsigned short* abuf = As + (chunk & 1) * kHQP * kKC;
-      const int q0 = (RW * wm + tap / 3) * kHW + li + tap % 3;  // halo pixel of row tile 0 for this lane
+      const int q0 = (RW * wm + tap / KS) * kHW + li + tap % KS;  // halo pixel of row tile 0 for this lane
 #pragma unroll
       for (int ks = 0; ks < kKC / 32; ++ks) {
         const int cg = 4 * ks + g;                              // logical 16-byte channel group
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
     const int r = u / (kTN / 8), c8 = (u - r * (kTN / 8)) * 8;
     const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
     const int n = n0 + c8;
-    if (gy >= gm.H || gx >= gm.W || n >= gm.Cout) continue;
+    if (gy >= gm.H || gx >= gm.W || n >= gm.Cout || (long long)(b * gm.H + gy) * gm.W + gx >= gm.npix) continue;
     const float4 v0 = *reinterpret_cast<const float4*>(Os + r * kLDO + c8);
     const float4 v1 = *reinterpret_cast<const float4*>(Os + r * kLDO + c8 + 4);
     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -671,13 +678,13 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (Cin % kKC != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH)};
+  ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W};
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
   static bool attr_set = false;
   if (!attr_set) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(128)));
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(64)));
     attr_set = true;
   }
@@ -686,13 +693,46 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   UdProfScope prof("conv2d.k_conv3x3", stream);
   // 64-wide output tiles when Cout <= 64, and on small maps where 128-wide tiles would leave CUs idle
   if (Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256)
-    k_conv3x3_bf16<64><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64), stream>>>(
+    k_conv3x3_bf16<64, 3><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64), stream>>>(
         reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
         reinterpret_cast<unsigned short*>(y), gm, ep);
   else
-    k_conv3x3_bf16<128><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128), stream>>>(
+    k_conv3x3_bf16<128, 3><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128), stream>>>(
         reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
         reinterpret_cast<unsigned short*>(y), gm, ep);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+extern "C" int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                                    const float* bias, const float* scale, const float* shift,
+                                    const void* residual, int relu, ud_stream_t stream_) {
+  if (!x || !w || !y || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
+  if (Cin % kKC != 0 || Cout % 8 != 0 || P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  // pixels as a [ceil(P/16)][16] image: 8 x 16 tiles of 128 consecutive pixels, no halo
+  const int H = (int)((P + kTW - 1) / kTW);
+  ConvGeom gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P};
+  ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, 0};
+  static bool attr_set = false;
+  if (!attr_set) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(128, 1)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(64, 1)));
+    attr_set = true;
+  }
+  const int ntiles = gm.tiles_y;
+  const int gx = (ntiles + 7) / 8 * 8;
+  UdProfScope prof("conv2d.k_conv1x1", stream);
+  const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
+  const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
+  unsigned short* ys = reinterpret_cast<unsigned short*>(y);
+  if (Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256)
+    k_conv3x3_bf16<64, 1><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64, 1), stream>>>(xs, ws, ys, gm, ep);
+  else
+    k_conv3x3_bf16<128, 1><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128, 1), stream>>>(xs, ws, ys, gm, ep);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -715,7 +755,7 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   float* partial = reinterpret_cast<float*>(workspace);
   const size_t n = (size_t)Cout * 9 * Cin;
   if (wgrad_use_dma(B, H, W)) {
-    ConvGeom gd{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH)};
+    ConvGeom gd{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W};
     int per;
     const int S = wgrad_dma_slices(B, H, W, Cin, Cout, &per);
     static bool set_dma = false;
@@ -732,7 +772,7 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     UD_LAUNCH_CHECK();
     return UD_OK;
   }
-  ConvGeom gm{B, H, W, Cin, Cout, 0, 0};
+  ConvGeom gm{B, H, W, Cin, Cout, 0, 0, (long long)B * H * W};
   int CT;
   const int S = wgrad_slices(Cin, Cout, (long long)B * H * W, &CT);
   const int c_tiles = ud_div_up(Cin, CT), n_tiles = ud_div_up(Cout, 128);

@@ -3,7 +3,7 @@
 Stands in for nn.Conv2d(k=3, s=1, p=1) in the BEV trunk and the detection head of the reference
 (unidistill/layers/blocks_2d/det3d/base_bev_backbone.py:30-110, layers/head/det3d/center_head.py:408-420)
 in the bf16 mixed-precision mode.  Forward, data gradient and weight gradient run on the hand-written MFMA
-kernels.  ``conv1x1`` covers the 1x1 / stride-1 convolutions of the ResNet bottlenecks: the library computes
+kernels.  ``conv1x1`` covers the 1x1 / stride-1 convolutions of the ResNet bottlenecks: ud_conv1x1_nhwc_bf16 (maps above 1 k pixels) or the library computes
 y and dx (MIOpen on large maps, a plain GEMM on small ones), the weight gradient -- a pixel-reduced GEMM that
 BLAS libraries run on a handful of CUs -- is ud_conv1x1_wgrad_nhwc_bf16.
 """
@@ -172,6 +172,28 @@ def _w1x1(weight):
     return _cached(weight, "_ud_1x1", lambda w: w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
 
 
+def _w1x1_t(weight):
+    """[Cin, Cout] bf16: the weights of the data-gradient 1x1 convolution."""
+    return _cached(weight, "_ud_1x1_t",
+                   lambda w: torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=w.device).copy_(
+                       w.view(w.shape[0], w.shape[1]).t()))
+
+
+HIP_1X1_MIN_PIXELS = 1025      # per image: maps at least this large run the hand-written 1x1 kernel (forward
+                               # and data gradient); smaller ones the library GEMM (tools/time_conv1x1.py)
+
+
+def _launch1x1(x, w2d, cout, bias=None, scale=None, shift=None, residual=None, relu=False):
+    """x: [B, Cin, H, W] bf16 channels-last; w2d: [Cout, Cin] bf16 contiguous."""
+    B, cin, H, W = x.shape
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().ud_conv1x1_nhwc_bf16(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), B * H * W, cin, cout,
+                                                _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
+                                                _lib.ptr(residual), 1 if relu else 0, _lib.stream_of(x)),
+               "ud_conv1x1_nhwc_bf16")
+    return y
+
+
 class _Conv1x1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -181,7 +203,10 @@ class _Conv1x1Fn(torch.autograd.Function):
         B, cin, H, W = x.shape
         cout = weight.shape[0]
         ctx.gemm = H * W <= GEMM_1X1_MAX_PIXELS
-        if ctx.gemm:
+        ctx.hip = H * W >= HIP_1X1_MIN_PIXELS
+        if ctx.hip:
+            y = _launch1x1(x, wb.view(cout, cin), cout, None if bias is None else bias.detach().float().contiguous())
+        elif ctx.gemm:
             # a 1x1 convolution of a channels-last map IS a plain GEMM [pixels, Cin] x [Cin, Cout]: on the
             # small maps of the deep ResNet stages the library GEMM is 1.2-2.5x faster than the conv solver
             y = x.permute(0, 2, 3, 1).reshape(B * H * W, cin) @ wb.view(cout, cin).t()
@@ -203,7 +228,9 @@ class _Conv1x1Fn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wb = _w1x1(weight)
-            if ctx.gemm:
+            if ctx.hip and cout % 64 == 0:       # the kernel's reduction dimension comes in 64-channel slices
+                gx = _launch1x1(gy, _w1x1_t(weight), cin)
+            elif ctx.gemm:
                 gx = (gy.permute(0, 2, 3, 1).reshape(B * H * W, cout) @ wb.view(cout, cin)) \
                     .view(B, H, W, cin).permute(0, 3, 1, 2)
             else:

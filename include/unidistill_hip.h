@@ -381,6 +381,13 @@ int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const floa
 int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
                          const float* bias, const float* scale, const float* shift,
                          const void* residual, int relu, ud_stream_t stream);
+/* 1x1 / stride-1 convolution (the ResNet bottleneck 1x1 convs of the reference's image branch) on the same
+ * kernel family: x [P][Cin] bf16 (P = B*H*W channels-last pixels), w [Cout][Cin] bf16, y [P][Cout] bf16,
+ * same fused epilogue (bit 0 of `relu` only).  The data gradient is the same call on dy with w^T
+ * [Cin][Cout].  Cin % 64 == 0, Cout % 8 == 0, else UD_ERR_UNSUPPORTED. */
+int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                         const float* bias, const float* scale, const float* shift,
+                         const void* residual, int relu, ud_stream_t stream);
 /* Weight gradient of the same convolution: dw [Cout][9][Cin] fp32 = sum over pixels of
  * dy [B][H][W][Cout] (bf16) x shifted x [B][H][W][Cin] (bf16); fp32 accumulation, fixed-order
  * reduction of pixel slices (deterministic).  Cin % 64 == 0, Cout % 8 == 0. */

@@ -111,10 +111,12 @@ def test_conv3x3_matches_numpy_oracle(hip_lib):
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [(1, 64, 8, 16, 64), (2, 64, 64, 41, 256), (3, 256, 33, 17, 64),
-                                            (2, 128, 20, 20, 368), (1, 512, 7, 9, 8), (2, 1024, 16, 44, 256)])
+                                            (2, 128, 20, 20, 368), (1, 512, 7, 9, 8), (2, 1024, 16, 44, 256),
+                                            (1, 64, 37, 53, 64), (3, 128, 40, 41, 72), (1, 256, 64, 176, 64)])
 def test_conv1x1_forward_backward(hip_lib, B, Cin, H, W, Cout):
-    """1x1 convolution: library forward / data gradient, hand-written pixel-reduced MFMA weight gradient
-    (ud_conv1x1_wgrad_nhwc_bf16) vs fp32 autograd; the weight gradient is bitwise repeatable."""
+    """1x1 convolution vs fp32 autograd: forward / data gradient on ud_conv1x1_nhwc_bf16 for maps above 1024
+    pixels (pixel counts that are not multiples of the 128-pixel tile included) and on the library GEMM
+    below, weight gradient on the pixel-reduced MFMA kernel ud_conv1x1_wgrad_nhwc_bf16 (bitwise repeatable)."""
     from unidistill_amd.ops import conv2d as c2
     g = torch.Generator().manual_seed(Cin + Cout + H)
     dev = torch.device("cuda:0")
@@ -164,3 +166,20 @@ def test_conv3x3_weight_gradient_large_map_kernel(hip_lib):
         assert torch.equal(got, again)
         np.testing.assert_allclose(got.cpu().numpy(), w.grad.cpu().numpy(), rtol=0,
                                    atol=1e-4 * float(w.grad.abs().max()))
+
+
+def test_conv1x1_fused_epilogue(hip_lib):
+    from unidistill_amd.ops import conv2d as c2
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    B, Cin, H, W, Cout = 2, 192, 31, 47, 136
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).bfloat16()
+    b, scale, shift = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g).bfloat16()
+    ref = F.relu((F.conv2d(x.float(), w.float()[:, :, None, None], b) * scale[None, :, None, None]
+                  + shift[None, :, None, None]) + res.float())
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    y = c2._launch1x1(cl(x), w.to(dev), Cout, b.to(dev), scale.to(dev), shift.to(dev), cl(res), relu=True)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=0, atol=6e-3 * float(ref.abs().max()))
