@@ -3,9 +3,9 @@
 Stands in for nn.Conv2d(k=3, s=1, p=1) in the BEV trunk and the detection head of the reference
 (unidistill/layers/blocks_2d/det3d/base_bev_backbone.py:30-110, layers/head/det3d/center_head.py:408-420)
 in the bf16 mixed-precision mode.  Forward, data gradient and weight gradient run on the hand-written MFMA
-kernels.  ``conv1x1`` covers the 1x1 / stride-1 convolutions of the ResNet bottlenecks: ud_conv1x1_nhwc_bf16 (maps above 1 k pixels) or the library computes
-y and dx (MIOpen on large maps, a plain GEMM on small ones), the weight gradient -- a pixel-reduced GEMM that
-BLAS libraries run on a handful of CUs -- is ud_conv1x1_wgrad_nhwc_bf16.
+kernels.  ``conv1x1`` covers the 1x1 / stride-1 convolutions of the ResNet bottlenecks: y and dx come from
+ud_conv1x1_nhwc_bf16 on maps above 1 k pixels and from the library GEMM below, the weight gradient -- a
+pixel-reduced GEMM that BLAS libraries run on a handful of CUs -- is ud_conv1x1_wgrad_nhwc_bf16.
 """
 import torch
 
