@@ -143,12 +143,20 @@ def check(code, what):
 
 
 def ptr(t):
-    return None if t is None else c_void_p(t.data_ptr())
+    """Device address as a plain int (ctypes converts it for a c_void_p parameter; None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream_of(t):
-    """hipStream_t torch is currently enqueuing on for t's device."""
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """hipStream_t torch is currently enqueuing on for t's device (host cost matters: the wrappers are
+    launch-bound at small batches, so this avoids building a torch.cuda.Stream object per call)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def require_gpu(*tensors):

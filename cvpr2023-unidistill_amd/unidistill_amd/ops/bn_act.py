@@ -23,6 +23,16 @@ def _like(t, ref):
     return t.contiguous() if ref.dim() == 2 else t.contiguous(memory_format=torch.channels_last)
 
 
+_ws_bytes = {}
+
+
+def _workspace(dev, C):
+    n = _ws_bytes.get(C)
+    if n is None:
+        n = _ws_bytes[C] = _lib.load().ud_bn_act_workspace_bytes(C)
+    return _lib.workspace(dev, n, "bn_act")
+
+
 class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu,
@@ -36,36 +46,38 @@ class _BnActFn(torch.autograd.Function):
         b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
         stream = _lib.stream_of(x)
         if training:
+            # one [5, C] block: mean, var, invstd, scale, shift (addressed by offset: no per-row views)
             vec = torch.empty((5, C), dtype=torch.float32, device=dev)
-            mean, var, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3], vec[4]
-            ws = _lib.workspace(dev, lib.ud_bn_act_workspace_bytes(C), "bn_act")
+            v0, row = vec.data_ptr(), 4 * C
+            ws = _workspace(dev, C)
             fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
             rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
-            _lib.check(lib.ud_bn_stats(_lib.ptr(x), P, C, _lib.ptr(g32), _lib.ptr(b32), float(eps),
-                                       _lib.ptr(mean), _lib.ptr(var), _lib.ptr(invstd), _lib.ptr(scale),
-                                       _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
-                                       _lib.ptr(tracked), _lib.ptr(ws), ws.numel(), stream), "ud_bn_stats")
+            _lib.check(lib.ud_bn_stats(x.data_ptr(), P, C, g32.data_ptr(), b32.data_ptr(), float(eps),
+                                       v0, v0 + row, v0 + 2 * row, v0 + 3 * row, v0 + 4 * row,
+                                       _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
+                                       _lib.ptr(tracked), ws.data_ptr(), ws.numel(), stream), "ud_bn_stats")
             if running_mean is not None and not fp32_buffers:
                 with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(var, alpha=momentum * P / max(P - 1, 1))
+                    running_mean.mul_(1 - momentum).add_(vec[0], alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(vec[1], alpha=momentum * P / max(P - 1, 1))
         else:
             invstd = torch.rsqrt(running_var.float() + eps)
             mean = running_mean.float()
-            scale = (g32 * invstd).contiguous()
-            shift = (b32 - mean * scale).contiguous()
+            scale = g32 * invstd
+            vec = torch.stack((mean, invstd * invstd, invstd, scale, b32 - mean * scale))
+            v0, row = vec.data_ptr(), 4 * C
         if residual is not None:
             residual = _like(residual, x)
         y = torch.empty_like(x)
-        _lib.check(lib.ud_bn_act_fwd(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(scale), _lib.ptr(shift),
-                                     _lib.ptr(y), P, C, 1 if relu else 0, stream), "ud_bn_act_fwd")
+        _lib.check(lib.ud_bn_act_fwd(x.data_ptr(), _lib.ptr(residual), v0 + 3 * row, v0 + 4 * row,
+                                     y.data_ptr(), P, C, 1 if relu else 0, stream), "ud_bn_act_fwd")
         ctx.cfg = (bool(training), bool(relu), residual is not None)
-        ctx.save_for_backward(x, y if (residual is not None and relu) else None, scale, shift, mean, invstd)
+        ctx.save_for_backward(x, y if (residual is not None and relu) else None, vec)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, scale, shift, mean, invstd = ctx.saved_tensors
+        x, y, vec = ctx.saved_tensors
         training, relu, has_res = ctx.cfg
         if not training:
             raise NotImplementedError("fused BatchNorm backward covers training-mode statistics only")
@@ -78,11 +90,12 @@ class _BnActFn(torch.autograd.Function):
         if dres is not None and not relu:
             dres = None                                   # no mask: the residual gradient is dy itself
         dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        ws = _lib.workspace(x.device, lib.ud_bn_act_workspace_bytes(C), "bn_act")
-        _lib.check(lib.ud_bn_act_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(scale), _lib.ptr(shift),
-                                     _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(dres),
-                                     _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), P, C, 1 if relu else 0,
-                                     _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd")
+        ws = _workspace(x.device, C)
+        v0, row, g0 = vec.data_ptr(), 4 * C, dgb.data_ptr()
+        _lib.check(lib.ud_bn_act_bwd(x.data_ptr(), _lib.ptr(y), dy.data_ptr(), v0 + 3 * row, v0 + 4 * row,
+                                     v0, v0 + 2 * row, dx.data_ptr(), _lib.ptr(dres),
+                                     g0, g0 + row, P, C, 1 if relu else 0,
+                                     ws.data_ptr(), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd")
         if has_res and ctx.needs_input_grad[3] and dres is None:
             dres = dy
         return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
