@@ -402,6 +402,17 @@ size_t ud_conv1x1_wgrad_workspace_bytes(int64_t P, int Cin, int Cout);
 int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
                                void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
+/* ---- LiDAR input side ------------------------------------------------------------------
+ * Replaces the numpy point transforms of the reference's data pipeline:
+ * CollectLidarSweeps.forward (unidistill/data/multisensorfusion/transforms3d.py:379-414) and the point part
+ * of BevAffineTransformation.forward (:417-443).  in/out f32 [rows][D] (D >= 3; in == out allowed); seg:
+ * S+1 ascending row offsets (device, int64); mats: S row-major 4x4 float64 matrices (device); segment s
+ * gets xyz <- (mats[s] @ [x y z 1]^T)[:3] evaluated in float64 in numpy's order and rounded to float32
+ * (bit-identical to the reference), columns 3.. copied, and, when `last` (device, f32[S]) is given and
+ * last[s] is not NaN, column D-1 <- last[s] (the sweep's time lag).  max_rows = longest segment. */
+int ud_points_transform(const float* in, float* out, const int64_t* seg, const double* mats, const float* last,
+                        int S, int D, int64_t max_rows, ud_stream_t stream);
+
 /* ---- BatchNorm2d (+ residual) (+ ReLU), channels-last bf16 ------------------------------------------
  * The Conv2d -> BatchNorm2d -> ReLU links of the reference's dense layers (base_bev_backbone.py:48-66,
  * center_head.py:408-420, the mmdet ResNet bottlenecks) as HBM-bound streaming kernels over

@@ -269,3 +269,74 @@ def conv3x3_nhwc(x, w, bias=None):
     if bias is not None:
         y += np.asarray(bias, np.float64)
     return y
+
+
+# ---- LiDAR input side -- numpy restatements, pinned by tests/golden/input_prep.npz --------
+def sweep_to_key_matrix(key_lidar_to_ego, key_ego_to_global, sweep_pose):
+    """The 4x4 (float64) that CollectLidarSweeps applies to a sweep's points
+    (data/multisensorfusion/transforms3d.py:394-400; numpy's @ is left-associative, so the four matrices
+    are multiplied first and the product meets the points last)."""
+    L, G, S = (np.asarray(m, np.float64) for m in (key_lidar_to_ego, key_ego_to_global, sweep_pose))
+    return np.linalg.inv(L) @ np.linalg.inv(G) @ S @ L
+
+
+def points_transform(points, mat, last=None):
+    """points f32[N,D]: xyz <- (mat @ [x y z 1]^T)[:3] in float64, stored back as float32; the other columns
+    are kept, the last one is overwritten with ``last`` when given (transforms3d.py:392-408, 434-438)."""
+    pts = np.array(points, dtype=np.float32, copy=True)
+    h = np.ones((pts.shape[0], 4))
+    h[:, :3] = pts[:, :3]
+    pts[:, :3] = (np.asarray(mat, np.float64) @ h.T).T[:, :3]
+    if last is not None:
+        pts[:, -1] = last
+    return pts
+
+
+def collect_lidar_sweeps(points, sweeps, key_lidar_to_ego, key_ego_to_global, timestamp, sweep_poses,
+                         sweep_timestamps):
+    """CollectLidarSweeps.forward (transforms3d.py:379-414) on plain arrays."""
+    allp = np.array(points, dtype=np.float32, copy=True)
+    if allp.shape[-1] == 5:
+        allp[:, -1] = 0.0
+    for frame, pose, ts in zip(sweeps, sweep_poses, sweep_timestamps):
+        lag = (int(timestamp) - int(ts)) / 1e6 if allp.shape[-1] == 5 else None
+        allp = np.concatenate([allp, points_transform(frame, sweep_to_key_matrix(key_lidar_to_ego, key_ego_to_global,
+                                                                                pose), lag)])
+    return allp
+
+
+def bev_transform_matrix(rotate_deg, scale, trans, flip_dx, flip_dy):
+    """functional.bev_transform's matrix (data/multisensorfusion/functional.py:595-632)."""
+    a = rotate_deg / 180 * np.pi
+    s, c = np.sin(a), np.cos(a)
+    rot = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    sc = np.diag([scale, scale, scale, 1.0])
+    tr = np.eye(4)
+    tr[:3, 3] = trans
+    flip = np.eye(4)
+    if flip_dx:
+        flip = flip @ np.diag([-1.0, 1.0, 1.0, 1.0])
+    if flip_dy:
+        flip = flip @ np.diag([1.0, -1.0, 1.0, 1.0])
+    return flip @ tr @ sc @ rot
+
+
+def bev_transform_boxes(gt_boxes, rotate_deg, scale, trans, flip_dx, flip_dy):
+    """functional.bev_transform's box update (functional.py:633-646): centres through the matrix, sizes
+    scaled, yaw rotated / mirrored, velocities through the matrix's 2x2 block."""
+    boxes = np.array(gt_boxes, dtype=np.float32, copy=True)
+    rotate_deg, scale = float(rotate_deg), float(scale)    # python scalars: the float32 array ops stay float32
+    mat = bev_transform_matrix(rotate_deg, scale, trans, flip_dx, flip_dy)
+    if boxes.shape[0] > 0:
+        h = np.ones((boxes.shape[0], 4))
+        h[:, :3] = boxes[:, :3]
+        boxes[:, :3] = (mat @ h.T).T[:, :3]
+        boxes[:, 3:6] *= scale
+        boxes[:, 6] += rotate_deg / 180 * np.pi
+        if flip_dx:
+            boxes[:, 6] = np.pi - boxes[:, 6]
+        if flip_dy:
+            boxes[:, 6] = -boxes[:, 6]
+        if boxes.shape[1] > 7:
+            boxes[:, 7:] = (mat[:2, :2] @ boxes[:, 7:].T).T
+    return boxes, mat

@@ -399,6 +399,78 @@ def gold_proposals():
 
 ALL["proposals"] = gold_proposals
 
+def gold_input_prep():
+    """LiDAR input side: CollectLidarSweeps.forward (data/multisensorfusion/transforms3d.py:379-414:
+    sweeps into the key frame, time-lag channel) and BevAffineTransformation.forward (:417-443) with
+    functional.bev_transform (functional.py:595-646: rotate / scale / translate / flip of points and boxes).
+    The random augmentation draw is pinned by overriding sample_augs; everything else is the reference's code."""
+    from unidistill.data.multisensorfusion import transforms3d as T
+    rng = np.random.default_rng(77)
+
+    def pose():
+        a = rng.uniform(-np.pi, np.pi)
+        c, s_ = np.cos(a), np.sin(a)
+        tilt = rng.normal(scale=0.02, size=2)
+        rx = np.array([[1, 0, 0], [0, np.cos(tilt[0]), -np.sin(tilt[0])], [0, np.sin(tilt[0]), np.cos(tilt[0])]])
+        ry = np.array([[np.cos(tilt[1]), 0, np.sin(tilt[1])], [0, 1, 0], [-np.sin(tilt[1]), 0, np.cos(tilt[1])]])
+        m = np.eye(4)
+        m[:3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]) @ rx @ ry
+        m[:3, 3] = rng.normal(scale=[300.0, 300.0, 1.0])
+        return m
+
+    def cloud(n):
+        pts = np.zeros((n, 5), dtype=np.float32)
+        pts[:, :3] = rng.normal(scale=[25.0, 25.0, 1.5], size=(n, 3))
+        pts[:, 3] = rng.uniform(0, 255, size=n)
+        pts[:, 4] = rng.uniform(0, 31, size=n)          # ring index: overwritten by the time lag
+        return pts
+
+    out = {}
+    key_l2e, key_e2g = pose(), pose()
+    key_l2e[:3, 3] = [0.94, 0.0, 1.84]
+    sizes = [1500, 1200, 0, 977]
+    sweeps = [cloud(n) for n in sizes[1:]]
+    sweep_infos, t0 = [], 1533151603547590
+    for i in range(len(sweeps)):
+        m = key_e2g.copy()
+        m[:3, 3] += rng.normal(scale=[1.5, 1.5, 0.02])                      # ego moved a little between sweeps
+        sweep_infos.append({"sweep_lidar_to_ego": m, "sweep_lidar_timestamp": t0 - 50000 * (i + 1) - int(rng.integers(0, 900))})
+    key = cloud(sizes[0])
+    out["key_points"], out["key_lidar_to_ego"], out["key_ego_to_global"] = key.copy(), key_l2e, key_e2g
+    out["timestamp"] = np.array([t0], dtype=np.int64)
+    for i, (sw, inf) in enumerate(zip(sweeps, sweep_infos)):
+        out[f"sweep{i}_points"] = sw.copy()
+        out[f"sweep{i}_lidar_to_ego"] = inf["sweep_lidar_to_ego"]
+        out[f"sweep{i}_timestamp"] = np.array([inf["sweep_lidar_timestamp"]], dtype=np.int64)
+    dd = {"points": key.copy(), "sweep_points": [s_.copy() for s_ in sweeps],
+          "info": {"ego_to_global": key_e2g, "lidar_to_ego": key_l2e, "timestamp": t0,
+                   "sweep_lidar_infos": [dict(d) for d in sweep_infos]}}
+    dd = T.CollectLidarSweeps().forward(dd)
+    out["collected_points"] = dd["points"]
+    assert dd["points"].dtype == np.float32 and dd["points"].shape == (sum(sizes), 5)
+
+    boxes = np.zeros((7, 9), dtype=np.float32)
+    boxes[:, :3] = rng.normal(scale=[20.0, 20.0, 1.0], size=(7, 3))
+    boxes[:, 3:6] = rng.uniform(0.5, 5.0, size=(7, 3))
+    boxes[:, 6] = rng.uniform(-np.pi, np.pi, size=7)
+    boxes[:, 7:] = rng.normal(scale=3.0, size=(7, 2))
+    out["gt_boxes_in"] = boxes.copy()
+    cases = [(11.25, 1.04, np.array([0.3, -0.2, 0.05]), False, False), (-20.0, 0.93, np.array([0.0, 0.0, 0.0]), True, False),
+             (5.5, 1.0, np.array([-0.4, 0.1, 0.0]), False, True), (0.0, 1.07, np.array([0.2, 0.2, -0.1]), True, True)]
+    for ci, augs in enumerate(cases):
+        bda = T.BevAffineTransformation(rot_lim=(-22.5, 22.5), scale_lim=(0.9, 1.1), trans_lim=(0.5, 0.5, 0.5),
+                                        flip_dx_ratio=0.5, flip_dy_ratio=0.5)
+        bda.sample_augs = lambda augs=augs: augs
+        d2 = {"gt_boxes": boxes.copy(), "points": dd["points"].copy(), "imgs": {}}
+        d2 = bda.forward(d2)
+        out[f"bda{ci}_augs"] = np.array([augs[0], augs[1], *augs[2], float(augs[3]), float(augs[4])])
+        out[f"bda{ci}_points"], out[f"bda{ci}_boxes"], out[f"bda{ci}_mat"] = d2["points"], d2["gt_boxes"], d2["bda_mat"]
+    _save("input_prep", **out)
+
+
+ALL["input_prep"] = gold_input_prep
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)
     for n in names:

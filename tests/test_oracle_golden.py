@@ -95,3 +95,21 @@ def test_spconv_oracle_vs_dense_conv3d():
                      stride=2, padding=1).numpy()[:, 0] > 0
     np.testing.assert_array_equal(np.argwhere(reach).astype(np.int32), oc)
     assert ((inbr >= 0).sum() == (onbr >= 0).sum())
+
+
+def test_input_prep_oracle_matches_reference(golden):
+    """CollectLidarSweeps / BevAffineTransformation restatements vs the reference's own outputs: bit-exact
+    (float64 matrix products rounded once into the float32 cloud)."""
+    g = golden("input_prep")
+    sweeps = [g[f"sweep{i}_points"] for i in range(3)]
+    got = oracle.collect_lidar_sweeps(g["key_points"], sweeps, g["key_lidar_to_ego"], g["key_ego_to_global"],
+                                      g["timestamp"][0], [g[f"sweep{i}_lidar_to_ego"] for i in range(3)],
+                                      [g[f"sweep{i}_timestamp"][0] for i in range(3)])
+    np.testing.assert_array_equal(got, g["collected_points"])
+    assert np.all(got[:1500, 4] == 0.0) and np.all(got[1500:, 4] > 0.04)     # key frame lag 0, sweeps ~50 ms apart
+    for ci in range(4):
+        a = g[f"bda{ci}_augs"]
+        boxes, mat = oracle.bev_transform_boxes(g["gt_boxes_in"], a[0], a[1], a[2:5], bool(a[5]), bool(a[6]))
+        np.testing.assert_array_equal(mat, g[f"bda{ci}_mat"])
+        np.testing.assert_array_equal(boxes, g[f"bda{ci}_boxes"])
+        np.testing.assert_array_equal(oracle.points_transform(g["collected_points"], mat), g[f"bda{ci}_points"])
