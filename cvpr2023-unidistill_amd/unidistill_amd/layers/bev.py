@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .dense import Conv2d, FusedSequential
+from .dense import Conv2d, ConvTranspose2d, FusedSequential
 
 
 def _bn(c):
@@ -44,7 +44,7 @@ class BaseBEVBackbone(nn.Module):
             if upsample_strides:
                 us, uc = upsample_strides[lvl], num_upsample_filters[lvl]
                 if us >= 1:
-                    up = nn.ConvTranspose2d(c, uc, us, stride=us, bias=False)
+                    up = ConvTranspose2d(c, uc, us, stride=us, bias=False)
                 else:
                     k = int(np.round(1 / us))
                     up = nn.Conv2d(c, uc, k, stride=k, bias=False)

@@ -49,6 +49,21 @@ class Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class ConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d (same parameters / state_dict keys).  Its 1x1 / stride-1 case -- the first deblock
+    of BaseBEVBackbone and of the image neck (reference base_bev_backbone.py:67-92, upsample stride 1) -- is
+    a plain 1x1 convolution with the weight's two channel axes swapped and runs on hipconv.conv1x1."""
+
+    def forward(self, x, output_size=None):
+        if (Conv2d.hip_enabled and output_size is None and x.dim() == 4 and _mixed_precision(x)
+                and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                and self.output_padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1
+                and self.in_channels % 64 == 0 and self.out_channels % 8 == 0
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            return hipconv.conv1x1(x.to(torch.bfloat16), self.weight.permute(1, 0, 2, 3), self.bias)
+        return super().forward(x, output_size)
+
+
 def _can_fuse_inference(x, bn):
     return (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.affine and bn.track_running_stats
             and not (torch.is_grad_enabled() and x.requires_grad))

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .dense import Conv2d, FusedSequential, batchnorm_act
+from .dense import Conv2d, ConvTranspose2d, FusedSequential, batchnorm_act
 
 
 class Bottleneck(nn.Module):
@@ -94,7 +94,7 @@ class SECONDFPN(nn.Module):
         for cin, cout, s in zip(in_channels, out_channels, upsample_strides):
             if s >= 1:
                 k = int(s)
-                op = nn.ConvTranspose2d(cin, cout, k, stride=k, bias=False)
+                op = ConvTranspose2d(cin, cout, k, stride=k, bias=False)
             else:
                 k = int(np.round(1 / s))
                 op = nn.Conv2d(cin, cout, k, stride=k, bias=False)

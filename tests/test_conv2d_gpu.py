@@ -183,3 +183,33 @@ def test_conv1x1_fused_epilogue(hip_lib):
     y = c2._launch1x1(cl(x), w.to(dev), Cout, b.to(dev), scale.to(dev), shift.to(dev), cl(res), relu=True)
     assert y.is_contiguous(memory_format=torch.channels_last)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=0, atol=6e-3 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("H,W", [(12, 20), (40, 33)])
+def test_conv_transpose_1x1_routes_to_conv1x1(hip_lib, H, W):
+    """dense.ConvTranspose2d(k=1, s=1) -- the stride-1 deblocks -- equals nn.ConvTranspose2d (fp32) in
+    forward, input gradient and weight gradient, on the GEMM (small map) and kernel (large map) paths."""
+    from unidistill_amd.layers import dense
+    dev = torch.device("cuda:0")
+    torch.manual_seed(H)
+    ours = dense.ConvTranspose2d(128, 72, 1, stride=1, bias=False).to(dev)
+    ref = torch.nn.ConvTranspose2d(128, 72, 1, stride=1, bias=False).to(dev)
+    with torch.no_grad():
+        ours.weight.copy_(ours.weight.bfloat16().float())
+        ref.weight.copy_(ours.weight)
+    x = torch.randn(2, 128, H, W, device=dev).bfloat16()
+    xr = x.float().requires_grad_(True)
+    xo = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yr = ref(xr)
+    gy = torch.randn_like(yr).bfloat16().float()
+    yr.backward(gy)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yo = ours(xo)
+    assert yo.dtype == torch.bfloat16 and yo.shape == yr.shape
+    yo.backward(gy.to(torch.bfloat16))
+    tol = lambda t: 1e-2 * float(t.abs().max())
+    np.testing.assert_allclose(yo.detach().float().cpu().numpy(), yr.detach().cpu().numpy(), rtol=0, atol=tol(yr))
+    np.testing.assert_allclose(xo.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=0, atol=tol(xr.grad))
+    assert ours.weight.grad.shape == ref.weight.grad.shape
+    np.testing.assert_allclose(ours.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=0,
+                               atol=1e-4 * float(ref.weight.grad.abs().max()))
