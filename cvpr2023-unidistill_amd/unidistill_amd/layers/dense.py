@@ -42,11 +42,21 @@ class Conv2d(nn.Conv2d):
         if Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x):
             if _is3x3(self, 1):
                 return hipconv.conv3x3(x.to(torch.bfloat16), self.weight, self.bias)
-            if _is1x1(self) and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 \
-                    and x.is_contiguous(memory_format=torch.channels_last):
-                # library forward / data gradient (GEMM on small maps), hand-written weight gradient
+            if self._hip_1x1(x):
                 return hipconv.conv1x1(x.to(torch.bfloat16), self.weight, self.bias)
         return super().forward(x)
+
+    def _hip_1x1(self, x):
+        return (_is1x1(self) and self.in_channels % 64 == 0 and self.out_channels % 8 == 0
+                and x.is_contiguous(memory_format=torch.channels_last))
+
+    def forward_with_skip(self, x):
+        """(self(x), x'): x' is x, handed back through the convolution's autograd node so that the gradient of
+        an identity branch fed from it is added inside the data-gradient kernel (residual blocks)."""
+        if (Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x) and x.dtype == torch.bfloat16
+                and self._hip_1x1(x) and torch.is_grad_enabled() and x.requires_grad):
+            return hipconv.conv1x1_skip(x, self.weight, self.bias)
+        return self(x), x
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):

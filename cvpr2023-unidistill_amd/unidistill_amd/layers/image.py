@@ -30,8 +30,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        y = batchnorm_act(self.bn1, self.conv1(x))
+        if self.downsample is None:
+            y, idt = self.conv1.forward_with_skip(x)      # identity gradient joins inside conv1's data gradient
+        else:
+            idt, y = self.downsample(x), self.conv1(x)
+        y = batchnorm_act(self.bn1, y)
         y = batchnorm_act(self.bn2, self.conv2(y))
         return batchnorm_act(self.bn3, self.conv3(y), residual=idt)
 
@@ -51,7 +54,7 @@ class ResNet(nn.Module):
         inplanes = 64
         for i, n in enumerate(self.arch[depth]):
             planes, stride = 64 * 2 ** i, (1 if i == 0 else 2)
-            down = FusedSequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+            down = FusedSequential(Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
                                    nn.BatchNorm2d(planes * 4))
             blocks = [Bottleneck(inplanes, planes, stride, down)]
             inplanes = planes * 4

@@ -195,8 +195,12 @@ def _launch1x1(x, w2d, cout, bias=None, scale=None, shift=None, residual=None, r
 
 
 class _Conv1x1Fn(torch.autograd.Function):
+    """with_skip: the function also returns its input (an alias) for the caller's identity branch, so that the
+    gradient arriving through that branch is added in the data-gradient kernel's epilogue (or the GEMM's
+    beta term) instead of by a separate elementwise add of two full-size tensors (ResNet residual joins)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, with_skip=False):
         _lib.require_gpu(x, weight)
         x = _nhwc(x)
         wb = _w1x1(weight)
@@ -217,10 +221,10 @@ class _Conv1x1Fn(torch.autograd.Function):
             y = torch.nn.functional.conv2d(x, wb, None if bias is None else bias.to(torch.bfloat16))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return y
+        return (y, x) if with_skip else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, weight = ctx.saved_tensors
         gy = _nhwc(gy.to(torch.bfloat16))
         B, cin, H, W = x.shape
@@ -228,21 +232,31 @@ class _Conv1x1Fn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wb = _w1x1(weight)
+            if gskip is not None:
+                gskip = _nhwc(gskip.to(torch.bfloat16))
             if ctx.hip and cout % 64 == 0:       # the kernel's reduction dimension comes in 64-channel slices
-                gx = _launch1x1(gy, _w1x1_t(weight), cin)
+                gx = _launch1x1(gy, _w1x1_t(weight), cin, residual=gskip)
             elif ctx.gemm:
-                gx = (gy.permute(0, 2, 3, 1).reshape(B * H * W, cout) @ wb.view(cout, cin)) \
-                    .view(B, H, W, cin).permute(0, 3, 1, 2)
+                g2, w2 = gy.permute(0, 2, 3, 1).reshape(B * H * W, cout), wb.view(cout, cin)
+                gx = g2 @ w2 if gskip is None else torch.addmm(gskip.permute(0, 2, 3, 1).reshape(B * H * W, cin), g2, w2)
+                gx = gx.view(B, H, W, cin).permute(0, 3, 1, 2)
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
+                if gskip is not None:
+                    gx = gx + gskip
         if ctx.needs_input_grad[1]:
             gw = weight_grad_1x1(x, gy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def conv1x1(x, weight, bias=None):
     """y = conv2d(x, weight, bias) for a 1x1 / stride-1 convolution of a bf16 channels-last map."""
     return _Conv1x1Fn.apply(x, weight, bias)
+
+
+def conv1x1_skip(x, weight, bias=None):
+    """(conv1x1(x), x): use the second value for the identity branch of a residual block (see _Conv1x1Fn)."""
+    return _Conv1x1Fn.apply(x, weight, bias, True)

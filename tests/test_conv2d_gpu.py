@@ -213,3 +213,30 @@ def test_conv_transpose_1x1_routes_to_conv1x1(hip_lib, H, W):
     assert ours.weight.grad.shape == ref.weight.grad.shape
     np.testing.assert_allclose(ours.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=0,
                                atol=1e-4 * float(ref.weight.grad.abs().max()))
+
+
+@pytest.mark.parametrize("H,W", [(10, 12), (40, 41)])
+def test_conv1x1_skip_adds_identity_gradient_in_kernel(hip_lib, H, W):
+    """conv1x1_skip: the gradient of the identity branch is added in the data-gradient epilogue (large maps)
+    or the GEMM's beta term (small maps): same result as conv + separate residual add."""
+    from unidistill_amd.ops import conv2d as c2
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(W)
+    x = torch.randn(2, 128, H, W, generator=g).bfloat16()
+    w = (torch.randn(64, 128, 1, 1, generator=g) / 128 ** 0.5).bfloat16().float()
+    w2 = (torch.randn(128, 64, 1, 1, generator=g) / 8).bfloat16().float()
+    xr, wr, w2r = x.float().to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), w2.to(dev)
+    out_r = F.conv2d(F.conv2d(xr, wr), w2r) + xr                       # bottleneck-like: conv -> conv, + identity
+    gy = torch.randn(out_r.shape, generator=g).bfloat16().float().to(dev)
+    out_r.backward(gy)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    y, idt = c2.conv1x1_skip(xd, wd)
+    out = F.conv2d(y.float(), w2r) + idt.float()
+    out.backward(gy)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_r.detach().cpu().numpy(), rtol=0,
+                               atol=1.5e-2 * float(out_r.abs().max()))
+    np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=0,
+                               atol=1.5e-2 * float(xr.grad.abs().max()))
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=0,
+                               atol=2e-2 * float(wr.grad.abs().max()))
