@@ -1179,7 +1179,6 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
                                                         const int32_t* __restrict__ nbr, int K,
                                                         const unsigned short* __restrict__ gout,
                                                         float* __restrict__ partial, int Mout,
-                                                        const int32_t* __restrict__ order,
                                                         const unsigned* __restrict__ masks, int ntiles,
                                                         int tiles_per_chunk) {
   constexpr int SN = COUT_P / 8, SC = CIN_P / 8;             // 16-byte slots per row
@@ -1202,13 +1201,30 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
   auto fsw = [](int r, int slots) -> int {
     return slots == 16 ? (((r & 3) | ((r >> 1) & 4)) << 1) : ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
   };
-  auto stage = [&](int t, int buf) {
+  // The rows a tile gathers are known only through an index load (nbr; the host passes rulebook and gout rows
+  // already in tile order).  Issued inside the staging it would put a memory latency in front of every
+  // tile's DMA; it is issued one tile AHEAD instead, before this iteration's DMAs (so that nothing waits on
+  // them), and lands while the tile is multiplied.
+  struct TileIdx {
+    int t;              // tile
+    int rr[PC / 4];     // gathered input rows of this lane's pieces as loaded (validity is re-derived from t:
+                        // nothing may consume the loaded values before the next iteration)
+  };
+  auto load_idx = [&](int t, TileIdx& ix) {
+    ix.t = t;
+#pragma unroll
+    for (int j = 0; j < PC / 4; ++j) {
+      const int p = t * kWR + (wave + 4 * j) * RC + lane / SC;
+      ix.rr[j] = nbr[(size_t)min(p, Mout - 1) * K + k];         // branch-free: all loads issue back to back
+    }
+  };
+  auto stage = [&](const TileIdx& ix, int buf) {
 #pragma unroll
     for (int j = 0; j < PN / 4; ++j) {
       const int piece = wave + 4 * j, r = piece * RN + lane / SN, slot = lane % SN;
-      const int p = t * kWR + r;
+      const int p = ix.t * kWR + r;
       const unsigned short* src = zero;
-      if (p < Mout) src = gout + (size_t)(order ? order[p] : p) * COUT_P + ((slot ^ fsw(r, SN)) << 3);
+      if (p < Mout) src = gout + (size_t)p * COUT_P + ((slot ^ fsw(r, SN)) << 3);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(Ns + (buf * kWR + piece * RN) * COUT_P),
                                        16, 0, 0);
@@ -1216,12 +1232,9 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
 #pragma unroll
     for (int j = 0; j < PC / 4; ++j) {
       const int piece = wave + 4 * j, r = piece * RC + lane / SC, slot = lane % SC;
-      const int p = t * kWR + r;
+      const int p = ix.t * kWR + r;
       const unsigned short* src = zero;
-      if (p < Mout) {
-        const int rr = nbr[(size_t)(order ? order[p] : p) * K + k];
-        if (rr >= 0) src = in + (size_t)rr * CIN_P + ((slot ^ fsw(r, SC)) << 3);
-      }
+      if (p < Mout && ix.rr[j] >= 0) src = in + (size_t)ix.rr[j] * CIN_P + ((slot ^ fsw(r, SC)) << 3);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(Cs + (buf * kWR + piece * RC) * CIN_P),
                                        16, 0, 0);
@@ -1232,13 +1245,19 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (n_active > 0) stage(t_begin + s_list[0], 0);
+  TileIdx ix, nxt;
+  if (n_active > 0) {
+    load_idx(t_begin + s_list[0], ix);
+    stage(ix, 0);
+  }
+  if (n_active > 1) load_idx(t_begin + s_list[1], ix);
   __syncthreads();
   int buf = 0;
   const int sub = (li & 3) >> 1, half = (li & 1) << 2;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   for (int ai = 0; ai < n_active; ++ai) {
-    if (ai + 1 < n_active) stage(t_begin + s_list[ai + 1], buf ^ 1);
+    if (ai + 2 < n_active) load_idx(t_begin + s_list[ai + 2], nxt);  // lands while this tile is multiplied
+    if (ai + 1 < n_active) stage(ix, buf ^ 1);
     {
       // transposing fragment read: lane li of a 16-lane group points at [row k0 + (li>>2)][channels c0 + 4*(li&3) ..+3].
       // Issued as inline asm + an explicit lgkmcnt wait tied to the fragment registers: the compiler makes
@@ -1278,6 +1297,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
     }
     __syncthreads();
     buf ^= 1;
+    ix = nxt;
   }
   float* pbase = partial + ((size_t)chunk * K + k) * COUT_P * CIN_P;
 #pragma unroll
@@ -1565,7 +1585,7 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
     attr_set = true;
   }
   if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128)) {
-    if (io_bf16 && cin == CIN_P && cout == COUT_P) {
+    if (io_bf16 && cin == CIN_P && cout == COUT_P && order == nullptr) {   // rows already in tile order
       const size_t lds_d = (size_t)2 * kWR * (CIN_P + COUT_P) * sizeof(unsigned short);
       static bool dma_set = false;
       if (!dma_set && lds_d > 64 * 1024) {
@@ -1575,7 +1595,7 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
       }
       k_wgrad_bf16_dma<CIN_P, COUT_P><<<dim3(K, G), 256, lds_d, stream>>>(
           reinterpret_cast<const unsigned short*>(in), nbr, K, reinterpret_cast<const unsigned short*>(gout),
-          partial, Mout, order, masks, ntiles, tpc);
+          partial, Mout, masks, ntiles, tpc);
       UD_LAUNCH_CHECK();
       k_wgrad_reduce<<<ud_div_up((long long)cout * K * cin, 256), 256, 0, stream>>>(
           partial, G, K, CIN_P, COUT_P, cin, cout, gW);
