@@ -1174,11 +1174,12 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ in
 // pieces are XOR-swizzled on the source address so that the transposing fragment reads
 // (ds_read_b64_tr_b16: 8 rows x 32 B per 32 lanes) hit 8 different pieces; double-buffered, one barrier
 // per tile.  Removes the ds_write pass that made the register-staged kernel LDS-bound.
-template <int CIN_P, int COUT_P>
+template <int CIN_P, int COUT_P, bool GATHER_G>   // GATHER_G: gout rows are fetched through gorder
 __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __restrict__ in,
                                                         const int32_t* __restrict__ nbr, int K,
                                                         const unsigned short* __restrict__ gout,
                                                         float* __restrict__ partial, int Mout,
+                                                        const int32_t* __restrict__ gorder,
                                                         const unsigned* __restrict__ masks, int ntiles,
                                                         int tiles_per_chunk) {
   constexpr int SN = COUT_P / 8, SC = CIN_P / 8;             // 16-byte slots per row
@@ -1209,9 +1210,15 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
     int t;              // tile
     int rr[PC / 4];     // gathered input rows of this lane's pieces as loaded (validity is re-derived from t:
                         // nothing may consume the loaded values before the next iteration)
+    int og[GATHER_G ? PN / 4 : 1];   // gout rows (GATHER_G)
   };
   auto load_idx = [&](int t, TileIdx& ix) {
     ix.t = t;
+    if (GATHER_G) {
+#pragma unroll
+      for (int j = 0; j < PN / 4; ++j)
+        ix.og[j] = gorder[min(t * kWR + (wave + 4 * j) * RN + lane / SN, Mout - 1)];
+    }
 #pragma unroll
     for (int j = 0; j < PC / 4; ++j) {
       const int p = t * kWR + (wave + 4 * j) * RC + lane / SC;
@@ -1224,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
       const int piece = wave + 4 * j, r = piece * RN + lane / SN, slot = lane % SN;
       const int p = ix.t * kWR + r;
       const unsigned short* src = zero;
-      if (p < Mout) src = gout + (size_t)p * COUT_P + ((slot ^ fsw(r, SN)) << 3);
+      if (p < Mout) src = gout + (size_t)(GATHER_G ? ix.og[j] : p) * COUT_P + ((slot ^ fsw(r, SN)) << 3);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(Ns + (buf * kWR + piece * RN) * COUT_P),
                                        16, 0, 0);
@@ -1585,17 +1592,27 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
     attr_set = true;
   }
   if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128)) {
-    if (io_bf16 && cin == CIN_P && cout == COUT_P && order == nullptr) {   // rows already in tile order
+    // the DMA kernel walks nbr in tile order: either nothing is permuted (order NULL) or the caller passes a
+    // rulebook already in row_order (io bit 1) and row_order only locates the gout rows
+    const bool presorted = (io_bf16 & 2) != 0;
+    if ((io_bf16 & 1) && cin == CIN_P && cout == COUT_P && (order == nullptr || presorted)) {
       const size_t lds_d = (size_t)2 * kWR * (CIN_P + COUT_P) * sizeof(unsigned short);
       static bool dma_set = false;
       if (!dma_set && lds_d > 64 * 1024) {
-        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16_dma<CIN_P, COUT_P>,
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16_dma<CIN_P, COUT_P, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16_dma<CIN_P, COUT_P, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
         dma_set = true;
       }
-      k_wgrad_bf16_dma<CIN_P, COUT_P><<<dim3(K, G), 256, lds_d, stream>>>(
-          reinterpret_cast<const unsigned short*>(in), nbr, K, reinterpret_cast<const unsigned short*>(gout),
-          partial, Mout, masks, ntiles, tpc);
+      const unsigned short* in16 = reinterpret_cast<const unsigned short*>(in);
+      const unsigned short* g16 = reinterpret_cast<const unsigned short*>(gout);
+      if (order)
+        k_wgrad_bf16_dma<CIN_P, COUT_P, true><<<dim3(K, G), 256, lds_d, stream>>>(in16, nbr, K, g16, partial, Mout,
+                                                                                   order, masks, ntiles, tpc);
+      else
+        k_wgrad_bf16_dma<CIN_P, COUT_P, false><<<dim3(K, G), 256, lds_d, stream>>>(in16, nbr, K, g16, partial, Mout,
+                                                                                    nullptr, masks, ntiles, tpc);
       UD_LAUNCH_CHECK();
       k_wgrad_reduce<<<ud_div_up((long long)cout * K * cin, 256), 256, 0, stream>>>(
           partial, G, K, CIN_P, COUT_P, cin, cout, gW);
@@ -1603,7 +1620,8 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
       return UD_OK;
     }
   }
-  if (io_bf16)
+  if (io_bf16 & 2) return UD_ERR_UNSUPPORTED;     // the pre-sorted-rulebook mode exists for the DMA kernel only
+  if (io_bf16 & 1)
     k_wgrad_bf16<CIN_P, COUT_P, true><<<dim3(K, G), 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
                                                                         Mout, order, masks, ntiles, tpc);
   else
@@ -1647,7 +1665,8 @@ extern "C" int ud_spconv_wgrad_bf16(const void* in_, const int32_t* nbr, const v
   const float* in = reinterpret_cast<const float*>(in_);
   const float* gout = reinterpret_cast<const float*>(gout_);
   if (Mout < 0 || K <= 0 || K > 32 || Cin <= 0 || Cout <= 0 || !gW) return UD_ERR_INVALID_ARG;
-  if (io_bf16 && ((Cin & 7) || (Cout & 7))) return UD_ERR_UNSUPPORTED;
+  if ((io_bf16 & 1) && ((Cin & 7) || (Cout & 7))) return UD_ERR_UNSUPPORTED;
+  if ((io_bf16 & 2) && (!(io_bf16 & 1) || !row_order || !tile_masks)) return UD_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   if (Mout == 0) {
     UD_HIP_TRY(hipMemsetAsync(gW, 0, (size_t)Cout * K * Cin * sizeof(float), stream));

@@ -300,10 +300,15 @@ class _SparseConvFn(torch.autograd.Function):
                 need = lib.ud_spconv_wgrad_bf16_workspace_bytes(Mout, K, cin, cout)
                 ws = _lib.workspace(w.device, need, "spconv_wgrad")
                 order = mask_order(nbr, False)
-                g_sorted = gout if order is None else gout.index_select(0, order.long())
+                if order is not None and cin in (64, 128) and cout in (64, 128):
+                    # rulebook pre-sorted (cached), gout rows located through row_order inside the kernel
+                    g_rows, io, row_order = gout, 3, order
+                else:
+                    g_rows = gout if order is None else gout.index_select(0, order.long())
+                    io, row_order = 1, None
                 _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(sorted_rulebook(nbr)),
-                                                    _lib.ptr(g_sorted), _lib.ptr(gw), Mout, K, cin, cout, 1,
-                                                    None, _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
+                                                    _lib.ptr(g_rows), _lib.ptr(gw), Mout, K, cin, cout, io,
+                                                    _lib.ptr(row_order), _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
             if has_bias and ctx.needs_input_grad[2]:
                 gb = gout.float().sum(0)

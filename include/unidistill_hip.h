@@ -243,8 +243,10 @@ int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t 
 /* Mixed-precision weight gradient (training under bf16 autocast): operands rounded to bf16 when the
  * 64-row tiles are staged, fp32 accumulation on v_mfma_f32_16x16x32_bf16, ordered reduction of the row
  * chunks (deterministic).  row_order (optional) is the forward kernel's row permutation; tiles that
- * have no pair for an offset are skipped.  K <= 32.  gW f32[Cout,K,Cin].  io_bf16 != 0: `in` and `gout`
- * already hold bf16 rows (Cin, Cout % 8 == 0); otherwise they are fp32. */
+ * have no pair for an offset are skipped.  K <= 32.  gW f32[Cout,K,Cin].  io_bf16 bit 0: `in` and `gout`
+ * already hold bf16 rows (Cin, Cout % 8 == 0); otherwise they are fp32.  Bit 1 (with bit 0, row_order and
+ * tile_masks; Cin, Cout in {64, 128}, else UD_ERR_UNSUPPORTED): `nbr` and `tile_masks` are ALREADY permuted
+ * into row_order and row_order only locates the gout rows -- spares the caller a gather pass over gout. */
 size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin, int Cout);
 int ud_spconv_wgrad_bf16(const void* in, const int32_t* nbr, const void* gout, float* gW, int Mout,
                          int K, int Cin, int Cout, int io_bf16, const int32_t* row_order,

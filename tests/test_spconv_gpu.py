@@ -254,3 +254,41 @@ def test_bev_nhwc_bf16_equals_dense_view():
     bev.backward(g)
     ref.backward(g.float())
     assert torch.equal(fb.grad.float(), ff.grad)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64)])
+def test_bf16_weight_gradient_many_tiles_per_chunk(cin, cout):
+    """The LDS-DMA weight-gradient kernel on a rulebook long enough that every workgroup walks many 64-row
+    tiles (index prefetch two tiles ahead, double-buffered DMA, skipped inactive tiles), with the rulebook
+    pre-sorted and the gout rows located through row_order (io bit 1), and with nothing permuted: both equal
+    the CPU oracle on bf16-rounded operands and each other bit for bit."""
+    from unidistill_amd import _lib
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(cin + cout)
+    shape = (1, 12, 70, 80)
+    coords = _sites(rng, *shape, 0.35)
+    M, K = len(coords), 27
+    assert M > 20000
+    nbr_np = oracle.spconv_subm_rulebook(coords, shape, (3, 3, 3))
+    feat = rng.standard_normal((M, cin)).astype(np.float32)
+    gout = rng.standard_normal((M, cout)).astype(np.float32)
+    ref = oracle.spconv_wgrad(_bf16(feat), nbr_np, _bf16(gout), cout)
+    nbr = torch.from_numpy(nbr_np).cuda()
+    f16, g16 = torch.from_numpy(feat).cuda().bfloat16(), torch.from_numpy(gout).cuda().bfloat16()
+    lib = _lib.load()
+    ws = _lib.workspace(nbr.device, lib.ud_spconv_wgrad_bf16_workspace_bytes(M, K, cin, cout), "spconv_wgrad")
+    order = sp.mask_order(nbr, False)
+    assert order is not None
+
+    def run(nbr_t, g_t, io, row_order, masks):
+        gw = torch.empty((cout, K, cin), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(f16), _lib.ptr(nbr_t), _lib.ptr(g_t), _lib.ptr(gw), M, K, cin, cout,
+                                            io, _lib.ptr(row_order), _lib.ptr(masks), _lib.ptr(ws), ws.numel(),
+                                            _lib.stream_of(gw)), "ud_spconv_wgrad_bf16")
+        return gw
+    a = run(sp.sorted_rulebook(nbr), g16, 3, order, sp.tile_masks(nbr))                       # gout through row_order
+    b = run(sp.sorted_rulebook(nbr), g16.index_select(0, order.long()), 1, None, sp.tile_masks(nbr))   # all pre-sorted
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, **_tol(ref))
+    c = run(nbr, g16, 1, None, None)                                                          # nothing permuted
+    np.testing.assert_allclose(c.cpu().numpy(), ref, **_tol(ref))
