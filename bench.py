@@ -164,6 +164,9 @@ def cpu_baseline_leg():
 
 def main():
     args = parse()
+    if os.environ.get("UD_FAULT_DUMP"):           # debugging aid: python stacks of a stuck rank after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["UD_FAULT_DUMP"]), exit=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -215,6 +218,10 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the MFMA leg takes extra training steps: under DDP those are collective, so EVERY rank runs it
+    mfma = None
+    if not args.no_roofline and ac is not None and not isinstance(trainer, train.GraphTrainer):
+        mfma = mfma_leg(trainer, batch)
     if rank == 0:
         samples = args.batch * world * args.steps
         line = {
@@ -235,8 +242,8 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = roofline_leg(device, 1)
-            if ac is not None and not isinstance(trainer, train.GraphTrainer):
-                line["roofline_mfma"] = mfma_leg(trainer, batch)
+            if mfma is not None:
+                line["roofline_mfma"] = mfma
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg()
         print(json.dumps(line))
