@@ -101,8 +101,9 @@ def roofline_leg(device, batch):
             # (profiles/r01_pmc_k_pool.md: FETCH_SIZE 182401 KB x2 (gfx950) + WRITE_SIZE 32400 KB);
             # counters cannot be read from inside this process, so the committed figure is reported.
             "traffic": 406.8e6 if (C, nx, ny, N) == (256, 180, 180, 473088) else None,
-            "note": "measured after the timed region; the training step itself uses the fused "
-                    "lift+splat (no [B,N,C] tensor), see DESIGN.md"}
+            "note": "measured after the timed region; HIP events bracket each launch, so avg_kernel_us carries "
+                    "the ~6 us dispatch latency that rocprofv3's kernel duration (profiles/) does not; the "
+                    "training step itself uses the fused lift+splat (no [B,N,C] tensor), see DESIGN.md"}
 
 
 MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
