@@ -303,10 +303,11 @@ class _SparseConvFn(torch.autograd.Function):
                 if order is not None and cin in (64, 128) and cout in (64, 128):
                     # rulebook pre-sorted (cached), gout rows located through row_order inside the kernel
                     g_rows, io, row_order = gout, 3, order
+                    nbr_rows = sorted_rulebook(nbr)
                 else:
-                    g_rows = gout if order is None else gout.index_select(0, order.long())
-                    io, row_order = 1, None
-                _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(sorted_rulebook(nbr)),
+                    # narrow layers (register-staged kernel): it follows row_order for both operands itself
+                    g_rows, io, row_order, nbr_rows = gout, 1, order, nbr
+                _lib.check(lib.ud_spconv_wgrad_bf16(_lib.ptr(features), _lib.ptr(nbr_rows),
                                                     _lib.ptr(g_rows), _lib.ptr(gw), Mout, K, cin, cout, io,
                                                     _lib.ptr(row_order), _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
