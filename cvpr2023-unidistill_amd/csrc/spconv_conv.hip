@@ -1200,7 +1200,9 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16_dma(const unsigned short* __
   const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_sp_zero16);
   // swizzle of the 32-byte piece index by the row (see the header comment); in 16-byte slot units << 1
   auto fsw = [](int r, int slots) -> int {
-    return slots == 16 ? (((r & 3) | ((r >> 1) & 4)) << 1) : ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
+    // 256-, 128- and 64-byte rows: the 8 rows x 32 B of a half-wave fragment read land on distinct banks
+    return slots == 16 ? (((r & 3) | ((r >> 1) & 4)) << 1)
+                       : (slots == 8 ? ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1) : (((r >> 3) & 1) << 1));
   };
   // The rows a tile gathers are known only through an index load (nbr; the host passes rulebook and gout rows
   // already in tile order).  Issued inside the staging it would put a memory latency in front of every
@@ -1591,7 +1593,7 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128)) {
+  if constexpr ((CIN_P == 32 || CIN_P == 64 || CIN_P == 128) && (COUT_P == 32 || COUT_P == 64 || COUT_P == 128)) {
     // the DMA kernel walks nbr in tile order: either nothing is permuted (order NULL) or the caller passes a
     // rulebook already in row_order (io bit 1) and row_order only locates the gout rows
     const bool presorted = (io_bf16 & 2) != 0;

@@ -300,7 +300,7 @@ class _SparseConvFn(torch.autograd.Function):
                 need = lib.ud_spconv_wgrad_bf16_workspace_bytes(Mout, K, cin, cout)
                 ws = _lib.workspace(w.device, need, "spconv_wgrad")
                 order = mask_order(nbr, False)
-                if order is not None and cin in (64, 128) and cout in (64, 128):
+                if order is not None and cin in (32, 64, 128) and cout in (32, 64, 128):
                     # rulebook pre-sorted (cached), gout rows located through row_order inside the kernel
                     g_rows, io, row_order = gout, 3, order
                     nbr_rows = sorted_rulebook(nbr)

@@ -245,7 +245,7 @@ int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t 
  * chunks (deterministic).  row_order (optional) is the forward kernel's row permutation; tiles that
  * have no pair for an offset are skipped.  K <= 32.  gW f32[Cout,K,Cin].  io_bf16 bit 0: `in` and `gout`
  * already hold bf16 rows (Cin, Cout % 8 == 0); otherwise they are fp32.  Bit 1 (with bit 0, row_order and
- * tile_masks; Cin, Cout in {64, 128}, else UD_ERR_UNSUPPORTED): `nbr` and `tile_masks` are ALREADY permuted
+ * tile_masks; Cin, Cout in {32, 64, 128}, else UD_ERR_UNSUPPORTED): `nbr` and `tile_masks` are ALREADY permuted
  * into row_order and row_order only locates the gout rows -- spares the caller a gather pass over gout. */
 size_t ud_spconv_wgrad_bf16_workspace_bytes(int Mout, int K, int Cin, int Cout);
 int ud_spconv_wgrad_bf16(const void* in, const int32_t* nbr, const void* gout, float* gW, int Mout,

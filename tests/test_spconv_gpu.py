@@ -256,7 +256,7 @@ def test_bev_nhwc_bf16_equals_dense_view():
     assert torch.equal(fb.grad.float(), ff.grad)
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (32, 32), (32, 64)])
 def test_bf16_weight_gradient_many_tiles_per_chunk(cin, cout):
     """The LDS-DMA weight-gradient kernel on a rulebook long enough that every workgroup walks many 64-row
     tiles (index prefetch two tiles ahead, double-buffered DMA, skipped inactive tiles), with the rulebook
