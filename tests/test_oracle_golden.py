@@ -113,3 +113,20 @@ def test_input_prep_oracle_matches_reference(golden):
         np.testing.assert_array_equal(mat, g[f"bda{ci}_mat"])
         np.testing.assert_array_equal(boxes, g[f"bda{ci}_boxes"])
         np.testing.assert_array_equal(oracle.points_transform(g["collected_points"], mat), g[f"bda{ci}_points"])
+
+
+def test_input_prep_host_matrices_match_reference(golden):
+    """Host half of ops/input_prep.py (no GPU needed): the float64 matrices it hands to ud_points_transform
+    are the reference's, bit for bit."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cvpr2023-unidistill_amd"))
+    from unidistill_amd.ops import input_prep as ip
+    g = golden("input_prep")
+    for ci in range(4):
+        a = g[f"bda{ci}_augs"]
+        np.testing.assert_array_equal(ip.bev_transform_matrix(float(a[0]), float(a[1]), a[2:5], bool(a[5]), bool(a[6])),
+                                      g[f"bda{ci}_mat"])
+    for i in range(3):
+        m = ip.sweep_to_key_matrix(g["key_lidar_to_ego"], g["key_ego_to_global"], g[f"sweep{i}_lidar_to_ego"])
+        np.testing.assert_array_equal(m, oracle.sweep_to_key_matrix(g["key_lidar_to_ego"], g["key_ego_to_global"],
+                                                                    g[f"sweep{i}_lidar_to_ego"]))
