@@ -53,44 +53,58 @@ __device__ bool inv4x4(const float* a, double* o) {
   return true;
 }
 
+// Products follow the arithmetic of the reference's CPU path bit for bit: torch's small batched
+// matmul (contraction*rows*cols < 400, aten/native/LinearAlgebra.cpp baddbmm_cpu_kernel) is a plain
+// loop  acc = 0; acc += a[k]*b[k]  in fp32 with separately rounded product and sum (no FMA).
+__device__ __forceinline__ float dot4_seq(float a0, float b0, float a1, float b1, float a2, float b2,
+                                          float a3, float b3) {
+  float acc = __fadd_rn(0.0f, __fmul_rn(a0, b0));
+  acc = __fadd_rn(acc, __fmul_rn(a1, b1));
+  acc = __fadd_rn(acc, __fmul_rn(a2, b2));
+  acc = __fadd_rn(acc, __fmul_rn(a3, b3));
+  return acc;
+}
+
 __global__ void k_prepare_mats(const float* __restrict__ s2e, const float* __restrict__ intrin,
                                const float* __restrict__ ida, const float* __restrict__ bda,
+                               const float* __restrict__ ida_inv, const float* __restrict__ intrin_inv,
                                float* __restrict__ mats, int B, int ncam) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * ncam) return;
   const int b = i / ncam;
   double inv[16];
   float* o = mats + (size_t)i * 48;
-  // inverse(ida), rounded to fp32 like torch.inverse's fp32 result
-  if (!inv4x4(ida + (size_t)i * 16, inv))
-    for (int k = 0; k < 16; ++k) inv[k] = __builtin_nan("");
-  for (int k = 0; k < 16; ++k) o[k] = (float)inv[k];
-  // combine = sensor2ego @ inverse(intrin): the inverse is rounded to fp32 first (a torch tensor),
-  // the fp32 product accumulates k = 0..3 with fma
-  if (!inv4x4(intrin + (size_t)i * 16, inv))
-    for (int k = 0; k < 16; ++k) inv[k] = __builtin_nan("");
+  // inverse(ida): the caller's fp32 inverse (torch.inverse, as the reference computes it), or the
+  // correctly rounded one (Gauss-Jordan in fp64, one rounding to fp32)
+  if (ida_inv) {
+    for (int k = 0; k < 16; ++k) o[k] = ida_inv[(size_t)i * 16 + k];
+  } else {
+    if (!inv4x4(ida + (size_t)i * 16, inv))
+      for (int k = 0; k < 16; ++k) inv[k] = __builtin_nan("");
+    for (int k = 0; k < 16; ++k) o[k] = (float)inv[k];
+  }
+  // combine = sensor2ego @ inverse(intrin) (lss_fpn.py:233): fp32 inverse, then the fp32 product
   float kin[16];
-  for (int k = 0; k < 16; ++k) kin[k] = (float)inv[k];
+  if (intrin_inv) {
+    for (int k = 0; k < 16; ++k) kin[k] = intrin_inv[(size_t)i * 16 + k];
+  } else {
+    if (!inv4x4(intrin + (size_t)i * 16, inv))
+      for (int k = 0; k < 16; ++k) inv[k] = __builtin_nan("");
+    for (int k = 0; k < 16; ++k) kin[k] = (float)inv[k];
+  }
   const float* s = s2e + (size_t)i * 16;
   for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) {
-      float acc = __fmul_rn(s[r * 4 + 0], kin[0 * 4 + c]);
-      for (int k = 1; k < 4; ++k) acc = fmaf(s[r * 4 + k], kin[k * 4 + c], acc);
-      o[16 + r * 4 + c] = acc;
-    }
+    for (int c = 0; c < 4; ++c)
+      o[16 + r * 4 + c] = dot4_seq(s[r * 4 + 0], kin[0 * 4 + c], s[r * 4 + 1], kin[1 * 4 + c],
+                                   s[r * 4 + 2], kin[2 * 4 + c], s[r * 4 + 3], kin[3 * 4 + c]);
   for (int k = 0; k < 16; ++k)
     o[32 + k] = bda ? bda[(size_t)b * 16 + k] : ((k % 5 == 0) ? 1.0f : 0.0f);
 }
 
 __device__ __forceinline__ void mat4_apply(const float* __restrict__ m, const float* p, float* q) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float acc = __fmul_rn(m[r * 4 + 0], p[0]);
-    acc = fmaf(m[r * 4 + 1], p[1], acc);
-    acc = fmaf(m[r * 4 + 2], p[2], acc);
-    acc = fmaf(m[r * 4 + 3], p[3], acc);
-    q[r] = acc;
-  }
+  for (int r = 0; r < 4; ++r)
+    q[r] = dot4_seq(m[r * 4 + 0], p[0], m[r * 4 + 1], p[1], m[r * 4 + 2], p[2], m[r * 4 + 3], p[3]);
 }
 
 // One thread per frustum point (b, cam, d, h, w): ego coordinates + BEV bin.
@@ -318,12 +332,13 @@ bool lss_ok(int BN, int D, int fH, int fW, int C) {
 }  // namespace
 
 extern "C" int ud_lss_prepare_mats(const float* sensor2ego, const float* intrin, const float* ida,
-                                   const float* bda, int B, int ncam, float* mats,
+                                   const float* bda, const float* ida_inv,
+                                   const float* intrin_inv, int B, int ncam, float* mats,
                                    ud_stream_t stream_) {
   if (!sensor2ego || !intrin || !ida || !mats || B <= 0 || ncam <= 0) return UD_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  k_prepare_mats<<<ud_div_up((long long)B * ncam, 64), 64, 0, stream>>>(sensor2ego, intrin, ida,
-                                                                       bda, mats, B, ncam);
+  k_prepare_mats<<<ud_div_up((long long)B * ncam, 64), 64, 0, stream>>>(
+      sensor2ego, intrin, ida, bda, ida_inv, intrin_inv, mats, B, ncam);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

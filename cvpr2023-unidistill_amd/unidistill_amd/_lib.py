@@ -28,7 +28,7 @@ _SIGS = {
     "ud_bev_pool_bwd_workspace_bytes": (c_size_t, [c_int] * 4 + [c_i64]),
     "ud_bev_pool_bwd": (c_int, [c_void_p] + [c_i64] * 4 + [c_void_p, c_void_p] + [c_int] * 5
                         + [c_void_p, c_size_t, c_void_p]),
-    "ud_lss_prepare_mats": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p]),
+    "ud_lss_prepare_mats": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p]),
     "ud_lss_geometry": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p,
                                                               c_void_p, c_void_p]),
     "ud_lss_depth_ctx": (c_int, [c_void_p] + [c_i64] * 4 + [c_int] * 5 + [c_void_p] * 3),

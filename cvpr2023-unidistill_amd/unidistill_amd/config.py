@@ -34,7 +34,8 @@ CAMERA_ENCODER = dict(
     z_bound=[POINT_CLOUD_RANGE[2], POINT_CLOUD_RANGE[5], POINT_CLOUD_RANGE[5] - POINT_CLOUD_RANGE[2]],
     d_bound=[2.0, 58.0, 0.5], final_dim=IMG_DIM, output_channels=256, downsample_factor=16,
     img_backbone_conf=dict(type="ResNet", depth=50, frozen_stages=0, out_indices=[0, 1, 2, 3],
-                           norm_eval=False),
+                           norm_eval=False,
+                           init_cfg=dict(type="Pretrained", checkpoint="torchvision://resnet50")),
     img_neck_conf=dict(type="SECONDFPN", in_channels=[256, 512, 1024, 2048],
                        upsample_strides=[0.25, 0.5, 1, 2], out_channels=[128, 128, 128, 128]),
     depth_net_conf=dict(in_channels=512, mid_channels=512))

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from ..ops import bn_act as hipbn, conv2d as hipconv
-from ..ops.spconv import folded_batchnorm
+from ..ops.spconv import folded_batchnorm, wants_grad
 
 
 def _mixed_precision(x):
@@ -74,9 +74,11 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         return super().forward(x, output_size)
 
 
-def _can_fuse_inference(x, bn):
+def _can_fuse_inference(x, bn, conv):
+    """conv + BN + ReLU as one inference kernel: BN in eval and no gradient wanted by the input, the
+    conv or the BN (a frozen-BN fine-tune keeps trainable conv weights: that must take the autograd path)."""
     return (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.affine and bn.track_running_stats
-            and not (torch.is_grad_enabled() and x.requires_grad))
+            and not wants_grad(x, bn, conv))
 
 
 _HIP_BN = os.environ.get("UD_HIP_BN", "1") != "0"      # A/B switch for the streaming BatchNorm kernels
@@ -85,8 +87,7 @@ _HIP_BN = os.environ.get("UD_HIP_BN", "1") != "0"      # A/B switch for the stre
 def batchnorm_act(bn, x, residual=None, relu=True):
     """relu(bn(x) (+ residual)): the streaming HIP kernels in bf16 channels-last mode (training-mode
     statistics with autograd, or eval-mode without), the PyTorch ops otherwise."""
-    frozen_grad = (not bn.training) and torch.is_grad_enabled() and (
-        x.requires_grad or (residual is not None and residual.requires_grad))
+    frozen_grad = (not bn.training) and wants_grad(x, residual, bn)
     if Conv2d.hip_enabled and _HIP_BN and isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm1d)) \
             and not frozen_grad and hipbn.supported(x, bn):
         return hipbn.bn_act(bn, x, residual, relu)
@@ -120,8 +121,7 @@ class FusedSequential(nn.Sequential):
                 continue
             j = i + skip
             bn = mods[j] if j < n else None
-            if bn is not None and _can_fuse_inference(x, bn) and not (torch.is_grad_enabled() and (
-                    conv.weight.requires_grad and x.requires_grad)):
+            if bn is not None and _can_fuse_inference(x, bn, conv):
                 relu = j + 1 < n and isinstance(mods[j + 1], nn.ReLU)
                 scale, shift = folded_batchnorm(bn)
                 x = hipconv.conv3x3_inference(x.to(torch.bfloat16), conv.weight, conv.bias, scale, shift,

@@ -43,10 +43,12 @@ class ResNet(nn.Module):
     """ResNet-50/101 trunk returning the feature maps listed in ``out_indices``."""
     arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
-    def __init__(self, depth=50, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False, **_):
+    def __init__(self, depth=50, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False,
+                 init_cfg=None, **_):
         super().__init__()
         self.out_indices = tuple(out_indices)
         self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
+        self.init_cfg = init_cfg
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
@@ -60,6 +62,22 @@ class ResNet(nn.Module):
             inplanes = planes * 4
             blocks += [Bottleneck(inplanes, planes) for _ in range(1, n)]
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self._freeze_stages()
+
+    def _freeze_stages(self):
+        """mmdet ResNet._freeze_stages: frozen_stages >= 0 freezes the stem (conv1 / bn1: no gradient,
+        bn1 on its running statistics), frozen_stages = n >= 1 additionally layer1..layer_n.  The
+        reference configuration has frozen_stages=0 (centerhead_fusion_exp.py:24-31)."""
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f"layer{i}")
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
 
     def init_weights(self):
         for m in self.modules():
@@ -68,6 +86,22 @@ class ResNet(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+        cfg = self.init_cfg or {}
+        if cfg.get("type") == "Pretrained":
+            # mmcv's Pretrained initialiser: torchvision://resnet50 needs the network; a local file works
+            import os
+            import warnings
+            path = str(cfg.get("checkpoint", ""))
+            if os.path.isfile(path):
+                state = torch.load(path, map_location="cpu")
+                state = state.get("state_dict", state)
+                missing = self.load_state_dict(state, strict=False)
+                if missing.missing_keys:
+                    warnings.warn(f"ResNet init_cfg: {len(missing.missing_keys)} keys missing in {path}")
+            else:
+                warnings.warn(f"ResNet init_cfg checkpoint {path!r} is not a local file (no network here): "
+                              "the backbone keeps its Kaiming initialisation, unlike the reference's "
+                              "ImageNet start")
 
     def forward(self, x):
         x = self.maxpool(batchnorm_act(self.bn1, self.conv1(x)))
@@ -80,6 +114,7 @@ class ResNet(nn.Module):
 
     def train(self, mode=True):
         super().train(mode)
+        self._freeze_stages()
         if mode and self.norm_eval:
             for m in self.modules():
                 if isinstance(m, nn.BatchNorm2d):
@@ -114,19 +149,24 @@ class SECONDFPN(nn.Module):
         return [torch.cat(ups, 1) if len(ups) > 1 else ups[0]]
 
 
+# type name -> class, like mmdet's BACKBONES / mmdet3d's NECKS registries (lss_fpn.py:143-149 builds through
+# them); tests register small stand-in networks here to pin LSSFPN / the model against the reference
+BACKBONES = {"ResNet": ResNet}
+NECKS = {"SECONDFPN": SECONDFPN}
+
+
 def build_backbone(cfg):
     cfg = dict(cfg)
     kind = cfg.pop("type")
-    if kind != "ResNet":
+    if kind not in BACKBONES:
         raise NotImplementedError(f"image backbone {kind!r}: every experiment overrides the default "
                                   "Swin config with ResNet-50 (centerhead_fusion_exp.py:24-31)")
-    cfg.pop("init_cfg", None)
-    return ResNet(**cfg)
+    return BACKBONES[kind](**cfg)
 
 
 def build_neck(cfg):
     cfg = dict(cfg)
     kind = cfg.pop("type")
-    if kind != "SECONDFPN":
+    if kind not in NECKS:
         raise NotImplementedError(kind)
-    return SECONDFPN(**cfg)
+    return NECKS[kind](**cfg)

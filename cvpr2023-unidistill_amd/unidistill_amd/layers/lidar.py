@@ -51,7 +51,7 @@ class SparseBasicBlock(sp.SparseModule):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
-        if x.indices.shape[0] != 0 and sp.can_fuse_inference(x, self.bn1) and not self.bn2.training \
+        if x.indices.shape[0] != 0 and sp.can_fuse_inference(x, self.bn1, self.conv1, self.conv2, self.bn2, skip.features) and not self.bn2.training \
                 and self.conv1.kernel_algo == 0:
             # inference: two kernels for the whole block (BN folded, residual + ReLU in the epilogue)
             y = self.conv1.forward_fused(x, self.bn1, relu=True)

@@ -23,8 +23,13 @@ from .image import build_backbone, build_neck
 class LSSFPN(nn.Module):
     def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, downsample_factor,
                  output_channels, img_backbone_conf, img_neck_conf, depth_net_conf,
-                 timestamp_net_conf=None, materialise=False):
+                 timestamp_net_conf=None, materialise=False, inverse="exact"):
         super().__init__()
+        # "exact": correctly rounded 4x4 inverses inside the matrix kernel (default: no solver launch,
+        # no sync).  "torch": torch.linalg.inv_ex on the device, i.e. the reference's own
+        # ida_mat.inverse() / torch.inverse(intrin_mat) call with that backend's rounding.
+        assert inverse in ("exact", "torch")
+        self.inverse = inverse
         self.downsample_factor = downsample_factor
         self.d_bound = d_bound
         self.final_dim = final_dim
@@ -70,7 +75,11 @@ class LSSFPN(nn.Module):
     def get_geometry_bins(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat, want_geom=False):
         """-> bins i32[B, N, 3] (and optionally ego coordinates f32[B,ncam,D,fH,fW,3])."""
         B, ncam = sensor2ego_mat.shape[:2]
-        mats = _lss.prepare_mats(sensor2ego_mat, intrin_mat, ida_mat, bda_mat)
+        ai = ki = None
+        if self.inverse == "torch":
+            ai = torch.linalg.inv_ex(ida_mat.float()).inverse
+            ki = torch.linalg.inv_ex(intrin_mat.float()).inverse
+        mats = _lss.prepare_mats(sensor2ego_mat, intrin_mat, ida_mat, bda_mat, ai, ki)
         fu, fv, fd = self._frustum_axes()
         return _lss.geometry(mats, fu, fv, fd, B, ncam, self._lo, self._size,
                              has_bda=bda_mat is not None, want_geom=want_geom)

@@ -23,16 +23,21 @@ def bin_origin_fp32(voxel_coord, voxel_size):
     return (vc - vs / np.float32(2.0)).astype(np.float32), vs
 
 
-def prepare_mats(sensor2ego, intrin, ida, bda):
-    """[B,ncam,4,4] x3 (+ bda [B,4,4] or None) -> mats f32[B*ncam,3,16] on the GPU."""
-    _lib.require_gpu(sensor2ego, intrin, ida, bda)
+def prepare_mats(sensor2ego, intrin, ida, bda, ida_inv=None, intrin_inv=None):
+    """[B,ncam,4,4] x3 (+ bda [B,4,4] or None) -> mats f32[B*ncam,3,16] on the GPU.
+
+    ida_inv / intrin_inv: the fp32 inverses exactly as the reference's ``ida_mat.inverse()`` /
+    ``torch.inverse(intrin_mat)`` (lss_fpn.py:222,233) produced them; with them the ego coordinates
+    and bins are bit-identical to the reference's CPU output.  None -> correctly rounded inverse
+    (fp64 Gauss-Jordan in the kernel; no solver launch, no host sync)."""
+    _lib.require_gpu(sensor2ego, intrin, ida, bda, ida_inv, intrin_inv)
     B, ncam = sensor2ego.shape[:2]
     s2e, k, a = (t.contiguous().float() for t in (sensor2ego, intrin, ida))
-    bd = None if bda is None else bda.contiguous().float()
+    bd, ai, ki = (None if t is None else t.contiguous().float() for t in (bda, ida_inv, intrin_inv))
     mats = torch.empty((B * ncam, 3, 16), dtype=torch.float32, device=s2e.device)
     _lib.check(_lib.load().ud_lss_prepare_mats(_lib.ptr(s2e), _lib.ptr(k), _lib.ptr(a), _lib.ptr(bd),
-                                               B, ncam, _lib.ptr(mats), _lib.stream_of(s2e)),
-               "ud_lss_prepare_mats")
+                                               _lib.ptr(ai), _lib.ptr(ki), B, ncam, _lib.ptr(mats),
+                                               _lib.stream_of(s2e)), "ud_lss_prepare_mats")
     return mats
 
 
@@ -67,20 +72,34 @@ def depth_ctx(depth_feature, D, C):
     return prob, ctx
 
 
+def _dense_permutation(shape, strides):
+    """True when (shape, strides) is a non-overlapping dense layout (some permutation of contiguous)."""
+    expect = 1
+    for n, st in sorted(((n, st) for n, st in zip(shape, strides) if n > 1), key=lambda t: t[1]):
+        if st != expect:
+            return False
+        expect *= n
+    return True
+
+
 def _lift_bwd(gsrc, pos, prob, ctx, like, ncam, D, C, nx, ny):
-    BN, _, fH, fW = like.shape
-    g = torch.zeros_like(like, dtype=torch.float32) if like.shape[1] > D + C else \
-        torch.empty_like(like, dtype=torch.float32)
+    """like = (shape, strides, device) of the forward's depth_feature (only its meta data is kept, the
+    activation itself is not held alive).  Channels beyond D+C are never written by the kernel and get
+    a zero gradient whichever layout branch allocates the buffer."""
+    shape, strides, device = like
+    BN, ch, fH, fW = shape
+    alloc = torch.zeros if ch > D + C else torch.empty
+    if strides[3] * fW == strides[2] and _dense_permutation(shape, strides):
+        g = alloc(BN * ch * fH * fW, dtype=torch.float32, device=device).as_strided(shape, strides)
+    else:
+        g = alloc(shape, dtype=torch.float32, device=device)
     sn, sc, sh, sw = g.stride()
-    if sw * fW != sh:
-        g = torch.empty(like.shape, dtype=torch.float32, device=like.device)
-        sn, sc, sh, sw = g.stride()
     lib = _lib.load()
     need = lib.ud_lss_lift_bwd_workspace_bytes(BN, D, C, fH, fW)
-    ws = _lib.workspace(like.device, need, "lss_bwd")
+    ws = _lib.workspace(device, need, "lss_bwd")
     _lib.check(lib.ud_lss_lift_bwd(_lib.ptr(gsrc), _lib.ptr(pos), _lib.ptr(prob), _lib.ptr(ctx),
                                    _lib.ptr(g), sn, sc, sh, sw, BN, ncam, D, C, fH, fW, nx, ny,
-                                   _lib.ptr(ws), ws.numel(), _lib.stream_of(like)), "ud_lss_lift_bwd")
+                                   _lib.ptr(ws), ws.numel(), _lib.stream_of(g)), "ud_lss_lift_bwd")
     return g
 
 
@@ -96,7 +115,7 @@ class Lift(torch.autograd.Function):
         _lib.check(_lib.load().ud_lss_lift_fwd(_lib.ptr(prob), _lib.ptr(cpm), _lib.ptr(lifted), BN, D,
                                                C, fH, fW, _lib.stream_of(lifted)), "ud_lss_lift_fwd")
         ctx.save_for_backward(prob, cpm)
-        ctx.meta = (depth_feature, D, C)
+        ctx.meta = ((tuple(depth_feature.shape), tuple(depth_feature.stride()), depth_feature.device), D, C)
         ctx.mark_non_differentiable()
         return lifted
 
@@ -132,7 +151,8 @@ class LiftSplat(torch.autograd.Function):
                                         _lib.ptr(ws), ws.numel(), _lib.stream_of(out)),
                    "ud_lss_splat_fwd")
         ctx.save_for_backward(prob, cpm, pos)
-        ctx.meta = (depth_feature, ncam, D, C, nx, ny)
+        ctx.meta = ((tuple(depth_feature.shape), tuple(depth_feature.stride()), depth_feature.device),
+                    ncam, D, C, nx, ny)
         ctx.mark_non_differentiable(bins)
         return out.permute(0, 3, 1, 2)
 

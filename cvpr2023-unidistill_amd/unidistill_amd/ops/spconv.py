@@ -235,9 +235,27 @@ def folded_batchnorm(bn):
     return hit[1], hit[2]
 
 
-def can_fuse_inference(x, bn=None):
-    """The fused conv(+BN+residual+ReLU) epilogue is inference-only: no autograd graph, BN in eval."""
-    if torch.is_grad_enabled() and x.features.requires_grad:
+def wants_grad(*objs):
+    """True when autograd is recording and any of the tensors / any parameter of the modules needs a
+    gradient -- then an inference-only fused kernel (which builds no graph) must NOT be used: with a
+    frozen BatchNorm in eval mode but trainable conv weights the input alone says nothing."""
+    if not torch.is_grad_enabled():
+        return False
+    for o in objs:
+        if o is None:
+            continue
+        if torch.is_tensor(o):
+            if o.requires_grad:
+                return True
+        elif any(p.requires_grad for p in o.parameters()):
+            return True
+    return False
+
+
+def can_fuse_inference(x, bn=None, *modules):
+    """The fused conv(+BN+residual+ReLU) epilogue is inference-only: BN in eval and nobody -- the input,
+    the conv(s) or the BatchNorm(s) in ``modules`` -- needs a gradient."""
+    if wants_grad(x.features, bn, *modules):
         return False
     return bn is None or (isinstance(bn, nn.BatchNorm1d) and not bn.training and bn.affine
                           and bn.track_running_stats)
@@ -471,7 +489,7 @@ class SparseSequential(SparseModule):
             if isinstance(m, _SparseConvBase) and isinstance(x, SparseConvTensor) and m.kernel_algo == 0:
                 # inference fast path: conv [+ BatchNorm1d(eval)] [+ ReLU] as one kernel
                 bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
-                if x.indices.shape[0] != 0 and can_fuse_inference(x, bn) and (bn is None or not bn.training):
+                if x.indices.shape[0] != 0 and can_fuse_inference(x, bn, m) and (bn is None or not bn.training):
                     j = i + (2 if bn is not None else 1)
                     relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
                     if bn is not None or relu:

@@ -40,10 +40,16 @@ class DistillStep(nn.Module):
     """Holds the trainable student and the frozen teacher; forward(batch) returns the loss dict."""
 
     def __init__(self, experiment="camera_exp_distill_lidar", teacher_train_mode=False,
-                 student=None, teacher=None):
+                 student=None, teacher=None, geometry=None):
         super().__init__()
         e = dict(C.DISTILL_EXPERIMENTS[experiment]) if isinstance(experiment, str) else dict(experiment)
         self.exp = e
+        # the experiment modules' _POINT_CLOUD_RANGE / _VOXEL_SIZE / _OUT_SIZE_FACTOR / _GRID_SIZE constants
+        # (distill_lidar.py:33-50); overridable so shrunk configurations can be pinned against the reference
+        geo = dict(point_cloud_range=C.POINT_CLOUD_RANGE, voxel_size=C.VOXEL_SIZE,
+                   out_size_factor=C.OUT_SIZE_FACTOR, grid_size=C.GRID_SIZE)
+        geo.update(geometry or {})
+        self.geo = geo
         self.model = student if student is not None else build_model(e["student"])
         self.teacher_model = teacher if teacher is not None else build_model(e["teacher"])
         self.teacher_model.det_head.dense_head.distill = True
@@ -52,6 +58,7 @@ class DistillStep(nn.Module):
         # Lightning's model.train() flips the registered teacher back to train
         # mode (BN batch statistics); teacher_train_mode reproduces that, default is eval.
         self.teacher_train_mode = teacher_train_mode
+        self.teacher_model.train(self.training and teacher_train_mode)   # frozen teacher: eval from the start
 
     def train(self, mode=True):
         super().train(mode)
@@ -77,10 +84,11 @@ class DistillStep(nn.Module):
         targets = head.assign_targets(gt)
         for enc in targets["box_encoding"].values():
             enc[torch.isinf(enc)] = 0
-        corners, valid = D.box_corners_bev(gt9, C.POINT_CLOUD_RANGE, C.VOXEL_SIZE, C.OUT_SIZE_FACTOR)
-        hw = C.GRID_SIZE[0] // C.OUT_SIZE_FACTOR
-        mask = D.calculate_box_mask_gaussian((gt.shape[0], 1, hw, hw), gt, C.POINT_CLOUD_RANGE,
-                                             C.VOXEL_SIZE, C.OUT_SIZE_FACTOR)
+        G = self.geo
+        pcr, vs, osf = G["point_cloud_range"], G["voxel_size"], G["out_size_factor"]
+        corners, valid = D.box_corners_bev(gt9, pcr, vs, osf)
+        mask = D.calculate_box_mask_gaussian((gt.shape[0], 1, G["grid_size"][1] // osf, G["grid_size"][0] // osf),
+                                             gt, pcr, vs, osf)
         local = torch.stack(head.local_normalisers(targets) + [valid.float().sum(), mask.sum()])
         return {"gt": gt, "targets": targets, "corners": corners, "valid": valid, "mask": mask,
                 "local": local}
@@ -114,9 +122,9 @@ class DistillStep(nn.Module):
         w_box, w_mask = norm[nh], norm[nh + 1]
         loss_feat = D.FeatureDistillLoss(feat_s, feat_t, prep["corners"], prep["valid"], weight=w_box)
         loss_rel = D.BEVDistillLoss(bev_s, bev_t, prep["corners"], prep["valid"], weight=w_box)
-        loss_cls, loss_reg = D.ResponseDistillLoss(resp_s, resp_t, prep["gt"], C.POINT_CLOUD_RANGE,
-                                                   C.VOXEL_SIZE, C.OUT_SIZE_FACTOR, clamp=e["clamp"],
-                                                   weight=w_mask, mask=prep["mask"])
+        loss_cls, loss_reg = D.ResponseDistillLoss(resp_s, resp_t, prep["gt"], self.geo["point_cloud_range"],
+                                                   self.geo["voxel_size"], self.geo["out_size_factor"],
+                                                   clamp=e["clamp"], weight=w_mask, mask=prep["mask"])
         loss = ret["loss"].mean() + e["feat"] * loss_feat + e["rel"] * loss_rel \
             + e["resp"] * (loss_cls + loss_reg)
         tb.update(loss_feature=loss_feat.detach(), loss_bev_rel=loss_rel.detach(),

@@ -104,9 +104,15 @@ int ud_bev_pool_bwd(const float* gout, int64_t sb, int64_t sc, int64_t sy, int64
 /*
  * mats[b*ncam+cam] = { inverse(ida), sensor2ego @ inverse(intrin), bda }  f32[B*ncam,3,16]
  * (lss_fpn.py:221-222,233,235-239).  sensor2ego/intrin/ida f32[B,ncam,4,4]; bda f32[B,4,4] or NULL.
+ * ida_inv / intrin_inv f32[B,ncam,4,4]: the fp32 inverses as the caller's torch.inverse produced
+ * them (the reference's own call; its rounding depends on the LAPACK/solver backend), or NULL for
+ * the correctly rounded inverse computed in fp64 in the kernel.  Every product is evaluated as the
+ * reference's CPU path does (acc = 0; acc += a[k]*b[k], fp32, no FMA), so with the reference's
+ * inverses the ego coordinates and bins of ud_lss_geometry are bit-identical to its CPU output.
  */
 int ud_lss_prepare_mats(const float* sensor2ego, const float* intrin, const float* ida,
-                        const float* bda, int B, int ncam, float* mats, ud_stream_t stream);
+                        const float* bda, const float* ida_inv, const float* intrin_inv, int B,
+                        int ncam, float* mats, ud_stream_t stream);
 
 /*
  * LSSFPN.get_geometry + binning (lss_fpn.py:200-240, :311-313) for every frustum point

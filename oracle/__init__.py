@@ -111,9 +111,24 @@ def lss_frustum(final_dim, downsample, d_bound):
     return u, v, d
 
 
-def lss_geometry(sensor2ego, intrin, ida, bda, u, v, d, voxel_coord, voxel_size):
-    """get_geometry + binning (lss_fpn.py:200-240, 311-313) in float32 numpy.
-    sensor2ego/intrin/ida [B,ncam,4,4], bda [B,4,4] -> geom f32[B,ncam,D,fH,fW,3], bins i32[...,3]."""
+def _matvec4_seq(A, x):
+    """A [...,4,4] @ x [...,4] the way torch's CPU small-bmm kernel evaluates it
+    (aten/native/LinearAlgebra.cpp baddbmm_cpu_kernel: acc = 0; acc += a[k]*b[k] in fp32, product and
+    sum rounded separately -- no FMA)."""
+    f32 = np.float32
+    acc = np.zeros(np.broadcast_shapes(A.shape[:-2], x.shape[:-1]) + (4,), f32)
+    for k in range(4):
+        acc = (acc + (A[..., :, k] * x[..., k:k + 1]).astype(f32)).astype(f32)
+    return acc
+
+
+def lss_geometry(sensor2ego, intrin, ida, bda, u, v, d, voxel_coord, voxel_size, ida_inv=None,
+                 intrin_inv=None):
+    """get_geometry + binning (lss_fpn.py:200-240, 311-313) in float32 numpy, operation for operation.
+    sensor2ego/intrin/ida [B,ncam,4,4], bda [B,4,4] -> geom f32[B,ncam,D,fH,fW,3], bins i32[...,3].
+    ida_inv / intrin_inv: the reference's fp32 torch.inverse results (then the output is bit-identical
+    to the reference's CPU output, pinned by tests/golden/lss_geometry.npz); None -> the correctly
+    rounded inverse (fp64, one rounding)."""
     f32 = np.float32
     D, fH, fW = len(d), len(v), len(u)
     fr = np.stack([np.broadcast_to(u.reshape(1, 1, fW), (D, fH, fW)),
@@ -121,18 +136,23 @@ def lss_geometry(sensor2ego, intrin, ida, bda, u, v, d, voxel_coord, voxel_size)
                    np.broadcast_to(d.reshape(D, 1, 1), (D, fH, fW)),
                    np.ones((D, fH, fW), f32)], -1).astype(f32)              # [D,fH,fW,4]
     B, ncam = sensor2ego.shape[:2]
-    ida_inv = np.linalg.inv(ida.astype(np.float64)).astype(f32)
-    k_inv = np.linalg.inv(intrin.astype(np.float64)).astype(f32)
-    combine = np.matmul(sensor2ego.astype(f32), k_inv)
-    p = np.einsum("bnij,dhwj->bndhwi", ida_inv, fr).astype(f32)
-    p = np.concatenate([p[..., :2] * p[..., 2:3], p[..., 2:]], -1).astype(f32)
-    p = np.einsum("bnij,bndhwj->bndhwi", combine, p).astype(f32)
+    if ida_inv is None:
+        ida_inv = np.linalg.inv(ida.astype(np.float64)).astype(f32)
+    if intrin_inv is None:
+        intrin_inv = np.linalg.inv(intrin.astype(np.float64)).astype(f32)
+    ida_inv, k_inv, s2e = ida_inv.astype(f32), intrin_inv.astype(f32), sensor2ego.astype(f32)
+    combine = np.zeros_like(s2e)
+    for k in range(4):
+        combine = (combine + (s2e[..., :, k:k + 1] * k_inv[..., k:k + 1, :]).astype(f32)).astype(f32)
+    p = _matvec4_seq(ida_inv.reshape(B, ncam, 1, 1, 1, 4, 4), fr[None, None])
+    p = np.concatenate([(p[..., :2] * p[..., 2:3]).astype(f32), p[..., 2:]], -1)
+    p = _matvec4_seq(combine.reshape(B, ncam, 1, 1, 1, 4, 4), p)
     if bda is not None:
-        p = np.einsum("bij,bndhwj->bndhwi", bda.astype(f32), p).astype(f32)
+        p = _matvec4_seq(bda.astype(f32).reshape(B, 1, 1, 1, 1, 4, 4), p)
     geom = p[..., :3]
     vc, vs = np.asarray(voxel_coord, f32), np.asarray(voxel_size, f32)
     lo = (vc - vs / f32(2.0)).astype(f32)
-    bins = np.trunc(((geom - lo) / vs).astype(f32)).astype(np.int32)
+    bins = np.trunc(((geom - lo).astype(f32) / vs).astype(f32)).astype(np.int32)
     return geom, bins
 
 

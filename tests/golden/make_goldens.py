@@ -91,7 +91,10 @@ def gold_lss_geometry():
           x_bound=[-54.0, 54.0, 0.6], y_bound=[-54.0, 54.0, 0.6], z_bound=[-5.0, 3.0, 8.0],
           sensor2ego=s2e, intrin=intr, ida=ida, bda=bda, frustum=lss.frustum,
           voxel_size=lss.voxel_size, voxel_coord=lss.voxel_coord, voxel_num=lss.voxel_num,
-          geom=geom, geom_xyz=geom_xyz)
+          geom=geom, geom_xyz=geom_xyz,
+          # the two inverses exactly as get_geometry's own calls produce them (lss_fpn.py:222,233);
+          # their last-bit rounding belongs to the LAPACK backend (MKL here), not to the algorithm
+          ida_inv=ida.inverse(), intrin_inv=torch.inverse(intr))
 
 
 def gold_lss_lift():
@@ -470,6 +473,148 @@ def gold_input_prep():
 
 ALL["input_prep"] = gold_input_prep
 
+
+
+def gold_fusion_encoder():
+    """FusionEncoder(use_elementwise=False) -- BEVFusion_nuscenes_base_exp.py:107-135: cat -> channel attention
+    (global average pool -> 1x1 conv -> sigmoid) -> 3x3 conv + BN + ReLU; eval and train forward, input grads.
+    128 -> 64 channels so that the MFMA conv path (channel multiples of 64) is exercised on the GPU."""
+    from unidistill.exps.multisensor_fusion.nuscenes.BEVFusion.BEVFusion_nuscenes_base_exp import FusionEncoder
+    torch.manual_seed(108)
+    g = torch.Generator().manual_seed(108)
+    m = FusionEncoder(use_elementwise=False, input_channel=128, output_channel=64)
+    bn = m.reduce_conv[1]
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    out = {"sd/" + k: v.clone() for k, v in m.state_dict().items()}
+    x1 = torch.randn(2, 64, 10, 12, generator=g, requires_grad=True)
+    x2 = torch.randn(2, 64, 10, 12, generator=g, requires_grad=True)
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x1, x2)
+    m.train()
+    y = m(x1, x2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update(x1=x1.detach(), x2=x2.detach(), y_eval=y_eval, y_train=y.detach(), gy=gy, g1=x1.grad, g2=x2.grad,
+               gw=m.reduce_conv[0].weight.grad, gatt=m.att[1].weight.grad,
+               y_sum=FusionEncoder(use_elementwise=True)(x1.detach(), x2.detach()))
+    _save("fusion_encoder", **out)
+
+
+ALL["fusion_encoder"] = gold_fusion_encoder
+
+
+def gold_model_step():
+    """Composition golden at a shrunk size (tests/golden/shrunk.py), everything executed by the reference's own
+    code on CPU:
+      * LSSFPN._forward_single_sweep (lss_fpn.py:266-320) incl. the lifted [B,N,C] tensor it hands to the
+        pooling extension (captured at the call site, lss_fpn.py:48-59) and the returned depth;
+      * BEVFusionCenterHead.forward, training and return_feature modes (centerhead_fusion_exp.py:134-171);
+      * Exp.training_step of the distillation experiment (camera_exp_distill_lidar.py:438-513): valid-box scan,
+        label +1, teacher call, corner scaling, the three distillation losses and the 100 / 40 / 10 weights --
+        called unbound on a stand-in ``self`` that owns the (reference) student and teacher models.
+    The image backbone / neck are small stand-ins registered on both sides (mmdet is not available)."""
+    import importlib
+    import shrunk as S
+    base = "unidistill.exps.multisensor_fusion.nuscenes.BEVFusion."
+    fus = importlib.import_module(base + "BEVFusion_nuscenes_centerhead_fusion_exp")
+    dis = importlib.import_module(base + "BEVFusion_nuscenes_centerhead_camera_exp_distill_lidar")
+    ref_lss.build_backbone = lambda cfg: S.TinyBackbone()
+    ref_lss.build_neck = lambda cfg: S.TinyNeck()
+    captured = {}
+    ext = sys.modules["unidistill.layers.blocks_3d.mmdet3d.voxel_pooling_ext"]
+
+    def capture(B, N, C, nx, ny, nz, geom, feat, out_, pos):
+        captured["lifted"], captured["geom_xyz"] = feat.detach().clone(), geom.detach().clone()
+        return _ref_import._cpu_voxel_pooling_forward_wrapper(B, N, C, nx, ny, nz, geom, feat, out_, pos)
+    ref_lss.voxel_pooling_ext.voxel_pooling_forward_wrapper = capture
+
+    def build(seed):
+        torch.manual_seed(seed)
+        cfg = S.reference_model_cfg()
+        for part in ("target_assigner", "proposal_layer", "dense_head"):     # mmcv.Config wraps list items too
+            cfg["det_head"][part]["densehead_tasks"] = [_ref_import._AttrDict(t)
+                                                        for t in cfg["det_head"][part]["densehead_tasks"]]
+        m = fus.BEVFusionCenterHead(model_cfg=_ref_import._AttrDict(cfg))
+        gg = torch.Generator().manual_seed(seed)
+        for mod in m.modules():                      # non-trivial BN state so eval != train != identity
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1, generator=gg)
+                mod.running_var.uniform_(0.6, 1.4, generator=gg)
+                mod.weight.data.uniform_(0.7, 1.3, generator=gg)
+                mod.bias.data.normal_(0, 0.1, generator=gg)
+        return m
+    student, teacher = build(109), build(110)
+    out = {}
+    for tag, m in (("student", student), ("teacher", teacher)):
+        for k, v in m.state_dict().items():
+            out[f"{tag}_sd/{k}"] = v.clone()
+    g = torch.Generator().manual_seed(111)
+    B, ncam, M = 2, 2, 8
+    imgs = torch.randn(B, 1, ncam, 3, *S.IMG_DIM, generator=g)
+    s2e, intr, ida, bda = _rand_calib(g, B, ncam, S.IMG_DIM)
+    mats = {"sensor2ego_mats": s2e.unsqueeze(1), "intrin_mats": intr.unsqueeze(1), "ida_mats": ida.unsqueeze(1),
+            "sensor2sensor_mats": torch.eye(4).repeat(B, 1, ncam, 1, 1), "bda_mat": bda}
+    gt = _rand_gt(g, B, M, [6, 3], 4, -11.0, 11.0)
+    gt[0, 2] = 0.0                                   # an all-zero row before the last valid one stays "valid"
+    gt_boxes, gt_labels = gt[..., :9].clone(), gt[..., 9].clone() - 1.0     # loader labels are 0-based
+    out.update(imgs=imgs, sensor2ego=s2e, intrin=intr, ida=ida, bda=bda, gt_boxes=gt_boxes, gt_labels=gt_labels,
+               ida_inv=ida.inverse(), intrin_inv=torch.inverse(intr))
+    # ---- LSSFPN._forward_single_sweep on the student's camera encoder (eval statistics: deterministic BN)
+    lss = student.camera_encoder.backbone
+    student.eval()
+    with torch.no_grad():
+        bev, depth = lss._forward_single_sweep(0, imgs, mats, is_return_depth=True)
+    out.update(lss_bev=bev, lss_depth=depth, lss_lifted=captured["lifted"], lss_geom_xyz=captured["geom_xyz"])
+    # ---- the distillation training step (student in train mode, frozen teacher in eval)
+    teacher.det_head.dense_head.distill = True
+    for p_ in teacher.parameters():
+        p_.requires_grad = False
+    teacher.eval()
+    student.train()
+    with torch.no_grad():
+        tf, tb, tr = teacher(None, imgs, mats, torch.cat([gt_boxes, (gt_labels + 1).unsqueeze(2)], 2),
+                             return_feature=True)
+    out.update(teacher_feat=tf, teacher_head0_hm=tr[0]["hm"])        # spot checks of the return_feature mode
+
+    class _Self:
+        """what Exp.training_step touches on ``self``"""
+        def __init__(self):
+            self.teacher_model, self.checkpoint_state_dict = teacher, teacher.state_dict()
+            self.calls = {}
+
+        def __call__(self, *a, **k):
+            r = student(*a, **k)
+            self.calls["student"] = r
+            return r
+    for name in ("_POINT_CLOUD_RANGE", "_VOXEL_SIZE", "_OUT_SIZE_FACTOR", "_GRID_SIZE"):
+        setattr(dis, name, {"_POINT_CLOUD_RANGE": S.PCR, "_VOXEL_SIZE": S.VOXEL, "_OUT_SIZE_FACTOR": S.OSF,
+                            "_GRID_SIZE": S.GRID}[name])
+    me = _Self()
+    batch = {"imgs": imgs, "mats_dict": mats, "gt_boxes": gt_boxes.clone(), "gt_labels": gt_labels.clone()}
+    loss = dis.Exp.training_step(me, batch)
+    loss.backward()
+    ret, tbd, feat_s, trunk_s, heads_s, _ = me.calls["student"]
+    out.update(loss=loss.detach(), loss_rpn=ret["loss"].detach(), student_feat=feat_s.detach(),
+               student_trunk_mean=trunk_s.detach().mean((0, 2, 3)), student_trunk_std=trunk_s.detach().std((0, 2, 3)))
+    for k in ("loss_feature", "loss_bev_rel", "loss_resp_cls", "loss_resp_reg"):
+        out[k] = tbd[k].detach()
+    for t in range(len(S.TASKS)):
+        for hn, v in heads_s[t].items():
+            out[f"student_head{t}_{hn}"] = v.detach()     # hm is post-sigmoid after get_loss (quirk 1)
+    for n, p_ in student.named_parameters():
+        if p_.grad is not None:
+            out[f"grad/{n}"] = p_.grad.clone()
+    for k, v in student.state_dict().items():             # BN running statistics after the train-mode pass
+        if "running_" in k:
+            out[f"student_after/{k}"] = v.clone()
+    _save("model_step", **out)
+
+
+ALL["model_step"] = gold_model_step
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)
