@@ -54,8 +54,6 @@ def parse():
     ap.add_argument("--autocast", default="bf16", choices=["none", "bf16"],
                     help="bf16 autocast for the dense (MIOpen) convs; the HIP ops always compute in fp32")
     ap.add_argument("--nchw", action="store_true", help="keep dense convs NCHW (default: channels-last)")
-    ap.add_argument("--graph", action="store_true",
-                    help="hipGraph-captured student pass (train.GraphTrainer; camera students only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -195,11 +193,7 @@ def main():
                                       with_imgs=args.workload != "lidar",
                                       with_points=args.workload != "camera")
     ac = torch.bfloat16 if args.autocast == "bf16" else None
-    if args.graph and wl["kind"] == "distill" and args.workload.startswith("camera"):
-        trainer = train.GraphTrainer(step, batch, device=device, autocast_dtype=ac,
-                                     channels_last=not args.nchw)
-    else:
-        trainer = train.Trainer(step, device=device, autocast_dtype=ac, channels_last=not args.nchw)
+    trainer = train.Trainer(step, device=device, autocast_dtype=ac, channels_last=not args.nchw)
 
     def barrier():
         if world > 1:
@@ -221,7 +215,7 @@ def main():
         dt = float(t.item())
     # the MFMA leg takes extra training steps: under DDP those are collective, so EVERY rank runs it
     mfma = None
-    if not args.no_roofline and ac is not None and not isinstance(trainer, train.GraphTrainer):
+    if not args.no_roofline and ac is not None:
         mfma = mfma_leg(trainer, batch)
     if rank == 0:
         samples = args.batch * world * args.steps
@@ -239,7 +233,7 @@ def main():
                        "precision": "fp32 everywhere" if ac is None else
                        "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the teacher's sparse convs (HIP MFMA kernels incl. 1x1 convs and all 3x3 / 1x1 weight gradients; libraries for strided / transposed convs and small-map 1x1 GEMMs); fp32 voxelize/splat/losses; fp32 master weights",
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
-                       "executor": "hipGraph" if isinstance(trainer, train.GraphTrainer) else "eager+DDP"},
+                       "executor": "eager+DDP"},
         }
         if not args.no_roofline:
             line["roofline"] = roofline_leg(device, 1)

@@ -16,6 +16,7 @@
 // For site sets that arrive in arbitrary row order (the voxelizer's first-appearance order) a
 // perm[] maps rank -> row.
 #include "ud_common.h"
+#include "ud_prof.h"
 #include <limits.h>
 
 namespace {
@@ -253,21 +254,64 @@ __global__ __launch_bounds__(256) void k_down_rulebook(const int32_t* __restrict
   if (r >= 0 && in_nbr) in_nbr[(long long)r * K + k] = o;
 }
 
-// dense[b, c, z, y, x] = feat[row, c]   (thread index: row fastest so x-neighbours coalesce)
+// dense[b, c, z, y, x] = feat[row(b,z,y,x), c] (0 where no voxel): NCDHW is x-fastest, the feature rows
+// are c-fastest, so a 64-cell x 64-channel tile is transposed through LDS and BOTH sides move 256-byte
+// pieces.  A workgroup owns 64 consecutive x of one (b, z, y) line and walks the channel chunks; the dense
+// tensor is written exactly once, zeros included (no memset of the 33 MB-per-sample tensor).  BWD reads
+// the dense gradient the same way and writes the rows of the occupied cells.
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_dense(float* __restrict__ feat,
-                                               const int32_t* __restrict__ coords, int M, int C,
+                                               const int32_t* __restrict__ rowmap, int C,
                                                GridShape g, float* __restrict__ dense) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)M * C) return;
-  const int c = (int)(t / M), row = (int)(t - (long long)c * M);
-  const int b = coords[row * 4 + 0], z = coords[row * 4 + 1], y = coords[row * 4 + 2],
-            x = coords[row * 4 + 3];
-  const size_t d = ((((size_t)b * C + c) * g.Dz + z) * g.Hy + y) * g.Wx + x;
-  if (BWD)
-    feat[(size_t)row * C + c] = dense[d];
-  else
-    dense[d] = feat[(size_t)row * C + c];
+  __shared__ float s_t[64][65];
+  __shared__ int s_row[64];
+  const int lane = ud_lane(), wv = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * 64;
+  const int line = blockIdx.y;                    // (b * Dz + z) * Hy + y
+  const int y = line % g.Hy, z = (line / g.Hy) % g.Dz, b = line / (g.Hy * g.Dz);
+  const int nx = min(64, g.Wx - x0);
+  if (threadIdx.x < 64)
+    s_row[threadIdx.x] = (threadIdx.x < nx) ? rowmap[(long long)line * g.Wx + x0 + threadIdx.x] : -1;
+  __syncthreads();
+  const size_t plane = (size_t)g.Dz * g.Hy * g.Wx;
+  const size_t base = (size_t)b * C * plane + ((size_t)z * g.Hy + y) * g.Wx + x0;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int nc = min(64, C - c0);
+    if (!BWD) {
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {              // wave wv stages cells wv*16 .. +15, lanes along c
+        const int x = wv * 16 + i;
+        const int row = s_row[x];
+        float v = 0.0f;
+        if (row >= 0 && lane < nc) v = feat[(size_t)row * C + c0 + lane];
+        s_t[x][lane] = v;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {              // wave wv stores channels wv*16 .. +15, lanes along x
+        const int c = wv * 16 + i;
+        if (c < nc && lane < nx)
+          __builtin_nontemporal_store(s_t[lane][c], &dense[base + (size_t)(c0 + c) * plane + lane]);
+      }
+      __syncthreads();
+    } else {
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int c = wv * 16 + i;
+        float v = 0.0f;
+        if (c < nc && lane < nx) v = __builtin_nontemporal_load(&dense[base + (size_t)(c0 + c) * plane + lane]);
+        s_t[lane][c] = v;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int x = wv * 16 + i;
+        const int row = s_row[x];
+        if (row >= 0 && lane < nc) feat[(size_t)row * C + c0 + lane] = s_t[x][lane];
+      }
+      __syncthreads();
+    }
+  }
 }
 
 bool shape_ok(const GridShape& g) {
@@ -409,21 +453,6 @@ extern "C" int ud_spconv_down_rulebook(const void* in_index, int in_rows_sorted,
   return UD_OK;
 }
 
-// SparseConvTensor.dense(): dense f32[B, C, Dz, Hy, Wx] = 0 everywhere, feat[row, :] at coords.
-extern "C" int ud_sparse_to_dense(const float* feat, const int32_t* coords, int M, int C, int B,
-                                  int Dz, int Hy, int Wx, float* dense, ud_stream_t stream_) {
-  GridShape g{B, Dz, Hy, Wx};
-  if (!shape_ok(g) || C <= 0 || M < 0 || !dense) return UD_ERR_INVALID_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  UD_HIP_TRY(hipMemsetAsync(dense, 0, (size_t)g.cells() * C * sizeof(float), stream));
-  if (M == 0) return UD_OK;
-  if (!feat || !coords) return UD_ERR_INVALID_ARG;
-  k_dense<false><<<ud_div_up((long long)M * C, 256), 256, 0, stream>>>((float*)feat, coords, M, C,
-                                                                       g, dense);
-  UD_LAUNCH_CHECK();
-  return UD_OK;
-}
-
 // ---- HeightCompression for the mixed-precision path ----------------------------------------------------
 // bev[b][y][x][c * Dz + z] = feat[row(b,z,y,x)][c] (0 where no voxel) as a channels-last bf16 map: what
 // `dense()` + `view(N, C*D, H, W)` (reference height_compression.py:19-22) + the trunk's bf16 cast produce,
@@ -517,16 +546,45 @@ extern "C" int ud_bev_to_sparse_bf16(const void* gbev, const int32_t* coords, in
   return UD_OK;
 }
 
-// Backward of dense(): gfeat[row, :] = gdense[b, :, z, y, x].
+// SparseConvTensor.dense(): dense f32[B, C, Dz, Hy, Wx] = 0 everywhere, feat[row, :] at coords.
+// workspace: ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx) (the cell -> row map).
+extern "C" int ud_sparse_to_dense(const float* feat, const int32_t* coords, int M, int C, int B,
+                                  int Dz, int Hy, int Wx, float* dense, void* workspace,
+                                  size_t workspace_bytes, ud_stream_t stream_) {
+  GridShape g{B, Dz, Hy, Wx};
+  if (!shape_ok(g) || C <= 0 || M < 0 || !dense) return UD_ERR_INVALID_ARG;
+  if ((long long)B * Dz * Hy > 65535ll) return UD_ERR_UNSUPPORTED;   // grid.y
+  if (M > 0 && (!feat || !coords)) return UD_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx)) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int32_t* rowmap = reinterpret_cast<int32_t*>(workspace);
+  UD_HIP_TRY(hipMemsetAsync(rowmap, 0xFF, (size_t)g.cells() * sizeof(int32_t), stream));
+  if (M > 0) {
+    k_fill_rowmap<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, rowmap);
+    UD_LAUNCH_CHECK();
+  }
+  UdProfScope prof("spconv.k_dense", stream);
+  k_dense<false><<<dim3(ud_div_up(Wx, 64), B * Dz * Hy), 256, 0, stream>>>((float*)feat, rowmap, C, g, dense);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+// Backward of dense(): gfeat[row, :] = gdense[b, :, z, y, x].  Same workspace.
 extern "C" int ud_dense_to_sparse(const float* gdense, const int32_t* coords, int M, int C, int B,
-                                  int Dz, int Hy, int Wx, float* gfeat, ud_stream_t stream_) {
+                                  int Dz, int Hy, int Wx, float* gfeat, void* workspace,
+                                  size_t workspace_bytes, ud_stream_t stream_) {
   GridShape g{B, Dz, Hy, Wx};
   if (!shape_ok(g) || C <= 0 || M < 0) return UD_ERR_INVALID_ARG;
   if (M == 0) return UD_OK;
   if (!gdense || !coords || !gfeat) return UD_ERR_INVALID_ARG;
+  if ((long long)B * Dz * Hy > 65535ll) return UD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx)) return UD_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  k_dense<true><<<ud_div_up((long long)M * C, 256), 256, 0, stream>>>(gfeat, coords, M, C, g,
-                                                                      (float*)gdense);
+  int32_t* rowmap = reinterpret_cast<int32_t*>(workspace);
+  UD_HIP_TRY(hipMemsetAsync(rowmap, 0xFF, (size_t)g.cells() * sizeof(int32_t), stream));
+  k_fill_rowmap<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, rowmap);
+  UD_LAUNCH_CHECK();
+  k_dense<true><<<dim3(ud_div_up(Wx, 64), B * Dz * Hy), 256, 0, stream>>>(gfeat, rowmap, C, g, (float*)gdense);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

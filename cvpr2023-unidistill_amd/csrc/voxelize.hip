@@ -9,22 +9,31 @@
 //   voxels are numbered in order of first appearance in the point list, per sample, and no new
 //   voxel is created once a sample has max_voxels; a voxel keeps its first P points in input
 //   order; num = min(#points, P); coords are emitted (b, z, y, x).
-// The GPU gets the same result without any order-dependent race:
-//   k_insert   open-addressing hash insert of the linear key; atomicMin records the FIRST point id
-//   k_flag_*   two-level scan over "I am my voxel's first point" flags -> first-appearance rank
-//   k_assign   per point: voxel row = sample base + rank; count (wave-aggregated integer atomic);
-//              the P smallest point ids of a voxel are kept by an atomicMin insertion chain
-//              (slot j always ends up holding the j-th smallest id, whatever the arrival order)
-//   k_gather   per voxel: copy the kept points (zero padded), num, and the mean (sum in slot order
-//              / max(num,1)) -- voxels[M,P,F] is optional, so the fused path writes M*(F+5) words
-//              instead of M*(P*F+4).
+// The GPU gets the same result without any order-dependent race, in five launches + one memset:
+//   k_insert   open-addressing hash over 64-bit entries (key << 32 | first point id): one word per
+//              voxel, so a point touches ONE random cache line (a plain load settles points whose voxel
+//              already holds a smaller id without any atomic; otherwise CAS on the empty slot / a 64-bit
+//              atomicMin on the matching one)
+//   k_first    per point ONE random read (its voxel's final entry) -> first id, kept for k_assign; the
+//              "I am the first point" flags become a bitmap over the points by wave ballots (no atomics),
+//              with in-block popcount prefixes; k_scan (one workgroup) scans the ~N/1024 block totals -> the
+//              first-appearance rank of a voxel is a three-term lookup in cache-resident tables
+//   k_assign   per point: rank -> output row; count (wave-aggregated integer atomic); the P smallest
+//              point ids of a voxel are kept by an atomicMin insertion chain (slot j always ends up
+//              holding the j-th smallest id, whatever the arrival order)
+//   k_gather   a wave per 64 output rows, the lanes spread over the (point slot, feature) elements of one
+//              row at a time: coalesced 4*P*F-byte row stores, num / count rows as 64-wide vectors, the
+//              mean as an ordered sum over the slots (shuffles) -- voxels[M,P,F] is optional, so the fused
+//              path writes M*(F+5) words instead of M*(P*F+4).
 #include "ud_common.h"
+#include "ud_prof.h"
 #include <limits.h>
+#include <algorithm>
 
 namespace {
 
 constexpr unsigned kEmpty = 0xFFFFFFFFu;
-constexpr int kTile = 1024;  // points per workgroup in the flag scan
+constexpr unsigned long long kEmpty64 = 0xFFFFFFFFFFFFFFFFull;
 
 struct VoxParams {
   float lo[3];
@@ -44,8 +53,7 @@ __device__ __forceinline__ unsigned hash_slot(unsigned key, int shift) {
 }
 
 __global__ __launch_bounds__(256) void k_insert(const float* __restrict__ pts, VoxParams p,
-                                                unsigned* __restrict__ tkey,
-                                                unsigned* __restrict__ tfirst,
+                                                unsigned long long* __restrict__ table,
                                                 int* __restrict__ pslot) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)p.B * p.N;
@@ -64,96 +72,139 @@ __global__ __launch_bounds__(256) void k_insert(const float* __restrict__ pts, V
     const int b = (int)(gid / p.N);
     const unsigned key =
         (unsigned)(((b * p.grid[2] + c[2]) * p.grid[1] + c[1])) * (unsigned)p.grid[0] + (unsigned)c[0];
+    const unsigned long long mine = ((unsigned long long)key << 32) | (unsigned long long)(unsigned)gid;
     unsigned h = hash_slot(key, p.tshift);
     while (true) {
-      const unsigned old = atomicCAS(&tkey[h], kEmpty, key);
-      if (old == kEmpty || old == key) break;
+      // relaxed peek: an entry of this voxel that already holds a smaller id needs no atomic at all
+      unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == kEmpty64) {
+        cur = atomicCAS(&table[h], kEmpty64, mine);
+        if (cur == kEmpty64) break;
+      }
+      if ((unsigned)(cur >> 32) == key) {
+        if (cur > mine) atomicMin(&table[h], mine);
+        break;
+      }
       h = (h + 1) & p.tmask;
     }
-    atomicMin(&tfirst[h], (unsigned)gid);
     slot = (int)h;
   }
   pslot[gid] = slot;
 }
 
-// exclusive scan of one int per thread across a 256-thread block
-__device__ __forceinline__ int block_excl_scan(int v, int* s_w, int& total) {
-  const int lane = ud_lane(), wave = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int a = __shfl_up(inc, o);
-    if (lane >= o) inc += a;
-  }
-  if (lane == 63) s_w[wave] = inc;
-  __syncthreads();
-  int base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int t = s_w[w];
-    if (w < wave) base += t;
-    tot += t;
-  }
-  total = tot;
-  __syncthreads();
-  return base + inc - v;
+// Per point: the final first id of its voxel (the one random read of the table after the inserts), kept
+// for k_assign; "I am my voxel's first point" flags leave the wave as one ballot word, so the first-point
+// bitmap costs no atomics.  A workgroup covers 1024 consecutive points = 16 bitmap words and stores their
+// in-block exclusive popcount prefixes + the block total; k_scan (one workgroup) scans the block totals
+// (a thousand values) and derives the per-sample voxel ranks / counts.  The first-appearance rank
+// of any voxel is then  bprefix[fp >> 10] + wlocal[fp >> 6] + popc(bitmap[fp >> 6] below bit fp & 63).
+constexpr int kFirstTile = 1024;
+
+__device__ __forceinline__ int rank_of(unsigned fp, const unsigned long long* bitmap, const int* bprefix,
+                                       const unsigned short* wlocal) {
+  return bprefix[fp >> 10] + (int)wlocal[fp >> 6] +
+         __popcll(bitmap[fp >> 6] & ((1ull << (fp & 63)) - 1ull));
 }
 
-__device__ __forceinline__ int4 load_flags(const unsigned* __restrict__ tfirst,
-                                           const int* __restrict__ pslot, long long g0,
-                                           long long total) {
-  int f[4];
+__global__ __launch_bounds__(256) void k_first(const unsigned long long* __restrict__ table,
+                                               const int* __restrict__ pslot, VoxParams p,
+                                               unsigned* __restrict__ fpid,
+                                               unsigned long long* __restrict__ bitmap,
+                                               unsigned short* __restrict__ wlocal,
+                                               int* __restrict__ part) {
+  __shared__ int s_cnt[16];
+  const long long total = (long long)p.B * p.N;
+  const int lane = ud_lane(), wv = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * kFirstTile;
+  // all four slot reads, then all four (random) table reads, are in flight together
+  int sl[4];
+  unsigned fp[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const long long g = g0 + u;
-    int v = 0;
-    if (g < total) {
-      const int s = pslot[g];
-      v = (s >= 0) && (tfirst[s] == (unsigned)g);
-    }
-    f[u] = v;
+  for (int k = 0; k < 4; ++k) {
+    const long long g = base + k * 256 + threadIdx.x;
+    sl[k] = (g < total) ? pslot[g] : -1;
   }
-  return make_int4(f[0], f[1], f[2], f[3]);
-}
-
-__global__ __launch_bounds__(256) void k_flag_partials(const unsigned* __restrict__ tfirst,
-                                                       const int* __restrict__ pslot,
-                                                       int* __restrict__ part, long long total) {
-  __shared__ int s_w[4];
-  const long long g0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  const int4 f = load_flags(tfirst, pslot, g0, total);
-  int tot;
-  block_excl_scan(f.x + f.y + f.z + f.w, s_w, tot);
-  if (threadIdx.x == 0) part[blockIdx.x] = tot;
-}
-
-// first-appearance rank of every voxel (global over the batch) + rank at each sample boundary
-__global__ __launch_bounds__(256) void k_flag_ranks(const unsigned* __restrict__ tfirst,
-                                                    const int* __restrict__ pslot,
-                                                    const int* __restrict__ part,
-                                                    int* __restrict__ tvid,
-                                                    int* __restrict__ samp_rank, long long total,
-                                                    int N, int B) {
-  __shared__ int s_w[4];
-  int pre = 0;
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) pre += part[i];
-  int pre_tot;
-  block_excl_scan(pre, s_w, pre_tot);
-  const long long g0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  const int4 f = load_flags(tfirst, pslot, g0, total);
-  int tot;
-  int run = pre_tot + block_excl_scan(f.x + f.y + f.z + f.w, s_w, tot);
-  const int fl[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const long long g = g0 + u;
-    if (g < total) {
-      if (g % N == 0) samp_rank[g / N] = run;
-      if (fl[u]) tvid[pslot[g]] = run;
-      run += fl[u];
+  for (int k = 0; k < 4; ++k)
+    fp[k] = (sl[k] >= 0) ? (unsigned)table[sl[k]] : kEmpty;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long g = base + k * 256 + threadIdx.x;
+    if (g < total) fpid[g] = fp[k];
+    const unsigned long long bits = __ballot(fp[k] == (unsigned)g && g < total);
+    if (lane == 0) {
+      const long long w = (base >> 6) + k * 4 + wv;
+      if (w * 64 < total) bitmap[w] = bits;
+      s_cnt[k * 4 + wv] = __popcll(bits);
     }
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) samp_rank[B] = pre_tot + tot;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    int pre = 0;
+    for (int i = 0; i < 16; ++i) pre += (i < (int)threadIdx.x) ? s_cnt[i] : 0;
+    const long long w = (base >> 6) + threadIdx.x;
+    if (w * 64 < total) wlocal[w] = (unsigned short)pre;
+    if (threadIdx.x == 15) part[blockIdx.x] = pre + s_cnt[15];
+  }
+}
+
+// One workgroup: exclusive scan of the ~N/1024 block totals, the voxel rank at every sample boundary, the
+// per-sample voxel counts (capped at max_voxels) and their total.  A separate launch on purpose: folding it
+// into k_first as a "last workgroup" tail needs a release fence per workgroup, and on this chip an
+// agent-scope release writes the L2 back -- with the L2 full of the hash table's dirty lines that cost
+// 110 us per call (measured), against ~3 us for this launch.
+__global__ __launch_bounds__(256) void k_scan(const int* __restrict__ part, int nb, VoxParams p,
+                                              const unsigned long long* __restrict__ bitmap,
+                                              const unsigned short* __restrict__ wlocal,
+                                              int* __restrict__ bprefix, int* __restrict__ samp_rank,
+                                              int32_t* __restrict__ m_out) {
+  __shared__ int s_w[4];
+  const int lane = ud_lane(), wv = threadIdx.x >> 6;
+  int run = 0;
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    const int i = b0 + threadIdx.x;
+    const int v = (i < nb) ? part[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int a = __shfl_up(inc, o);
+      if (lane >= o) inc += a;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = s_w[k];
+      if (k < wv) pre += t;
+      tot += t;
+    }
+    if (i < nb) bprefix[i] = run + pre + inc - v;
+    run += tot;
+    __syncthreads();
+  }
+  __syncthreads();
+  // rank at every sample boundary, then the per-sample voxel counts (capped) and their total
+  // (bprefix was written by this workgroup: read it back at agent scope, past the L1)
+  if (threadIdx.x == 0) {
+    int prev = 0, tot = 0;
+    for (int b = 0; b <= p.B; ++b) {
+      int r = run;
+      if (b < p.B) {
+        const unsigned g = (unsigned)((long long)b * p.N);
+        r = __hip_atomic_load(&bprefix[g >> 10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+            (int)wlocal[g >> 6] + __popcll(bitmap[g >> 6] & ((1ull << (g & 63)) - 1ull));
+      }
+      samp_rank[b] = r;
+      if (b > 0) {
+        const int m = min(r - prev, p.maxM);
+        m_out[b - 1] = m;
+        tot += m;
+      }
+      prev = r;
+    }
+    m_out[p.B] = tot;
+  }
 }
 
 // Output row base of sample b = sum over earlier samples of min(#voxels, maxM).
@@ -164,49 +215,38 @@ __device__ __forceinline__ int sample_row_base(const int* __restrict__ samp_rank
 }
 
 __global__ __launch_bounds__(256) void k_assign(const float* __restrict__ pts, VoxParams p,
-                                                const unsigned* __restrict__ tfirst,
-                                                const int* __restrict__ pslot,
-                                                const int* __restrict__ tvid,
+                                                const unsigned* __restrict__ fpid,
+                                                const unsigned long long* __restrict__ bitmap,
+                                                const int* __restrict__ bprefix,
+                                                const unsigned short* __restrict__ wlocal,
                                                 const int* __restrict__ samp_rank,
                                                 unsigned* __restrict__ top,
                                                 unsigned* __restrict__ cnt,
-                                                int32_t* __restrict__ coords,
-                                                int32_t* __restrict__ m_out) {
+                                                int32_t* __restrict__ coords) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)p.B * p.N;
   int row = -1;
   if (gid < total) {
-    const int s = pslot[gid];
-    if (s >= 0) {
+    const unsigned first = fpid[gid];
+    if (first != kEmpty) {
       const int b = (int)(gid / p.N);
-      const int r = tvid[s] - samp_rank[b];
+      const int r = rank_of(first, bitmap, bprefix, wlocal) - samp_rank[b];
       if (r < p.maxM) {
         row = sample_row_base(samp_rank, b, p.maxM) + r;
-        if (tfirst[s] == (unsigned)gid) {  // first point of the voxel writes its coordinates
+        if (first == (unsigned)gid) {  // first point of the voxel writes its coordinates
           const float* q = pts + gid * p.F;
           int c[3];
 #pragma unroll
           for (int a = 0; a < 3; ++a)
             c[a] = (int)floorf(__fdiv_rn(__fsub_rn(q[a], p.lo[a]), p.vs[a]));
-          coords[row * 4 + 0] = b;
-          coords[row * 4 + 1] = c[2];
-          coords[row * 4 + 2] = c[1];
-          coords[row * 4 + 3] = c[0];
+          *reinterpret_cast<int4*>(coords + (size_t)row * 4) = make_int4(b, c[2], c[1], c[0]);
         }
       }
     }
   }
-  if (gid == 0) {  // per-sample voxel counts + total, for the host / downstream kernels
-    int tot = 0;
-    for (int b = 0; b < p.B; ++b) {
-      const int m = min(samp_rank[b + 1] - samp_rank[b], p.maxM);
-      m_out[b] = m;
-      tot += m;
-    }
-    m_out[p.B] = tot;
-  }
   // Point count per voxel: one integer atomic per run of equal rows inside the wave (zero-padded
-  // clouds put thousands of consecutive points into one voxel).
+  // clouds put thousands of consecutive points into one voxel).  cnt starts at 0xFFFFFFFF (the one
+  // memset of the workspace), i.e. it holds count - 1.
   const int lane = ud_lane();
   const int prev = __shfl_up(row, 1);
   const bool start = (lane == 0) || (prev != row);
@@ -230,6 +270,13 @@ __global__ __launch_bounds__(256) void k_assign(const float* __restrict__ pts, V
   }
 }
 
+// A wave owns 64 consecutive output rows = one contiguous block of 64*P*F output floats, and walks that
+// block 64 elements at a time (element -> row r, point slot j, feature f): every store instruction is a
+// full 256-byte piece and the iterations are independent, so many gathered point reads are in flight.
+// The rows' kept point ids are staged once in LDS (coalesced).  mean[f] = (((v0 + v1) + v2) + ...) /
+// max(n, 1) in slot order, like MeanVFE's sum over the slot axis.
+constexpr int kGatherPMax = 16;  // ids staged in LDS up to this many slots per voxel
+
 __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, VoxParams p,
                                                 const unsigned* __restrict__ top,
                                                 const unsigned* __restrict__ cnt,
@@ -237,38 +284,81 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, V
                                                 float* __restrict__ voxels,
                                                 int32_t* __restrict__ num,
                                                 float* __restrict__ mean) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= m_out[p.B]) return;
-  const int n = min((int)cnt[row], p.P);
-  if (num) num[row] = n;
-  const unsigned* t = top + (size_t)row * p.P;
-  const float inv_den = (float)max(n, 1);
-  for (int f = 0; f < p.F; ++f) {
-    float acc = 0.0f;
-    for (int j = 0; j < p.P; ++j) {
+  __shared__ unsigned s_id[4][64 * kGatherPMax];
+  __shared__ int s_n[4][64];
+  const int lane = ud_lane(), wv = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wv) * 64;
+  const int M = m_out[p.B];
+  if (row0 >= M) return;
+  const int rows = min(64, M - row0);
+  const int P = p.P, F = p.F, E = P * F;
+  int n_l = 0;
+  if (lane < rows) {
+    n_l = min((int)(cnt[row0 + lane] + 1u), P);
+    if (num) num[row0 + lane] = n_l;
+  }
+  s_n[wv][lane] = n_l;
+  const bool staged = P <= kGatherPMax;
+  const unsigned* trow = top + (size_t)row0 * P;
+  if (staged)
+    for (int i = lane; i < rows * P; i += 64) s_id[wv][i] = trow[i];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+  const float invF = 1.0f / (float)F, invE = 1.0f / (float)E;
+  if (voxels) {
+    float* vrow = voxels + (size_t)row0 * E;
+    const int total = rows * E;
+    for (int e = lane; e < total; e += 64) {
+      int r = (int)(((float)e + 0.5f) * invE);
+      const int rem = e - r * E;
+      const int j = (int)(((float)rem + 0.5f) * invF);
+      const int f = rem - j * F;
       float v = 0.0f;
-      if (j < n) v = pts[(size_t)t[j] * p.F + f];
-      if (voxels) voxels[((size_t)row * p.P + j) * p.F + f] = v;
-      acc = __fadd_rn(acc, v);
+      if (j < s_n[wv][r]) {
+        const unsigned pid = staged ? s_id[wv][r * P + j] : trow[r * P + j];
+        v = pts[(size_t)pid * F + f];
+      }
+      __builtin_nontemporal_store(v, &vrow[e]);
     }
-    if (mean) mean[(size_t)row * p.F + f] = __fdiv_rn(acc, inv_den);
+  }
+  if (mean) {
+    float* mrow = mean + (size_t)row0 * F;
+    const int total = rows * F;
+    for (int e = lane; e < total; e += 64) {
+      const int r = (int)(((float)e + 0.5f) * invF);
+      const int f = e - r * F;
+      const int n = s_n[wv][r];
+      float acc = 0.0f;
+      for (int j = 0; j < P; ++j) {
+        float v = 0.0f;
+        if (j < n) {
+          const unsigned pid = staged ? s_id[wv][r * P + j] : trow[r * P + j];
+          v = pts[(size_t)pid * F + f];
+        }
+        acc = __fadd_rn(acc, v);
+      }
+      mrow[e] = __fdiv_rn(acc, (float)max(n, 1));
+    }
   }
 }
 
 struct VoxWs {
-  unsigned* tkey;    // ---- 0xFF-initialised block
-  unsigned* tfirst;
+  unsigned long long* table;  // ---- 0xFF-initialised block: hash entries, top lists, counts - 1, ticket
   unsigned* top;
+  unsigned* cnt;
+  unsigned* ticket;
   size_t ff_bytes;
-  unsigned* cnt;     // ---- zero-initialised block
-  size_t zero_off, zero_bytes;
-  int* pslot;
-  int* tvid;
+  unsigned long long* bitmap;  // ---- fully written by k_first (no initialisation)
+  unsigned short* wlocal;
   int* part;
+  int* bprefix;
+  unsigned* fpid;
+  int* pslot;
   int* samp_rank;
   size_t total_bytes;
   unsigned T;
   int tshift;
+  int nwords;
   int ntile;
   int cap;
 };
@@ -279,24 +369,26 @@ VoxWs carve(void* ws, int B, int N, int P, int maxM) {
   const size_t total = (size_t)B * N;
   unsigned T = 1024;
   int lg = 10;
-  while ((size_t)T < 2 * total) {
+  while ((size_t)T * 3 < total * 4) {  // load factor <= 0.75 even if every point opens a voxel
     T <<= 1;
     ++lg;
   }
   w.T = T;
   w.tshift = 32 - lg;
   w.cap = (int)((size_t)B * maxM < total ? (size_t)B * maxM : total);
-  w.ntile = (int)((total + kTile - 1) / kTile);
-  w.tkey = a.take<unsigned>(T);
-  w.tfirst = a.take<unsigned>(T);
+  w.nwords = (int)((total + 63) / 64);
+  w.ntile = (int)((total + kFirstTile - 1) / kFirstTile);
+  w.table = a.take<unsigned long long>(T);
   w.top = a.take<unsigned>((size_t)w.cap * P);
-  w.ff_bytes = a.used;
-  w.zero_off = a.used;
   w.cnt = a.take<unsigned>(w.cap);
-  w.zero_bytes = a.used - w.zero_off;
-  w.pslot = a.take<int>(total);
-  w.tvid = a.take<int>(T);
+  w.ticket = a.take<unsigned>(4);
+  w.ff_bytes = a.used;
+  w.bitmap = a.take<unsigned long long>(w.nwords);
+  w.wlocal = a.take<unsigned short>(w.nwords);
   w.part = a.take<int>(w.ntile);
+  w.bprefix = a.take<int>(w.ntile);
+  w.fpid = a.take<unsigned>(total);
+  w.pslot = a.take<int>(total);
   w.samp_rank = a.take<int>(B + 1);
   w.total_bytes = a.used;
   return w;
@@ -352,20 +444,30 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
   p.tshift = w.tshift;
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * N;
-  UD_HIP_TRY(hipMemsetAsync(w.tkey, 0xFF, w.ff_bytes, stream));
-  UD_HIP_TRY(hipMemsetAsync(w.cnt, 0, w.zero_bytes, stream));
-  k_insert<<<ud_div_up(total, 256), 256, 0, stream>>>(points, p, w.tkey, w.tfirst, w.pslot);
-  UD_LAUNCH_CHECK();
-  k_flag_partials<<<w.ntile, 256, 0, stream>>>(w.tfirst, w.pslot, w.part, total);
-  UD_LAUNCH_CHECK();
-  k_flag_ranks<<<w.ntile, 256, 0, stream>>>(w.tfirst, w.pslot, w.part, w.tvid, w.samp_rank, total,
-                                            N, B);
-  UD_LAUNCH_CHECK();
-  k_assign<<<ud_div_up(total, 256), 256, 0, stream>>>(points, p, w.tfirst, w.pslot, w.tvid,
-                                                      w.samp_rank, w.top, w.cnt, coords, m_out);
-  UD_LAUNCH_CHECK();
-  k_gather<<<ud_div_up(w.cap, 256), 256, 0, stream>>>(points, p, w.top, w.cnt, m_out, voxels,
-                                                      num_points, mean_feats);
-  UD_LAUNCH_CHECK();
+  UD_HIP_TRY(hipMemsetAsync(w.table, 0xFF, w.ff_bytes, stream));
+  {
+    UdProfScope prof("voxelize.k_insert", stream);
+    k_insert<<<ud_div_up(total, 256), 256, 0, stream>>>(points, p, w.table, w.pslot);
+    UD_LAUNCH_CHECK();
+  }
+  {
+    UdProfScope prof("voxelize.k_first", stream);
+    k_first<<<w.ntile, 256, 0, stream>>>(w.table, w.pslot, p, w.fpid, w.bitmap, w.wlocal, w.part);
+    UD_LAUNCH_CHECK();
+    k_scan<<<1, 256, 0, stream>>>(w.part, w.ntile, p, w.bitmap, w.wlocal, w.bprefix, w.samp_rank, m_out);
+    UD_LAUNCH_CHECK();
+  }
+  {
+    UdProfScope prof("voxelize.k_assign", stream);
+    k_assign<<<ud_div_up(total, 256), 256, 0, stream>>>(points, p, w.fpid, w.bitmap, w.bprefix, w.wlocal,
+                                                        w.samp_rank, w.top, w.cnt, coords);
+    UD_LAUNCH_CHECK();
+  }
+  {
+    UdProfScope prof("voxelize.k_gather", stream);
+    k_gather<<<ud_div_up(w.cap, 256), 256, 0, stream>>>(points, p, w.top, w.cnt, m_out, voxels,
+                                                        num_points, mean_feats);
+    UD_LAUNCH_CHECK();
+  }
   return UD_OK;
 }

@@ -57,8 +57,8 @@ _SIGS = {
     "ud_sparse_bev_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_sparse_to_bev_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_bev_to_sparse_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
-    "ud_dense_to_sparse": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_dense_to_sparse": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_distill_box_corners": (c_int, [c_void_p, c_int, c_int, c_int] + [ctypes.c_double] * 4
                                + [c_void_p, c_void_p, c_void_p]),
     "ud_distill_box_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -90,8 +90,8 @@ class LSSFPN(nn.Module):
     def get_cam_feats(self, imgs):
         B, S, N, C, H, W = imgs.shape
         x = imgs.reshape(B * S * N, C, H, W)
-        if self.img_backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last) and \
-                not self.img_backbone.conv1.weight.is_contiguous():
+        w = next((p for p in self.img_backbone.parameters() if p.dim() == 4), None)   # the stem convolution
+        if w is not None and w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous():
             x = x.contiguous(memory_format=torch.channels_last)        # NHWC model -> NHWC input
         f = self.img_neck(self.img_backbone(x))[0]
         return f.reshape(B, S, N, f.shape[1], f.shape[2], f.shape[3])

@@ -364,8 +364,10 @@ class _DenseFn(torch.autograd.Function):
         B, Dz, Hy, Wx = grid
         M, C = features.shape
         dense = torch.empty((B, C, Dz, Hy, Wx), dtype=torch.float32, device=features.device)
-        _lib.check(_lib.load().ud_sparse_to_dense(_lib.ptr(features), _lib.ptr(indices), M, C, B, Dz,
-                                                  Hy, Wx, _lib.ptr(dense), _lib.stream_of(dense)),
+        lib = _lib.load()
+        ws = _lib.workspace(features.device, lib.ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx), "sparse_bev")
+        _lib.check(lib.ud_sparse_to_dense(_lib.ptr(features), _lib.ptr(indices), M, C, B, Dz, Hy, Wx,
+                                          _lib.ptr(dense), _lib.ptr(ws), ws.numel(), _lib.stream_of(dense)),
                    "ud_sparse_to_dense")
         ctx.save_for_backward(indices)
         ctx.grid = grid
@@ -378,9 +380,11 @@ class _DenseFn(torch.autograd.Function):
         B, Dz, Hy, Wx = ctx.grid
         M, C = ctx.mc
         gdense = gdense.contiguous().float()
-        g = torch.empty((M, C), dtype=torch.float32, device=gdense.device)
-        _lib.check(_lib.load().ud_dense_to_sparse(_lib.ptr(gdense), _lib.ptr(indices), M, C, B, Dz,
-                                                  Hy, Wx, _lib.ptr(g), _lib.stream_of(g)),
+        g = torch.zeros((M, C), dtype=torch.float32, device=gdense.device)    # rows outside the grid: 0
+        lib = _lib.load()
+        ws = _lib.workspace(g.device, lib.ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx), "sparse_bev")
+        _lib.check(lib.ud_dense_to_sparse(_lib.ptr(gdense), _lib.ptr(indices), M, C, B, Dz, Hy, Wx,
+                                          _lib.ptr(g), _lib.ptr(ws), ws.numel(), _lib.stream_of(g)),
                    "ud_dense_to_sparse")
         return g, None, None
 

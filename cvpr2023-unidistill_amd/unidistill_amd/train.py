@@ -66,7 +66,7 @@ class DistillStep(nn.Module):
         return self
 
     # The step is split into phases so that neither the network pass nor its backward contains a
-    # collective or a host sync (needed for hipGraph capture, useful for eager too):
+    # collective or a host sync:
     #   prep (gt-only work + local normalisers) -> reduce (ONE all-reduce) -> teacher -> student.
     @staticmethod
     def _points(batch):
@@ -136,7 +136,7 @@ class DistillStep(nn.Module):
     def forward(self, batch):
         prep = self.reduce(self.prep(batch))
         gt = prep["gt"]
-        if not (self.overlap_teacher and gt.is_cuda) or torch.cuda.is_current_stream_capturing():
+        if not (self.overlap_teacher and gt.is_cuda):
             return self.student_loss(batch, prep, self.teacher(batch, prep))
         # The teacher and the student forward are independent until the distillation losses, and both
         # are chains of short dependent kernels: on two streams the GPU fills one chain's gaps with the
@@ -246,168 +246,3 @@ def synthetic_batch(device, batch_size=1, rank=0, ncam=6, sweeps=1, n_boxes=40, 
     batch["gt_boxes"] = torch.from_numpy(boxes).to(device)
     batch["gt_labels"] = torch.from_numpy(labels).to(device)
     return batch
-
-
-def _tree_map(fn, x):
-    if torch.is_tensor(x):
-        return fn(x)
-    if isinstance(x, dict):
-        return {k: _tree_map(fn, v) for k, v in x.items()}
-    if isinstance(x, (list, tuple)):
-        return type(x)(_tree_map(fn, v) for v in x)
-    return x
-
-
-def _tree_copy_(dst, src):
-    if torch.is_tensor(dst):
-        dst.copy_(src)
-    elif isinstance(dst, dict):
-        for k in dst:
-            _tree_copy_(dst[k], src[k])
-    elif isinstance(dst, (list, tuple)):
-        for d, s_ in zip(dst, src):
-            _tree_copy_(d, s_)
-
-
-class GraphTrainer:
-    """hipGraph-captured distillation trainer for students with static shapes (camera students).
-
-    One eager step issues ~5 000 kernel launches and is bound by host dispatch; here the whole
-    student side is captured once into three hipGraphs and replayed:
-        G_prep     FCOS targets, box corners, gaussian mask, local loss normalisers
-        [eager]    one all-reduce of the packed normalisers            (world > 1 only)
-        [eager]    teacher sparse LiDAR encoder (dynamic shapes)  ->  G_tdense: teacher trunk + head
-        G_student  zero grads, student forward, all losses, backward into ONE flat gradient buffer
-        [eager]    all-reduce of the flat gradient buffer over RCCL    (world > 1 only)
-        G_opt      grad-norm clip + fused AdamW
-    No collective and no host sync sits inside a captured region, so the same graphs serve any
-    world size.  Inputs are copied into static buffers before the replays.
-    """
-
-    def __init__(self, step_module, example_batch, lr=2e-4, weight_decay=1e-7, grad_clip=0.1,
-                 device=None, autocast_dtype=None, warmup=3, channels_last=False):
-        assert isinstance(step_module, DistillStep)
-        self.device = device or torch.device("cuda", torch.cuda.current_device())
-        self.m = step_module.to(self.device)
-        if channels_last:
-            to_channels_last(self.m)
-        self.m.train()
-        self.world = get_world_size()
-        self.grad_clip = grad_clip
-        self.ac = autocast_dtype
-        self.params = [p for p in self.m.model.parameters() if p.requires_grad]
-        # one flat fp32 gradient buffer; every .grad is a view into it (single RCCL all-reduce)
-        n = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, capturable=True,
-                                     foreach=True)
-        self.batch = _tree_map(lambda t: t.clone(), example_batch)      # static input buffers
-        self.lidar_teacher = self.m.teacher_model.lidar_encoder is not None
-        with _lib.workspace_scope(f"graph{id(self)}"):     # private scratch: pointers get baked in
-            self._capture(warmup)
-
-    # ---- pieces ---------------------------------------------------------------------------
-    def _autocast(self):
-        return torch.autocast("cuda", dtype=self.ac) if self.ac is not None else torch.autocast("cuda", enabled=False)
-
-    def _teacher_sparse(self):
-        """eager part of the teacher: sparse LiDAR encoder (host reads of voxel counts inside)."""
-        t = self.m.teacher_model
-        with torch.no_grad():
-            return t.lidar_encoder(DistillStep._points(self.batch))
-
-    def _teacher_dense(self, lidar_bev):
-        t = self.m.teacher_model
-        with torch.no_grad(), self._autocast():
-            cam = t.camera_encoder(self.batch["imgs"], self.batch["mats_dict"]) if t.camera_encoder is not None else None
-            if t.fusion_encoder is not None:
-                bev = t.fusion_encoder(lidar_bev, cam)
-            else:
-                bev = cam if cam is not None else lidar_bev
-            trunk, _ = t.bev_encoder(bev)
-            ret = t.det_head(trunk, None)
-        return bev, trunk, ret["multi_head_features"]
-
-    def _student(self):
-        self.flat_grad.zero_()
-        with self._autocast():
-            out = self.m.student_loss(self.batch, self.prep, self.teacher_out)
-        out["loss"].backward()
-        return out
-
-    def _optimizer(self):
-        if self.grad_clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip, foreach=True)
-        self.opt.step()
-
-    def _reduce_norm(self):
-        if self.world > 1:
-            torch.distributed.all_reduce(self.prep["local"], op=torch.distributed.ReduceOp.SUM)
-            self.prep["local"].div_(float(self.world))
-        self.prep["norm"] = self.prep["local"]
-
-    # ---- capture --------------------------------------------------------------------------
-    def _capture(self, warmup):
-        # Warm-up on a side stream initialises MIOpen / hipBLASLt handles, workspaces and the
-        # allocator (none of that is legal inside a capture); the model / optimizer state it
-        # touched is restored afterwards so training starts from the caller's weights.
-        warmup = max(int(warmup), 1)
-        snap_m = {k: v.detach().clone() for k, v in self.m.state_dict().items()}
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.prep = self.m.prep(self.batch)
-                self._reduce_norm()
-                lb = self._teacher_sparse() if self.lidar_teacher else None
-                self.teacher_out = self._teacher_dense(lb)
-                self._student()
-                self._optimizer()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        with torch.no_grad():
-            self.m.load_state_dict(snap_m)
-            for st in self.opt.state.values():          # exp_avg / exp_avg_sq / step back to zero
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
-        del snap_m
-        self.g_prep = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_prep):
-            self.prep = self.m.prep(self.batch)
-        pool = self.g_prep.pool()
-        self._reduce_norm()
-        self.lidar_bev = self._teacher_sparse().clone() if self.lidar_teacher else None
-        self.g_tdense = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_tdense, pool=pool):
-            self.teacher_out = self._teacher_dense(self.lidar_bev)
-        self.g_student = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_student, pool=pool):
-            self.out = self._student()
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, pool=pool):
-            self._optimizer()
-        torch.cuda.synchronize(self.device)
-
-    # ---- one training step ----------------------------------------------------------------
-    def step(self, batch):
-        # Back-to-back replays without a host-side join fault on this ROCm ("write access to a read-only
-        # page" inside a replayed graph); one stream join per step avoids it (tools/dbg_graph_b4.py).
-        torch.cuda.current_stream(self.device).synchronize()
-        if batch is not self.batch:
-            _tree_copy_(self.batch, batch)
-        self.g_prep.replay()
-        self._reduce_norm()
-        if self.lidar_teacher:
-            self.lidar_bev.copy_(self._teacher_sparse())
-        self.g_tdense.replay()
-        self.g_student.replay()
-        if self.world > 1:
-            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM)
-            self.flat_grad.div_(float(self.world))
-        self.g_opt.replay()
-        return self.out

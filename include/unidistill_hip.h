@@ -275,12 +275,16 @@ int ud_spconv_wgrad(const float* in, const int32_t* nbr, const float* gout, floa
                     int K, int Cin, int Cout, int algo, void* workspace, size_t workspace_bytes,
                     ud_stream_t stream);
 
-/* SparseConvTensor.dense() (height_compression.py:19): dense f32[B,C,Dz,Hy,Wx], zero filled, and
- * its backward gather gfeat[row,:] = gdense[b,:,z,y,x]. */
+/* SparseConvTensor.dense() (height_compression.py:19): dense f32[B,C,Dz,Hy,Wx], every element written
+ * once (feature or zero; the caller need not clear it), and its backward gather
+ * gfeat[row,:] = gdense[b,:,z,y,x].  workspace: ud_sparse_bev_workspace_bytes(B,Dz,Hy,Wx) (cell -> row map).
+ * B*Dz*Hy <= 65535. */
 int ud_sparse_to_dense(const float* feat, const int32_t* coords, int M, int C, int B, int Dz,
-                       int Hy, int Wx, float* dense, ud_stream_t stream);
+                       int Hy, int Wx, float* dense, void* workspace, size_t workspace_bytes,
+                       ud_stream_t stream);
 int ud_dense_to_sparse(const float* gdense, const int32_t* coords, int M, int C, int B, int Dz,
-                       int Hy, int Wx, float* gfeat, ud_stream_t stream);
+                       int Hy, int Wx, float* gfeat, void* workspace, size_t workspace_bytes,
+                       ud_stream_t stream);
 /* HeightCompression in the mixed-precision path (reference layers/blocks_2d/det3d/map_to_bev/
  * height_compression.py:19-22: dense() then view(N, C*D, H, W)): bev bf16[B,Hy,Wx,C*Dz] (channels-last,
  * channel = c*Dz + z) straight from feat bf16[M,C], zeros where no voxel; and its backward. (C*Dz) % 4 == 0. */

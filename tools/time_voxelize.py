@@ -32,6 +32,14 @@ def bench(B, sweeps, fused):
     M = int(m[B])
     alg = B * N * F * 4 + M * ((0 if fused else P * F * 4) + F * 4 + 16 + 4) if fused else B * N * 20 + M * 216
     print(f"B={B} sweeps={sweeps} N={N} M={M} fused={fused}: {t:.1f} us, algorithmic {alg/1e6:.2f} MB -> {alg/t/1e3:.1f} GB/s")
+    _lib.prof_enable(True)
+    for _ in range(10): run()
+    torch.cuda.synchronize(); _lib.prof_enable(False)
+    parts = []
+    for k in ("k_insert", "k_first", "k_assign", "k_gather"):
+        ms, n = _lib.prof_read("voxelize." + k)
+        parts.append(f"{k} {ms / max(n, 1) * 1e3:.1f}")
+    print("    per-kernel us (HIP events, incl. ~6 us dispatch each): " + ", ".join(parts))
 for B, sw in ((1, 1), (1, 10), (4, 10)):
     for fused in (False, True):
         bench(B, sw, fused)
