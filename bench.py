@@ -9,10 +9,19 @@ nuScenes-shaped input.  The path is pure data parallel: every ran
 own samples and gradients are averaged with RCCL, so `scaling` is "weak" and
 value = samples of all ranks / max-over-ranks wall time.
 
-After the timed region (never counted in `value`) two extra legs run on rank 0:
-  * roofline: the reference-boundary bev_pool forward (BASELINE.json: "bev_pool+voxelize HBM GB/s")
-    at the BASELINE shape, its dominant kernel timed with HIP events on its launch stream;
-  * cpu_baseline: the CPU oracle (oracle/, scalar C) on a bounded sample of the same hot path.
+HEADLINE = fp32, the reference's arithmetic (it has no autocast anywhere: base_cli.py:40-45); the bf16
+mixed-precision step (BASELINE.json configs[4] style) is timed afterwards with its own trainer and reported
+as the labelled object `bf16_mixed_precision` -- never as `value`.
+
+After the timed region (never counted in `value`) further legs run:
+  * bf16_mixed_precision (all ranks): the same workload under bf16 autocast + channels-last;
+  * roofline (rank 0): the reference-boundary bev_pool forward (BASELINE.json: "bev_pool+voxelize HBM GB/s")
+    at the BASELINE shape, its dominant kernel timed with HIP events on its launch stream, plus the
+    op-level and counter-byte fractions; roofline_voxelize: ud_voxelize at 30 k and 4 x 300 k points;
+    roofline_mfma: the 3x3 conv kernel family inside the bf16 step;
+  * cpu_baseline (rank 0, N=1): BASELINE configs[0] (camera-only student, 1 camera, batch 1, fwd+bwd) end to end
+    on the host cores -- torch CPU ops + the CPU oracle for the native ops (oracle/cpu_step.py), all cores and
+    one thread -- with the GPU timed on the same configuration beside it.
 """
 import argparse
 import json
@@ -51,8 +60,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=4,
                     help="samples per GPU (reference Exp default batch_size_per_device=4; BASELINE configs[3])")
     ap.add_argument("--workload", default="camera_exp_distill_lidar", choices=sorted(WORKLOADS))
-    ap.add_argument("--autocast", default="bf16", choices=["none", "bf16"],
-                    help="bf16 autocast for the dense (MIOpen) convs; the HIP ops always compute in fp32")
+    ap.add_argument("--autocast", default="none", choices=["none", "bf16"],
+                    help="precision of the HEADLINE: none = fp32 (the reference's arithmetic, default); bf16 = "
+                         "mixed precision as the headline (then no second leg)")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 mixed-precision leg")
     ap.add_argument("--nchw", action="store_true", help="keep dense convs NCHW (default: channels-last)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -95,6 +106,11 @@ def roofline_leg(device, batch):
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "avg_kernel_us": k_us, "launches": k_calls, "algorithmic_bytes_per_launch": alg,
             "op_avg_us": op_ms / reps * 1e3, "op_GBps": alg / (op_ms / reps * 1e-3) / 1e9,
+            # whole op (memset + k_bin + scan + k_fill + k_pool) against the same algorithmic bytes
+            "frac_op": alg / (op_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # the kernel against the HBM bytes it really moves (PMC traffic below: out-of-grid rows are never read)
+            "frac_counter_bytes": (406.8e6 / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+            if (C, nx, ny, N) == (256, 180, 180, 473088) else None,
             # HBM bytes per launch from the PMC passes of the same op at the same shape
             # (profiles/r01_pmc_k_pool.md: FETCH_SIZE 182401 KB x2 (gfx950) + WRITE_SIZE 32400 KB);
             # counters cannot be read from inside this process, so the committed figure is reported.
@@ -131,34 +147,162 @@ def mfma_leg(trainer, batch, steps=3):
             "note": "measured over %d extra steps after the timed region (HIP events around every launch)" % steps}
 
 
-def cpu_baseline_leg():
-    """Oracle (scalar C, 1 thread) on a bounded sample: 1 of 6 cameras of lift + bev_pool fwd+bwd,
-    a single-sweep voxelize+mean, a 2k-voxel slice of one 64->64 sparse conv, the 3 distill losses'
-    mask; extrapolated by the work ratio to one distillation step of the BEV extraction path."""
-    import oracle
-    from unidistill_amd import synthetic as syn
-    g = syn.rng(99)
-    s2e, intr, ida, bda = syn.camera_rig(g, 1, 1)
-    geom, _ = syn.frustum_bins_torch(s2e, intr, ida, bda, "cpu")
-    geom = geom.numpy()
-    n1 = geom.shape[1]
-    rs = np.random.default_rng(0)
-    feat = rs.standard_normal((1, n1, 256)).astype(np.float32)
-    gout = rs.standard_normal((1, 256, 180, 180)).astype(np.float32)
-    pts = syn.lidar_cloud(g, 30000, 1)
+def voxelize_leg(device):
+    """ud_voxelize at the reference op boundary (voxels[M,P,F] + coords + num):
+    one 30 k-point cloud (BASELINE configs[1]) and 4 x ten-sweep clouds (configs[3]/[4], 1.2 M points)."""
+    from unidistill_amd import _lib, synthetic as syn
+    from unidistill_amd.ops.voxelize import _f3
+    lib = _lib.load()
+    cases = []
+    for B, sweeps in ((1, 1), (4, 10)):
+        g = syn.rng(5)
+        pts = torch.from_numpy(syn.pad_clouds([syn.lidar_cloud(g, 30000, sweeps) for _ in range(B)])).to(device)
+        _, N, F = pts.shape
+        P, maxM = 10, 120000
+        cap = lib.ud_voxelize_capacity(B, N, maxM)
+        ws = _lib.workspace(device, lib.ud_voxelize_workspace_bytes(B, N, P, maxM), "voxelize")
+        vox = torch.empty(cap, P, F, device=device)
+        coords = torch.empty(cap, 4, dtype=torch.int32, device=device)
+        num = torch.empty(cap, dtype=torch.int32, device=device)
+        m = torch.empty(B + 1, dtype=torch.int32, device=device)
+        vs, rg, st = _f3(syn.VOXEL_SIZE), _f3(syn.POINT_CLOUD_RANGE), _lib.stream_of(pts)
+
+        def run():
+            _lib.check(lib.ud_voxelize(_lib.ptr(pts), B, N, F, vs, rg, P, maxM, _lib.ptr(vox), _lib.ptr(coords),
+                                       _lib.ptr(num), None, _lib.ptr(m), _lib.ptr(ws), ws.numel(), st), "ud_voxelize")
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 30
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        op_us = e0.elapsed_time(e1) / reps * 1e3
+        _lib.prof_enable(True)
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        kern = {}
+        for k in ("k_insert", "k_first", "k_assign", "k_gather"):
+            ms, n = _lib.prof_read("voxelize." + k)
+            kern[k] = ms / max(n, 1) * 1e3
+        M = int(m[B])
+        alg = B * N * F * 4 + M * (P * F * 4 + 12 + 4)          # SURVEY 8d: N*20 + M*216 bytes
+        dom = max(kern, key=kern.get)
+        cases.append({"points": B * N, "voxels": M, "algorithmic_bytes": alg, "op_us": op_us,
+                      "op_GBps": alg / op_us / 1e3, "frac_op": alg / op_us / 1e3 / HBM_PEAK_GBS,
+                      "kernel_us": kern, "dominant_kernel": "voxelize." + dom})
+    big = cases[-1]
+    return {"bound": "hbm", "kernel": "ud_voxelize (reference op boundary: voxels[M,10,5] + coords + num), whole op",
+            "achieved": big["op_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big["frac_op"],
+            "traffic": None, "cases": cases,
+            "note": "op-level (memset + 5 launches); per-kernel times are HIP-event brackets incl. ~6 us dispatch. "
+                    "The op is bound by random 8-byte hash-table accesses (k_insert), not by streaming bytes: see DESIGN.md"}
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container that sees
+    the host's core count but owns a fraction of it thrashes when torch spawns one thread per visible core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def cpu_baseline_leg(device):
+    """BASELINE.json configs[0] end to end on the host cores (oracle/cpu_step.py: torch CPU ops for the
+    image branch / trunk / head / losses + the CPU oracle for geometry, lift and voxel pooling), all cores
+    and one thread; the GPU product path on the SAME configuration is timed beside it."""
+    from oracle import cpu_step
+    from unidistill_amd import train
+    ncores = min(usable_cores(), 64)      # torch's intra-op pool stops scaling long before that on these convs
+    model, batch = cpu_step.build()
+
+    def timed(iters, warm):
+        for _ in range(warm):
+            cpu_step.step(model, batch)
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            cpu_step.step(model, batch)
+            ts.append(time.perf_counter() - t0)
+        return ts
+    prev = torch.get_num_threads()
+    torch.set_num_threads(ncores)
+    t_all = timed(3, 1)
+    torch.set_num_threads(1)
+    t_one = timed(1, 0)
+    torch.set_num_threads(prev)
+    # the product path on the same configuration (camera detector, 1 camera, batch 1, fp32, fwd+bwd+AdamW)
+    torch.manual_seed(1234)
+    tr = train.Trainer(train.DetectStep("camera"), device=device)
+    gb = train.synthetic_batch(device, 1, ncam=1, with_points=False)
+    for _ in range(3):
+        tr.step(gb)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 12.0:
-        _, pos = oracle.bev_pool_fwd(geom, feat, 180, 180, 1)
-        oracle.bev_pool_bwd(gout, pos)
-        oracle.voxelize(pts, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 10, 120000, with_voxels=False)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    est = 6.0 * dt      # 6 cameras; the sparse/dense conv stacks are NOT included (they dominate on CPU)
-    return {"value": 1.0 / est, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": "oracle C, 1 thread, BEV-extraction ops only: 1 of 6 cameras of bev_pool "
-                      "fwd+bwd (78848 pts x 256 ch) + 1-sweep (30k pt) voxelize+mean, x6 -> upper "
-                      "bound on the CPU samples/s of a full step (conv trunks excluded)"}
+    for _ in range(10):
+        tr.step(gb)
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / 10
+    med = sorted(t_all)[len(t_all) // 2]
+    try:
+        cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_name = "unknown"
+    return {"value": 1.0 / med, "unit": "samples/s", "cores": ncores, "kind": "port",
+            "sample": "BASELINE configs[0]: camera-only student, 1 camera 256x704, batch 1, random weights, "
+                      "forward+backward; torch CPU ops (image branch, BEV trunk, head, target assignment, loss) + "
+                      "CPU oracle (geometry, lift, voxel pooling fwd/bwd); median of 3 iterations after 1 warm-up",
+            "seconds_per_step_all_cores": {"median": med, "min": min(t_all)},
+            "one_thread": {"value": 1.0 / t_one[0], "seconds_per_step": t_one[0], "iterations": 1},
+            "cpu_model": cpu_name,
+            "gpu_same_config": {"value": 1.0 / gpu_s, "ms_per_step": gpu_s * 1e3, "dtype": "f32",
+                                "note": "unidistill_amd camera detector, 1 camera, batch 1, fwd+bwd+AdamW on 1 MI355X"}}
+
+
+def timed_steps(trainer, batch, args, world, device):
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        trainer.step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(out["loss"].item())
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, loss
+
+
+PRECISION_NOTE = {
+    None: "fp32 everywhere (the reference's arithmetic): hand-written HIP for voxelize / sparse convs (fp32 MFMA) / "
+          "lift-splat / target assignment / losses; dense convolutions through MIOpen fp32",
+    torch.bfloat16: "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the sparse convs "
+                    "(HIP MFMA kernels incl. 1x1 convs and all 3x3 / 1x1 weight gradients; libraries for strided / "
+                    "transposed convs and small-map 1x1 GEMMs); fp32 voxelize/splat/losses; fp32 master weights",
+}
 
 
 def main():
@@ -194,28 +338,23 @@ def main():
                                       with_points=args.workload != "camera")
     ac = torch.bfloat16 if args.autocast == "bf16" else None
     trainer = train.Trainer(step, device=device, autocast_dtype=ac, channels_last=not args.nchw)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        trainer.step(batch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = trainer.step(batch)
-    barrier()
-    dt = time.perf_counter() - t0
-    loss = float(out["loss"].item())
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # the MFMA leg takes extra training steps: under DDP those are collective, so EVERY rank runs it
-    mfma = None
-    if not args.no_roofline and ac is not None:
+    dt, loss = timed_steps(trainer, batch, args, world, device)
+    # second precision + the MFMA leg take extra (collective) training steps: EVERY rank runs them
+    bf16, mfma = None, None
+    if ac is None and not args.no_bf16_leg:
+        del trainer
+        torch.manual_seed(1234)
+        step16 = train.DistillStep(args.workload) if wl["kind"] == "distill" else train.DetectStep(args.workload)
+        trainer16 = train.Trainer(step16, device=device, autocast_dtype=torch.bfloat16, channels_last=not args.nchw)
+        dt16, loss16 = timed_steps(trainer16, batch, args, world, device)
+        bf16 = {"value": args.batch * world * args.steps / dt16, "unit": "samples/s",
+                "ms_per_step": dt16 / args.steps * 1e3, "dtype": "bf16", "steps": args.steps, "warmup": args.warmup,
+                "final_loss": loss16, "precision": PRECISION_NOTE[torch.bfloat16],
+                "note": "same workload, batch and step as the headline under bf16 autocast + channels-last "
+                        "(BASELINE.json configs[4]-style mixed precision; NOT the headline: the reference trains in fp32)"}
+        if not args.no_roofline:
+            mfma = mfma_leg(trainer16, batch)
+    elif ac is not None and not args.no_roofline:
         mfma = mfma_leg(trainer, batch)
     if rank == 0:
         samples = args.batch * world * args.steps
@@ -230,17 +369,19 @@ def main():
                        if wl["kind"] == "distill" else f"{args.workload} detector training step",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": loss,
-                       "precision": "fp32 everywhere" if ac is None else
-                       "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the teacher's sparse convs (HIP MFMA kernels incl. 1x1 convs and all 3x3 / 1x1 weight gradients; libraries for strided / transposed convs and small-map 1x1 GEMMs); fp32 voxelize/splat/losses; fp32 master weights",
+                       "precision": PRECISION_NOTE[ac],
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
                        "executor": "eager+DDP"},
         }
+        if bf16 is not None:
+            line["bf16_mixed_precision"] = bf16
         if not args.no_roofline:
             line["roofline"] = roofline_leg(device, 1)
+            line["roofline_voxelize"] = voxelize_leg(device)
             if mfma is not None:
                 line["roofline_mfma"] = mfma
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_leg()
+            line["cpu_baseline"] = cpu_baseline_leg(device)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

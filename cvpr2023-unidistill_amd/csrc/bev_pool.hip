@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256) void k_cell_partials(const int* __restrict__ c
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
+// DIRECT: with few tiles (one or two samples) every workgroup sums the counts of the tiles before it
+// straight from count[] (<= 64 int4 loads per thread, L2 resident) -- one launch less than the partials pass.
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void k_cell_offsets(const int* __restrict__ count,
                                                       const int2* __restrict__ part,
                                                       int* __restrict__ off,
@@ -120,10 +123,19 @@ __global__ __launch_bounds__(256) void k_cell_offsets(const int* __restrict__ co
   __shared__ int2 s_w[4];
   // sum of the partials of all tiles before this one
   int2 pre = make_int2(0, 0);
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
-    const int2 p = part[i];
-    pre.x += p.x;
-    pre.y += p.y;
+  if (DIRECT) {
+    const int4* c4 = reinterpret_cast<const int4*>(count);
+    for (int i = threadIdx.x; i < (int)blockIdx.x * 256; i += 256) {
+      const int4 c = c4[i];
+      pre.x += c.x + c.y + c.z + c.w;
+      pre.y += (c.x > kLightMax) + (c.y > kLightMax) + (c.z > kLightMax) + (c.w > kLightMax);
+    }
+  } else {
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
+      const int2 p = part[i];
+      pre.x += p.x;
+      pre.y += p.y;
+    }
   }
   int2 pre_tot;
   block_excl_scan2(pre, s_w, pre_tot);
@@ -566,11 +578,17 @@ static int build_lists(const int32_t* geom, int32_t* pos, int B, int N, int nx, 
   k_bin<<<ud_div_up(total, 256), 256, 0, stream>>>(geom, pos, w.count, w.rank, w.cellid, total, N,
                                                    nx, ny, nz);
   UD_LAUNCH_CHECK();
-  k_cell_partials<<<w.ntile, 256, 0, stream>>>(w.count, w.part);
-  UD_LAUNCH_CHECK();
-  k_cell_offsets<<<w.ntile, 256, 0, stream>>>(w.count, w.part, w.off, w.heavy_list, w.heavy_cnt,
-                                              ncell);
-  UD_LAUNCH_CHECK();
+  if (w.ntile <= 64) {
+    k_cell_offsets<true><<<w.ntile, 256, 0, stream>>>(w.count, w.part, w.off, w.heavy_list, w.heavy_cnt,
+                                                      ncell);
+    UD_LAUNCH_CHECK();
+  } else {
+    k_cell_partials<<<w.ntile, 256, 0, stream>>>(w.count, w.part);
+    UD_LAUNCH_CHECK();
+    k_cell_offsets<false><<<w.ntile, 256, 0, stream>>>(w.count, w.part, w.off, w.heavy_list, w.heavy_cnt,
+                                                       ncell);
+    UD_LAUNCH_CHECK();
+  }
   k_fill<<<ud_div_up(total, 256), 256, 0, stream>>>(w.cellid, w.rank, w.off, w.list, total);
   UD_LAUNCH_CHECK();
   return UD_OK;

@@ -1,0 +1,227 @@
+// fp32 twin of conv2d.hip: 3x3 / stride 1 / pad 1 and 1x1 convolutions on channels-last FP32 tensors for the
+// reference's own arithmetic (it trains in fp32: base_cli.py:40-45 has no precision flag) -- the BEV trunk
+// (base_bev_backbone.py:30-110), the head (center_head.py:311-420), the fusion conv (base_exp.py:107-135) and
+// the ResNet / neck convolutions (lss_fpn.py:143-149) -- on v_mfma_f32_16x16x4_f32 (exact fp32 products,
+// fp32 accumulation: 157 TFLOP/s matrix peak, 1/16 of the bf16 pipe).
+//
+//   y[b,oy,ox,n] = epilogue( sum_{tap,c} x[b, oy+ty-1, ox+tx-1, c] * w[n, tap, c] )
+//
+// Same skeleton as the bf16 kernel: a workgroup (4 waves) owns 8 x 16 output pixels x TN output channels;
+// per 32-channel slice (one 128-byte LDS row per pixel) the 10 x 18 input halo is staged once and serves all
+// nine taps; halo and weight slices travel L2 -> LDS by LDS-DMA into unpadded, source-swizzled, double-buffered
+// tiles.  With a 32-cycle MFMA the kernel is MFMA-bound by a wide margin (16 KB of fragments per 4096 MFMA
+// cycles per wave), so the lever here is simply to keep the MFMA pipe issuing back to back.
+// Fragment trick: a lane reads ONE 16-byte piece (4 consecutive channels) per operand and feeds four MFMAs
+// with its elements 0..3; MFMA e then reduces over the channels {4g + e : g = lane group 0..3} -- a
+// permutation of the slice's channels that A and B share, so the sum is the same.
+#include "ud_common.h"
+#include "ud_prof.h"
+
+namespace {
+
+constexpr int kTW = 16, kTH = 8, kTM = kTW * kTH;
+constexpr int kKC = 32;                      // fp32 input channels per staged slice (one 128-byte LDS row)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvGeomF {
+  int B, H, W, Cin, Cout, tiles_x, tiles_y;
+  long long npix;
+};
+struct ConvEpF {
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  int relu;
+  int reverse_taps;
+};
+
+constexpr size_t conv_smem_bytes_f(int tn, int ks) {
+  const size_t hq = ks == 3 ? ((kTW + 2) * (kTH + 2) + 7) / 8 * 8 : kTM;
+  const size_t operands = 2 * hq * 128 + 2 * (size_t)tn * 128;
+  const size_t out = (size_t)kTM * (tn + 4) * 4;
+  return operands > out ? operands : out;
+}
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16f[4];
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TN, int KS>
+__global__ __launch_bounds__(256) void k_conv_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                  float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
+  constexpr int kTN = TN, kLDO = TN + 4, kBInstr = TN / 8;
+  constexpr int WM = TN == 128 ? 2 : 4;
+  constexpr int kTaps = KS * KS, kPad = KS / 2;
+  constexpr int kHW = kTW + 2 * kPad, kHQ = kHW * (kTH + 2 * kPad);
+  constexpr int kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
+  constexpr int RW = 8 / WM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);            // [2][kHQP][32]
+  float* Bs = As + 2 * kHQP * kKC;                        // [2][kTN][32]
+  float* Os = reinterpret_cast<float*>(smem);            // [kTM][kLDO] after the K loop
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
+  const int ntiles = gm.B * gm.tiles_x * gm.tiles_y;
+  const int per = (ntiles + 7) / 8;
+  int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);     // XCD-aware: each XCD walks a contiguous band
+  if (tile >= ntiles) return;
+  const int b = tile / (gm.tiles_x * gm.tiles_y);
+  tile -= b * gm.tiles_x * gm.tiles_y;
+  const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
+  const int n0 = blockIdx.y * kTN;
+  const float* zero = reinterpret_cast<const float*>(g_zero16f);
+
+  f32x4 acc[RW][4];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int r8 = lane >> 3, slot = lane & 7;
+  auto stage_a = [&](int chunk, int buf) {
+    for (int piece = wave; piece < kAInstr; piece += 4) {
+      const int q = piece * 8 + r8;
+      const int qy = q / kHW, qx = q - qy * kHW;
+      const int gy = ty0 + qy - kPad, gx = tx0 + qx - kPad;
+      const long long pix = (long long)(b * gm.H + gy) * gm.W + gx;
+      const float* src = zero;
+      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && pix < gm.npix)
+        src = x + (size_t)pix * gm.Cin + chunk * kKC + ((slot ^ (q & 7)) << 2);
+      dma16(src, As + (buf * kHQP + piece * 8) * kKC);
+    }
+  };
+  auto stage_b = [&](int chunk, int tap, int buf) {
+#pragma unroll
+    for (int j = 0; j < kBInstr / 4; ++j) {
+      const int piece = wave + 4 * j;
+      const int n = piece * 8 + r8;
+      const float* src = zero;
+      if (n0 + n < gm.Cout)
+        src = w + ((size_t)(n0 + n) * kTaps + (ep.reverse_taps ? kTaps - 1 - tap : tap)) * gm.Cin + chunk * kKC +
+              ((slot ^ (n & 7)) << 2);
+      dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
+    }
+  };
+
+  const int nchunks = gm.Cin / kKC, total = nchunks * kTaps;
+  stage_a(0, 0);
+  stage_b(0, 0, 0);
+  __syncthreads();
+  for (int it = 0; it < total; ++it) {
+    const int chunk = it / kTaps, tap = it - chunk * kTaps;
+    if (it + 1 < total)
+      stage_b(tap == kTaps - 1 ? chunk + 1 : chunk, tap == kTaps - 1 ? 0 : tap + 1, (it + 1) & 1);
+    if (tap == 0 && chunk + 1 < nchunks) stage_a(chunk + 1, (chunk + 1) & 1);
+    {
+      const float* bbuf = Bs + (it & 1) * kTN * kKC;
+      const float* abuf = As + (chunk & 1) * kHQP * kKC;
+      const int q0 = (RW * wm + tap / KS) * kHW + li + tap % KS;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cg = 4 * ks + g;                              // 16-byte channel group (4 fp32) of the slice
+        f32x4 a[RW];
+#pragma unroll
+        for (int ti = 0; ti < RW; ++ti) {
+          const int q = q0 + ti * kHW;
+          a[ti] = *reinterpret_cast<const f32x4*>(abuf + q * kKC + ((cg ^ (q & 7)) << 2));
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const int n = 64 * wn + 16 * tj + li;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bbuf + n * kKC + ((cg ^ (n & 7)) << 2));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ti = 0; ti < RW; ++ti)
+              acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti][e], bb[e], acc[ti][tj], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ti = 0; ti < RW; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
+  __syncthreads();
+  for (int u = tid; u < kTM * (kTN / 4); u += 256) {
+    const int r = u / (kTN / 4), c4 = (u - r * (kTN / 4)) * 4;
+    const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+    const int n = n0 + c4;
+    if (gy >= gm.H || gx >= gm.W || n >= gm.Cout || (long long)(b * gm.H + gy) * gm.W + gx >= gm.npix) continue;
+    float4 v = *reinterpret_cast<const float4*>(Os + r * kLDO + c4);
+    if (ep.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(ep.bias + n);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    if (ep.scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(ep.scale + n);
+      const float4 sh = *reinterpret_cast<const float4*>(ep.shift + n);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    }
+    const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+    if (ep.residual) {
+      const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
+      v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+    }
+    if (ep.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + off) = v;
+  }
+}
+
+template <int KS>
+int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, const ConvEpF& ep, int ntiles,
+               const char* name, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32<128, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes_f(128, KS)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32<64, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes_f(64, KS)));
+    attr_set = true;
+  }
+  const int gx = (ntiles + 7) / 8 * 8;
+  UdProfScope prof(name, stream);
+  if (gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256)
+    k_conv_f32<64, KS><<<dim3(gx, ud_div_up(gm.Cout, 64)), 256, conv_smem_bytes_f(64, KS), stream>>>(x, w, y, gm, ep);
+  else
+    k_conv_f32<128, KS><<<dim3(gx, ud_div_up(gm.Cout, 128)), 256, conv_smem_bytes_f(128, KS), stream>>>(x, w, y, gm, ep);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+}  // namespace
+
+extern "C" int ud_conv3x3_nhwc_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin,
+                                   int Cout, const float* bias, const float* scale, const float* shift,
+                                   const float* residual, int flags, ud_stream_t stream_) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
+  if (Cin % kKC != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;
+  ConvGeomF gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W};
+  ConvEpF ep{bias, scale, shift, residual, flags & 1, (flags >> 1) & 1};
+  return launch_f32<3>(x, w, y, gm, ep, B * gm.tiles_x * gm.tiles_y, "conv2d.k_conv3x3_f32", (hipStream_t)stream_);
+}
+
+extern "C" int ud_conv1x1_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
+                                   const float* bias, const float* scale, const float* shift,
+                                   const float* residual, int flags, ud_stream_t stream_) {
+  if (!x || !w || !y || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
+  if (Cin % kKC != 0 || Cout % 4 != 0 || P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;
+  const int H = (int)((P + kTW - 1) / kTW);
+  ConvGeomF gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P};
+  ConvEpF ep{bias, scale, shift, residual, flags & 1, 0};
+  return launch_f32<1>(x, w, y, gm, ep, gm.tiles_y, "conv2d.k_conv1x1_f32", (hipStream_t)stream_);
+}

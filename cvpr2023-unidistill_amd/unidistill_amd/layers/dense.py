@@ -14,7 +14,7 @@ import os
 import torch
 from torch import nn
 
-from ..ops import bn_act as hipbn, conv2d as hipconv
+from ..ops import bn_act as hipbn, conv2d as hipconv, conv2d_f32 as hipconv32
 from ..ops.spconv import folded_batchnorm, wants_grad
 
 
@@ -30,13 +30,38 @@ def _is3x3(conv, padding):
             and conv.out_channels % 64 == 0)
 
 
+def _is3x3_any(conv, padding):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (padding, padding) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros")
+
+
 def _is1x1(conv):
     return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1)
 
 
+def _fp32_mode(x):
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
+
+
+def _fp32_kernel_pays(conv, x):
+    """fp32 mode: MIOpen's assembly implicit-GEMM kernels already run at ~105 TFLOP/s (two thirds of the fp32
+    matrix peak) on the large regular shapes and ours at 90-113 (tools/time_conv2d_f32.py), so the hand-written
+    fp32 kernels are used where they measured faster: mid-size maps (the 90 x 90 trunk level: 1.6x), very wide
+    or very narrow channel counts (head first convs, depth net: 1.06-1.9x); "all" forces them everywhere."""
+    if Conv2d.hip_fp32 == "all":
+        return True
+    px = x.shape[2] * x.shape[3]
+    if conv.kernel_size == (3, 3):
+        return (4000 <= px <= 12000 and conv.in_channels >= 128) or conv.out_channels >= 512 or conv.in_channels >= 512
+    return conv.out_channels % 64 != 0 or (conv.in_channels <= 64 and px * x.shape[0] >= 65536)
+
+
 class Conv2d(nn.Conv2d):
     hip_enabled = True          # class-wide switch (tests / A-B timing)
+    # fp32 MFMA kernels for the fp32 (reference) mode: False / True (where they pay) / "all"
+    hip_fp32 = {"0": False, "all": "all"}.get(os.environ.get("UD_HIP_FP32_CONV", "1"), True)
 
     def forward(self, x):
         if Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x):
@@ -44,6 +69,11 @@ class Conv2d(nn.Conv2d):
                 return hipconv.conv3x3(x.to(torch.bfloat16), self.weight, self.bias)
             if self._hip_1x1(x):
                 return hipconv.conv1x1(x.to(torch.bfloat16), self.weight, self.bias)
+        elif Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x):
+            if _is3x3_any(self, 1) and hipconv32.supported(x, self.weight, 3) and _fp32_kernel_pays(self, x):
+                return hipconv32.conv3x3(x, self.weight, self.bias)
+            if _is1x1(self) and hipconv32.supported(x, self.weight, 1) and _fp32_kernel_pays(self, x):
+                return hipconv32.conv1x1(x, self.weight, self.bias)
         return super().forward(x)
 
     def _hip_1x1(self, x):
@@ -110,6 +140,14 @@ class FusedSequential(nn.Sequential):
                     conv, skip = mods[i + 1], 2
                 elif _is3x3(m, 1):
                     conv, skip = m, 1
+            if conv is None and Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x) \
+                    and isinstance(m, nn.ZeroPad2d) and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < n \
+                    and _is3x3_any(mods[i + 1], 0) and hipconv32.supported(x, mods[i + 1].weight, 3) \
+                    and _fp32_kernel_pays(mods[i + 1], x):
+                # fp32 mode: ZeroPad2d(1) + unpadded 3x3 conv == the kernel's implicit padding
+                x = hipconv32.conv3x3(x, mods[i + 1].weight, mods[i + 1].bias)
+                i += 2
+                continue
             if conv is None:
                 if isinstance(m, nn.BatchNorm2d) and x.dim() == 4:
                     relu = i + 1 < n and isinstance(mods[i + 1], nn.ReLU)

@@ -1,0 +1,87 @@
+"""fp32 3x3 / stride-1 / pad-1 and 1x1 convolutions on channels-last fp32 tensors (ud_conv3x3_nhwc_f32,
+ud_conv1x1_nhwc_f32: exact fp32 products on the fp32 MFMA pipe) -- the reference's own arithmetic for the BEV
+trunk, head, fusion conv and the ResNet / neck convs (base_bev_backbone.py:30-110, center_head.py:311-420,
+BEVFusion_nuscenes_base_exp.py:107-135, lss_fpn.py:143-149).  Forward and data gradient are hand-written;
+the weight gradient of the fp32 mode goes through aten.convolution_backward.
+"""
+import torch
+
+from .. import _lib
+
+
+def _nhwc(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else \
+        t.contiguous(memory_format=torch.channels_last)
+
+
+def supported(x, weight, ks):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dtype == torch.float32
+            and tuple(weight.shape[2:]) == (ks, ks) and weight.shape[1] % 32 == 0 and weight.shape[0] % 4 == 0
+            and x.shape[1] == weight.shape[1])
+
+
+def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False):
+    B, cin, H, W = x.shape
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().ud_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
+                                               _lib.ptr(bias), None, None, None,
+                                               (1 if relu else 0) | (2 if reverse_taps else 0), _lib.stream_of(x)),
+               "ud_conv3x3_nhwc_f32")
+    return y
+
+
+def _launch1(x, w, cout, bias=None):
+    B, cin, H, W = x.shape
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().ud_conv1x1_nhwc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), B * H * W, cin, cout,
+                                               _lib.ptr(bias), None, None, None, 0, _lib.stream_of(x)),
+               "ud_conv1x1_nhwc_f32")
+    return y
+
+
+class _ConvF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, ks):
+        _lib.require_gpu(x, weight)
+        x = _nhwc(x)
+        b = None if bias is None else bias.detach().contiguous()
+        w = weight.detach()
+        if ks == 3:
+            y = _launch3(x, w.permute(0, 2, 3, 1).contiguous(), weight.shape[0], b)       # [Cout, 3, 3, Cin]
+        else:
+            y = _launch1(x, w.reshape(weight.shape[0], weight.shape[1]).contiguous(), weight.shape[0], b)
+        ctx.save_for_backward(x, weight)
+        ctx.ks, ctx.has_bias = ks, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        ks = ctx.ks
+        gy = _nhwc(gy.float())
+        gx = gw = gb = None
+        w = weight.detach()
+        p = ks // 2
+        if ctx.needs_input_grad[0] and weight.shape[0] % 32 != 0:
+            # the data gradient reduces over Cout: not a multiple of the kernel's 32-channel slice -> library
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        elif ctx.needs_input_grad[0]:
+            if ks == 3:      # un-flipped transposed weights [Cin, 3, 3, Cout], taps walked in reverse
+                gx = _launch3(gy, w.permute(1, 2, 3, 0).contiguous(), weight.shape[1], reverse_taps=True)
+            else:
+                gx = _launch1(gy, w.reshape(weight.shape[0], weight.shape[1]).t().contiguous(), weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None
+
+
+def conv3x3(x, weight, bias=None):
+    return _ConvF32.apply(x, weight, bias, 3)
+
+
+def conv1x1(x, weight, bias=None):
+    return _ConvF32.apply(x, weight, bias, 1)

@@ -400,6 +400,16 @@ int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, in
 int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
                          const float* bias, const float* scale, const float* shift,
                          const void* residual, int relu, ud_stream_t stream);
+/* fp32 twins (the reference trains in fp32: exps/base_cli.py:40-45 has no precision flag): channels-last
+ * FP32 x / w / y, exact fp32 products and fp32 accumulation on v_mfma_f32_16x16x4_f32.  Same argument
+ * meaning and fused epilogue as the bf16 calls (residual is fp32, y's layout); `flags` bit 0 = ReLU, bit 1 =
+ * walk the taps in reverse (data gradient on un-flipped transposed weights).  Cin % 32 == 0, Cout % 4 == 0. */
+int ud_conv3x3_nhwc_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout,
+                        const float* bias, const float* scale, const float* shift, const float* residual,
+                        int flags, ud_stream_t stream);
+int ud_conv1x1_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
+                        const float* bias, const float* scale, const float* shift, const float* residual,
+                        int flags, ud_stream_t stream);
 /* Weight gradient of the same convolution: dw [Cout][9][Cin] fp32 = sum over pixels of
  * dy [B][H][W][Cout] (bf16) x shifted x [B][H][W][Cin] (bf16); fp32 accumulation, fixed-order
  * reduction of pixel slices (deterministic).  Cin % 64 == 0, Cout % 8 == 0. */

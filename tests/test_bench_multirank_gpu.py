@@ -16,11 +16,55 @@ def test_two_rank_bench_completes(hip_lib):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--workload", "lidar", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["dtype"] == "f32"
     assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
-    assert "roofline" in out and "roofline_mfma" in out
+    assert "roofline" in out and "roofline_voxelize" in out and "roofline_mfma" in out
+    assert out["bf16_mixed_precision"]["value"] > 0 and out["bf16_mixed_precision"]["dtype"] == "bf16"
+    # DDP hygiene: every gradient already has its bucket view's strides (no per-step copy)
+    assert "Grad strides do not match bucket view strides" not in res.stderr, res.stderr[-1500:]
+
+
+_NCCL_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path[:0] = [{root!r}, {pkg!r}]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))      # "nccl" is RCCL on ROCm
+from unidistill_amd import train, dist as ud
+t = torch.full((4,), float(rank + 1), device="cuda")
+dist.all_reduce(t)
+assert torch.equal(t, torch.full((4,), 3.0, device="cuda"))
+assert float(ud.reduce_mean(torch.tensor(float(rank), device="cuda"))) == 0.5
+torch.manual_seed(0)
+tr = train.Trainer(train.DetectStep("lidar"), device=torch.device("cuda", rank))
+out = tr.step(train.synthetic_batch(torch.device("cuda", rank), 1, rank=rank, with_imgs=False))
+assert torch.isfinite(out["loss"])
+flat = torch.cat([p.detach().flatten() for p in tr.params])
+other = flat.clone()
+dist.broadcast(other, 0)
+assert torch.equal(flat, other), "ranks diverged after one DDP step"
+dist.barrier(); dist.destroy_process_group()
+print("NCCL_OK", rank)
+'''
+
+
+def test_two_rank_rccl_ddp_step(hip_lib, tmp_path):
+    """RCCL itself (backend "nccl"): all-reduce, reduce_mean and one DDP training step on two GPUs keep the
+    ranks' parameters identical.  Needs two devices: skipped on the one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    from conftest import PKG
+    script = _NCCL_SCRIPT.format(root=ROOT, pkg=PKG)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    path = tmp_path / "rccl_two_ranks.py"
+    path.write_text(script)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29534", str(path)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.count("NCCL_OK") == 2, res.stdout[-1500:] + res.stderr[-3000:]

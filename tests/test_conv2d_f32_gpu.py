@@ -1,0 +1,83 @@
+"""GPU: the fp32 MFMA convolutions (ud_conv3x3_nhwc_f32 / ud_conv1x1_nhwc_f32: forward + data gradient) against
+plain PyTorch fp32 convolutions of the same tensors.  fp32 products and accumulation on both sides, only the
+summation order differs: tolerance 2e-5 of the output's max."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 20, 36), (1, 256, 128, 45, 45), (3, 32, 64, 9, 17),
+                                   (1, 128, 76, 33, 40), (2, 512, 64, 24, 24), (1, 64, 2688, 16, 16)])
+def test_conv3x3_f32_forward_and_dgrad(hip_lib, shape):
+    from unidistill_amd.ops import conv2d_f32 as c
+    B, cin, cout, H, W = shape
+    torch.manual_seed(sum(shape))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda")).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    b = torch.randn(cout, device="cuda").requires_grad_(True)
+    y = c.conv3x3(x, w, b)
+    gy = _cl(torch.randn_like(y))
+    y.backward(gy)
+    gx, gw, gb = x.grad.clone(), w.grad.clone(), b.grad.clone()
+    x.grad = w.grad = b.grad = None
+    with torch.backends.cudnn.flags(enabled=False):      # reference: direct (non-library-heuristic) path
+        yr = F.conv2d(x, w, b, padding=1)
+        yr.backward(gy)
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.dtype == torch.float32
+    assert (y - yr).abs().max() <= 2e-5 * yr.abs().max()
+    assert (gx - x.grad).abs().max() <= 2e-5 * x.grad.abs().max()
+    assert (gw - w.grad).abs().max() <= 1e-4 * w.grad.abs().max()
+    assert (gb - b.grad).abs().max() <= 1e-4 * b.grad.abs().max()
+
+
+@pytest.mark.parametrize("shape", [(24, 64, 256, 16, 44), (2, 256, 64, 31, 33), (1, 512, 368, 16, 44), (4, 32, 128, 20, 20)])
+def test_conv1x1_f32_forward_and_dgrad(hip_lib, shape):
+    from unidistill_amd.ops import conv2d_f32 as c
+    B, cin, cout, H, W = shape
+    torch.manual_seed(sum(shape))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda")).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, device="cuda") * 0.05).requires_grad_(True)
+    y = c.conv1x1(x, w, None)
+    gy = _cl(torch.randn_like(y))
+    y.backward(gy)
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    yr = F.conv2d(x, w)
+    yr.backward(gy)
+    assert (y - yr).abs().max() <= 2e-5 * yr.abs().max()
+    assert (gx - x.grad).abs().max() <= 2e-5 * x.grad.abs().max()
+    assert (gw - w.grad).abs().max() <= 1e-4 * w.grad.abs().max()
+
+
+def test_fp32_trunk_routes_to_the_fp32_kernels_and_matches_library(hip_lib):
+    """BaseBEVBackbone in fp32 mode: ZeroPad + unpadded conv folding, stride-1 convs on ud_conv3x3_nhwc_f32."""
+    from unidistill_amd import _lib
+    from unidistill_amd.layers import dense
+    from unidistill_amd.layers.bev import BaseBEVBackbone
+    torch.manual_seed(0)
+    dense.Conv2d.hip_fp32 = "all"          # everywhere, not only where the kernel measured faster than the library
+    m = BaseBEVBackbone([2, 2], [1, 2], [64, 128], [1, 2], [64, 64], 64).cuda().train()
+    x = _cl(torch.randn(2, 64, 40, 40, device="cuda"))
+    _lib.prof_read("conv2d.k_conv3x3_f32", reset=True)
+    _lib.prof_enable(True)
+    y, _ = m(x)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    _, calls = _lib.prof_read("conv2d.k_conv3x3_f32")
+    assert calls == 5, calls           # 3 stride-1 convs of level 0 (incl. the ZeroPad one) + 2 of level 1
+    dense.Conv2d.hip_enabled = False
+    try:
+        for mod in m.modules():        # same batch statistics on the second pass: reset what BN accumulated
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+        yr, _ = m(x)
+    finally:
+        dense.Conv2d.hip_enabled = True
+        dense.Conv2d.hip_fp32 = True
+    assert (y - yr).abs().max() <= 1e-4 * yr.abs().max()
