@@ -39,6 +39,20 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
   return make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]),
                     ud_pack_bf16x2(v[4], v[5]), ud_pack_bf16x2(v[6], v[7]));
 }
+// element access: 8 consecutive channels of a bf16 (16 bytes) or fp32 (2 x 16 bytes) activation row
+__device__ __forceinline__ void ld8(const unsigned short* p, float* v) { unpack8(*reinterpret_cast<const uint4*>(p), v); }
+__device__ __forceinline__ void st8(unsigned short* p, const float* v) { *reinterpret_cast<uint4*>(p) = pack8(v); }
+__device__ __forceinline__ void ld8(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ float elem_f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ float elem_f(float u) { return u; }
+
 __device__ __forceinline__ void load8(const float* p, float* v) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -47,12 +61,11 @@ __device__ __forceinline__ void load8(const float* p, float* v) {
 // Thread = (8-channel chunk, pixel lane): the chunk's scale / shift live in registers for the whole
 // pixel loop (a flat unit loop re-loaded 4 constant vectors and took a 64-bit modulo per 16 bytes).
 // grid (pixel slices, channel blocks); CH = chunks per workgroup (power of two <= 256).
-__global__ __launch_bounds__(256) void k_bn_act_fwd(const unsigned short* __restrict__ x,
-                                                    const unsigned short* __restrict__ res,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const T* __restrict__ x, const T* __restrict__ res,
                                                     const float* __restrict__ scale,
-                                                    const float* __restrict__ shift,
-                                                    unsigned short* __restrict__ y, long long P, int C,
-                                                    int CH, int relu) {
+                                                    const float* __restrict__ shift, T* __restrict__ y,
+                                                    long long P, int C, int CH, int relu) {
   const int chunk = blockIdx.y * CH + threadIdx.x % CH, lanes = 256 / CH, pl = threadIdx.x / CH;
   if (chunk * 8 >= C) return;
   float s[8], t[8];
@@ -61,12 +74,12 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const unsigned short* __rest
   for (long long p = (long long)blockIdx.x * lanes + pl; p < P; p += (long long)gridDim.x * lanes) {
     const size_t off = (size_t)p * C + chunk * 8;
     float v[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + off), v);
+    ld8(x + off, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], s[e], t[e]);
     if (res) {
       float r[8];
-      unpack8(*reinterpret_cast<const uint4*>(res + off), r);
+      ld8(res + off, r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += r[e];
     }
@@ -74,21 +87,19 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const unsigned short* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    *reinterpret_cast<uint4*>(y + off) = pack8(v);
+    st8(y + off, v);
   }
 }
 
 // mask source: y (the saved output) when a residual took part, else recomputed from x.
-__device__ __forceinline__ void masked_grad(const float* xv, const uint4* yraw, const float* dyv,
+__device__ __forceinline__ void masked_grad(const float* xv, const float* yv, const float* dyv,
                                             const float* s, const float* t, int relu, float* dr) {
   if (!relu) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dr[e] = dyv[e];
     return;
   }
-  if (yraw) {
-    float yv[8];
-    unpack8(*yraw, yv);
+  if (yv) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dr[e] = yv[e] > 0.f ? dyv[e] : 0.f;
   } else {
@@ -104,20 +115,20 @@ struct GroupMap {
 };
 
 // grid (slices, C/GW): partial[slice][C][2] = sum (x - pivot), sum (x - pivot)^2, pivot = x[row 0][c]
-template <int GW>
-__global__ __launch_bounds__(256) void k_bn_stats_partial(const unsigned short* __restrict__ x, long long P,
+template <int GW, typename T>
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const T* __restrict__ x, long long P,
                                                           int C, float* __restrict__ partial) {
   using M = GroupMap<GW>;
   __shared__ float red[M::kLanes][GW + 1][2];
   const int cg = blockIdx.y, tid = threadIdx.x, chunk = tid % M::kChunks, pl = tid / M::kChunks;
   const int c0 = cg * GW + chunk * 8;
   float piv[8], s1[8], s2[8];
-  unpack8(*reinterpret_cast<const uint4*>(x + c0), piv);
+  ld8(x + c0, piv);
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
   for (long long p = (long long)blockIdx.x * M::kLanes + pl; p < P; p += (long long)gridDim.x * M::kLanes) {
     float v[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)p * C + c0), v);
+    ld8(x + (size_t)p * C + c0, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float d = v[e] - piv[e];
@@ -137,7 +148,8 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const unsigned short* 
 }
 
 // one wave per channel: mean / biased variance / invstd, folded scale+shift, running statistics
-__global__ void k_bn_stats_final(const unsigned short* __restrict__ x, const float* __restrict__ partial,
+template <typename T>
+__global__ void k_bn_stats_final(const T* __restrict__ x, const float* __restrict__ partial,
                                  int slices, long long P, int C, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float eps, float* __restrict__ mean,
                                  float* __restrict__ var, float* __restrict__ invstd,
@@ -157,7 +169,7 @@ __global__ void k_bn_stats_final(const unsigned short* __restrict__ x, const flo
     q += __shfl_xor(q, o);
   }
   if (lane != 0) return;
-  const double piv = __uint_as_float((unsigned)x[c] << 16);
+  const double piv = elem_f(x[c]);
   const double m = a / (double)P;
   double v = q / (double)P - m * m;
   if (v < 0.0) v = 0.0;
@@ -176,10 +188,9 @@ __global__ void k_bn_stats_final(const unsigned short* __restrict__ x, const flo
 }
 
 // grid (slices, C/GW): partial[slice][C][2] = sum dr, sum dr * (x - mean)
-template <int GW>
-__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const unsigned short* __restrict__ x,
-                                                       const unsigned short* __restrict__ y,
-                                                       const unsigned short* __restrict__ dy,
+template <int GW, typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ y,
+                                                       const T* __restrict__ dy,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ mean, long long P,
@@ -196,12 +207,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const unsigned short* __r
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
   for (long long p = (long long)blockIdx.x * M::kLanes + pl; p < P; p += (long long)gridDim.x * M::kLanes) {
     const size_t off = (size_t)p * C + c0;
-    float xv[8], dyv[8], dr[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
-    unpack8(*reinterpret_cast<const uint4*>(dy + off), dyv);
-    uint4 yr;
-    if (y) yr = *reinterpret_cast<const uint4*>(y + off);
-    masked_grad(xv, y ? &yr : nullptr, dyv, s, t, relu, dr);
+    float xv[8], dyv[8], dr[8], yv[8];
+    ld8(x + off, xv);
+    ld8(dy + off, dyv);
+    if (y) ld8(y + off, yv);
+    masked_grad(xv, y ? yv : nullptr, dyv, s, t, relu, dr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       s1[e] += dr[e];
@@ -243,15 +253,14 @@ __global__ void k_bn_bwd_final(const float* __restrict__ partial, int slices, in
   k0[c] = -scale[c] * (a * inv_p) - kk2 * mean[c];
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_dx(const unsigned short* __restrict__ x,
-                                                   const unsigned short* __restrict__ y,
-                                                   const unsigned short* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_dx(const T* __restrict__ x, const T* __restrict__ y,
+                                                   const T* __restrict__ dy,
                                                    const float* __restrict__ scale,
                                                    const float* __restrict__ shift,
                                                    const float* __restrict__ k0,
-                                                   const float* __restrict__ k2,
-                                                   unsigned short* __restrict__ dx,
-                                                   unsigned short* __restrict__ dres, long long P, int C,
+                                                   const float* __restrict__ k2, T* __restrict__ dx,
+                                                   T* __restrict__ dres, long long P, int C,
                                                    int CH, int relu) {
   const int chunk = blockIdx.y * CH + threadIdx.x % CH, lanes = 256 / CH, pl = threadIdx.x / CH;
   if (chunk * 8 >= C) return;
@@ -262,16 +271,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const unsigned short* __restr
   load8(k2 + chunk * 8, a2);
   for (long long p = (long long)blockIdx.x * lanes + pl; p < P; p += (long long)gridDim.x * lanes) {
     const size_t off = (size_t)p * C + chunk * 8;
-    float xv[8], dyv[8], dr[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
-    unpack8(*reinterpret_cast<const uint4*>(dy + off), dyv);
-    uint4 yr;
-    if (y) yr = *reinterpret_cast<const uint4*>(y + off);
-    masked_grad(xv, y ? &yr : nullptr, dyv, s, t, relu, dr);
+    float xv[8], dyv[8], dr[8], o[8], yv[8];
+    ld8(x + off, xv);
+    ld8(dy + off, dyv);
+    if (y) ld8(y + off, yv);
+    masked_grad(xv, y ? yv : nullptr, dyv, s, t, relu, dr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = fmaf(s[e], dr[e], fmaf(a2[e], xv[e], a0[e]));
-    *reinterpret_cast<uint4*>(dx + off) = pack8(o);
-    if (dres) *reinterpret_cast<uint4*>(dres + off) = pack8(dr);
+    st8(dx + off, o);
+    if (dres) st8(dres + off, dr);
   }
 }
 
@@ -298,6 +306,81 @@ void stream_grid(long long P, int C, int* CH, dim3* grid) {
 
 }  // namespace
 
+template <typename T>
+int bn_stats_impl(const T* x, long long P, int C, const float* gamma, const float* beta, float eps,
+                  float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
+                  float* running_var, float momentum, long long* batches_tracked, void* workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
+  if (!x || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || P <= 0 || C <= 0 ||
+      ((running_mean == nullptr) != (running_var == nullptr)))
+    return UD_ERR_INVALID_ARG;
+  if (C % 16) return UD_ERR_UNSUPPORTED;
+  UdArena ar(workspace, workspace_bytes);
+  BnWs w;
+  carve(ar, C, &w);
+  if (!ar.ok()) return UD_ERR_WORKSPACE;
+  UdProfScope prof("bn_act.stats", stream);
+  const int slices = slices_for(P, C), gw = group_width(C);
+  if (gw == 64)
+    k_bn_stats_partial<64, T><<<dim3(slices, C / 64), 256, 0, stream>>>(x, P, C, w.partial);
+  else if (gw == 32)
+    k_bn_stats_partial<32, T><<<dim3(slices, C / 32), 256, 0, stream>>>(x, P, C, w.partial);
+  else
+    k_bn_stats_partial<16, T><<<dim3(slices, C / 16), 256, 0, stream>>>(x, P, C, w.partial);
+  UD_LAUNCH_CHECK();
+  k_bn_stats_final<T><<<C, 64, 0, stream>>>(x, w.partial, slices, P, C, gamma, beta, eps, mean, var, invstd, scale,
+                                            shift, running_mean, running_var, momentum, batches_tracked);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+template <typename T>
+int bn_fwd_impl(const T* x, const T* residual, const float* scale, const float* shift, T* y, long long P, int C,
+                int relu, hipStream_t stream) {
+  if (!x || !scale || !shift || !y || P <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
+  if (C % 8) return UD_ERR_UNSUPPORTED;
+  int CH;
+  dim3 grid;
+  stream_grid(P, C, &CH, &grid);
+  UdProfScope prof("bn_act.k_fwd", stream);
+  k_bn_act_fwd<T><<<grid, 256, 0, stream>>>(x, residual, scale, shift, y, P, C, CH, relu);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+template <typename T>
+int bn_bwd_impl(const T* x, const T* y, const T* dy, const float* scale, const float* shift, const float* mean,
+                const float* invstd, T* dx, T* dresidual, float* dgamma, float* dbeta, long long P, int C, int relu,
+                void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || P <= 0 || C <= 0)
+    return UD_ERR_INVALID_ARG;
+  if (C % 16) return UD_ERR_UNSUPPORTED;
+  UdArena ar(workspace, workspace_bytes);
+  BnWs w;
+  carve(ar, C, &w);
+  if (!ar.ok()) return UD_ERR_WORKSPACE;
+  {
+    UdProfScope prof("bn_act.k_bwd_reduce", stream);
+    const int slices = slices_for(P, C), gw = group_width(C);
+    if (gw == 64)
+      k_bn_bwd_reduce<64, T><<<dim3(slices, C / 64), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial);
+    else if (gw == 32)
+      k_bn_bwd_reduce<32, T><<<dim3(slices, C / 32), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial);
+    else
+      k_bn_bwd_reduce<16, T><<<dim3(slices, C / 16), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial);
+    UD_LAUNCH_CHECK();
+    k_bn_bwd_final<<<C, 64, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd, dgamma, dbeta, w.k0, w.k2);
+    UD_LAUNCH_CHECK();
+  }
+  int CH;
+  dim3 grid;
+  stream_grid(P, C, &CH, &grid);
+  UdProfScope prof("bn_act.k_bwd_dx", stream);
+  k_bn_bwd_dx<T><<<grid, 256, 0, stream>>>(x, y, dy, scale, shift, w.k0, w.k2, dx, dresidual, P, C, CH, relu);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
 extern "C" {
 
 size_t ud_bn_act_workspace_bytes(int C) {
@@ -307,85 +390,47 @@ size_t ud_bn_act_workspace_bytes(int C) {
   return carve(ar, C, &w);
 }
 
+typedef unsigned short bf16_t;
+
 int ud_bn_stats(const void* x, long long P, int C, const float* gamma, const float* beta, float eps,
                 float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
                 float* running_var, float momentum, long long* batches_tracked, void* workspace,
-                size_t workspace_bytes, ud_stream_t stream_) {
-  if (!x || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || P <= 0 || C <= 0 ||
-      ((running_mean == nullptr) != (running_var == nullptr)))
-    return UD_ERR_INVALID_ARG;
-  if (C % 16) return UD_ERR_UNSUPPORTED;
-  UdArena ar(workspace, workspace_bytes);
-  BnWs w;
-  carve(ar, C, &w);
-  if (!ar.ok()) return UD_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
-  UdProfScope prof("bn_act.stats", stream);
-  const int slices = slices_for(P, C), gw = group_width(C);
-  if (gw == 64)
-    k_bn_stats_partial<64><<<dim3(slices, C / 64), 256, 0, stream>>>((const unsigned short*)x, P, C, w.partial);
-  else if (gw == 32)
-    k_bn_stats_partial<32><<<dim3(slices, C / 32), 256, 0, stream>>>((const unsigned short*)x, P, C, w.partial);
-  else
-    k_bn_stats_partial<16><<<dim3(slices, C / 16), 256, 0, stream>>>((const unsigned short*)x, P, C, w.partial);
-  UD_LAUNCH_CHECK();
-  k_bn_stats_final<<<C, 64, 0, stream>>>((const unsigned short*)x, w.partial, slices, P, C, gamma, beta, eps,
-                                         mean, var, invstd, scale, shift, running_mean, running_var, momentum,
-                                         batches_tracked);
-  UD_LAUNCH_CHECK();
-  return UD_OK;
+                size_t workspace_bytes, ud_stream_t stream) {
+  return bn_stats_impl<bf16_t>((const bf16_t*)x, P, C, gamma, beta, eps, mean, var, invstd, scale, shift, running_mean,
+                               running_var, momentum, batches_tracked, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int ud_bn_stats_f32(const float* x, long long P, int C, const float* gamma, const float* beta, float eps,
+                    float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
+                    float* running_var, float momentum, long long* batches_tracked, void* workspace,
+                    size_t workspace_bytes, ud_stream_t stream) {
+  return bn_stats_impl<float>(x, P, C, gamma, beta, eps, mean, var, invstd, scale, shift, running_mean, running_var,
+                              momentum, batches_tracked, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,
-                  long long P, int C, int relu, ud_stream_t stream_) {
-  if (!x || !scale || !shift || !y || P <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
-  if (C % 8) return UD_ERR_UNSUPPORTED;
-  hipStream_t stream = (hipStream_t)stream_;
-  int CH;
-  dim3 grid;
-  stream_grid(P, C, &CH, &grid);
-  UdProfScope prof("bn_act.k_fwd", stream);
-  k_bn_act_fwd<<<grid, 256, 0, stream>>>((const unsigned short*)x, (const unsigned short*)residual, scale, shift,
-                                         (unsigned short*)y, P, C, CH, relu);
-  UD_LAUNCH_CHECK();
-  return UD_OK;
+                  long long P, int C, int relu, ud_stream_t stream) {
+  return bn_fwd_impl<bf16_t>((const bf16_t*)x, (const bf16_t*)residual, scale, shift, (bf16_t*)y, P, C, relu,
+                             (hipStream_t)stream);
+}
+int ud_bn_act_fwd_f32(const float* x, const float* residual, const float* scale, const float* shift, float* y,
+                      long long P, int C, int relu, ud_stream_t stream) {
+  return bn_fwd_impl<float>(x, residual, scale, shift, y, P, C, relu, (hipStream_t)stream);
 }
 
 int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* scale, const float* shift,
                   const float* mean, const float* invstd, void* dx, void* dresidual, float* dgamma,
                   float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
-                  ud_stream_t stream_) {
-  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || P <= 0 || C <= 0)
-    return UD_ERR_INVALID_ARG;
-  if (C % 16) return UD_ERR_UNSUPPORTED;
-  UdArena ar(workspace, workspace_bytes);
-  BnWs w;
-  carve(ar, C, &w);
-  if (!ar.ok()) return UD_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
-  {
-    UdProfScope prof("bn_act.k_bwd_reduce", stream);
-    const int slices = slices_for(P, C), gw = group_width(C);
-#define UD_BN_REDUCE(GW)                                                                                   \
-  k_bn_bwd_reduce<GW><<<dim3(slices, C / GW), 256, 0, stream>>>(                                           \
-      (const unsigned short*)x, (const unsigned short*)y, (const unsigned short*)dy, scale, shift, mean, P, \
-      C, relu, w.partial)
-    if (gw == 64) UD_BN_REDUCE(64); else if (gw == 32) UD_BN_REDUCE(32); else UD_BN_REDUCE(16);
-#undef UD_BN_REDUCE
-    UD_LAUNCH_CHECK();
-    k_bn_bwd_final<<<C, 64, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd,
-                                                           dgamma, dbeta, w.k0, w.k2);
-    UD_LAUNCH_CHECK();
-  }
-  int CH;
-  dim3 grid;
-  stream_grid(P, C, &CH, &grid);
-  UdProfScope prof("bn_act.k_bwd_dx", stream);
-  k_bn_bwd_dx<<<grid, 256, 0, stream>>>((const unsigned short*)x, (const unsigned short*)y,
-                                        (const unsigned short*)dy, scale, shift, w.k0, w.k2, (unsigned short*)dx,
-                                        (unsigned short*)dresidual, P, C, CH, relu);
-  UD_LAUNCH_CHECK();
-  return UD_OK;
+                  ud_stream_t stream) {
+  return bn_bwd_impl<bf16_t>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, scale, shift, mean, invstd,
+                             (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, P, C, relu, workspace, workspace_bytes,
+                             (hipStream_t)stream);
+}
+int ud_bn_act_bwd_f32(const float* x, const float* y, const float* dy, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, float* dx, float* dresidual, float* dgamma,
+                      float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
+                      ud_stream_t stream) {
+  return bn_bwd_impl<float>(x, y, dy, scale, shift, mean, invstd, dx, dresidual, dgamma, dbeta, P, C, relu, workspace,
+                            workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

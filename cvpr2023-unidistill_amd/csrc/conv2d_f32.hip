@@ -16,6 +16,7 @@
 // permutation of the slice's channels that A and B share, so the sum is the same.
 #include "ud_common.h"
 #include "ud_prof.h"
+#include <cstdlib>
 
 namespace {
 
@@ -193,7 +194,8 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
   }
   const int gx = (ntiles + 7) / 8 * 8;
   UdProfScope prof(name, stream);
-  if (gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256)
+  static const int force64 = getenv("UD_F32_TN64") ? atoi(getenv("UD_F32_TN64")) : 0;
+  if (force64 || gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256)
     k_conv_f32<64, KS><<<dim3(gx, ud_div_up(gm.Cout, 64)), 256, conv_smem_bytes_f(64, KS), stream>>>(x, w, y, gm, ep);
   else
     k_conv_f32<128, KS><<<dim3(gx, ud_div_up(gm.Cout, 128)), 256, conv_smem_bytes_f(128, KS), stream>>>(x, w, y, gm, ep);

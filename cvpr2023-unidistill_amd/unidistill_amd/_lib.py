@@ -85,6 +85,8 @@ _SIGS = {
     "ud_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_conv3x3_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_points_transform": (c_int, [c_void_p] * 5 + [c_int, c_int, c_i64, c_void_p]),
+    "ud_image_normalize": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "ud_collate_pad": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p]),
     "ud_conv1x1_wgrad_workspace_bytes": (c_size_t, [c_i64, c_int, c_int]),
     "ud_conv1x1_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p, c_size_t, c_void_p]),
     "ud_assign_targets": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p, c_void_p] + [c_int] * 8 + [c_float] * 5
@@ -106,6 +108,10 @@ _SIGS = {
                     + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_bn_act_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_int, c_void_p]),
     "ud_bn_act_bwd": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ud_bn_stats_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7
+                        + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_bn_act_fwd_f32": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_int, c_void_p]),
+    "ud_bn_act_bwd_f32": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_workspace_bytes": (c_size_t, [c_int]),
     "ud_head_tail_stats": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_float]
                            + [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),

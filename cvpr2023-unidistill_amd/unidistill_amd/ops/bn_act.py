@@ -10,16 +10,17 @@ from .. import _lib
 
 
 def supported(x, bn):
-    """4-D channels-last maps [B, C, H, W] or 2-D row tensors [M, C] (sparse voxel features), bf16."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() in (2, 4) and x.shape[1] % 16 == 0
+    """4-D channels-last maps [B, C, H, W] or 2-D row tensors [M, C] (sparse voxel features); bf16 (mixed
+    precision mode) or fp32 (the reference's arithmetic)."""
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() in (2, 4) and x.shape[1] % 16 == 0
             and x.shape[0] > 0 and bn.affine and bn.track_running_stats and bn.momentum is not None):
         return False
     return x.is_contiguous() if x.dim() == 2 else x.is_contiguous(memory_format=torch.channels_last)
 
 
 def _like(t, ref):
-    """t in ref's dtype/layout (bf16; contiguous rows or channels-last map)."""
-    t = t.to(torch.bfloat16)
+    """t in ref's dtype/layout (contiguous rows or channels-last map)."""
+    t = t.to(ref.dtype)
     return t.contiguous() if ref.dim() == 2 else t.contiguous(memory_format=torch.channels_last)
 
 
@@ -39,6 +40,8 @@ class _BnActFn(torch.autograd.Function):
                 tracked=None):
         lib = _lib.load()
         _lib.require_gpu(x, gamma, beta)
+        f32 = x.dtype == torch.float32
+        k_stats, k_fwd = (lib.ud_bn_stats_f32, lib.ud_bn_act_fwd_f32) if f32 else (lib.ud_bn_stats, lib.ud_bn_act_fwd)
         C = x.shape[1]
         P = x.numel() // C
         dev = x.device
@@ -52,7 +55,7 @@ class _BnActFn(torch.autograd.Function):
             ws = _workspace(dev, C)
             fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
             rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
-            _lib.check(lib.ud_bn_stats(x.data_ptr(), P, C, g32.data_ptr(), b32.data_ptr(), float(eps),
+            _lib.check(k_stats(x.data_ptr(), P, C, g32.data_ptr(), b32.data_ptr(), float(eps),
                                        v0, v0 + row, v0 + 2 * row, v0 + 3 * row, v0 + 4 * row,
                                        _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
                                        _lib.ptr(tracked), ws.data_ptr(), ws.numel(), stream), "ud_bn_stats")
@@ -69,7 +72,7 @@ class _BnActFn(torch.autograd.Function):
         if residual is not None:
             residual = _like(residual, x)
         y = torch.empty_like(x)
-        _lib.check(lib.ud_bn_act_fwd(x.data_ptr(), _lib.ptr(residual), v0 + 3 * row, v0 + 4 * row,
+        _lib.check(k_fwd(x.data_ptr(), _lib.ptr(residual), v0 + 3 * row, v0 + 4 * row,
                                      y.data_ptr(), P, C, 1 if relu else 0, stream), "ud_bn_act_fwd")
         ctx.cfg = (bool(training), bool(relu), residual is not None)
         ctx.save_for_backward(x, y if (residual is not None and relu) else None, vec)
@@ -92,7 +95,8 @@ class _BnActFn(torch.autograd.Function):
         dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
         ws = _workspace(x.device, C)
         v0, row, g0 = vec.data_ptr(), 4 * C, dgb.data_ptr()
-        _lib.check(lib.ud_bn_act_bwd(x.data_ptr(), _lib.ptr(y), dy.data_ptr(), v0 + 3 * row, v0 + 4 * row,
+        k_bwd = lib.ud_bn_act_bwd_f32 if x.dtype == torch.float32 else lib.ud_bn_act_bwd
+        _lib.check(k_bwd(x.data_ptr(), _lib.ptr(y), dy.data_ptr(), v0 + 3 * row, v0 + 4 * row,
                                      v0, v0 + 2 * row, dx.data_ptr(), _lib.ptr(dres),
                                      g0, g0 + row, P, C, 1 if relu else 0,
                                      ws.data_ptr(), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd")

@@ -93,3 +93,75 @@ def bev_affine(points, gt_boxes, rotate_deg, scale, trans, flip_dx, flip_dy):
             boxes[:, 7] = (float(mat[0, 0]) * v[:, 0] + float(mat[0, 1]) * v[:, 1]).float()
             boxes[:, 8] = (float(mat[1, 0]) * v[:, 0] + float(mat[1, 1]) * v[:, 1]).float()
     return out, boxes, mat
+
+
+# ---- camera side + collate ---------------------------------------------------------------------
+IMG_MEAN, IMG_STD, TO_RGB = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375), True    # base_nuscenes_cfg.py:31
+
+
+def image_normalize(imgs_u8, mean=IMG_MEAN, std=IMG_STD, to_rgb=TO_RGB, channels_last=False):
+    """ImageNormalize.forward (transforms3d.py:350-368 -> mmcv.imnormalize) + the dataset's HWC -> CHW permute /
+    stack (nuscenes_multimodal.py:262-293) for uint8 images on the device: imgs_u8 [..., H, W, 3] -> float32
+    [..., 3, H, W] (``channels_last``: same shape, NHWC memory)."""
+    _lib.require_gpu(imgs_u8)
+    if imgs_u8.dtype != torch.uint8 or imgs_u8.shape[-1] != 3 or imgs_u8.dim() < 3:
+        raise ValueError("imgs_u8 must be uint8 [..., H, W, 3]")
+    x = imgs_u8.contiguous()
+    lead, (H, W) = x.shape[:-3], x.shape[-3:-1]
+    NI = int(np.prod(lead)) if lead else 1
+    import ctypes
+    f3 = lambda v: (ctypes.c_float * 3)(*[float(a) for a in v])
+    if channels_last:
+        out = torch.empty((NI, H, W, 3), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((NI, 3, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ud_image_normalize(_lib.ptr(x), _lib.ptr(out), f3(mean), f3(std), 1 if to_rgb else 0,
+                                              NI, H, W, 1 if channels_last else 0, _lib.stream_of(x)),
+               "ud_image_normalize")
+    if channels_last:
+        out = out.permute(0, 3, 1, 2)              # [NI, 3, H, W] view of the NHWC buffer
+    return out.reshape(*lead, 3, H, W)             # only splits the leading axis: a view in both layouts
+
+
+def _fill_batch_tensor(batch_data, device):
+    """fill_batch_tensor of collate_fn (nuscenes_multimodal.py:441-463): stack equal-length samples, zero-pad
+    ragged ones to the longest (one ud_collate_pad launch); float32 on ``device``."""
+    ts = [d if torch.is_tensor(d) else torch.as_tensor(np.asarray(d)) for d in batch_data]
+    lens = [len(t) for t in ts]
+    if max(lens) == min(lens):
+        return torch.stack([t.to(device=device, dtype=torch.float32, non_blocking=True) for t in ts])
+    tail = next(tuple(t.shape[1:]) for t in ts if t.numel() != 0)
+    W = int(np.prod(tail)) if tail else 1
+    L, B = max(lens), len(ts)
+    dev_ts = [t.to(device=device, dtype=torch.float32, non_blocking=True).contiguous() for t in ts]
+    out = torch.empty((B, L) + tail, dtype=torch.float32, device=device)
+    import ctypes
+    ptrs = (ctypes.c_void_p * B)(*[t.data_ptr() if t.numel() else None for t in dev_ts])
+    rows = (ctypes.c_int64 * B)(*[n if t.numel() else 0 for n, t in zip(lens, dev_ts)])
+    _lib.check(_lib.load().ud_collate_pad(ptrs, rows, B, L, W, _lib.ptr(out), _lib.stream_of(out)), "ud_collate_pad")
+    return out
+
+
+def collate_fn(data, device="cuda", is_return_depth=False, with_points=True):
+    """collate_fn of the reference (data/multisensorfusion/nuscenes_multimodal.py:418-495) with the batch
+    assembled ON THE DEVICE: same keys, shapes and dtypes (float32) -- ``imgs`` [B, sweeps, cams, 3, h, w],
+    ``points`` [B, Nmax, D] zero padded, ``gt_boxes`` [B, Mmax, S], ``gt_labels`` [B, Mmax], ``mats_dict`` of
+    stacked 4x4 matrices, ``img_metas`` passed through.  A sample may carry ``imgs_u8`` ([sweeps, cams, H, W, 3]
+    uint8, not yet normalised) instead of ``imgs``: normalisation + permute then run here in one launch."""
+    device = torch.device(device)
+    batch = {}
+    if "imgs_u8" in data[0]:
+        u8 = torch.stack([torch.as_tensor(np.asarray(d["imgs_u8"])) for d in data]).to(device, non_blocking=True)
+        batch["imgs"] = image_normalize(u8)
+    for key in ("imgs", "points", "gt_boxes", "gt_labels"):
+        if key in data[0] and key not in batch:
+            batch[key] = _fill_batch_tensor([d[key] for d in data], device)
+    if "mats_dict" in data[0]:
+        batch["mats_dict"] = {}
+        for key in ("sensor2ego_mats", "intrin_mats", "ida_mats", "sensor2sensor_mats", "bda_mat"):
+            if key in data[0]["mats_dict"]:
+                batch["mats_dict"][key] = torch.stack(
+                    [torch.as_tensor(np.asarray(d["mats_dict"][key])) if not torch.is_tensor(d["mats_dict"][key])
+                     else d["mats_dict"][key] for d in data]).to(device=device, dtype=torch.float32)
+    batch["img_metas"] = [d.get("img_metas") for d in data]
+    return batch

@@ -435,6 +435,19 @@ int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t
 int ud_points_transform(const float* in, float* out, const int64_t* seg, const double* mats, const float* last,
                         int S, int D, int64_t max_rows, ud_stream_t stream);
 
+/* ---- camera input side + collate ------------------------------------------------------
+ * ImageNormalize.forward (data/multisensorfusion/transforms3d.py:350-368 -> mmcv.imnormalize, third party:
+ * float32(img) [channel order reversed when to_rgb] - float32(mean), * float32(1 / float64(std))) fused with the
+ * dataset's HWC -> CHW permute + stack (nuscenes_multimodal.py:262-293).  img u8 [NI][H][W][3] (device), out f32
+ * [NI][3][H][W], or [NI][H][W][3] memory when out_channels_last (a channels-last view for the NHWC model);
+ * mean/std: HOST float[3]. */
+int ud_image_normalize(const unsigned char* img, float* out, const float* mean, const float* std, int to_rgb,
+                       int NI, int H, int W, int out_channels_last, ud_stream_t stream);
+/* collate_fn.fill_batch_tensor for ragged samples (nuscenes_multimodal.py:441-463): out f32 [B][L][W] (device),
+ * out[b, :rows[b]] = samples[b] (device pointers, HOST array of B), zero rows up to L.  rows: HOST int64[B]. */
+int ud_collate_pad(const float* const* samples, const int64_t* rows, int B, int64_t L, int W, float* out,
+                   ud_stream_t stream);
+
 /* ---- BatchNorm2d (+ residual) (+ ReLU), channels-last bf16 ------------------------------------------
  * The Conv2d -> BatchNorm2d -> ReLU links of the reference's dense layers (base_bev_backbone.py:48-66,
  * center_head.py:408-420, the mmdet ResNet bottlenecks) as HBM-bound streaming kernels over
@@ -461,6 +474,18 @@ int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* sca
                   const float* mean, const float* invstd, void* dx, void* dresidual, float* dgamma,
                   float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
                   ud_stream_t stream);
+/* fp32 twins for the fp32 (reference-arithmetic) mode: x / residual / y / dy / dx are FP32 rows, everything
+ * else as above (C % 16 == 0). */
+int ud_bn_stats_f32(const float* x, long long P, int C, const float* gamma, const float* beta, float eps,
+                    float* mean, float* var, float* invstd, float* scale, float* shift, float* running_mean,
+                    float* running_var, float momentum, long long* batches_tracked, void* workspace,
+                    size_t workspace_bytes, ud_stream_t stream);
+int ud_bn_act_fwd_f32(const float* x, const float* residual, const float* scale, const float* shift, float* y,
+                      long long P, int C, int relu, ud_stream_t stream);
+int ud_bn_act_bwd_f32(const float* x, const float* y, const float* dy, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, float* dx, float* dresidual, float* dgamma,
+                      float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
+                      ud_stream_t stream);
 
 /* ---- Proposal layer: rotated-BEV IoU + greedy NMS -----------------------------------------------------
  * Replaces `iou3d_nms_cuda.nms_gpu(boxes, keep, thresh)` (reference layers/head/det3d/generate_proposals/

@@ -360,3 +360,31 @@ def bev_transform_boxes(gt_boxes, rotate_deg, scale, trans, flip_dx, flip_dy):
         if boxes.shape[1] > 7:
             boxes[:, 7:] = (mat[:2, :2] @ boxes[:, 7:].T).T
     return boxes, mat
+
+
+def image_normalize(img_u8, mean, std, to_rgb=True):
+    """mmcv.imnormalize as ImageNormalize.forward calls it (transforms3d.py:361-366).  mmcv (pinned mmcv-full
+    1.4.2, README.md:17) is absent from the reference tree -- PARITY UNPINNED; published algorithm restated:
+    img = float32(img); cv2.cvtColor(BGR2RGB) when to_rgb (channel reversal); cv2.subtract(img, float64(mean));
+    cv2.multiply(img, 1 / float64(std)) -- OpenCV evaluates both on a float32 image in float32.  HWC in, HWC out."""
+    x = np.asarray(img_u8).astype(np.float32)
+    if to_rgb:
+        x = x[..., ::-1]
+    m = np.asarray(mean, np.float64).astype(np.float32)
+    sinv = (1.0 / np.asarray(std, np.float64)).astype(np.float32)
+    return ((x - m).astype(np.float32) * sinv).astype(np.float32)
+
+
+def collate_fill(batch_data):
+    """fill_batch_tensor of the reference's collate_fn (nuscenes_multimodal.py:441-463): stack equal-length
+    samples, zero-pad ragged ones to the longest; float32."""
+    arrs = [np.asarray(d) for d in batch_data]
+    lens = [len(a) for a in arrs]
+    if max(lens) == min(lens):
+        return np.stack(arrs).astype(np.float32)
+    tail = next(a.shape[1:] for a in arrs if a.size != 0)
+    out = np.zeros((len(arrs), max(lens)) + tuple(tail), np.float32)
+    for i, a in enumerate(arrs):
+        if a.size != 0:
+            out[i, :len(a)] = a
+    return out

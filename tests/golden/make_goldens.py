@@ -616,6 +616,38 @@ def gold_model_step():
 
 ALL["model_step"] = gold_model_step
 
+
+def gold_collate():
+    """collate_fn (data/multisensorfusion/nuscenes_multimodal.py:418-495) executed by the reference on ragged
+    samples: equal-size images / matrices are stacked, clouds and boxes zero-padded, an empty box list handled."""
+    from unidistill.data.multisensorfusion.nuscenes_multimodal import collate_fn
+    rng = np.random.default_rng(91)
+    n_pts, n_box = [37, 52, 11], [4, 0, 7]
+    data, out = [], {}
+    for i, (n, m) in enumerate(zip(n_pts, n_box)):
+        d = {"imgs": rng.standard_normal((1, 2, 3, 6, 10)).astype(np.float32),
+             "points": rng.standard_normal((n, 5)).astype(np.float32),
+             "gt_boxes": rng.standard_normal((m, 9)).astype(np.float32),
+             "gt_labels": rng.integers(0, 10, (m,)).astype(np.int64),
+             "mats_dict": {"sensor2ego_mats": rng.standard_normal((1, 2, 4, 4)), "intrin_mats": rng.standard_normal((1, 2, 4, 4)),
+                           "ida_mats": rng.standard_normal((1, 2, 4, 4)), "sensor2sensor_mats": rng.standard_normal((1, 2, 4, 4)),
+                           "bda_mat": rng.standard_normal((4, 4))},
+             "img_metas": {"token": f"t{i}"}}
+        data.append(d)
+        for k in ("imgs", "points", "gt_boxes", "gt_labels"):
+            out[f"in{i}_{k}"] = d[k]
+        for k, v in d["mats_dict"].items():
+            out[f"in{i}_{k}"] = v
+    res = collate_fn(data)
+    for k in ("imgs", "points", "gt_boxes", "gt_labels"):
+        out["out_" + k] = res[k]
+    for k, v in res["mats_dict"].items():
+        out["out_" + k] = v
+    _save("collate", **out)
+
+
+ALL["collate"] = gold_collate
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)
     for n in names:

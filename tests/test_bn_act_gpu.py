@@ -94,3 +94,50 @@ def test_bn_act_voxel_rows(hip_lib, M, C, residual):
         _close(rd.grad, rr.grad, 8e-3, "dres")
     _close(bn.running_mean, bn_ref.running_mean, 1e-3, "running_mean")
     _close(bn.running_var, bn_ref.running_var, 1e-3, "running_var")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 9, 13), (3, 128, 16, 20), (777, 32), (300, 128)])
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_act_fp32_mode(hip_lib, shape, residual, relu):
+    """fp32 twins (ud_bn_*_f32: the reference-arithmetic mode) vs torch BatchNorm in fp32: 2e-5 of the max."""
+    from unidistill_amd import _lib
+    from unidistill_amd.layers.dense import batchnorm_act
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if len(shape) == 4 else (lambda t: t.contiguous())
+    x = torch.randn(*shape, generator=g) * 2 + 0.5
+    r = torch.randn(*shape, generator=g) if residual else None
+    gy = torch.randn(*shape, generator=g)
+    BN = torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d
+    bn_ref = BN(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.normal_(0, 0.3)
+    bn = BN(C, eps=1e-3, momentum=0.01).cuda()
+    bn.load_state_dict(bn_ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if residual else None
+    yr = bn_ref(xr)
+    if residual:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(gy)
+    xd = cl(x.cuda()).requires_grad_(True)
+    rd = cl(r.cuda()).requires_grad_(True) if residual else None
+    _lib.prof_read("bn_act.k_fwd", reset=True)
+    _lib.prof_enable(True)
+    y = batchnorm_act(bn, xd, rd, relu)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    assert _lib.prof_read("bn_act.k_fwd")[1] == 1, "the fp32 tensor must take the HIP kernel, not the library"
+    assert y.dtype == torch.float32
+    y.backward(cl(gy.cuda()))
+    _close(y, yr, 2e-5, "y")
+    _close(xd.grad, xr.grad, 1e-4, "dx")
+    _close(bn.weight.grad, bn_ref.weight.grad, 1e-4, "dgamma")
+    _close(bn.bias.grad, bn_ref.bias.grad, 1e-4, "dbeta")
+    if residual:
+        _close(rd.grad, rr.grad, 2e-5, "dres")
+    _close(bn.running_mean, bn_ref.running_mean, 1e-5, "running_mean")
+    _close(bn.running_var, bn_ref.running_var, 1e-5, "running_var")

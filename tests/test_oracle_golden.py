@@ -140,3 +140,9 @@ def test_input_prep_host_matrices_match_reference(golden):
         m = ip.sweep_to_key_matrix(g["key_lidar_to_ego"], g["key_ego_to_global"], g[f"sweep{i}_lidar_to_ego"])
         np.testing.assert_array_equal(m, oracle.sweep_to_key_matrix(g["key_lidar_to_ego"], g["key_ego_to_global"],
                                                                     g[f"sweep{i}_lidar_to_ego"]))
+
+
+def test_collate_oracle_matches_reference_golden(golden):
+    g = golden("collate")
+    for k in ("imgs", "points", "gt_boxes", "gt_labels"):
+        np.testing.assert_array_equal(oracle.collate_fill([g[f"in{i}_{k}"] for i in range(3)]), g["out_" + k])
