@@ -1,37 +1,48 @@
 #!/bin/bash
 # Regenerate the rocprofv3 evidence on the GPU box (run through gpurun); summaries land in
 # gpurun_out/profiles_rNN/ and are then copied to profiles/ (tracked).
-#   gpurun --timeout 1500 -- 'bash tools/make_profiles.sh r01'
+#   gpurun --timeout 2400 -- 'bash tools/make_profiles.sh r02'
 set -u
-R=${1:-r01}
+R=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T=$GRAFT_REPO_ROOT/tools
-# 1. the bench command itself: kernel trace + stats
+# 1. the bench command itself: kernel trace; summary restricted to the steady state (no warm-up / MIOpen find kernels)
 rm -rf /tmp/p_bench; rocprofv3 --kernel-trace --stats -d /tmp/p_bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_stdout.txt 2>&1
 DB=$(ls /tmp/p_bench/*/*.db | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo;
-  echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt; echo '```'; echo; echo "## Kernels by total time (whole run incl. warm-up, MIOpen find and the roofline leg)"; echo;
-  python $T/rocpd_summary.py $DB | head -60;
-  echo; echo "## Roofline kernel (bench.py roofline leg: 2 warm-up + 10 timed launches of bev_pool forward, cache scrubbed)"; echo;
-  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4"; } > $OUT/${R}_bench_kernel_stats.md
-# 2. steady-state training step by category (marker-delimited window)
-rm -rf /tmp/p_step; B=4 CL=1 AC=bf16 STEPS=6 rocprofv3 --kernel-trace -d /tmp/p_step -- python $T/profile_step.py > $OUT/step_stdout.txt 2>&1
-{ echo "# Steady-state distillation step, B=4, bf16 + channels-last (6 steps between marker kernels) ($R)"; echo; echo '```'; grep "samples/s" $OUT/step_stdout.txt; echo '```'; echo;
-  python $T/rocpd_categories.py $(ls /tmp/p_step/*/*.db | head -1) 6 --top; } > $OUT/${R}_step_categories.md
-# 3. bev_pool / voxelize op level
-{ echo "# bev_pool + voxelize op-level timings ($R)"; echo; echo '```'; python $T/time_bev_pool.py 2>&1 | tail -4; python $T/exp_pool.py 2>&1 | tail -4; python $T/time_voxelize.py 2>&1 | tail -6; python $T/exp_stream.py 2>&1 | tail -5; echo '```'; } > $OUT/${R}_bevpool_voxelize_ops.md
+  echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt; echo '```'; echo;
+  echo "## Roofline kernels of the bench legs (rocprofv3 durations; bench.py's own HIP-event figures are in the JSON above)"; echo;
+  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_insert|k_first|k_scan|k_assign|k_gather|k_bin|k_cell|k_fill|k_conv3x3_bf16";
+  echo; echo "## Kernels by total time, naive_conv / find-mode kernels excluded"; echo;
+  python $T/rocpd_summary.py $DB | grep -v "naive_conv\|MIOpenConvUni\|Im2d2Col\|Col2Im" | head -45; } > $OUT/${R}_bench_kernel_stats.md
+# 2. steady-state training step by category (marker-delimited window): fp32 (headline) and bf16
+for AC in "" bf16; do
+  TAG=${AC:-fp32}
+  rm -rf /tmp/p_step; B=4 CL=1 AC=$AC STEPS=6 rocprofv3 --kernel-trace -d /tmp/p_step -- python $T/profile_step.py > $OUT/step_stdout_$TAG.txt 2>&1
+  { echo "# Steady-state distillation step, B=4, $TAG, channels-last (6 steps between marker kernels) ($R)"; echo; echo '```'; grep "samples/s" $OUT/step_stdout_$TAG.txt; echo '```'; echo;
+    TOP=30 python $T/rocpd_categories.py $(ls /tmp/p_step/*/*.db | head -1) 6 --top | cut -c1-180; } > $OUT/${R}_step_categories_$TAG.md
+done
+# 3. bev_pool / voxelize / dense() op level
+{ echo "# bev_pool + voxelize + dense() op-level timings ($R)"; echo; echo '```'; python $T/time_bev_pool.py 2>&1 | tail -4; python $T/exp_pool.py 2>&1 | tail -4; python $T/time_voxelize.py 2>&1 | tail -12; python $T/time_dense.py 2>&1 | tail -2; python $T/exp_stream.py 2>&1 | tail -5; echo '```'; } > $OUT/${R}_bevpool_voxelize_ops.md
 rm -rf /tmp/p_vox; rocprofv3 --kernel-trace --stats -d /tmp/p_vox -- python $T/time_voxelize.py > /dev/null 2>&1
-{ echo; echo "## voxelize kernels (all six configurations of tools/time_voxelize.py pooled)"; echo; python $T/rocpd_summary.py $(ls /tmp/p_vox/*/*.db | head -1) namespace; } >> $OUT/${R}_bevpool_voxelize_ops.md
-# 4. HBM traffic of the dominant kernel (separate --pmc passes, as MI355X_MICROARCH.md prescribes)
+{ echo; echo "## voxelize kernels (all six configurations of tools/time_voxelize.py pooled; rocprofv3 kernel durations)"; echo; python $T/rocpd_summary.py $(ls /tmp/p_vox/*/*.db | head -1) namespace; } >> $OUT/${R}_bevpool_voxelize_ops.md
+# 4. HBM traffic of the dominant kernels (separate --pmc passes, as MI355X_MICROARCH.md prescribes)
 rm -rf /tmp/pmc1 /tmp/pmc2
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc1 -- python $T/pmc_pool.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc2 -- python $T/pmc_pool.py > /dev/null 2>&1
 { echo "# HBM traffic of bev_pool.k_pool from PMC counters ($R)"; echo;
   echo "Separate passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace -- python tools/pmc_pool.py"; echo '```';
   python $T/rocpd_pmc.py $(ls /tmp/pmc1/*/*.db | head -1) k_pool | tail -1; python $T/rocpd_pmc.py $(ls /tmp/pmc2/*/*.db | head -1) k_pool | tail -1; echo '```'; } > $OUT/${R}_pmc_k_pool.md
+rm -rf /tmp/pmc3 /tmp/pmc4
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc3 -- python $T/time_voxelize.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc4 -- python $T/time_voxelize.py > /dev/null 2>&1
+{ echo "# HBM traffic of the voxelize kernels from PMC counters ($R; all six configurations of tools/time_voxelize.py pooled)"; echo; echo '```';
+  for k in k_insert k_first k_assign k_gather; do python $T/rocpd_pmc.py $(ls /tmp/pmc3/*/*.db | head -1) $k | tail -1; python $T/rocpd_pmc.py $(ls /tmp/pmc4/*/*.db | head -1) $k | tail -1; done; echo '```'; } > $OUT/${R}_pmc_voxelize.md
 # 5. sparse encoder
 rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T/time_spconv.py > $OUT/spconv_stdout.txt 2>&1
 { echo "# LiDAR sparse encoder forward, B=4 x 30k points ($R)"; echo; echo '```'; grep "encoder fwd" $OUT/spconv_stdout.txt; echo '```'; echo; python $T/rocpd_summary.py $(ls /tmp/p_sp/*/*.db | head -1) namespace | head -30; } > $OUT/${R}_spconv_encoder.md
+# 6. fp32 convolutions: ours vs library
+{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo '```'; } > $OUT/${R}_conv_f32.md
 ls -la $OUT
