@@ -20,7 +20,8 @@ import torch
 from torch import nn
 
 from ..dist import reduce_mean, reduce_mean_many
-from ..ops import conv2d as hipconv, det_loss as hiploss, head_tail
+from ..ops import bn_act as hipbn, conv2d as hipconv, conv2d_f32 as hipconv32, det_loss as hiploss, head_tail, \
+    head_tail_f32
 from .dense import Conv2d, FusedSequential
 
 
@@ -460,6 +461,9 @@ class PackedSepHeads(nn.Module):
         if Conv2d.hip_enabled and self.k == 3 and x.is_cuda and x.dtype == torch.bfloat16 \
                 and hipconv.supported(x, self.c1_weight):
             y = hipconv.conv3x3(x, self.c1_weight, self.c1_bias)      # 64 -> 42*64 on the MFMA kernel
+        elif Conv2d.hip_enabled and Conv2d.hip_fp32 and self.k == 3 and x.is_cuda and x.dtype == torch.float32 \
+                and not torch.is_autocast_enabled("cuda") and hipconv32.supported(x, self.c1_weight, 3):
+            y = hipconv32.conv3x3(x, self.c1_weight, self.c1_bias)    # fp32 MFMA kernel (1.02x the library, deterministic)
         else:
             y = torch.nn.functional.conv2d(x, self.c1_weight, self.c1_bias, padding=pad)
         if self.training:
@@ -473,6 +477,15 @@ class PackedSepHeads(nn.Module):
                                     self.bn_running_mean, self.bn_running_var, self.training,
                                     self.bn_momentum, self.bn_eps, G, self.kmax)
             return self._split(z)
+        if Conv2d.hip_enabled and Conv2d.hip_fp32 and not torch.is_autocast_enabled("cuda") and not frozen_bn_grad \
+                and head_tail_f32.supported(y, self.head_conv, self.kmax, self.k) and (self.training or not torch.is_grad_enabled()):
+            # fp32 mode on the GPU: BN + ReLU as one streaming pass, then the 42 second convs as ONE grouped fp32
+            # kernel (the block-diagonal dense conv below costs 42x the FLOPs: 19 ms per fwd+bwd at B = 4)
+            a = hipbn._BnActFn.apply(y if y.is_contiguous(memory_format=torch.channels_last)
+                                     else y.contiguous(memory_format=torch.channels_last),
+                                     self.bn_weight, self.bn_bias, None, self.bn_running_mean, self.bn_running_var,
+                                     self.training, self.bn_momentum, self.bn_eps, True, None)
+            return self._split(head_tail_f32.group_tail(a, self.c2_weight, self.c2_bias, G, self.kmax))
         y = torch.nn.functional.batch_norm(y, self.bn_running_mean, self.bn_running_var, self.bn_weight,
                                            self.bn_bias, self.training, self.bn_momentum, self.bn_eps)
         y = torch.relu(y)

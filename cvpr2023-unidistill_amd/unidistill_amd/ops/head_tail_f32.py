@@ -1,0 +1,58 @@
+"""fp32 mode of the second SepHead convolutions (reference layers/head/det3d/center_head.py:311-362): the 42
+(conv3x3 64 -> k <= 3) stacks as ONE grouped convolution on the channels-last fp32 hidden tensor
+(ud_head_tail_f32_fwd / _dgrad / _wgrad: exact fp32 FMAs, HBM-bound streaming kernels, deterministic)."""
+import torch
+
+from .. import _lib
+
+
+def supported(a, head_conv, kmax, k):
+    return (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and head_conv == 64 and k == 3
+            and 1 <= kmax <= 4 and a.shape[1] % 64 == 0)
+
+
+class _GroupTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, weight, bias, G, KM):
+        """a [B, G*64, H, W] (any layout; made channels-last), weight [G*KM, 64, 3, 3], bias [G*KM]."""
+        _lib.require_gpu(a, weight)
+        a = a if a.is_contiguous(memory_format=torch.channels_last) else a.contiguous(memory_format=torch.channels_last)
+        B, C, H, W = a.shape
+        assert C == G * 64 and weight.shape == (G * KM, 64, 3, 3)
+        wt = weight.detach().permute(0, 2, 3, 1).contiguous()          # [G*KM, 3, 3, 64] = [G][KM][9][64]
+        z = torch.empty((B, G * KM, H, W), dtype=torch.float32, device=a.device, memory_format=torch.channels_last)
+        b = None if bias is None else bias.detach().contiguous()
+        _lib.check(_lib.load().ud_head_tail_f32_fwd(_lib.ptr(a), _lib.ptr(wt), _lib.ptr(b), _lib.ptr(z), B, H, W, G,
+                                                    KM, _lib.stream_of(a)), "ud_head_tail_f32_fwd")
+        ctx.save_for_backward(a, wt)
+        ctx.cfg = (G, KM, bias is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        a, wt = ctx.saved_tensors
+        G, KM, has_bias = ctx.cfg
+        lib = _lib.load()
+        B, C, H, W = a.shape
+        dz = dz.float()
+        dz = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
+        da = dw = db = None
+        st = _lib.stream_of(a)
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            _lib.check(lib.ud_head_tail_f32_dgrad(_lib.ptr(dz), _lib.ptr(wt), _lib.ptr(da), B, H, W, G, KM, st),
+                       "ud_head_tail_f32_dgrad")
+        if ctx.needs_input_grad[1]:
+            need = lib.ud_head_tail_f32_wgrad_workspace_bytes(B, H, W, G, KM)
+            ws = _lib.workspace(a.device, need, "head_tail_f32")
+            dwt = torch.empty((G * KM, 3, 3, 64), dtype=torch.float32, device=a.device)
+            _lib.check(lib.ud_head_tail_f32_wgrad(_lib.ptr(a), _lib.ptr(dz), _lib.ptr(dwt), B, H, W, G, KM,
+                                                  _lib.ptr(ws), ws.numel(), st), "ud_head_tail_f32_wgrad")
+            dw = dwt.permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dz.sum((0, 2, 3))
+        return da, dw, db, None, None
+
+
+def group_tail(a, weight, bias, G, KM):
+    return _GroupTail.apply(a, weight, bias, G, KM)

@@ -381,6 +381,20 @@ int ud_head_tail_bwd(const void* y, const float* dz, const float* w2, const floa
                      float* dw2, float* dgamma, float* dbeta, int B, int H, int W, int G, int kmax,
                      void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
+/* fp32 mode (the reference's arithmetic) of the second SepHead convolutions (center_head.py:311-362): a grouped
+ * 3x3 / pad-1 convolution with 64 inputs and KM <= 4 outputs per group on channels-last fp32 tensors, exact fp32
+ * FMAs, HBM-bound streaming kernels (the libraries run it as a 42x padded block-diagonal conv).
+ *   a  f32 [B][H][W][G*64]   hidden tensor after BatchNorm + ReLU        w  f32 [G][KM][9][64] (tap = ky*3+kx)
+ *   z  f32 [B][H][W][G*KM]   = bias[G*KM] + conv                          dz same layout as z
+ *   dgrad: da [B][H][W][G*64];  wgrad: dw [G][KM][9][64], fixed-order slice reduction (deterministic). */
+int ud_head_tail_f32_fwd(const float* a, const float* w, const float* bias, float* z, int B, int H, int W, int G,
+                         int KM, ud_stream_t stream);
+int ud_head_tail_f32_dgrad(const float* dz, const float* w, float* da, int B, int H, int W, int G, int KM,
+                           ud_stream_t stream);
+size_t ud_head_tail_f32_wgrad_workspace_bytes(int B, int H, int W, int G, int KM);
+int ud_head_tail_f32_wgrad(const float* a, const float* dz, float* dw, int B, int H, int W, int G, int KM,
+                           void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
 /* ---- Dense 3x3 / stride 1 / pad 1 convolution, channels-last bf16 (BEV trunk + head convs) ----------
  * Replaces nn.Conv2d(k=3, s=1, p=1) of BaseBEVBackbone (reference unidistill/layers/blocks_2d/det3d/
  * base_bev_backbone.py:30-110) and CenterHead.shared_conv (layers/head/det3d/center_head.py:408-420)

@@ -107,3 +107,64 @@ def test_packed_heads_fused_tail_matches_library_path(hip_lib):
         assert torch.allclose(a, b, rtol=0, atol=2e-2 * float(b.detach().abs().max()) + 1e-3)
     for a, b in zip(outs[True][1:], outs[False][1:]):
         assert torch.allclose(a, b, rtol=0, atol=4e-2 * float(b.detach().abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 36, 5, 3), (1, 17, 9, 42, 3), (2, 8, 16, 3, 4), (1, 33, 40, 2, 1)])
+def test_fp32_group_tail_vs_grouped_conv(hip_lib, shape):
+    """fp32 mode: ud_head_tail_f32_fwd / _dgrad / _wgrad == torch's grouped 3x3 convolution (fp32), forward,
+    input gradient, weight and bias gradients; 2e-5 of the max (summation order only)."""
+    import torch
+    import torch.nn.functional as F
+    from unidistill_amd.ops import head_tail_f32 as h
+    B, H, W, G, KM = shape
+    torch.manual_seed(sum(shape))
+    a = torch.randn(B, G * 64, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(G * KM, 64, 3, 3, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.randn(G * KM, device="cuda").requires_grad_(True)
+    z = h.group_tail(a, w, b, G, KM)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    got = (z.detach().clone(), a.grad.clone(), w.grad.clone(), b.grad.clone())
+    a.grad = w.grad = b.grad = None
+    zr = F.conv2d(a, w, b, padding=1, groups=G)
+    zr.backward(gz)
+    for x, y, name in zip(got, (zr.detach(), a.grad, w.grad, b.grad), ("z", "da", "dw", "db")):
+        assert (x - y).abs().max() <= 2e-5 * y.abs().max() + 1e-6, name
+
+
+def test_fp32_packed_heads_use_the_group_kernel_and_match_the_library_path(hip_lib):
+    import torch
+    from unidistill_amd import _lib
+    from unidistill_amd.layers import center_head as ch
+    from unidistill_amd.layers.dense import Conv2d
+    torch.manual_seed(3)
+    heads = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "hm": (2, 2)}
+    m = ch.PackedSepHeads(64, [heads, heads], head_conv=64, final_kernel=3).cuda().train()
+    with torch.no_grad():
+        m.c2_weight.normal_(0, 0.05)
+    x = torch.randn(2, 64, 24, 20, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+    def run():
+        m.zero_grad()
+        x.grad = None
+        m.bn_running_mean.zero_(); m.bn_running_var.fill_(1.0)
+        outs = m(x)
+        loss = sum((v ** 2).sum() for d in outs for v in d.values())
+        loss.backward()
+        return [v.detach().clone() for d in outs for v in d.values()], x.grad.clone(), m.c2_weight.grad.clone(), \
+            m.c1_weight.grad.clone(), m.bn_weight.grad.clone()
+    _lib.prof_read("head_tail.k_gtail_fwd", reset=True)
+    _lib.prof_enable(True)
+    ours = run()
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    assert _lib.prof_read("head_tail.k_gtail_fwd")[1] == 1
+    Conv2d.hip_enabled = False
+    try:
+        ref = run()
+    finally:
+        Conv2d.hip_enabled = True
+    for a, b in zip(ours[0], ref[0]):
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max() + 1e-6
+    for a, b, name in zip(ours[1:], ref[1:], ("dx", "dw2", "dw1", "dgamma")):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, name
