@@ -34,35 +34,50 @@ __device__ __forceinline__ void tile_origin(const GTail& t, int tile, int& b, in
 }
 
 // z[pix, g*KM + k] = bias + sum_{tap, c} a[pix + tap - 1, g*64 + c] * w[g][k][tap][c]
-__global__ __launch_bounds__(128) void k_gtail_fwd(const float* __restrict__ a, const float* __restrict__ w,
+// 256 threads: two threads per output pixel, each over one half of the channels (combined through LDS);
+// the halo is staged as independent 16-byte loads (23 in flight per thread) -- a row-per-iteration loop
+// serialised one memory latency per halo row and made the kernel 15x slower.
+__global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ z, GTail t) {
   __shared__ __attribute__((aligned(16))) float s_a[kHQ * kLD];
   __shared__ __attribute__((aligned(16))) float s_w[kKMax * 9 * kHC];
-  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float s_p[kTW * kTH][kKMax];
+  const int g = blockIdx.y, tid = threadIdx.x;
   int b, ty0, tx0;
   tile_origin(t, blockIdx.x, b, ty0, tx0);
   const int Ct = t.G * kHC;
-  for (int i = tid; i < t.KM * 9 * kHC; i += 128) s_w[i] = w[(size_t)g * t.KM * 9 * kHC + i];
-  for (int q = wave; q < kHQ; q += 2) {                       // a wave stages whole 256-byte rows
+  for (int i = tid; i < t.KM * 9 * kHC; i += 256) s_w[i] = w[(size_t)g * t.KM * 9 * kHC + i];
+  constexpr int kPieces = kHQ * (kHC / 4);                      // 16-byte pieces of the halo: 2880
+  float4 v[(kPieces + 255) / 256];
+#pragma unroll
+  for (int j = 0; j < (kPieces + 255) / 256; ++j) {
+    const int i = tid + j * 256;
+    const int q = i >> 4, c4 = i & 15;
     const int gy = ty0 + q / kHW - 1, gx = tx0 + q % kHW - 1;
-    float v = 0.f;
-    if (gy >= 0 && gy < t.H && gx >= 0 && gx < t.W)
-      v = a[((size_t)(b * t.H + gy) * t.W + gx) * Ct + g * kHC + lane];
-    s_a[q * kLD + lane] = v;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < kPieces && gy >= 0 && gy < t.H && gx >= 0 && gx < t.W)
+      v[j] = *reinterpret_cast<const float4*>(a + ((size_t)(b * t.H + gy) * t.W + gx) * Ct + g * kHC + 4 * c4);
+  }
+#pragma unroll
+  for (int j = 0; j < (kPieces + 255) / 256; ++j) {
+    const int i = tid + j * 256;
+    if (i < kPieces) *reinterpret_cast<float4*>(s_a + (i >> 4) * kLD + 4 * (i & 15)) = v[j];
   }
   __syncthreads();
-  const int py = tid >> 4, px = tid & 15;
+  const int pix = tid & 127, half = tid >> 7;
+  const int py = pix >> 4, px = pix & 15;
   float acc[kKMax] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    const float* ar = s_a + ((py + tap / 3) * kHW + px + tap % 3) * kLD;
-#pragma unroll 4
-    for (int c4 = 0; c4 < kHC / 4; ++c4) {
+    const float* ar = s_a + ((py + tap / 3) * kHW + px + tap % 3) * kLD + 32 * half;
+    const float* wr = s_w + tap * kHC + 32 * half;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
       const float4 av = *reinterpret_cast<const float4*>(ar + 4 * c4);
 #pragma unroll
       for (int k = 0; k < kKMax; ++k) {
         if (k < t.KM) {
-          const float4 wv = *reinterpret_cast<const float4*>(s_w + (k * 9 + tap) * kHC + 4 * c4);
+          const float4 wv = *reinterpret_cast<const float4*>(wr + k * 9 * kHC + 4 * c4);
           acc[k] = fmaf(av.x, wv.x, acc[k]);
           acc[k] = fmaf(av.y, wv.y, acc[k]);
           acc[k] = fmaf(av.z, wv.z, acc[k]);
@@ -71,10 +86,15 @@ __global__ __launch_bounds__(128) void k_gtail_fwd(const float* __restrict__ a, 
       }
     }
   }
+  if (half) {
+#pragma unroll
+    for (int k = 0; k < kKMax; ++k) s_p[pix][k] = acc[k];
+  }
+  __syncthreads();
   const int gy = ty0 + py, gx = tx0 + px;
-  if (gy < t.H && gx < t.W) {
+  if (!half && gy < t.H && gx < t.W) {
     float* o = z + ((size_t)(b * t.H + gy) * t.W + gx) * (t.G * t.KM) + g * t.KM;
-    for (int k = 0; k < t.KM; ++k) o[k] = acc[k] + (bias ? bias[g * t.KM + k] : 0.f);
+    for (int k = 0; k < t.KM; ++k) o[k] = (acc[k] + s_p[pix][k]) + (bias ? bias[g * t.KM + k] : 0.f);
   }
 }
 
@@ -146,11 +166,16 @@ __global__ __launch_bounds__(256) void k_gtail_wgrad(const float* __restrict__ a
       s_z[q][k] = v;
     }
     __syncthreads();
-    for (int p = wave; p < kTW * kTH; p += 4) {
-      const int py = p >> 4, px = p & 15;
-      const int gy = ty0 + py, gx = tx0 + px;
-      if (gy >= t.H || gx >= t.W) continue;
-      const float av = a[((size_t)(b * t.H + gy) * t.W + gx) * Ct + g * kHC + lane];
+    float avs[kTW * kTH / 4];                                   // this wave's 32 pixels: all loads in flight at once
+#pragma unroll
+    for (int j = 0; j < kTW * kTH / 4; ++j) {
+      const int p = wave + 4 * j, gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+      avs[j] = (gy < t.H && gx < t.W) ? a[((size_t)(b * t.H + gy) * t.W + gx) * Ct + g * kHC + lane] : 0.f;
+    }
+#pragma unroll 4
+    for (int j = 0; j < kTW * kTH / 4; ++j) {
+      const int p = wave + 4 * j, py = p >> 4, px = p & 15;
+      const float av = avs[j];                                   // 0 outside the image: contributes nothing
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const float4 zv = *reinterpret_cast<const float4*>(&s_z[(py + 2 - tap / 3) * kHW + px + 2 - tap % 3][0]);
@@ -194,7 +219,7 @@ extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float*
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_fwd", stream);
-  k_gtail_fwd<<<dim3(B * t.tiles_x * t.tiles_y, G), 128, 0, stream>>>(a, w, bias, z, t);
+  k_gtail_fwd<<<dim3(B * t.tiles_x * t.tiles_y, G), 256, 0, stream>>>(a, w, bias, z, t);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
