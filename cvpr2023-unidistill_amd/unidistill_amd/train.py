@@ -179,6 +179,13 @@ class Trainer:
         trainable = [p for p in self.module.parameters() if p.requires_grad]
         self.ddp = None
         if get_world_size() > 1:
+            # DDP compares gradient strides with its bucket views literally; a 1x1 (transposed) convolution's weight
+            # gradient comes back from the channels-last kernels with different strides on its size-1 axes (same
+            # memory), which would cost a warning and a copy per step: re-label the strides, no data movement.
+            for p in trainable:
+                if p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1 and p.is_contiguous():
+                    p.register_hook(lambda g, st=p.stride(): g.as_strided(g.shape, st)
+                                    if (g.stride() != st and g.is_contiguous()) else g)
             # gradients are all-reduced over RCCL/xGMI in ~64 MB buckets, overlapped with backward
             self.ddp = nn.parallel.DistributedDataParallel(
                 self.module, device_ids=[self.device.index], output_device=self.device.index,
