@@ -255,22 +255,24 @@ __global__ __launch_bounds__(256) void k_down_rulebook(const int32_t* __restrict
 }
 
 // dense[b, c, z, y, x] = feat[row(b,z,y,x), c] (0 where no voxel): NCDHW is x-fastest, the feature rows
-// are c-fastest, so a 64-cell x 64-channel tile is transposed through LDS and BOTH sides move 256-byte
-// pieces.  A workgroup owns 64 consecutive x of one (b, z, y) line and walks the channel chunks; the dense
+// are c-fastest, so a (whole BEV row of <= 192 cells) x 64-channel tile is transposed through LDS: the feature
+// side moves 256-byte rows, the dense side one contiguous 4*Wx-byte run per channel.  A workgroup owns one
+// (b, z, y) line and walks the channel chunks; the dense
 // tensor is written exactly once, zeros included (no memset of the 33 MB-per-sample tensor).  BWD reads
 // the dense gradient the same way and writes the rows of the occupied cells.
+constexpr int kDenseX = 192;   // cells of one (b, z, y) line per workgroup: the whole 180-wide BEV row -> 720-byte runs
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_dense(float* __restrict__ feat,
                                                const int32_t* __restrict__ rowmap, int C,
                                                GridShape g, float* __restrict__ dense) {
-  __shared__ float s_t[64][65];
-  __shared__ int s_row[64];
+  __shared__ float s_t[kDenseX][65];
+  __shared__ int s_row[kDenseX];
   const int lane = ud_lane(), wv = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * 64;
+  const int x0 = blockIdx.x * kDenseX;
   const int line = blockIdx.y;                    // (b * Dz + z) * Hy + y
   const int y = line % g.Hy, z = (line / g.Hy) % g.Dz, b = line / (g.Hy * g.Dz);
-  const int nx = min(64, g.Wx - x0);
-  if (threadIdx.x < 64)
+  const int nx = min(kDenseX, g.Wx - x0);
+  if (threadIdx.x < kDenseX)
     s_row[threadIdx.x] = (threadIdx.x < nx) ? rowmap[(long long)line * g.Wx + x0 + threadIdx.x] : -1;
   __syncthreads();
   const size_t plane = (size_t)g.Dz * g.Hy * g.Wx;
@@ -278,34 +280,42 @@ __global__ __launch_bounds__(256) void k_dense(float* __restrict__ feat,
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int nc = min(64, C - c0);
     if (!BWD) {
-#pragma unroll 4
-      for (int i = 0; i < 16; ++i) {              // wave wv stages cells wv*16 .. +15, lanes along c
-        const int x = wv * 16 + i;
-        const int row = s_row[x];
-        float v = 0.0f;
-        if (row >= 0 && lane < nc) v = feat[(size_t)row * C + c0 + lane];
-        s_t[x][lane] = v;
+      float v[kDenseX / 4];                       // a wave stages whole 256-byte feature rows, lanes along c:
+#pragma unroll                                    // all 48 row loads in flight before the first LDS write
+      for (int j = 0; j < kDenseX / 4; ++j) {
+        const int x = wv + 4 * j;
+        const int row = x < nx ? s_row[x] : -1;
+        v[j] = (row >= 0 && lane < nc) ? feat[(size_t)row * C + c0 + lane] : 0.0f;
       }
+#pragma unroll
+      for (int j = 0; j < kDenseX / 4; ++j)
+        if (wv + 4 * j < nx) s_t[wv + 4 * j][lane] = v[j];
       __syncthreads();
-#pragma unroll 4
-      for (int i = 0; i < 16; ++i) {              // wave wv stores channels wv*16 .. +15, lanes along x
+#pragma unroll 2
+      for (int i = 0; i < 16; ++i) {              // wave wv stores channels wv*16 .. +15: one 4*nx-byte run each
         const int c = wv * 16 + i;
-        if (c < nc && lane < nx)
-          __builtin_nontemporal_store(s_t[lane][c], &dense[base + (size_t)(c0 + c) * plane + lane]);
+        if (c < nc)
+          for (int x = lane; x < nx; x += 64)
+            __builtin_nontemporal_store(s_t[x][c], &dense[base + (size_t)(c0 + c) * plane + x]);
       }
       __syncthreads();
     } else {
-#pragma unroll 4
-      for (int i = 0; i < 16; ++i) {
-        const int c = wv * 16 + i;
-        float v = 0.0f;
-        if (c < nc && lane < nx) v = __builtin_nontemporal_load(&dense[base + (size_t)(c0 + c) * plane + lane]);
-        s_t[lane][c] = v;
-      }
+      float v[16][kDenseX / 64];                  // 48 independent loads per lane, then the LDS writes
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int k = 0; k < kDenseX / 64; ++k) {
+          const int c = wv * 16 + i, x = lane + 64 * k;
+          v[i][k] = (c < nc && x < nx) ? __builtin_nontemporal_load(&dense[base + (size_t)(c0 + c) * plane + x]) : 0.0f;
+        }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int k = 0; k < kDenseX / 64; ++k)
+          if (lane + 64 * k < nx) s_t[lane + 64 * k][wv * 16 + i] = v[i][k];
       __syncthreads();
 #pragma unroll 4
-      for (int i = 0; i < 16; ++i) {
-        const int x = wv * 16 + i;
+      for (int x = wv; x < nx; x += 4) {
         const int row = s_row[x];
         if (row >= 0 && lane < nc) feat[(size_t)row * C + c0 + lane] = s_t[x][lane];
       }
@@ -564,7 +574,7 @@ extern "C" int ud_sparse_to_dense(const float* feat, const int32_t* coords, int 
     UD_LAUNCH_CHECK();
   }
   UdProfScope prof("spconv.k_dense", stream);
-  k_dense<false><<<dim3(ud_div_up(Wx, 64), B * Dz * Hy), 256, 0, stream>>>((float*)feat, rowmap, C, g, dense);
+  k_dense<false><<<dim3(ud_div_up(Wx, kDenseX), B * Dz * Hy), 256, 0, stream>>>((float*)feat, rowmap, C, g, dense);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -584,7 +594,7 @@ extern "C" int ud_dense_to_sparse(const float* gdense, const int32_t* coords, in
   UD_HIP_TRY(hipMemsetAsync(rowmap, 0xFF, (size_t)g.cells() * sizeof(int32_t), stream));
   k_fill_rowmap<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, rowmap);
   UD_LAUNCH_CHECK();
-  k_dense<true><<<dim3(ud_div_up(Wx, 64), B * Dz * Hy), 256, 0, stream>>>(gfeat, rowmap, C, g, (float*)gdense);
+  k_dense<true><<<dim3(ud_div_up(Wx, kDenseX), B * Dz * Hy), 256, 0, stream>>>(gfeat, rowmap, C, g, (float*)gdense);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
