@@ -33,68 +33,78 @@ __device__ __forceinline__ void tile_origin(const GTail& t, int tile, int& b, in
   tx0 = (tile % t.tiles_x) * kTW;
 }
 
+// Sum over the 64 lanes with DPP adds (VALU rate; a shuffle butterfly goes through the LDS pipe and was the
+// bottleneck of an earlier version): row_shr 1/2/4/8 reduce each row of 16, row_bcast15/31 chain the rows;
+// lane 63 holds the total.
+__device__ __forceinline__ float dpp_wave_sum_to_lane63(float v) {
+#define UD_DPP_ADD(ctrl, rmask)                                                                            \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
+  UD_DPP_ADD(0x111, 0xF);   // row_shr:1
+  UD_DPP_ADD(0x112, 0xF);   // row_shr:2
+  UD_DPP_ADD(0x114, 0xF);   // row_shr:4
+  UD_DPP_ADD(0x118, 0xF);   // row_shr:8
+  UD_DPP_ADD(0x142, 0xA);   // row_bcast:15 -> rows 1, 3
+  UD_DPP_ADD(0x143, 0xC);   // row_bcast:31 -> rows 2, 3
+#undef UD_DPP_ADD
+  return v;
+}
+
 // z[pix, g*KM + k] = bias + sum_{tap, c} a[pix + tap - 1, g*64 + c] * w[g][k][tap][c]
-// 256 threads: two threads per output pixel, each over one half of the channels (combined through LDS);
-// the halo is staged as independent 16-byte loads (23 in flight per thread) -- a row-per-iteration loop
-// serialised one memory latency per halo row and made the kernel 15x slower.
+// lane = channel, the lane's 9*KM weights in registers, no LDS.  A wave owns two pixel rows of the tile: it
+// loads their 4 x 18 halo of 256-byte rows ONCE (72 independent loads in flight; 2.25 row reads per output pixel
+// instead of 9, so the L2 sees the hidden tensor ~2.3x, HBM once) and reduces every partial sum over its lanes.
+// (Earlier versions: halo in LDS + a thread per pixel: 58 KB of LDS, 2 workgroups per CU, 2.1 ms; nine row reads
+// per pixel from L2 + shuffle reductions: 2.0 ms.)
 __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ z, GTail t) {
-  __shared__ __attribute__((aligned(16))) float s_a[kHQ * kLD];
-  __shared__ __attribute__((aligned(16))) float s_w[kKMax * 9 * kHC];
-  __shared__ float s_p[kTW * kTH][kKMax];
-  const int g = blockIdx.y, tid = threadIdx.x;
+  // groups vary fastest over the grid: the workgroups running together consume WHOLE pixel rows (all 42 x 256 B
+  // of them) -- with tiles fastest every sweep touched 256 bytes out of each 10.75 KB row and ran at 0.8 TB/s
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int b, ty0, tx0;
-  tile_origin(t, blockIdx.x, b, ty0, tx0);
-  const int Ct = t.G * kHC;
-  for (int i = tid; i < t.KM * 9 * kHC; i += 256) s_w[i] = w[(size_t)g * t.KM * 9 * kHC + i];
-  constexpr int kPieces = kHQ * (kHC / 4);                      // 16-byte pieces of the halo: 2880
-  float4 v[(kPieces + 255) / 256];
+  tile_origin(t, blockIdx.y, b, ty0, tx0);
+  const int Ct = t.G * kHC, Zt = t.G * t.KM;
+  float wr[kKMax][9];
 #pragma unroll
-  for (int j = 0; j < (kPieces + 255) / 256; ++j) {
-    const int i = tid + j * 256;
-    const int q = i >> 4, c4 = i & 15;
-    const int gy = ty0 + q / kHW - 1, gx = tx0 + q % kHW - 1;
-    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < kPieces && gy >= 0 && gy < t.H && gx >= 0 && gx < t.W)
-      v[j] = *reinterpret_cast<const float4*>(a + ((size_t)(b * t.H + gy) * t.W + gx) * Ct + g * kHC + 4 * c4);
-  }
+  for (int k = 0; k < kKMax; ++k)
 #pragma unroll
-  for (int j = 0; j < (kPieces + 255) / 256; ++j) {
-    const int i = tid + j * 256;
-    if (i < kPieces) *reinterpret_cast<float4*>(s_a + (i >> 4) * kLD + 4 * (i & 15)) = v[j];
-  }
-  __syncthreads();
-  const int pix = tid & 127, half = tid >> 7;
-  const int py = pix >> 4, px = pix & 15;
-  float acc[kKMax] = {0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < 9; ++tap)
+      wr[k][tap] = (k < t.KM) ? w[((size_t)(g * t.KM + k) * 9 + tap) * kHC + lane] : 0.f;
+  const float* ab = a + (size_t)b * t.H * t.W * Ct + g * kHC + lane;
+  const int y0 = ty0 + 2 * wave;                   // this wave's two output rows: y0, y0 + 1
+  if (y0 >= t.H) return;
+  float hv[4][kHW];                                // halo rows y0-1 .. y0+2, columns tx0-1 .. tx0+16
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const float* ar = s_a + ((py + tap / 3) * kHW + px + tap % 3) * kLD + 32 * half;
-    const float* wr = s_w + tap * kHC + 32 * half;
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c4 = 0; c4 < 8; ++c4) {
-      const float4 av = *reinterpret_cast<const float4*>(ar + 4 * c4);
+    for (int c = 0; c < kHW; ++c) {
+      const int yy = y0 - 1 + r, xx = tx0 - 1 + c;
+      hv[r][c] = (yy >= 0 && yy < t.H && xx >= 0 && xx < t.W) ? ab[((size_t)yy * t.W + xx) * Ct] : 0.f;
+    }
+  const float bv = (bias && lane < t.KM) ? bias[g * t.KM + lane] : 0.f;   // lanes 0..KM-1 (unused: lane 63 stores)
+  (void)bv;
 #pragma unroll
-      for (int k = 0; k < kKMax; ++k) {
-        if (k < t.KM) {
-          const float4 wv = *reinterpret_cast<const float4*>(wr + k * 9 * kHC + 4 * c4);
-          acc[k] = fmaf(av.x, wv.x, acc[k]);
-          acc[k] = fmaf(av.y, wv.y, acc[k]);
-          acc[k] = fmaf(av.z, wv.z, acc[k]);
-          acc[k] = fmaf(av.w, wv.w, acc[k]);
-        }
+  for (int u = 0; u < 2; ++u) {
+    const int gy = y0 + u;
+#pragma unroll
+    for (int x = 0; x < kTW; ++x) {
+      float acc[kKMax] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = hv[u + tap / 3][x + tap % 3];
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) acc[k] = fmaf(v, wr[k][tap], acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < kKMax; ++k)
+        if (k < t.KM) acc[k] = dpp_wave_sum_to_lane63(acc[k]);
+      const int gx = tx0 + x;
+      if (lane == 63 && gy < t.H && gx < t.W) {
+        float* o = z + ((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * t.KM;
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k)
+          if (k < t.KM) o[k] = acc[k] + (bias ? bias[g * t.KM + k] : 0.f);
       }
     }
-  }
-  if (half) {
-#pragma unroll
-    for (int k = 0; k < kKMax; ++k) s_p[pix][k] = acc[k];
-  }
-  __syncthreads();
-  const int gy = ty0 + py, gx = tx0 + px;
-  if (!half && gy < t.H && gx < t.W) {
-    float* o = z + ((size_t)(b * t.H + gy) * t.W + gx) * (t.G * t.KM) + g * t.KM;
-    for (int k = 0; k < t.KM; ++k) o[k] = (acc[k] + s_p[pix][k]) + (bias ? bias[g * t.KM + k] : 0.f);
   }
 }
 
@@ -102,9 +112,9 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
 __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ dz, const float* __restrict__ w,
                                                      float* __restrict__ da, GTail t) {
   __shared__ float s_z[kHQ][kKMax];
-  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // groups fastest (see k_gtail_fwd)
   int b, ty0, tx0;
-  tile_origin(t, blockIdx.x, b, ty0, tx0);
+  tile_origin(t, blockIdx.y, b, ty0, tx0);
   const int Zt = t.G * t.KM, Ct = t.G * kHC;
   for (int i = tid; i < kHQ * kKMax; i += 256) {
     const int q = i / kKMax, k = i - q * kKMax;
@@ -145,14 +155,14 @@ __global__ __launch_bounds__(256) void k_gtail_wgrad(const float* __restrict__ a
                                                      int tiles_per_slice) {
   __shared__ float s_z[kHQ][kKMax];
   __shared__ float s_red[4][kKMax * 9][kHC];
-  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Zt = t.G * t.KM, Ct = t.G * kHC;
   float acc[kKMax][9];
 #pragma unroll
   for (int k = 0; k < kKMax; ++k)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) acc[k][tap] = 0.f;
-  const int t0 = blockIdx.x * tiles_per_slice, t1 = min(ntiles, t0 + tiles_per_slice);
+  const int t0 = slice * tiles_per_slice, t1 = min(ntiles, t0 + tiles_per_slice);
   for (int tile = t0; tile < t1; ++tile) {
     int b, ty0, tx0;
     tile_origin(t, tile, b, ty0, tx0);
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256) void k_gtail_wgrad(const float* __restrict__ a
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) s_red[wave][k * 9 + tap][lane] = acc[k][tap];
   __syncthreads();
-  float* out = partial + ((size_t)blockIdx.x * t.G + g) * t.KM * 9 * kHC;
+  float* out = partial + ((size_t)slice * t.G + g) * t.KM * 9 * kHC;
   for (int i = tid; i < t.KM * 9 * kHC; i += 256) {
     const int kt = i / kHC, c = i - kt * kHC;
     out[i] = ((s_red[0][kt][c] + s_red[1][kt][c]) + s_red[2][kt][c]) + s_red[3][kt][c];
@@ -207,7 +217,8 @@ __global__ void k_gtail_wsum(const float* __restrict__ partial, int S, long long
 }
 
 bool gtail_ok(int B, int H, int W, int G, int KM) {
-  return B > 0 && H > 0 && W > 0 && G > 0 && G <= 65535 && KM >= 1 && KM <= kKMax;
+  return B > 0 && H > 0 && W > 0 && G > 0 && KM >= 1 && KM <= kKMax &&
+         (long long)B * ud_div_up(W, kTW) * ud_div_up(H, kTH) <= 65535;     // tiles ride on grid.y
 }
 int gtail_slices(int ntiles) { return ntiles < 32 ? ntiles : 32; }
 
@@ -219,7 +230,7 @@ extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float*
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_fwd", stream);
-  k_gtail_fwd<<<dim3(B * t.tiles_x * t.tiles_y, G), 256, 0, stream>>>(a, w, bias, z, t);
+  k_gtail_fwd<<<dim3(G, B * t.tiles_x * t.tiles_y), 256, 0, stream>>>(a, w, bias, z, t);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -230,7 +241,7 @@ extern "C" int ud_head_tail_f32_dgrad(const float* dz, const float* w, float* da
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_dgrad", stream);
-  k_gtail_dgrad<<<dim3(B * t.tiles_x * t.tiles_y, G), 256, 0, stream>>>(dz, w, da, t);
+  k_gtail_dgrad<<<dim3(G, B * t.tiles_x * t.tiles_y), 256, 0, stream>>>(dz, w, da, t);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -250,7 +261,7 @@ extern "C" int ud_head_tail_f32_wgrad(const float* a, const float* dz, float* dw
   const int ntiles = B * t.tiles_x * t.tiles_y, S = gtail_slices(ntiles), per = ud_div_up(ntiles, S);
   float* partial = reinterpret_cast<float*>(workspace);
   UdProfScope prof("head_tail.k_gtail_wgrad", stream);
-  k_gtail_wgrad<<<dim3(S, G), 256, 0, stream>>>(a, dz, partial, t, ntiles, per);
+  k_gtail_wgrad<<<dim3(G, S), 256, 0, stream>>>(a, dz, partial, t, ntiles, per);
   UD_LAUNCH_CHECK();
   const long long n = (long long)G * KM * 9 * kHC;
   k_gtail_wsum<<<ud_div_up(n, 256), 256, 0, stream>>>(partial, S, n, dw);
