@@ -31,9 +31,32 @@ constexpr int kAInstr = kHQP / 8;            // 1-KiB direct-to-LDS pieces of a 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Row p, element k of a VIRTUAL channels-last matrix [P'][K'] -> element offset in the physical tensor.  Lets the 1x1
+// kernels (forward / data gradient / weight gradient) run the convolutions whose im2col is a pure permutation:
+//   mode 0  identity: p * K + k
+//   mode 1  space-to-depth of x[B,H,W,C] with block s (conv k = s, stride s: K' = s*s*C, k = (dy, dx, c); the output
+//           side of a transposed conv k = s, stride s is the same map): p = (b, oy, ox) ->
+//           ((b*H + s*oy + k / (s*C)) * W + s*ox) * C + k % (s*C)
+//   mode 2  spatial subsampling by s (1x1 conv with stride s: K' = C): ((b*H + s*oy) * W + s*ox) * C + k
+struct PixMap {
+  int mode, s, Ho, Wo, H, W, C;
+  __device__ __forceinline__ size_t off(long long p, int k, int K) const {
+    if (mode == 0) return (size_t)p * K + k;
+    const int ox = (int)(p % Wo);
+    const long long t = p / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    if (mode == 1) {
+      const int sc = s * C, dy = k / sc, r = k - dy * sc;
+      return ((size_t)(b * H + s * oy + dy) * W + (size_t)s * ox) * C + r;
+    }
+    return ((size_t)(b * H + s * oy) * W + (size_t)s * ox) * C + k;
+  }
+};
+
 struct ConvGeom {
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
   long long npix;     // pixels of the tensor (1x1 convs are launched on a [P/16][16] view: the last row may be short)
+  PixMap imap, omap;  // 1x1 kernels only (mode 0 everywhere else)
 };
 struct ConvEp {
   const float* bias;
@@ -111,8 +134,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
       const int gy = ty0 + qy - kPad, gx = tx0 + qx - kPad;
       const long long pix = (long long)(b * gm.H + gy) * gm.W + gx;
       const unsigned short* src = zero;
-      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && pix < gm.npix)
-        src = x + (size_t)pix * gm.Cin + chunk * kKC + ((slot ^ (q & 7)) << 3);
+      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && pix < gm.npix) {
+        const int k = chunk * kKC + ((slot ^ (q & 7)) << 3);
+        src = x + (KS == 1 ? gm.imap.off(pix, k, gm.Cin) : (size_t)pix * gm.Cin + k);
+      }
       dma16(src, As + (buf * kHQP + piece * 8) * kKC);
     }
   };
@@ -190,7 +215,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.scale[n + e] + ep.shift[n + e];
     }
-    const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+    const size_t off = KS == 1 ? gm.omap.off((long long)(b * gm.H + gy) * gm.W + gx, n, gm.Cout)
+                               : ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
     if (ep.residual) {
       const uint4 h = *reinterpret_cast<const uint4*>(ep.residual + off);
       const unsigned hw[4] = {h.x, h.y, h.z, h.w};
@@ -525,7 +551,8 @@ template <int NT, int CT>
 __global__ __launch_bounds__(256) void k_conv1x1_wgrad_dma(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ dy,
                                                            float* __restrict__ partial, long long P, int Cin,
-                                                           int Cout, int c_tiles, int steps_per_slice) {
+                                                           int Cout, int c_tiles, int steps_per_slice,
+                                                           PixMap xmap, PixMap ymap) {
   constexpr int SN = NT / 8, SC = CT / 8;                 // 16-byte slots per row
   constexpr int RN = 64 / SN, RC = 64 / SC;               // rows per 1-KiB piece
   constexpr int PN = 64 / RN, PC = 64 / RC;               // pieces per 64-row tile
@@ -551,7 +578,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_dma(const unsigned short*
       const long long p = (long long)step * 64 + r;
       const int n = n0 + ((slot ^ fsw(r, SN)) << 3);
       const unsigned short* src = zero;
-      if (p < P && n < Cout) src = dy + (size_t)p * Cout + n;
+      if (p < P && n < Cout) src = dy + ymap.off(p, n, Cout);
       dma16(src, Ns + (buf * 64 + piece * RN) * NT);
     }
 #pragma unroll
@@ -559,7 +586,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_dma(const unsigned short*
       const int piece = wave + 4 * j, r = piece * RC + lane / SC, slot = lane % SC;
       const long long p = (long long)step * 64 + r;
       const unsigned short* src = zero;
-      if (p < P) src = x + (size_t)p * Cin + c0 + ((slot ^ fsw(r, SC)) << 3);
+      if (p < P) src = x + xmap.off(p, c0 + ((slot ^ fsw(r, SC)) << 3), Cin);
       dma16(src, Cs + (buf * 64 + piece * RC) * CT);
     }
   };
@@ -642,7 +669,7 @@ Wgrad1x1Plan wgrad1x1_plan(long long P, int Cin, int Cout) {
 }
 template <int NT, int CT>
 int launch_wgrad1x1(const void* x, const void* dy, float* partial, long long P, int Cin, int Cout,
-                    const Wgrad1x1Plan& pl, hipStream_t stream) {
+                    const Wgrad1x1Plan& pl, const PixMap& xmap, const PixMap& ymap, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 64 * (NT + CT) * 2;
   static bool set = false;
   if (!set) {
@@ -651,7 +678,8 @@ int launch_wgrad1x1(const void* x, const void* dy, float* partial, long long P, 
     set = true;
   }
   k_conv1x1_wgrad_dma<NT, CT><<<dim3(pl.slices, pl.n_tiles * pl.c_tiles), 256, lds, stream>>>(
-      (const unsigned short*)x, (const unsigned short*)dy, partial, P, Cin, Cout, pl.c_tiles, pl.steps_per_slice);
+      (const unsigned short*)x, (const unsigned short*)dy, partial, P, Cin, Cout, pl.c_tiles, pl.steps_per_slice,
+      xmap, ymap);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -678,7 +706,7 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (Cin % kKC != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W};
+  ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W, PixMap{}, PixMap{}};
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
   static bool attr_set = false;
   if (!attr_set) {
@@ -704,16 +732,26 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   return UD_OK;
 }
 
-extern "C" int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
-                                    const float* bias, const float* scale, const float* shift,
-                                    const void* residual, int relu, ud_stream_t stream_) {
+static bool map_from_ints(const int* m, PixMap* out) {
+  *out = PixMap{};
+  if (!m || m[0] == 0) return true;
+  *out = PixMap{m[0], m[1], m[2], m[3], m[4], m[5], m[6]};
+  if (!((m[0] == 1 || m[0] == 2) && m[1] >= 1 && m[2] > 0 && m[3] > 0 && m[6] > 0 && m[6] % 8 == 0)) return false;
+  if (m[0] == 1) return m[4] >= m[1] * m[2] && m[5] >= m[1] * m[3];            // every s x s block inside the tensor
+  return m[4] > m[1] * (m[2] - 1) && m[5] > m[1] * (m[3] - 1);                   // every sampled pixel inside
+}
+
+static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                        const float* bias, const float* scale, const float* shift,
+                        const void* residual, int relu, const PixMap& imap, const PixMap& omap,
+                        ud_stream_t stream_) {
   if (!x || !w || !y || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (Cin % kKC != 0 || Cout % 8 != 0 || P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   // pixels as a [ceil(P/16)][16] image: 8 x 16 tiles of 128 consecutive pixels, no halo
   const int H = (int)((P + kTW - 1) / kTW);
-  ConvGeom gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P};
+  ConvGeom gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P, imap, omap};
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, 0};
   static bool attr_set = false;
   if (!attr_set) {
@@ -735,6 +773,27 @@ extern "C" int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64
     k_conv3x3_bf16<128, 1><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128, 1), stream>>>(xs, ws, ys, gm, ep);
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+extern "C" int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                                    const float* bias, const float* scale, const float* shift,
+                                    const void* residual, int relu, ud_stream_t stream) {
+  return conv1x1_impl(x, w, y, P, Cin, Cout, bias, scale, shift, residual, relu, PixMap{}, PixMap{}, stream);
+}
+
+// 1x1 kernel over a mapped input and / or output (see PixMap): conv k = s / stride s, transposed conv k = s / stride s,
+// 1x1 / stride s -- forward and data gradient of all three.  in_map / out_map: 7 ints {mode, s, Ho, Wo, H, W, C} or
+// NULL for a plain [P][K] matrix; bias / BatchNorm / residual epilogues only with a plain output.
+extern "C" int ud_conv1x1_mapped_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                                           const int* in_map, const int* out_map, ud_stream_t stream) {
+  PixMap im, om;
+  if (!map_from_ints(in_map, &im) || !map_from_ints(out_map, &om)) return UD_ERR_INVALID_ARG;
+  if (im.mode == 1 && (im.s * im.C) % 64 != 0) return UD_ERR_UNSUPPORTED;   // a 64-channel slice must not straddle dy
+  if (im.mode == 1 && im.s * im.s * im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (im.mode == 2 && im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (om.mode == 1 && om.s * om.s * om.C != Cout) return UD_ERR_INVALID_ARG;
+  if (om.mode == 2 && om.C != Cout) return UD_ERR_INVALID_ARG;
+  return conv1x1_impl(x, w, y, P, Cin, Cout, nullptr, nullptr, nullptr, nullptr, 0, im, om, stream);
 }
 
 extern "C" size_t ud_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -802,8 +861,8 @@ extern "C" size_t ud_conv1x1_wgrad_workspace_bytes(int64_t P, int Cin, int Cout)
   return ud_align_up((size_t)pl.slices * Cout * Cin * sizeof(float));
 }
 
-extern "C" int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
-                                          void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+static int wgrad1x1_impl(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout, void* workspace,
+                         size_t workspace_bytes, const PixMap& xmap, const PixMap& ymap, ud_stream_t stream_) {
   if (!x || !dy || !dw || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
   if (Cin % 64 != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < ud_conv1x1_wgrad_workspace_bytes(P, Cin, Cout)) return UD_ERR_WORKSPACE;
@@ -812,13 +871,32 @@ extern "C" int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   float* partial = reinterpret_cast<float*>(workspace);
   UdProfScope prof("conv2d.k_wgrad_1x1", stream);
   int rc;
-  if (pl.nt == 128 && pl.ct == 128) rc = launch_wgrad1x1<128, 128>(x, dy, partial, P, Cin, Cout, pl, stream);
-  else if (pl.nt == 128) rc = launch_wgrad1x1<128, 64>(x, dy, partial, P, Cin, Cout, pl, stream);
-  else if (pl.ct == 128) rc = launch_wgrad1x1<64, 128>(x, dy, partial, P, Cin, Cout, pl, stream);
-  else rc = launch_wgrad1x1<64, 64>(x, dy, partial, P, Cin, Cout, pl, stream);
+  if (pl.nt == 128 && pl.ct == 128) rc = launch_wgrad1x1<128, 128>(x, dy, partial, P, Cin, Cout, pl, xmap, ymap, stream);
+  else if (pl.nt == 128) rc = launch_wgrad1x1<128, 64>(x, dy, partial, P, Cin, Cout, pl, xmap, ymap, stream);
+  else if (pl.ct == 128) rc = launch_wgrad1x1<64, 128>(x, dy, partial, P, Cin, Cout, pl, xmap, ymap, stream);
+  else rc = launch_wgrad1x1<64, 64>(x, dy, partial, P, Cin, Cout, pl, xmap, ymap, stream);
   if (rc != UD_OK) return rc;
   const size_t n = (size_t)Cout * Cin;
   k_wgrad_sum<<<ud_div_up((long long)(n / 4), 64), 256, 0, stream>>>(partial, pl.slices, n, dw);
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+extern "C" int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
+                                          void* workspace, size_t workspace_bytes, ud_stream_t stream) {
+  return wgrad1x1_impl(x, dy, dw, P, Cin, Cout, workspace, workspace_bytes, PixMap{}, PixMap{}, stream);
+}
+
+// dW[n][k] = sum_p dy'[p][n] * x'[p][k] with either operand read through a PixMap (weight gradients of the
+// convolutions ud_conv1x1_mapped_nhwc_bf16 runs).  Workspace: ud_conv1x1_wgrad_workspace_bytes(P, Cin, Cout).
+extern "C" int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin,
+                                                 int Cout, const int* x_map, const int* dy_map, void* workspace,
+                                                 size_t workspace_bytes, ud_stream_t stream) {
+  PixMap xm, ym;
+  if (!map_from_ints(x_map, &xm) || !map_from_ints(dy_map, &ym)) return UD_ERR_INVALID_ARG;
+  if (xm.mode == 1 && ((xm.s * xm.C) % 64 != 0 || xm.s * xm.s * xm.C != Cin)) return UD_ERR_UNSUPPORTED;
+  if (xm.mode == 2 && xm.C != Cin) return UD_ERR_INVALID_ARG;
+  if (ym.mode == 1 && ym.s * ym.s * ym.C != Cout) return UD_ERR_INVALID_ARG;
+  if (ym.mode == 2 && ym.C != Cout) return UD_ERR_INVALID_ARG;
+  return wgrad1x1_impl(x, dy, dw, P, Cin, Cout, workspace, workspace_bytes, xm, ym, stream);
 }

@@ -47,7 +47,7 @@ class BaseBEVBackbone(nn.Module):
                     up = ConvTranspose2d(c, uc, us, stride=us, bias=False)
                 else:
                     k = int(np.round(1 / us))
-                    up = nn.Conv2d(c, uc, k, stride=k, bias=False)
+                    up = Conv2d(c, uc, k, stride=k, bias=False)
                 self.deblocks.append(FusedSequential(up, _bn(uc), nn.ReLU()))
         c_out = sum(num_upsample_filters)
         if len(upsample_strides) > len(layer_nums):

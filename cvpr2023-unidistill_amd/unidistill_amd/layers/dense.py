@@ -69,12 +69,31 @@ class Conv2d(nn.Conv2d):
                 return hipconv.conv3x3(x.to(torch.bfloat16), self.weight, self.bias)
             if self._hip_1x1(x):
                 return hipconv.conv1x1(x.to(torch.bfloat16), self.weight, self.bias)
+            y = self._hip_permutation_conv(x)
+            if y is not None:
+                return y
         elif Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x):
             if _is3x3_any(self, 1) and hipconv32.supported(x, self.weight, 3) and _fp32_kernel_pays(self, x):
                 return hipconv32.conv3x3(x, self.weight, self.bias)
             if _is1x1(self) and hipconv32.supported(x, self.weight, 1) and _fp32_kernel_pays(self, x):
                 return hipconv32.conv1x1(x, self.weight, self.bias)
         return super().forward(x)
+
+    def _hip_permutation_conv(self, x):
+        """k = s / stride s (image-neck levels) and 1x1 / stride s (ResNet stage shortcuts): im2col is a permutation,
+        so all three passes run on the 1x1 MFMA kernels through a pixel map (ops/conv2d.py)."""
+        k, st = self.kernel_size, self.stride
+        if not (k[0] == k[1] and st[0] == st[1] and st[0] >= 2 and self.padding == (0, 0) and self.dilation == (1, 1)
+                and self.groups == 1 and self.padding_mode == "zeros"):
+            return None
+        s_ = st[0]
+        if k[0] == s_ and hipconv.supported_patch(x, self.weight, s_):
+            y = hipconv.conv_patch(x, self.weight, s_)
+        elif k[0] == 1 and hipconv.supported_1x1(x, self.weight):
+            y = hipconv.conv1x1_strided(x, self.weight, s_)
+        else:
+            return None
+        return y if self.bias is None else y + self.bias.to(y.dtype).view(1, -1, 1, 1)
 
     def _hip_1x1(self, x):
         return (_is1x1(self) and self.in_channels % 64 == 0 and self.out_channels % 8 == 0
@@ -101,6 +120,14 @@ class ConvTranspose2d(nn.ConvTranspose2d):
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0
                 and x.is_contiguous(memory_format=torch.channels_last)):
             return hipconv.conv1x1(x.to(torch.bfloat16), self.weight.permute(1, 0, 2, 3), self.bias)
+        if (Conv2d.hip_enabled and output_size is None and x.dim() == 4 and _mixed_precision(x)
+                and self.kernel_size[0] == self.kernel_size[1] == self.stride[0] == self.stride[1] and self.stride[0] >= 2
+                and self.padding == (0, 0) and self.output_padding == (0, 0) and self.dilation == (1, 1)
+                and self.groups == 1 and hipconv.supported_patch(x, self.weight, self.stride[0], transposed=True)):
+            # k = s / stride s: every input pixel writes its own s x s output block (BaseBEVBackbone's up-sampling
+            # deblock, base_bev_backbone.py:67-92; the image neck's last level) -- the 1x1 kernels with an output map
+            y = hipconv.conv_transpose_patch(x, self.weight, self.stride[0])
+            return y if self.bias is None else y + self.bias.to(y.dtype).view(1, -1, 1, 1)
         return super().forward(x, output_size)
 
 

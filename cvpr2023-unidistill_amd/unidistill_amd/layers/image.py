@@ -135,7 +135,7 @@ class SECONDFPN(nn.Module):
                 op = ConvTranspose2d(cin, cout, k, stride=k, bias=False)
             else:
                 k = int(np.round(1 / s))
-                op = nn.Conv2d(cin, cout, k, stride=k, bias=False)
+                op = Conv2d(cin, cout, k, stride=k, bias=False)
             self.deblocks.append(FusedSequential(op, nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01),
                                                  nn.ReLU(inplace=True)))
 

@@ -260,3 +260,173 @@ def conv1x1(x, weight, bias=None):
 def conv1x1_skip(x, weight, bias=None):
     """(conv1x1(x), x): use the second value for the identity branch of a residual block (see _Conv1x1Fn)."""
     return _Conv1x1Fn.apply(x, weight, bias, True)
+
+
+# ---- convolutions whose im2col is a permutation: k = s / stride s, transposed k = s / stride s, 1x1 / stride s ----
+# (SECONDFPN levels of the image neck, BaseBEVBackbone's up-sampling deblock -- base_bev_backbone.py:67-92 --, the
+#  stride-2 shortcut convs of the ResNet stages).  All three passes run on the 1x1 MFMA kernels through a pixel map
+#  (ud_conv1x1_mapped_nhwc_bf16 / ud_conv1x1_wgrad_mapped_nhwc_bf16); no im2col buffer, no library call.
+import ctypes as _ct
+
+
+def _pmap(mode, s, Ho, Wo, H, W, C):
+    return (_ct.c_int * 7)(mode, s, Ho, Wo, H, W, C)
+
+
+def _mapped(x, w2d, y, P, K, N, imap, omap):
+    _lib.check(_lib.load().ud_conv1x1_mapped_nhwc_bf16(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), P, K, N, imap, omap,
+                                                       _lib.stream_of(x)), "ud_conv1x1_mapped_nhwc_bf16")
+
+
+def _mapped_wgrad(x, gy, P, K, N, xmap, ymap):
+    lib = _lib.load()
+    ws = _lib.workspace(x.device, lib.ud_conv1x1_wgrad_workspace_bytes(P, K, N), "conv_wgrad")
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ud_conv1x1_wgrad_mapped_nhwc_bf16(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), P, K, N, xmap, ymap,
+                                                     _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+               "ud_conv1x1_wgrad_mapped_nhwc_bf16")
+    return dw
+
+
+def _bf16_cl_empty(shape, dev, zero=False):
+    t = torch.empty(shape, dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    return t.zero_() if zero else t
+
+
+def supported_patch(x, weight, s, transposed=False):
+    """conv k = s / stride s (weight [Cout, Cin, s, s]) or its transpose (weight [Cin, Cout, s, s])."""
+    if not (x.is_cuda and x.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (s, s) and s >= 2):
+        return False
+    cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    return cin % 64 == 0 and cout % 8 == 0 and x.shape[1] == cin and (transposed or (s * cin) % 64 == 0) \
+        and (not transposed or (s * s * cout) % 64 == 0)
+
+
+class _ConvPatchFn(torch.autograd.Function):
+    """nn.Conv2d(kernel_size=s, stride=s, padding=0, bias=None)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s):
+        _lib.require_gpu(x, weight)
+        x = _nhwc(x.to(torch.bfloat16))
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        Ho, Wo = H // s, W // s
+        K, P = s * s * C, B * Ho * Wo
+        w2 = _cached(weight, "_ud_patch", lambda w: torch.empty((w.shape[0], s, s, w.shape[1]), dtype=torch.bfloat16,
+                                                                  device=w.device).copy_(w.permute(0, 2, 3, 1)))
+        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device)
+        _mapped(x, w2, y, P, K, cout, _pmap(1, s, Ho, Wo, H, W, C), None)
+        ctx.save_for_backward(x, weight)
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        s = ctx.s
+        gy = _nhwc(gy.to(torch.bfloat16))
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        Ho, Wo = H // s, W // s
+        K, P = s * s * C, B * Ho * Wo
+        pm = _pmap(1, s, Ho, Wo, H, W, C)
+        gx = gw = None
+        if ctx.needs_input_grad[0] and cout % 64 == 0:
+            wt = _cached(weight, "_ud_patch_t", lambda w: torch.empty((s, s, w.shape[1], w.shape[0]), dtype=torch.bfloat16,
+                                                                        device=w.device).copy_(w.permute(2, 3, 1, 0)))
+            gx = _bf16_cl_empty((B, C, H, W), x.device, zero=(H % s != 0 or W % s != 0))
+            _mapped(gy, wt, gx, P, cout, K, None, pm)          # [P][Cout] x [K][Cout]^T -> rows scattered by the map
+        elif ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, weight.detach().to(torch.bfloat16), None, [s, s], [0, 0], [1, 1],
+                                                     False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = _mapped_wgrad(x, gy, P, K, cout, pm, None)    # [Cout][s][s][C]
+            gw = dw.view(cout, s, s, C).permute(0, 3, 1, 2).to(weight.dtype)
+        return gx, gw, None
+
+
+class _ConvTPatchFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(kernel_size=s, stride=s, padding=0, bias=None): every input pixel writes an s x s block."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s):
+        _lib.require_gpu(x, weight)
+        x = _nhwc(x.to(torch.bfloat16))
+        B, cin, H, W = x.shape
+        cout = weight.shape[1]
+        N, P = s * s * cout, B * H * W
+        wt = _cached(weight, "_ud_tpatch", lambda w: torch.empty((s, s, w.shape[1], w.shape[0]), dtype=torch.bfloat16,
+                                                                   device=w.device).copy_(w.permute(2, 3, 1, 0)))
+        y = _bf16_cl_empty((B, cout, H * s, W * s), x.device)
+        _mapped(x, wt, y, P, cin, N, None, _pmap(1, s, H, W, H * s, W * s, cout))
+        ctx.save_for_backward(x, weight)
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        s = ctx.s
+        gy = _nhwc(gy.to(torch.bfloat16))
+        B, cin, H, W = x.shape
+        cout = weight.shape[1]
+        N, P = s * s * cout, B * H * W
+        pm = _pmap(1, s, H, W, H * s, W * s, cout)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            w2 = _cached(weight, "_ud_tpatch_t", lambda w: torch.empty((w.shape[0], s, s, w.shape[1]), dtype=torch.bfloat16,
+                                                                         device=w.device).copy_(w.permute(0, 2, 3, 1)))
+            gx = _bf16_cl_empty((B, cin, H, W), x.device)
+            _mapped(gy, w2, gx, P, N, cin, pm, None)            # rows of dy gathered by the map: [P][N] x [Cin][N]^T
+        if ctx.needs_input_grad[1]:
+            dw = _mapped_wgrad(x, gy, P, cin, N, None, pm)      # [s][s][Cout][Cin]
+            gw = dw.view(s, s, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
+        return gx, gw, None
+
+
+class _Conv1x1StrideFn(torch.autograd.Function):
+    """nn.Conv2d(kernel_size=1, stride=s, bias=None): the ResNet stage shortcuts."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s):
+        _lib.require_gpu(x, weight)
+        x = _nhwc(x.to(torch.bfloat16))
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device)
+        _mapped(x, _w1x1(weight).view(cout, cin), y, B * Ho * Wo, cin, cout, _pmap(2, s, Ho, Wo, H, W, cin), None)
+        ctx.save_for_backward(x, weight)
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        s = ctx.s
+        gy = _nhwc(gy.to(torch.bfloat16))
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        P = B * Ho * Wo
+        pm = _pmap(2, s, Ho, Wo, H, W, cin)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _bf16_cl_empty((B, cin, H, W), x.device, zero=True)      # only the sampled pixels receive gradient
+            _mapped(gy, _w1x1_t(weight), gx, P, cout, cin, None, pm)
+        if ctx.needs_input_grad[1]:
+            gw = _mapped_wgrad(x, gy, P, cin, cout, pm, None).view(cout, cin, 1, 1).to(weight.dtype)
+        return gx, gw, None
+
+
+def conv_patch(x, weight, s):
+    return _ConvPatchFn.apply(x, weight, s)
+
+
+def conv_transpose_patch(x, weight, s):
+    return _ConvTPatchFn.apply(x, weight, s)
+
+
+def conv1x1_strided(x, weight, s):
+    return _Conv1x1StrideFn.apply(x, weight, s)

@@ -438,6 +438,22 @@ size_t ud_conv1x1_wgrad_workspace_bytes(int64_t P, int Cin, int Cout);
 int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
                                void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
+/* The convolutions whose im2col is a pure permutation, on the same 1x1 kernels through a pixel-address map
+ * {mode, s, Ho, Wo, H, W, C} (7 ints, HOST; NULL = plain [P][K] rows):
+ *   mode 1: row p = (b, oy, ox) of the virtual matrix is the s x s block of the channels-last tensor [B,H,W,C] at
+ *           (s*oy, s*ox), its K = s*s*C elements ordered (dy, dx, c)  -- conv k = s / stride s (neck levels, reference
+ *           lss_fpn.py:143-149 / SECONDFPN) on the input side, transposed conv k = s / stride s (BaseBEVBackbone
+ *           deblocks, base_bev_backbone.py:67-92; neck) on the output side;  (s*C) % 64 == 0 on an input side;
+ *   mode 2: row p = pixel (s*oy, s*ox), K = C -- the stride-s 1x1 shortcut convs of the ResNet stages.
+ * Forward and data gradient are ud_conv1x1_mapped_nhwc_bf16 with the map on the input or the output (a data gradient
+ * through a mode-2 output map writes only the sampled pixels: clear dx first); weight gradients are
+ * ud_conv1x1_wgrad_mapped_nhwc_bf16 with the map on x or dy.  w / dw as in the unmapped calls: [Cout][K] / [Cout][Cin]. */
+int ud_conv1x1_mapped_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                                const int* in_map, const int* out_map, ud_stream_t stream);
+int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
+                                      const int* x_map, const int* dy_map, void* workspace,
+                                      size_t workspace_bytes, ud_stream_t stream);
+
 /* ---- LiDAR input side ------------------------------------------------------------------
  * Replaces the numpy point transforms of the reference's data pipeline:
  * CollectLidarSweeps.forward (unidistill/data/multisensorfusion/transforms3d.py:379-414) and the point part

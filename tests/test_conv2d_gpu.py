@@ -240,3 +240,78 @@ def test_conv1x1_skip_adds_identity_gradient_in_kernel(hip_lib, H, W):
                                atol=1.5e-2 * float(xr.grad.abs().max()))
     np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=0,
                                atol=2e-2 * float(wr.grad.abs().max()))
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _cmp(a, b, tol, name):
+    a, b = a.float(), b.float()
+    assert (a - b).abs().max() <= tol * b.abs().max() + 1e-6, (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 128, 4, 16, 44), (3, 512, 128, 2, 8, 22), (1, 64, 64, 2, 10, 18), (2, 128, 72, 2, 9, 7)])
+def test_patch_conv_k_equals_stride(hip_lib, cfg):
+    """nn.Conv2d(k = s, stride = s) on the mapped 1x1 kernels: forward, data and weight gradient vs PyTorch fp32 on
+    the same bf16-valued tensors (odd sizes drop the remainder rows like the reference op)."""
+    import torch.nn.functional as F
+    from unidistill_amd.ops import conv2d as c
+    B, cin, cout, s, H, W = cfg
+    torch.manual_seed(sum(cfg))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda").bfloat16()).requires_grad_(True)
+    w = (torch.randn(cout, cin, s, s, device="cuda") * 0.05).bfloat16().float().requires_grad_(True)
+    y = c.conv_patch(x, w, s)
+    gy = _cl(torch.randn_like(y))
+    y.backward(gy)
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, stride=s)
+    yr.backward(gy.float())
+    _cmp(y, yr, 8e-3, "y")
+    _cmp(gx, xr.grad, 2e-2, "dx")
+    _cmp(gw, w.grad, 2e-2, "dw")
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 256, 2, 12, 20), (3, 2048, 128, 2, 8, 22), (1, 64, 64, 2, 5, 9)])
+def test_patch_conv_transpose(hip_lib, cfg):
+    import torch.nn.functional as F
+    from unidistill_amd.ops import conv2d as c
+    B, cin, cout, s, H, W = cfg
+    torch.manual_seed(sum(cfg))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda").bfloat16()).requires_grad_(True)
+    w = (torch.randn(cin, cout, s, s, device="cuda") * 0.05).bfloat16().float().requires_grad_(True)
+    y = c.conv_transpose_patch(x, w, s)
+    assert y.shape == (B, cout, H * s, W * s)
+    gy = _cl(torch.randn_like(y))
+    y.backward(gy)
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, w, None, stride=s)
+    yr.backward(gy.float())
+    _cmp(y, yr, 8e-3, "y")
+    _cmp(gx, xr.grad, 2e-2, "dx")
+    _cmp(gw, w.grad, 2e-2, "dw")
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 512, 2, 16, 44), (3, 1024, 2048, 2, 8, 22), (1, 64, 128, 2, 9, 7)])
+def test_strided_1x1_conv(hip_lib, cfg):
+    import torch.nn.functional as F
+    from unidistill_amd.ops import conv2d as c
+    B, cin, cout, s, H, W = cfg
+    torch.manual_seed(sum(cfg))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda").bfloat16()).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, device="cuda") * 0.05).bfloat16().float().requires_grad_(True)
+    y = c.conv1x1_strided(x, w, s)
+    gy = _cl(torch.randn_like(y))
+    y.backward(gy)
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, stride=s)
+    yr.backward(gy.float())
+    _cmp(y, yr, 8e-3, "y")
+    _cmp(gx, xr.grad, 2e-2, "dx")
+    _cmp(gw, w.grad, 2e-2, "dw")
