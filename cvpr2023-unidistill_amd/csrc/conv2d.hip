@@ -38,18 +38,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //           side of a transposed conv k = s, stride s is the same map): p = (b, oy, ox) ->
 //           ((b*H + s*oy + k / (s*C)) * W + s*ox) * C + k % (s*C)
 //   mode 2  spatial subsampling by s (1x1 conv with stride s: K' = C): ((b*H + s*oy) * W + s*ox) * C + k
+//   mode 3  im2col of a 3x3 / pad 1 / stride s convolution (input side only; K' = 9*C, k = (tap, c)):
+//           pixel (s*oy + ty - 1, s*ox + tx - 1), kNoPixel outside the tensor (the kernels read zeros there)
+//   mode 4  data gradient of the same convolution (s = 2) for the input pixels of one parity class (a, b) = (y & 1,
+//           x & 1): row p = (batch, i, j) is input pixel (2i + a, 2j + b); an even coordinate is reached by the centre
+//           tap only, an odd one by taps 0 and 2, so K' = (1 + a)(1 + b) * C with k = (jy, jx, c) and the source
+//           pixel of dy [B,H,W,C] is (i + a*(1 - jy), j + b*(1 - jx)), kNoPixel outside (input side only)
+// Modes 2 and 4 address pixel (s*oy + a, s*ox + b): (a, b) is the class offset (0, 0 for a plain strided 1x1).
+constexpr size_t kNoPixel = ~(size_t)0;
 struct PixMap {
-  int mode, s, Ho, Wo, H, W, C;
+  int mode, s, Ho, Wo, H, W, C, a, b;
   __device__ __forceinline__ size_t off(long long p, int k, int K) const {
     if (mode == 0) return (size_t)p * K + k;
     const int ox = (int)(p % Wo);
     const long long t = p / Wo;
     const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    if (mode == 4) {
+      const int tapi = k / C, c = k - tapi * C, nx = 1 + this->b;
+      const int jy = tapi / nx, jx = tapi - jy * nx;
+      const int sy = oy + a * (1 - jy), sx = ox + this->b * (1 - jx);
+      if (sy >= H || sx >= W) return kNoPixel;
+      return ((size_t)(b * H + sy) * W + sx) * C + c;
+    }
+    if (mode == 3) {
+      const int tap = k / C, c = k - tap * C;
+      const int iy = s * oy + tap / 3 - 1, ix = s * ox + tap % 3 - 1;
+      if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return kNoPixel;
+      return ((size_t)(b * H + iy) * W + ix) * C + c;
+    }
     if (mode == 1) {
       const int sc = s * C, dy = k / sc, r = k - dy * sc;
       return ((size_t)(b * H + s * oy + dy) * W + (size_t)s * ox) * C + r;
     }
-    return ((size_t)(b * H + s * oy) * W + (size_t)s * ox) * C + k;
+    return ((size_t)(b * H + s * oy + a) * W + (size_t)s * ox + this->b) * C + k;
   }
 };
 
@@ -136,7 +157,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
       const unsigned short* src = zero;
       if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && pix < gm.npix) {
         const int k = chunk * kKC + ((slot ^ (q & 7)) << 3);
-        src = x + (KS == 1 ? gm.imap.off(pix, k, gm.Cin) : (size_t)pix * gm.Cin + k);
+        const size_t o = KS == 1 ? gm.imap.off(pix, k, gm.Cin) : (size_t)pix * gm.Cin + k;
+        if (o != kNoPixel) src = x + o;
       }
       dma16(src, As + (buf * kHQP + piece * 8) * kKC);
     }
@@ -147,9 +169,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
       const int piece = wave + 4 * j;
       const int n = piece * 8 + r8;
       const unsigned short* src = zero;
-      if (n0 + n < gm.Cout)
-        src = w + ((size_t)(n0 + n) * kTaps + (ep.reverse_taps ? kTaps - 1 - tap : tap)) * gm.Cin + chunk * kKC +
-              ((slot ^ (n & 7)) << 3);
+      if (n0 + n < gm.Cout) {
+        if (KS == 1 && gm.imap.mode == 4) {
+          // parity-class data gradient: the weights stay in their [C][3][3][N] (tap-major, transposed) layout; slice
+          // k = (jy, jx, n) of the class is tap (ty, tx) of that tensor: even coordinate -> 1, odd -> 0 then 2
+          const int kk = chunk * kKC + ((slot ^ (n & 7)) << 3);
+          const int tapi = kk / gm.imap.C, nn = kk - tapi * gm.imap.C, nx = 1 + gm.imap.b;
+          const int jy = tapi / nx, jx = tapi - jy * nx;
+          const int ty = gm.imap.a ? 2 * jy : 1, tx = gm.imap.b ? 2 * jx : 1;
+          src = w + ((size_t)(n0 + n) * 9 + ty * 3 + tx) * gm.imap.C + nn;
+        } else {
+          src = w + ((size_t)(n0 + n) * kTaps + (ep.reverse_taps ? kTaps - 1 - tap : tap)) * gm.Cin + chunk * kKC +
+                ((slot ^ (n & 7)) << 3);
+        }
+      }
       dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
     }
   };
@@ -586,7 +619,10 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_dma(const unsigned short*
       const int piece = wave + 4 * j, r = piece * RC + lane / SC, slot = lane % SC;
       const long long p = (long long)step * 64 + r;
       const unsigned short* src = zero;
-      if (p < P) src = x + xmap.off(p, c0 + ((slot ^ fsw(r, SC)) << 3), Cin);
+      if (p < P) {
+        const size_t o = xmap.off(p, c0 + ((slot ^ fsw(r, SC)) << 3), Cin);
+        if (o != kNoPixel) src = x + o;
+      }
       dma16(src, Cs + (buf * 64 + piece * RC) * CT);
     }
   };
@@ -735,10 +771,13 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
 static bool map_from_ints(const int* m, PixMap* out) {
   *out = PixMap{};
   if (!m || m[0] == 0) return true;
-  *out = PixMap{m[0], m[1], m[2], m[3], m[4], m[5], m[6]};
-  if (!((m[0] == 1 || m[0] == 2) && m[1] >= 1 && m[2] > 0 && m[3] > 0 && m[6] > 0 && m[6] % 8 == 0)) return false;
+  *out = PixMap{m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]};
+  if (!((m[0] >= 1 && m[0] <= 4) && m[1] >= 1 && m[2] > 0 && m[3] > 0 && m[6] > 0 && m[6] % 8 == 0)) return false;
+  if (m[7] < 0 || m[8] < 0 || m[7] >= m[1] || m[8] >= m[1] || (m[0] != 2 && m[0] != 4 && (m[7] || m[8]))) return false;
+  if (m[0] == 3) return m[6] % 64 == 0 && m[4] > 0 && m[5] > 0;                    // a 64-channel slice inside one tap
+  if (m[0] == 4) return m[1] == 2 && m[6] % 64 == 0 && m[4] > 0 && m[5] > 0;
   if (m[0] == 1) return m[4] >= m[1] * m[2] && m[5] >= m[1] * m[3];            // every s x s block inside the tensor
-  return m[4] > m[1] * (m[2] - 1) && m[5] > m[1] * (m[3] - 1);                   // every sampled pixel inside
+  return m[4] > m[1] * (m[2] - 1) + m[7] && m[5] > m[1] * (m[3] - 1) + m[8];       // every sampled pixel inside
 }
 
 static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
@@ -782,8 +821,8 @@ extern "C" int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64
 }
 
 // 1x1 kernel over a mapped input and / or output (see PixMap): conv k = s / stride s, transposed conv k = s / stride s,
-// 1x1 / stride s -- forward and data gradient of all three.  in_map / out_map: 7 ints {mode, s, Ho, Wo, H, W, C} or
-// NULL for a plain [P][K] matrix; bias / BatchNorm / residual epilogues only with a plain output.
+// 1x1 / stride s -- forward and data gradient of all three.  in_map / out_map: 9 ints {mode, s, Ho, Wo, H, W, C, a, b} or
+// NULL for a plain [P][K] matrix (9 ints: {mode, s, Ho, Wo, H, W, C, a, b}); no bias / BatchNorm / residual epilogue.
 extern "C" int ud_conv1x1_mapped_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
                                            const int* in_map, const int* out_map, ud_stream_t stream) {
   PixMap im, om;
@@ -791,6 +830,9 @@ extern "C" int ud_conv1x1_mapped_nhwc_bf16(const void* x, const void* w, void* y
   if (im.mode == 1 && (im.s * im.C) % 64 != 0) return UD_ERR_UNSUPPORTED;   // a 64-channel slice must not straddle dy
   if (im.mode == 1 && im.s * im.s * im.C != Cin) return UD_ERR_INVALID_ARG;
   if (im.mode == 2 && im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (im.mode == 3 && 9 * im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (im.mode == 4 && (1 + im.a) * (1 + im.b) * im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (om.mode >= 3) return UD_ERR_UNSUPPORTED;                               // gather only
   if (om.mode == 1 && om.s * om.s * om.C != Cout) return UD_ERR_INVALID_ARG;
   if (om.mode == 2 && om.C != Cout) return UD_ERR_INVALID_ARG;
   return conv1x1_impl(x, w, y, P, Cin, Cout, nullptr, nullptr, nullptr, nullptr, 0, im, om, stream);
@@ -896,6 +938,8 @@ extern "C" int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, 
   if (!map_from_ints(x_map, &xm) || !map_from_ints(dy_map, &ym)) return UD_ERR_INVALID_ARG;
   if (xm.mode == 1 && ((xm.s * xm.C) % 64 != 0 || xm.s * xm.s * xm.C != Cin)) return UD_ERR_UNSUPPORTED;
   if (xm.mode == 2 && xm.C != Cin) return UD_ERR_INVALID_ARG;
+  if (xm.mode == 3 && 9 * xm.C != Cin) return UD_ERR_INVALID_ARG;
+  if (xm.mode == 4 || ym.mode >= 3) return UD_ERR_UNSUPPORTED;
   if (ym.mode == 1 && ym.s * ym.s * ym.C != Cout) return UD_ERR_INVALID_ARG;
   if (ym.mode == 2 && ym.C != Cout) return UD_ERR_INVALID_ARG;
   return wgrad1x1_impl(x, dy, dw, P, Cin, Cout, workspace, workspace_bytes, xm, ym, stream);

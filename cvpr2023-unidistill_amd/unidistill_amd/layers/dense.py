@@ -36,6 +36,12 @@ def _is3x3_any(conv, padding):
             and conv.padding_mode == "zeros")
 
 
+def _is3x3_s2(conv, padding):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+            and conv.padding == (padding, padding) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros" and conv.bias is None)
+
+
 def _is1x1(conv):
     return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1)
@@ -83,6 +89,9 @@ class Conv2d(nn.Conv2d):
         """k = s / stride s (image-neck levels) and 1x1 / stride s (ResNet stage shortcuts): im2col is a permutation,
         so all three passes run on the 1x1 MFMA kernels through a pixel map (ops/conv2d.py)."""
         k, st = self.kernel_size, self.stride
+        if _is3x3_s2(self, 1) and hipconv.supported_3x3_s2(x, self.weight):
+            y = hipconv.conv3x3_stride2(x, self.weight)         # ResNet stages 2-4, first block
+            return y if self.bias is None else y + self.bias.to(y.dtype).view(1, -1, 1, 1)
         if not (k[0] == k[1] and st[0] == st[1] and st[0] >= 2 and self.padding == (0, 0) and self.dilation == (1, 1)
                 and self.groups == 1 and self.padding_mode == "zeros"):
             return None
@@ -167,6 +176,13 @@ class FusedSequential(nn.Sequential):
                     conv, skip = mods[i + 1], 2
                 elif _is3x3(m, 1):
                     conv, skip = m, 1
+            if conv is None and Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x) \
+                    and isinstance(m, nn.ZeroPad2d) and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < n \
+                    and _is3x3_s2(mods[i + 1], 0) and hipconv.supported_3x3_s2(x, mods[i + 1].weight):
+                # ZeroPad2d(1) + unpadded 3x3 / stride 2 (first conv of BaseBEVBackbone's second level) == pad-1 conv
+                x = hipconv.conv3x3_stride2(x, mods[i + 1].weight)
+                i += 2
+                continue
             if conv is None and Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x) \
                     and isinstance(m, nn.ZeroPad2d) and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < n \
                     and _is3x3_any(mods[i + 1], 0) and hipconv32.supported(x, mods[i + 1].weight, 3) \

@@ -269,8 +269,8 @@ def conv1x1_skip(x, weight, bias=None):
 import ctypes as _ct
 
 
-def _pmap(mode, s, Ho, Wo, H, W, C):
-    return (_ct.c_int * 7)(mode, s, Ho, Wo, H, W, C)
+def _pmap(mode, s, Ho, Wo, H, W, C, a=0, b=0):
+    return (_ct.c_int * 9)(mode, s, Ho, Wo, H, W, C, a, b)
 
 
 def _mapped(x, w2d, y, P, K, N, imap, omap):
@@ -430,3 +430,55 @@ def conv_transpose_patch(x, weight, s):
 
 def conv1x1_strided(x, weight, s):
     return _Conv1x1StrideFn.apply(x, weight, s)
+
+
+class _Conv3x3S2Fn(torch.autograd.Function):
+    """nn.Conv2d(kernel_size=3, stride=2, padding=1, bias=None): the first conv of ResNet stages 2-4 and of
+    BaseBEVBackbone's second level (ZeroPad2d(1) + unpadded conv there).  Forward and weight gradient read x through
+    the im2col map (mode 3); the data gradient runs once per input-pixel parity class (mode 4 gather from dy, mode 2
+    scatter into dx): exactly the convolution's multiply-adds in every pass, no zero-stuffed taps, no library call."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _lib.require_gpu(x, weight)
+        x = _nhwc(x.to(torch.bfloat16))
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device)
+        _mapped(x, tap_major(weight), y, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _nhwc(gy.to(torch.bfloat16))
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        Ho, Wo = gy.shape[2], gy.shape[3]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wtt = tap_major_transposed(weight)        # [C][3][3][Cout]: the kernel picks each class's taps from it
+            gx = _bf16_cl_empty((B, C, H, W), x.device)
+            for a in (0, 1):
+                for b in (0, 1):
+                    Hc, Wc = (H - a + 1) // 2, (W - b + 1) // 2
+                    if Hc <= 0 or Wc <= 0:
+                        continue
+                    K = (1 + a) * (1 + b) * cout
+                    _mapped(gy, wtt, gx, B * Hc * Wc, K, C, _pmap(4, 2, Hc, Wc, Ho, Wo, cout, a, b),
+                            _pmap(2, 2, Hc, Wc, H, W, C, a, b))
+        if ctx.needs_input_grad[1]:
+            dw = _mapped_wgrad(x, gy, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)   # [Cout][9][C]
+            gw = dw.view(cout, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype)
+        return gx, gw
+
+
+def supported_3x3_s2(x, weight):
+    return (x.is_cuda and x.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0 and x.shape[1] == weight.shape[1])
+
+
+def conv3x3_stride2(x, weight):
+    return _Conv3x3S2Fn.apply(x, weight)

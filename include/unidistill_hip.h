@@ -439,12 +439,20 @@ int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t
                                void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* The convolutions whose im2col is a pure permutation, on the same 1x1 kernels through a pixel-address map
- * {mode, s, Ho, Wo, H, W, C} (7 ints, HOST; NULL = plain [P][K] rows):
+ * {mode, s, Ho, Wo, H, W, C, a, b} (9 ints, HOST; NULL = plain [P][K] rows; a = b = 0 unless stated):
  *   mode 1: row p = (b, oy, ox) of the virtual matrix is the s x s block of the channels-last tensor [B,H,W,C] at
  *           (s*oy, s*ox), its K = s*s*C elements ordered (dy, dx, c)  -- conv k = s / stride s (neck levels, reference
  *           lss_fpn.py:143-149 / SECONDFPN) on the input side, transposed conv k = s / stride s (BaseBEVBackbone
  *           deblocks, base_bev_backbone.py:67-92; neck) on the output side;  (s*C) % 64 == 0 on an input side;
- *   mode 2: row p = pixel (s*oy, s*ox), K = C -- the stride-s 1x1 shortcut convs of the ResNet stages.
+ *   mode 2: row p = pixel (s*oy + a, s*ox + b), K = C -- the stride-s 1x1 shortcut convs of the ResNet stages;
+ *   mode 3 (input / x side only): im2col of a 3x3 / pad 1 / stride s convolution, K = 9*C ordered (tap, c), zeros
+ *           outside the tensor -- the stride-2 3x3 convs of the ResNet stages and of BaseBEVBackbone's second level
+ *           (forward and weight gradient; C % 64 == 0);
+ *   mode 4 (input side only, s = 2): the data gradient of that convolution for the input pixels of parity class
+ *           (a, b): row p = (batch, i, j) is pixel (2i + a, 2j + b) (written through a mode-2 output map with the same
+ *           (a, b)), K = (1 + a)(1 + b) * C gathered from dy -- four launches cover the tensor with exactly the
+ *           multiply-adds of the convolution (no zero-stuffed taps).  With a mode-4 input map `w` is the whole
+ *           transposed tap-major weight [Cin][3][3][Cout] of the convolution (the kernel picks the class's taps).
  * Forward and data gradient are ud_conv1x1_mapped_nhwc_bf16 with the map on the input or the output (a data gradient
  * through a mode-2 output map writes only the sampled pixels: clear dx first); weight gradients are
  * ud_conv1x1_wgrad_mapped_nhwc_bf16 with the map on x or dy.  w / dw as in the unmapped calls: [Cout][K] / [Cout][Cin]. */

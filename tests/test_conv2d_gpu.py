@@ -315,3 +315,26 @@ def test_strided_1x1_conv(hip_lib, cfg):
     _cmp(y, yr, 8e-3, "y")
     _cmp(gx, xr.grad, 2e-2, "dx")
     _cmp(gw, w.grad, 2e-2, "dw")
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 128, 32, 88), (1, 128, 256, 45, 45), (2, 64, 64, 9, 7), (1, 256, 256, 16, 44), (1, 64, 128, 1, 5)])
+def test_conv3x3_stride2(hip_lib, cfg):
+    """3x3 / stride 2 / pad 1 on the mapped 1x1 kernels (im2col map, parity-class data gradient) vs PyTorch fp32."""
+    import torch.nn.functional as F
+    from unidistill_amd.ops import conv2d as c
+    B, cin, cout, H, W = cfg
+    torch.manual_seed(sum(cfg))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda").bfloat16()).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).bfloat16().float().requires_grad_(True)
+    y = c.conv3x3_stride2(x, w)
+    gy = _cl(torch.randn_like(y))
+    y.backward(gy)
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, stride=2, padding=1)
+    yr.backward(gy.float())
+    assert y.shape == yr.shape
+    _cmp(y, yr, 8e-3, "y")
+    _cmp(gx, xr.grad, 2e-2, "dx")
+    _cmp(gw, w.grad, 2e-2, "dw")
