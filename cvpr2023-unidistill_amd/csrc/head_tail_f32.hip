@@ -33,77 +33,88 @@ __device__ __forceinline__ void tile_origin(const GTail& t, int tile, int& b, in
   tx0 = (tile % t.tiles_x) * kTW;
 }
 
-// Sum over the 64 lanes with DPP adds (VALU rate; a shuffle butterfly goes through the LDS pipe and was the
-// bottleneck of an earlier version): row_shr 1/2/4/8 reduce each row of 16, row_bcast15/31 chain the rows;
-// lane 63 holds the total.
-__device__ __forceinline__ float dpp_wave_sum_to_lane63(float v) {
-#define UD_DPP_ADD(ctrl, rmask)                                                                            \
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
-  UD_DPP_ADD(0x111, 0xF);   // row_shr:1
-  UD_DPP_ADD(0x112, 0xF);   // row_shr:2
-  UD_DPP_ADD(0x114, 0xF);   // row_shr:4
-  UD_DPP_ADD(0x118, 0xF);   // row_shr:8
-  UD_DPP_ADD(0x142, 0xA);   // row_bcast:15 -> rows 1, 3
-  UD_DPP_ADD(0x143, 0xC);   // row_bcast:31 -> rows 2, 3
+// Sum over each ROW of 16 lanes with DPP adds (VALU rate; a shuffle butterfly goes through the LDS pipe): row_shr
+// 1/2/4/8 with zero fill; lane 15 of every row holds its row's total.
+__device__ __forceinline__ float dpp_row_sum_to_lane15(float v) {
+#define UD_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
+  UD_DPP_ADD(0x111);   // row_shr:1
+  UD_DPP_ADD(0x112);   // row_shr:2
+  UD_DPP_ADD(0x114);   // row_shr:4
+  UD_DPP_ADD(0x118);   // row_shr:8
 #undef UD_DPP_ADD
   return v;
 }
 
+__device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
+  acc = fmaf(a.x, b.x, acc);
+  acc = fmaf(a.y, b.y, acc);
+  acc = fmaf(a.z, b.z, acc);
+  return fmaf(a.w, b.w, acc);
+}
+
 // z[pix, g*KM + k] = bias + sum_{tap, c} a[pix + tap - 1, g*64 + c] * w[g][k][tap][c]
-// lane = channel, the lane's 9*KM weights in registers, no LDS.  A wave owns two pixel rows of the tile: it
-// loads their 4 x 18 halo of 256-byte rows ONCE (72 independent loads in flight; 2.25 row reads per output pixel
-// instead of 9, so the L2 sees the hidden tensor ~2.3x, HBM once) and reduces every partial sum over its lanes.
-// (Earlier versions: halo in LDS + a thread per pixel: 58 KB of LDS, 2 workgroups per CU, 2.1 ms; nine row reads
-// per pixel from L2 + shuffle reductions: 2.0 ms.)
+// No LDS.  lane = (pixel column of a 4-wide strip, channel quad): a wave walks its strip down the 8 rows of the tile
+// with a 3 x 3 window of 16-byte pieces in registers (3 new loads per pixel, the window's other 6 pieces are reused),
+// the lane's 9 * KM weight quads stay in registers, and each partial sum is reduced over the 16 lanes of its DPP row.
+// ~19 instructions per output pixel and wave.  (Earlier formulations, all 1.7-2.1 ms at B = 4: halo in LDS with a
+// thread per pixel; lane = channel with nine row reads per pixel and shuffle reductions; lane = channel with a register
+// halo and 64-lane DPP reductions -- instruction-bound: 140 instructions per pixel.)
+template <int KM>
 __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ z, GTail t) {
-  // groups vary fastest over the grid: the workgroups running together consume WHOLE pixel rows (all 42 x 256 B
-  // of them) -- with tiles fastest every sweep touched 256 bytes out of each 10.75 KB row and ran at 0.8 TB/s
+  // groups vary fastest over the grid: the workgroups running together consume whole pixel rows
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int b, ty0, tx0;
   tile_origin(t, blockIdx.y, b, ty0, tx0);
-  const int Ct = t.G * kHC, Zt = t.G * t.KM;
-  float wr[kKMax][9];
+  const int Ct = t.G * kHC, Zt = t.G * KM;
+  const int ps = lane >> 4, cq = lane & 15;
+  float4 wr[KM][9];
 #pragma unroll
-  for (int k = 0; k < kKMax; ++k)
+  for (int k = 0; k < KM; ++k)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
-      wr[k][tap] = (k < t.KM) ? w[((size_t)(g * t.KM + k) * 9 + tap) * kHC + lane] : 0.f;
-  const float* ab = a + (size_t)b * t.H * t.W * Ct + g * kHC + lane;
-  const int y0 = ty0 + 2 * wave;                   // this wave's two output rows: y0, y0 + 1
-  if (y0 >= t.H) return;
-  float hv[4][kHW];                                // halo rows y0-1 .. y0+2, columns tx0-1 .. tx0+16
+      wr[k][tap] = *reinterpret_cast<const float4*>(w + ((size_t)(g * KM + k) * 9 + tap) * kHC + 4 * cq);
+  const int gx = tx0 + 4 * wave + ps;
+  if (tx0 + 4 * wave >= t.W) return;
+  const float* ab = a + (size_t)b * t.H * t.W * Ct + g * kHC + 4 * cq;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_row = [&](int yy, float4* r) {        // the three pieces (gx-1, gx, gx+1) of image row yy
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < kHW; ++c) {
-      const int yy = y0 - 1 + r, xx = tx0 - 1 + c;
-      hv[r][c] = (yy >= 0 && yy < t.H && xx >= 0 && xx < t.W) ? ab[((size_t)yy * t.W + xx) * Ct] : 0.f;
+    for (int d = 0; d < 3; ++d) {
+      const int xx = gx - 1 + d;
+      r[d] = (yy >= 0 && yy < t.H && xx >= 0 && xx < t.W)
+                 ? *reinterpret_cast<const float4*>(ab + ((size_t)yy * t.W + xx) * Ct) : zero4;
     }
-  const float bv = (bias && lane < t.KM) ? bias[g * t.KM + lane] : 0.f;   // lanes 0..KM-1 (unused: lane 63 stores)
-  (void)bv;
+  };
+  float4 win[4][3];                                // rows y-1, y, y+1 and the prefetched y+2
+  load_row(ty0 - 1, win[0]);
+  load_row(ty0, win[1]);
+  load_row(ty0 + 1, win[2]);
+  float bv[KM];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int gy = y0 + u;
+  for (int k = 0; k < KM; ++k) bv[k] = bias ? bias[g * KM + k] : 0.f;
 #pragma unroll
-    for (int x = 0; x < kTW; ++x) {
-      float acc[kKMax] = {0.f, 0.f, 0.f, 0.f};
+  for (int y = 0; y < kTH; ++y) {
+    const int gy = ty0 + y;
+    if (y + 1 < kTH) load_row(gy + 2, win[3]);     // two rows ahead: its latency hides behind two pixels of FMAs
+    float acc[KM];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const float v = hv[u + tap / 3][x + tap % 3];
+    for (int k = 0; k < KM; ++k) {
+      float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < kKMax; ++k) acc[k] = fmaf(v, wr[k][tap], acc[k]);
-      }
+      for (int tap = 0; tap < 9; ++tap) s = dot4(win[tap / 3][tap % 3], wr[k][tap], s);
+      acc[k] = dpp_row_sum_to_lane15(s);
+    }
+    if (cq == 15 && gy < t.H && gx < t.W) {
+      float* o = z + ((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * KM;
 #pragma unroll
-      for (int k = 0; k < kKMax; ++k)
-        if (k < t.KM) acc[k] = dpp_wave_sum_to_lane63(acc[k]);
-      const int gx = tx0 + x;
-      if (lane == 63 && gy < t.H && gx < t.W) {
-        float* o = z + ((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * t.KM;
+      for (int k = 0; k < KM; ++k) o[k] = acc[k] + bv[k];
+    }
 #pragma unroll
-        for (int k = 0; k < kKMax; ++k)
-          if (k < t.KM) o[k] = acc[k] + (bias ? bias[g * t.KM + k] : 0.f);
-      }
+    for (int d = 0; d < 3; ++d) {
+      win[0][d] = win[1][d];
+      win[1][d] = win[2][d];
+      win[2][d] = win[3][d];
     }
   }
 }
@@ -230,7 +241,13 @@ extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float*
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_fwd", stream);
-  k_gtail_fwd<<<dim3(G, B * t.tiles_x * t.tiles_y), 256, 0, stream>>>(a, w, bias, z, t);
+  const dim3 grid(G, B * t.tiles_x * t.tiles_y);
+  switch (KM) {
+    case 1: k_gtail_fwd<1><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
+    case 2: k_gtail_fwd<2><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
+    case 3: k_gtail_fwd<3><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
+    default: k_gtail_fwd<4><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
+  }
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
