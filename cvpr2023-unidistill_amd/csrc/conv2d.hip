@@ -107,6 +107,58 @@ __device__ __forceinline__ void dma16(const unsigned short* src, unsigned short*
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Shared epilogue: accumulators -> fp32 tile in LDS (aliases the operand tiles; the K loop ended on a barrier), then
+// 16-byte channel pieces: bias, folded BN, residual, ReLU, bf16 store.
+template <int TN, int KS, int RW>
+__device__ __forceinline__ void conv_store_tile(const f32x4 (&acc)[RW][4], float* Os, int tid, int wm, int wn, int g,
+                                                int li, int b, int ty0, int tx0, int n0, unsigned short* __restrict__ y,
+                                                const ConvGeom& gm, const ConvEp& ep) {
+  constexpr int kTN = TN, kLDO = TN + 4;
+#pragma unroll
+  for (int ti = 0; ti < RW; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
+  __syncthreads();
+  for (int u = tid; u < kTM * (kTN / 8); u += 256) {
+    const int r = u / (kTN / 8), c8 = (u - r * (kTN / 8)) * 8;
+    const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+    const int n = n0 + c8;
+    if (gy >= gm.H || gx >= gm.W || n >= gm.Cout || (long long)(b * gm.H + gy) * gm.W + gx >= gm.npix) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(Os + r * kLDO + c8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Os + r * kLDO + c8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (ep.bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += ep.bias[n + e];
+    }
+    if (ep.scale) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.scale[n + e] + ep.shift[n + e];
+    }
+    const size_t off = KS == 1 ? gm.omap.off((long long)(b * gm.H + gy) * gm.W + gx, n, gm.Cout)
+                               : ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+    if (ep.residual) {
+      const uint4 h = *reinterpret_cast<const uint4*>(ep.residual + off);
+      const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] += __uint_as_float(hw[e] << 16);
+        v[2 * e + 1] += __uint_as_float(hw[e] & 0xFFFF0000u);
+      }
+    }
+    if (ep.relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + off) =
+        make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]), ud_pack_bf16x2(v[4], v[5]),
+                   ud_pack_bf16x2(v[6], v[7]));
+  }
+}
+
 // TN = output channels per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64; layers
 // with Cout <= 64 -- the head's shared conv, the data gradient of the packed first head convs -- would
 // waste half of a 128-wide tile).
@@ -116,7 +168,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
                                                       const unsigned short* __restrict__ w,
                                                       unsigned short* __restrict__ y, ConvGeom gm,
                                                       ConvEp ep) {
-  constexpr int kTN = TN, kLDO = TN + 4, kBInstr = TN / 8;
+  constexpr int kTN = TN, kBInstr = TN / 8;
   constexpr int WM = TN == 128 ? 2 : 4;          // waves along the pixel dimension
   constexpr int kTaps = KS * KS, kPad = KS / 2;
   constexpr int kHW = kTW + 2 * kPad, kHQ = kHW * (kTH + 2 * kPad);   // staged pixels: 18 x 10 or 16 x 8
@@ -222,51 +274,145 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
     }
     __syncthreads();
   }
-  // epilogue 1: accumulators -> fp32 tile in LDS (aliases the operand tiles; the loop ended on a barrier)
+  conv_store_tile<TN, KS, RW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+}
+
+// ---- 3x3 forward / data gradient: straight-line tap loop --------------------------------------------------------------
+// Same tiling, LDS layout and DMA staging as k_conv3x3_bf16<TN, 3>, but the nine taps of a 64-channel slice are unrolled so
+// that every per-tap quantity is an instruction immediate.  SQ counters on the generic kernel (tools/pmc_conv.sh, 128 -> 128
+// @180 x 180 x 4): per (tap, slice) a wave issued 32 MFMAs next to 123 other VALU and 93 scalar instructions -- 64-bit
+// multiply-adds and exec-masked branches rebuilding the four weight-piece addresses, the 16 swizzled fragment addresses and
+// the (slice, tap) split of the loop counter -- and MFMA busy was 23 % of the SIMD cycles.  Here
+//   * the swizzled fragment address of halo row q0 + d is  sa[ks][d & 7] + 128 d  (16 registers computed once; the shift d
+//     of (tile row, tap) goes into the ds_read offset field),
+//   * a weight piece is  (uniform slice base) + (per-lane 32-bit offset computed once): output channels past Cout re-read
+//     channel Cout - 1 (never stored), which removes the zero-page select from the loop,
+//   * the halo pointers are computed once and advanced by 128 B per slice,
+//   * the double buffers alternate through two register sets swapped per slice (nine taps: the parity flips).
+template <int TN>
+__global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __restrict__ x,
+                                                      const unsigned short* __restrict__ w,
+                                                      unsigned short* __restrict__ y, ConvGeom gm, ConvEp ep) {
+  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM;
+  constexpr int NB = TN / 32;                       // weight pieces (8 channels x 128 B) per wave and slice
+  constexpr int kBBytes = TN * 128, kABytes = kHQP * 128, kAOff = 2 * kBBytes;
+  constexpr int kAPer = (kAInstr + 3) / 4;          // halo pieces per wave (6; the last one on three waves only)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
+  const int ntiles = gm.B * gm.tiles_x * gm.tiles_y;
+  const int per = (ntiles + 7) / 8;
+  int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int b = tile / (gm.tiles_x * gm.tiles_y);
+  tile -= b * gm.tiles_x * gm.tiles_y;
+  const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
+  const int n0 = blockIdx.y * TN;
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
+
+  f32x4 acc[RW][4];
 #pragma unroll
-  for (int ti = 0; ti < RW; ++ti)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int r8 = lane >> 3, slot = lane & 7;
+  // halo pieces of this wave: source pointer of slice 0 and its per-slice step (0 for the out-of-image zero page)
+  const unsigned short* pa[kAPer];
+  int inca[kAPer];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
-  __syncthreads();
-  // epilogue 2: 16-byte channel pieces: bias, folded BN, residual, ReLU, bf16 store
-  for (int u = tid; u < kTM * (kTN / 8); u += 256) {
-    const int r = u / (kTN / 8), c8 = (u - r * (kTN / 8)) * 8;
-    const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
-    const int n = n0 + c8;
-    if (gy >= gm.H || gx >= gm.W || n >= gm.Cout || (long long)(b * gm.H + gy) * gm.W + gx >= gm.npix) continue;
-    const float4 v0 = *reinterpret_cast<const float4*>(Os + r * kLDO + c8);
-    const float4 v1 = *reinterpret_cast<const float4*>(Os + r * kLDO + c8 + 4);
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    if (ep.bias) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += ep.bias[n + e];
-    }
-    if (ep.scale) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.scale[n + e] + ep.shift[n + e];
-    }
-    const size_t off = KS == 1 ? gm.omap.off((long long)(b * gm.H + gy) * gm.W + gx, n, gm.Cout)
-                               : ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
-    if (ep.residual) {
-      const uint4 h = *reinterpret_cast<const uint4*>(ep.residual + off);
-      const unsigned hw[4] = {h.x, h.y, h.z, h.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[2 * e] += __uint_as_float(hw[e] << 16);
-        v[2 * e + 1] += __uint_as_float(hw[e] & 0xFFFF0000u);
-      }
-    }
-    if (ep.relu) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    *reinterpret_cast<uint4*>(y + off) =
-        make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]), ud_pack_bf16x2(v[4], v[5]),
-                   ud_pack_bf16x2(v[6], v[7]));
+  for (int i = 0; i < kAPer; ++i) {
+    const int q = (wave + 4 * i) * 8 + r8;
+    const int qy = q / kHW, qx = q - qy * kHW;
+    const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
+    const bool ok = q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
+    pa[i] = ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + ((slot ^ (q & 7)) << 3) : zero;
+    inca[i] = ok ? kKC : 0;
   }
+  auto stage_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kAPer; ++i) {
+      if (wave + 4 * i < kAInstr)
+        dma16(pa[i], reinterpret_cast<unsigned short*>(smem + kAOff + buf * kABytes + (wave + 4 * i) * 1024));
+      pa[i] += inca[i];
+    }
+  };
+  // weight pieces: byte offset of (channel row, swizzled slot) from the slice base
+  unsigned voffb[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave + 4 * j) * 8 + r8;
+    const int nn = min(n0 + n, gm.Cout - 1);
+    voffb[j] = (unsigned)(((size_t)nn * 9 * gm.Cin + ((slot ^ (n & 7)) << 3)) * 2);
+  }
+  auto stage_b = [&](int chunk, int tap, int buf) {
+    const int te = ep.reverse_taps ? 8 - tap : tap;
+    const char* wb = reinterpret_cast<const char*>(w) + ((size_t)te * gm.Cin + (size_t)chunk * kKC) * 2;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      dma16(reinterpret_cast<const unsigned short*>(wb + voffb[j]),
+            reinterpret_cast<unsigned short*>(smem + buf * kBBytes + (wave + 4 * j) * 1024));
+  };
+  // fragment addresses (bytes in LDS)
+  const int q0 = RW * wm * kHW + li;
+  unsigned sa[2][8], sb[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sa[ks][c] = kAOff + q0 * 128 + (((4 * ks + g) ^ ((q0 + c) & 7)) << 4);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) sb[ks][p] = p * kBBytes + (64 * wn + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+  }
+
+  const int nchunks = gm.Cin / kKC;
+  stage_a(0);
+  stage_b(0, 0, 0);
+  __syncthreads();                 // drains the DMAs (vmcnt(0)) and publishes the tiles
+  int adelta = kABytes;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int cpar = chunk & 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // next weight slice (and, at the start of a slice, the next halo) fly while this one is multiplied
+      if (tap < 8) stage_b(chunk, tap + 1, ((tap + 1) & 1) ^ cpar);
+      else if (chunk + 1 < nchunks) stage_b(chunk + 1, 0, cpar ^ 1);
+      if (tap == 0 && chunk + 1 < nchunks) stage_a(cpar ^ 1);
+      const int dy = tap / 3, dx = tap % 3;
+      bf16x8 a[2][RW], bb[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int ti = 0; ti < RW; ++ti) {
+          const int d = (ti + dy) * kHW + dx;
+          a[ks][ti] = *reinterpret_cast<const bf16x8*>(smem + sa[ks][d & 7] + d * 128);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          bb[ks][tj] = *reinterpret_cast<const bf16x8*>(smem + sb[ks][tap & 1] + tj * 2048);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < RW; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][ti], bb[ks][tj], acc[ti][tj], 0, 0, 0);
+      __syncthreads();
+    }
+    // nine taps: the weight double buffer ends a slice on the other parity; the halo buffer alternates per slice
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned t = sb[ks][0];
+      sb[ks][0] = sb[ks][1];
+      sb[ks][1] = t;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sa[ks][c] += adelta;
+    }
+    adelta = -adelta;
+  }
+  conv_store_tile<TN, 3, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------
@@ -745,25 +891,36 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W, PixMap{}, PixMap{}};
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
   static bool attr_set = false;
+  static bool generic = false;     // UD_CONV_GENERIC=1: the runtime-tap kernel (A/B timing only)
   if (!attr_set) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(128)));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(64)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(128)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(64)));
+    const char* e = getenv("UD_CONV_GENERIC");
+    generic = e && e[0] == '1';
     attr_set = true;
   }
   const int ntiles = B * gm.tiles_x * gm.tiles_y;
   const int gx = (ntiles + 7) / 8 * 8;
   UdProfScope prof("conv2d.k_conv3x3", stream);
+  const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
+  const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
+  unsigned short* ys = reinterpret_cast<unsigned short*>(y);
   // 64-wide output tiles when Cout <= 64, and on small maps where 128-wide tiles would leave CUs idle
-  if (Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256)
-    k_conv3x3_bf16<64, 3><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64), stream>>>(
-        reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
-        reinterpret_cast<unsigned short*>(y), gm, ep);
-  else
-    k_conv3x3_bf16<128, 3><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128), stream>>>(
-        reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w),
-        reinterpret_cast<unsigned short*>(y), gm, ep);
+  const bool narrow = Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256;
+  const dim3 grid(gx, ud_div_up(Cout, narrow ? 64 : 128));
+  if (generic) {
+    if (narrow) k_conv3x3_bf16<64, 3><<<grid, 256, conv_smem_bytes(64), stream>>>(xs, ws, ys, gm, ep);
+    else k_conv3x3_bf16<128, 3><<<grid, 256, conv_smem_bytes(128), stream>>>(xs, ws, ys, gm, ep);
+  } else {
+    if (narrow) k_conv3x3_taps<64><<<grid, 256, conv_smem_bytes(64), stream>>>(xs, ws, ys, gm, ep);
+    else k_conv3x3_taps<128><<<grid, 256, conv_smem_bytes(128), stream>>>(xs, ws, ys, gm, ep);
+  }
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
