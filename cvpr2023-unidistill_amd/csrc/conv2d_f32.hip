@@ -52,10 +52,52 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Shared epilogue: accumulators -> fp32 tile in LDS (aliases the operand tiles; the K loop ended on a barrier), then 16-byte
+// channel pieces: bias, folded BN, residual, ReLU.
+template <int TN, int RW>
+__device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float* Os, int tid, int wm, int wn, int g, int li,
+                                               int b, int ty0, int tx0, int n0, float* __restrict__ y,
+                                               const ConvGeomF& gm, const ConvEpF& ep) {
+  constexpr int kTN = TN, kLDO = TN + 4;
+#pragma unroll
+  for (int ti = 0; ti < RW; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
+  __syncthreads();
+  for (int u = tid; u < kTM * (kTN / 4); u += 256) {
+    const int r = u / (kTN / 4), c4 = (u - r * (kTN / 4)) * 4;
+    const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
+    const int n = n0 + c4;
+    if (gy >= gm.H || gx >= gm.W || n >= gm.Cout || (long long)(b * gm.H + gy) * gm.W + gx >= gm.npix) continue;
+    float4 v = *reinterpret_cast<const float4*>(Os + r * kLDO + c4);
+    if (ep.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(ep.bias + n);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    if (ep.scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(ep.scale + n);
+      const float4 sh = *reinterpret_cast<const float4*>(ep.shift + n);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    }
+    const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+    if (ep.residual) {
+      const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
+      v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+    }
+    if (ep.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + off) = v;
+  }
+}
+
 template <int TN, int KS>
 __global__ __launch_bounds__(256) void k_conv_f32(const float* __restrict__ x, const float* __restrict__ w,
                                                   float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
-  constexpr int kTN = TN, kLDO = TN + 4, kBInstr = TN / 8;
+  constexpr int kTN = TN, kBInstr = TN / 8;
   constexpr int WM = TN == 128 ? 2 : 4;
   constexpr int kTaps = KS * KS, kPad = KS / 2;
   constexpr int kHW = kTW + 2 * kPad, kHQ = kHW * (kTH + 2 * kPad);
@@ -146,39 +188,129 @@ __global__ __launch_bounds__(256) void k_conv_f32(const float* __restrict__ x, c
     }
     __syncthreads();
   }
+  store_tile_f32<TN, RW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+}
+
+// 3x3 only: the nine taps of a 32-channel slice unrolled so that every per-tap quantity is an instruction immediate (see
+// k_conv3x3_taps in conv2d.hip, whose SQ counters motivated it: the runtime-tap loop spends ~220 address / control
+// instructions per (tap, slice) next to the MFMAs).  Same tiling, LDS layout and results as k_conv_f32<TN, 3>.
+template <int TN>
+__global__ __launch_bounds__(256) void k_conv_f32_taps(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
+  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM, NB = TN / 32;
+  constexpr int kHW = kTW + 2, kHQ = kHW * (kTH + 2), kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
+  constexpr int kBBytes = TN * 128, kABytes = kHQP * 128, kAOff = 2 * kBBytes, kAPer = (kAInstr + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Os = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
+  const int ntiles = gm.B * gm.tiles_x * gm.tiles_y;
+  const int per = (ntiles + 7) / 8;
+  int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int b = tile / (gm.tiles_x * gm.tiles_y);
+  tile -= b * gm.tiles_x * gm.tiles_y;
+  const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
+  const int n0 = blockIdx.y * TN;
+  const float* zero = reinterpret_cast<const float*>(g_zero16f);
+
+  f32x4 acc[RW][4];
 #pragma unroll
-  for (int ti = 0; ti < RW; ++ti)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int r8 = lane >> 3, slot = lane & 7;
+  const float* pa[kAPer];       // halo pieces of this wave: source of slice 0, stepped by one slice (0 on the zero page)
+  int inca[kAPer];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
-  __syncthreads();
-  for (int u = tid; u < kTM * (kTN / 4); u += 256) {
-    const int r = u / (kTN / 4), c4 = (u - r * (kTN / 4)) * 4;
-    const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
-    const int n = n0 + c4;
-    if (gy >= gm.H || gx >= gm.W || n >= gm.Cout || (long long)(b * gm.H + gy) * gm.W + gx >= gm.npix) continue;
-    float4 v = *reinterpret_cast<const float4*>(Os + r * kLDO + c4);
-    if (ep.bias) {
-      const float4 bv = *reinterpret_cast<const float4*>(ep.bias + n);
-      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    }
-    if (ep.scale) {
-      const float4 sc = *reinterpret_cast<const float4*>(ep.scale + n);
-      const float4 sh = *reinterpret_cast<const float4*>(ep.shift + n);
-      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-    }
-    const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
-    if (ep.residual) {
-      const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
-      v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
-    }
-    if (ep.relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    *reinterpret_cast<float4*>(y + off) = v;
+  for (int i = 0; i < kAPer; ++i) {
+    const int q = (wave + 4 * i) * 8 + r8;
+    const int qy = q / kHW, qx = q - qy * kHW;
+    const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
+    const bool ok = q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
+    pa[i] = ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + ((slot ^ (q & 7)) << 2) : zero;
+    inca[i] = ok ? kKC : 0;
   }
+  auto stage_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kAPer; ++i) {
+      if (wave + 4 * i < kAInstr)
+        dma16(pa[i], reinterpret_cast<float*>(smem + kAOff + buf * kABytes + (wave + 4 * i) * 1024));
+      pa[i] += inca[i];
+    }
+  };
+  unsigned voffb[NB];           // weight pieces: byte offset from the (tap, slice) base; channels past Cout re-read the last one
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave + 4 * j) * 8 + r8;
+    const int nn = min(n0 + n, gm.Cout - 1);
+    voffb[j] = (unsigned)(((size_t)nn * 9 * gm.Cin + ((slot ^ (n & 7)) << 2)) * 4);
+  }
+  auto stage_b = [&](int chunk, int tap, int buf) {
+    const int te = ep.reverse_taps ? 8 - tap : tap;
+    const char* wb = reinterpret_cast<const char*>(w) + ((size_t)te * gm.Cin + (size_t)chunk * kKC) * 4;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      dma16(reinterpret_cast<const float*>(wb + voffb[j]),
+            reinterpret_cast<float*>(smem + buf * kBBytes + (wave + 4 * j) * 1024));
+  };
+  const int q0 = RW * wm * kHW + li;
+  unsigned sa[2][8], sb[2][2];  // swizzled fragment addresses: halo row q0 + d is sa[ks][d & 7] + 128 d
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sa[ks][c] = kAOff + q0 * 128 + (((4 * ks + g) ^ ((q0 + c) & 7)) << 4);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) sb[ks][p] = p * kBBytes + (64 * wn + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+  }
+
+  const int nchunks = gm.Cin / kKC;
+  stage_a(0);
+  stage_b(0, 0, 0);
+  __syncthreads();
+  int adelta = kABytes;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int cpar = chunk & 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) stage_b(chunk, tap + 1, ((tap + 1) & 1) ^ cpar);
+      else if (chunk + 1 < nchunks) stage_b(chunk + 1, 0, cpar ^ 1);
+      if (tap == 0 && chunk + 1 < nchunks) stage_a(cpar ^ 1);
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 a[RW];
+#pragma unroll
+        for (int ti = 0; ti < RW; ++ti) {
+          const int d = (ti + dy) * kHW + dx;
+          a[ti] = *reinterpret_cast<const f32x4*>(smem + sa[ks][d & 7] + d * 128);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(smem + sb[ks][tap & 1] + tj * 2048);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ti = 0; ti < RW; ++ti)
+              acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti][e], bb[e], acc[ti][tj], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {   // nine taps: the weight buffers end a slice on the other parity; the halo alternates
+      const unsigned t = sb[ks][0];
+      sb[ks][0] = sb[ks][1];
+      sb[ks][1] = t;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sa[ks][c] += adelta;
+    }
+    adelta = -adelta;
+  }
+  store_tile_f32<TN, RW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
 }
 
 template <int KS>
@@ -195,10 +327,27 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
   const int gx = (ntiles + 7) / 8 * 8;
   UdProfScope prof(name, stream);
   static const int force64 = getenv("UD_F32_TN64") ? atoi(getenv("UD_F32_TN64")) : 0;
-  if (force64 || gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256)
-    k_conv_f32<64, KS><<<dim3(gx, ud_div_up(gm.Cout, 64)), 256, conv_smem_bytes_f(64, KS), stream>>>(x, w, y, gm, ep);
-  else
-    k_conv_f32<128, KS><<<dim3(gx, ud_div_up(gm.Cout, 128)), 256, conv_smem_bytes_f(128, KS), stream>>>(x, w, y, gm, ep);
+  static const bool generic = getenv("UD_CONV_GENERIC") && getenv("UD_CONV_GENERIC")[0] == '1';   // A/B timing only
+  const bool narrow = force64 || gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256;
+  const dim3 grid(gx, ud_div_up(gm.Cout, narrow ? 64 : 128));
+  if constexpr (KS == 3) {
+    if (!generic) {
+      static bool taps_set = false;
+      if (!taps_set) {
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32_taps<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)conv_smem_bytes_f(128, 3)));
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32_taps<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)conv_smem_bytes_f(64, 3)));
+        taps_set = true;
+      }
+      if (narrow) k_conv_f32_taps<64><<<grid, 256, conv_smem_bytes_f(64, 3), stream>>>(x, w, y, gm, ep);
+      else k_conv_f32_taps<128><<<grid, 256, conv_smem_bytes_f(128, 3), stream>>>(x, w, y, gm, ep);
+      UD_LAUNCH_CHECK();
+      return UD_OK;
+    }
+  }
+  if (narrow) k_conv_f32<64, KS><<<grid, 256, conv_smem_bytes_f(64, KS), stream>>>(x, w, y, gm, ep);
+  else k_conv_f32<128, KS><<<grid, 256, conv_smem_bytes_f(128, KS), stream>>>(x, w, y, gm, ep);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
