@@ -95,6 +95,13 @@ constexpr size_t conv_smem_bytes(int tn, int ks = 3) {
   return operands > out ? operands : out;
 }
 
+constexpr size_t conv_taps_smem_bytes(int tn, int rw) {
+  const int th = (tn == 128 ? 2 : 4) * rw;
+  const size_t operands = 2 * (size_t)((kHW * (th + 2) + 7) / 8 * 8) * 128 + 2 * (size_t)tn * 128;
+  const size_t out = (size_t)th * kTW * (tn + 4) * 4;
+  return operands > out ? operands : out;
+}
+
 // Out-of-image halo pixels and output channels past Cout are loaded from here (LDS-DMA cannot
 // write a constant).
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
@@ -109,7 +116,7 @@ __device__ __forceinline__ void dma16(const unsigned short* src, unsigned short*
 
 // Shared epilogue: accumulators -> fp32 tile in LDS (aliases the operand tiles; the K loop ended on a barrier), then
 // 16-byte channel pieces: bias, folded BN, residual, ReLU, bf16 store.
-template <int TN, int KS, int RW>
+template <int TN, int KS, int RW, int TM = kTM>
 __device__ __forceinline__ void conv_store_tile(const f32x4 (&acc)[RW][4], float* Os, int tid, int wm, int wn, int g,
                                                 int li, int b, int ty0, int tx0, int n0, unsigned short* __restrict__ y,
                                                 const ConvGeom& gm, const ConvEp& ep) {
@@ -122,7 +129,7 @@ __device__ __forceinline__ void conv_store_tile(const f32x4 (&acc)[RW][4], float
       for (int r = 0; r < 4; ++r)
         Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
   __syncthreads();
-  for (int u = tid; u < kTM * (kTN / 8); u += 256) {
+  for (int u = tid; u < TM * (kTN / 8); u += 256) {
     const int r = u / (kTN / 8), c8 = (u - r * (kTN / 8)) * 8;
     const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
     const int n = n0 + c8;
@@ -289,14 +296,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
 //     channel Cout - 1 (never stored), which removes the zero-page select from the loop,
 //   * the halo pointers are computed once and advanced by 128 B per slice,
 //   * the double buffers alternate through two register sets swapped per slice (nine taps: the parity flips).
-template <int TN>
+template <int TN, int RW>
 __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __restrict__ x,
                                                       const unsigned short* __restrict__ w,
                                                       unsigned short* __restrict__ y, ConvGeom gm, ConvEp ep) {
-  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM;
+  constexpr int WM = TN == 128 ? 2 : 4;             // waves along the pixel rows; a wave owns RW rows of 16 pixels
+  constexpr int TH = WM * RW, TM = TH * kTW;        // tile: TH x 16 output pixels
+  constexpr int kHQ = kHW * (TH + 2), kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
   constexpr int NB = TN / 32;                       // weight pieces (8 channels x 128 B) per wave and slice
   constexpr int kBBytes = TN * 128, kABytes = kHQP * 128, kAOff = 2 * kBBytes;
-  constexpr int kAPer = (kAInstr + 3) / 4;          // halo pieces per wave (6; the last one on three waves only)
+  constexpr int kAPer = (kAInstr + 3) / 4;          // halo pieces per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __re
   if (tile >= ntiles) return;
   const int b = tile / (gm.tiles_x * gm.tiles_y);
   tile -= b * gm.tiles_x * gm.tiles_y;
-  const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
+  const int ty0 = (tile / gm.tiles_x) * TH, tx0 = (tile % gm.tiles_x) * kTW;
   const int n0 = blockIdx.y * TN;
   const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
 
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __re
     }
     adelta = -adelta;
   }
-  conv_store_tile<TN, 3, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+  conv_store_tile<TN, 3, RW, TM>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------
@@ -892,35 +901,62 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
   static bool attr_set = false;
   static bool generic = false;     // UD_CONV_GENERIC=1: the runtime-tap kernel (A/B timing only)
+  static int force_rw = 0;         // UD_CONV_RW=n: pixel rows per wave (A/B timing only)
   if (!attr_set) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(128)));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(64)));
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes(128)));
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes(64)));
+#define UD_TAPS_ATTR(TN, RW)                                                                                          \
+  UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps<TN, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                 (int)conv_taps_smem_bytes(TN, RW)))
+    UD_TAPS_ATTR(128, 4); UD_TAPS_ATTR(128, 3); UD_TAPS_ATTR(128, 2);
+    UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
+#undef UD_TAPS_ATTR
     const char* e = getenv("UD_CONV_GENERIC");
     generic = e && e[0] == '1';
+    if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
     attr_set = true;
   }
-  const int ntiles = B * gm.tiles_x * gm.tiles_y;
-  const int gx = (ntiles + 7) / 8 * 8;
   UdProfScope prof("conv2d.k_conv3x3", stream);
   const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
   const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
   unsigned short* ys = reinterpret_cast<unsigned short*>(y);
   // 64-wide output tiles when Cout <= 64, and on small maps where 128-wide tiles would leave CUs idle
-  const bool narrow = Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256;
-  const dim3 grid(gx, ud_div_up(Cout, narrow ? 64 : 128));
+  const bool narrow = Cout <= 64 || B * gm.tiles_x * gm.tiles_y * ud_div_up(Cout, 128) <= 256;
+  const int ntn = ud_div_up(Cout, narrow ? 64 : 128);
   if (generic) {
+    const dim3 grid((B * gm.tiles_x * gm.tiles_y + 7) / 8 * 8, ntn);
     if (narrow) k_conv3x3_bf16<64, 3><<<grid, 256, conv_smem_bytes(64), stream>>>(xs, ws, ys, gm, ep);
     else k_conv3x3_bf16<128, 3><<<grid, 256, conv_smem_bytes(128), stream>>>(xs, ws, ys, gm, ep);
-  } else {
-    if (narrow) k_conv3x3_taps<64><<<grid, 256, conv_smem_bytes(64), stream>>>(xs, ws, ys, gm, ep);
-    else k_conv3x3_taps<128><<<grid, 256, conv_smem_bytes(128), stream>>>(xs, ws, ys, gm, ep);
+    UD_LAUNCH_CHECK();
+    return UD_OK;
   }
+  // Pixel rows per wave (tile height = waves x rows): two workgroups per CU are resident, so a launch runs in
+  // ceil(workgroups / 512) waves of tiles; pick the height whose (rounds x per-tile cost) is smallest -- 180 x 180 x 4 at
+  // 8 rows is 1 104 tiles = 3 rounds, at 6 rows 1 440 tiles = 3 shorter ones.  Per-tile cost ~ rows + 1 (the weight
+  // fragments, DMA issue and barrier of a tap do not shrink with the tile).
+  const int wm = narrow ? 4 : 2;
+  int rw = narrow ? 2 : 4;
+  {
+    long long best = -1;
+    for (int r = narrow ? 2 : 4; r >= (narrow ? 1 : 2); --r) {
+      const long long wgs = (long long)B * gm.tiles_x * ud_div_up(H, wm * r) * ntn;
+      const long long cost = ((wgs + 511) / 512) * (r + 1);
+      if (best < 0 || cost < best) best = cost, rw = r;
+    }
+    if (force_rw) rw = force_rw < (narrow ? 1 : 2) ? (narrow ? 1 : 2) : force_rw > (narrow ? 2 : 4) ? (narrow ? 2 : 4) : force_rw;
+  }
+  gm.tiles_y = ud_div_up(H, wm * rw);
+  const dim3 grid((B * gm.tiles_x * gm.tiles_y + 7) / 8 * 8, ntn);
+#define UD_TAPS_LAUNCH(TN, RW)                                                                                        \
+  k_conv3x3_taps<TN, RW><<<grid, 256, conv_taps_smem_bytes(TN, RW), stream>>>(xs, ws, ys, gm, ep)
+  if (narrow) {
+    if (rw == 1) UD_TAPS_LAUNCH(64, 1); else UD_TAPS_LAUNCH(64, 2);
+  } else {
+    if (rw == 2) UD_TAPS_LAUNCH(128, 2); else if (rw == 3) UD_TAPS_LAUNCH(128, 3); else UD_TAPS_LAUNCH(128, 4);
+  }
+#undef UD_TAPS_LAUNCH
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
