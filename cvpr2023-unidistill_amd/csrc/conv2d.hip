@@ -932,17 +932,17 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
     UD_LAUNCH_CHECK();
     return UD_OK;
   }
-  // Pixel rows per wave (tile height = waves x rows): two workgroups per CU are resident, so a launch runs in
-  // ceil(workgroups / 512) waves of tiles; pick the height whose (rounds x per-tile cost) is smallest -- 180 x 180 x 4 at
-  // 8 rows is 1 104 tiles = 3 rounds, at 6 rows 1 440 tiles = 3 shorter ones.  Per-tile cost ~ rows + 1 (the weight
-  // fragments, DMA issue and barrier of a tap do not shrink with the tile).
+  // Pixel rows per wave (tile height = waves x rows).  A CU works through ceil(workgroups / 256) tiles, two at a time
+  // sharing its MFMA pipes, so a launch takes about ceil(WGs / 256) x (rows + 1) -- the +1 is what a tile costs whatever
+  // its height (prologue, first DMA round trip, epilogue: ~10 k of the 28 k cycles of an 8-row tile at Cin = 128).  Checked
+  // against the timings of tools/time_conv2d.py with UD_CONV_RW = 2 / 3 / 4 on all eleven shapes.
   const int wm = narrow ? 4 : 2;
   int rw = narrow ? 2 : 4;
   {
     long long best = -1;
     for (int r = narrow ? 2 : 4; r >= (narrow ? 1 : 2); --r) {
       const long long wgs = (long long)B * gm.tiles_x * ud_div_up(H, wm * r) * ntn;
-      const long long cost = ((wgs + 511) / 512) * (r + 1);
+      const long long cost = ((wgs + 255) / 256) * (r + 1);
       if (best < 0 || cost < best) best = cost, rw = r;
     }
     if (force_rw) rw = force_rw < (narrow ? 1 : 2) ? (narrow ? 1 : 2) : force_rw > (narrow ? 2 : 4) ? (narrow ? 2 : 4) : force_rw;

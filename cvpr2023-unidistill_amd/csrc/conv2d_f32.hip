@@ -54,7 +54,7 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
 
 // Shared epilogue: accumulators -> fp32 tile in LDS (aliases the operand tiles; the K loop ended on a barrier), then 16-byte
 // channel pieces: bias, folded BN, residual, ReLU.
-template <int TN, int RW>
+template <int TN, int RW, int TM = kTM>
 __device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float* Os, int tid, int wm, int wn, int g, int li,
                                                int b, int ty0, int tx0, int n0, float* __restrict__ y,
                                                const ConvGeomF& gm, const ConvEpF& ep) {
@@ -67,7 +67,7 @@ __device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float*
       for (int r = 0; r < 4; ++r)
         Os[(16 * RW * wm + 16 * ti + 4 * g + r) * kLDO + 64 * wn + 16 * tj + li] = acc[ti][tj][r];
   __syncthreads();
-  for (int u = tid; u < kTM * (kTN / 4); u += 256) {
+  for (int u = tid; u < TM * (kTN / 4); u += 256) {
     const int r = u / (kTN / 4), c4 = (u - r * (kTN / 4)) * 4;
     const int gy = ty0 + (r >> 4), gx = tx0 + (r & 15);
     const int n = n0 + c4;
@@ -194,11 +194,11 @@ __global__ __launch_bounds__(256) void k_conv_f32(const float* __restrict__ x, c
 // 3x3 only: the nine taps of a 32-channel slice unrolled so that every per-tap quantity is an instruction immediate (see
 // k_conv3x3_taps in conv2d.hip, whose SQ counters motivated it: the runtime-tap loop spends ~220 address / control
 // instructions per (tap, slice) next to the MFMAs).  Same tiling, LDS layout and results as k_conv_f32<TN, 3>.
-template <int TN>
+template <int TN, int RW>
 __global__ __launch_bounds__(256) void k_conv_f32_taps(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
-  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM, NB = TN / 32;
-  constexpr int kHW = kTW + 2, kHQ = kHW * (kTH + 2), kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
+  constexpr int WM = TN == 128 ? 2 : 4, TH = WM * RW, NB = TN / 32;   // tile: TH x 16 output pixels, RW rows per wave
+  constexpr int kHW = kTW + 2, kHQ = kHW * (TH + 2), kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
   constexpr int kBBytes = TN * 128, kABytes = kHQP * 128, kAOff = 2 * kBBytes, kAPer = (kAInstr + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Os = reinterpret_cast<float*>(smem);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_conv_f32_taps(const float* __restrict__
   if (tile >= ntiles) return;
   const int b = tile / (gm.tiles_x * gm.tiles_y);
   tile -= b * gm.tiles_x * gm.tiles_y;
-  const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
+  const int ty0 = (tile / gm.tiles_x) * TH, tx0 = (tile % gm.tiles_x) * kTW;
   const int n0 = blockIdx.y * TN;
   const float* zero = reinterpret_cast<const float*>(g_zero16f);
 
@@ -310,7 +310,14 @@ __global__ __launch_bounds__(256) void k_conv_f32_taps(const float* __restrict__
     }
     adelta = -adelta;
   }
-  store_tile_f32<TN, RW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+  store_tile_f32<TN, RW, TH * kTW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+}
+
+constexpr size_t conv_taps_smem_bytes_f(int tn, int rw) {
+  const int th = (tn == 128 ? 2 : 4) * rw;
+  const size_t operands = 2 * (size_t)(((kTW + 2) * (th + 2) + 7) / 8 * 8) * 128 + 2 * (size_t)tn * 128;
+  const size_t out = (size_t)th * kTW * (tn + 4) * 4;
+  return operands > out ? operands : out;
 }
 
 template <int KS>
@@ -333,15 +340,41 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
   if constexpr (KS == 3) {
     if (!generic) {
       static bool taps_set = false;
+      static int force_rw = 0;     // UD_CONV_RW=n: pixel rows per wave (A/B timing only)
       if (!taps_set) {
-        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32_taps<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)conv_smem_bytes_f(128, 3)));
-        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32_taps<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)conv_smem_bytes_f(64, 3)));
+#define UD_TAPS_ATTR(TN, RW)                                                                                          \
+  UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32_taps<TN, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                 (int)conv_taps_smem_bytes_f(TN, RW)))
+        UD_TAPS_ATTR(128, 4); UD_TAPS_ATTR(128, 3); UD_TAPS_ATTR(128, 2); UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
+#undef UD_TAPS_ATTR
+        if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
         taps_set = true;
       }
-      if (narrow) k_conv_f32_taps<64><<<grid, 256, conv_smem_bytes_f(64, 3), stream>>>(x, w, y, gm, ep);
-      else k_conv_f32_taps<128><<<grid, 256, conv_smem_bytes_f(128, 3), stream>>>(x, w, y, gm, ep);
+      // Tile height = waves x rows per wave.  A CU works through ceil(workgroups / 256) tiles (two at a time, sharing its
+      // MFMA pipes: with a 32-cycle fp32 MFMA a tap is MFMA-bound whatever the height), so the launch takes about
+      // ceil(WGs / 256) x rows: 180 x 180 x 4 at 8 rows = 1 104 tiles -> 5 x 4, at 6 rows 1 440 -> 6 x 3 (measured 104 -> 110
+      // TFLOP/s; 256 -> 256 @90 x 90: 87 -> 113).
+      ConvGeomF g2 = gm;
+      const int wmv = narrow ? 4 : 2, ntn = ud_div_up(gm.Cout, narrow ? 64 : 128);
+      int rw = narrow ? 2 : 4;
+      {
+        double best = -1;
+        for (int r = narrow ? 2 : 4; r >= (narrow ? 1 : 2); --r) {
+          const long long wgs = (long long)gm.B * gm.tiles_x * ud_div_up(gm.H, wmv * r) * ntn;
+          const double cost = (double)((wgs + 255) / 256) * (r + 0.1);
+          if (best < 0 || cost < best) best = cost, rw = r;
+        }
+        if (force_rw) rw = force_rw < (narrow ? 1 : 2) ? (narrow ? 1 : 2) : force_rw > (narrow ? 2 : 4) ? (narrow ? 2 : 4) : force_rw;
+      }
+      g2.tiles_y = ud_div_up(gm.H, wmv * rw);
+      const dim3 grid2((gm.B * g2.tiles_x * g2.tiles_y + 7) / 8 * 8, ntn);
+#define UD_TAPS_LAUNCH(TN, RW) k_conv_f32_taps<TN, RW><<<grid2, 256, conv_taps_smem_bytes_f(TN, RW), stream>>>(x, w, y, g2, ep)
+      if (narrow) {
+        if (rw == 1) UD_TAPS_LAUNCH(64, 1); else UD_TAPS_LAUNCH(64, 2);
+      } else {
+        if (rw == 2) UD_TAPS_LAUNCH(128, 2); else if (rw == 3) UD_TAPS_LAUNCH(128, 3); else UD_TAPS_LAUNCH(128, 4);
+      }
+#undef UD_TAPS_LAUNCH
       UD_LAUNCH_CHECK();
       return UD_OK;
     }

@@ -27,6 +27,7 @@ def _nhwc(t):
 
 
 FLOP_COUNTER = None      # set to [0] to accumulate the multiply-add count of every kernel launch (bench.py)
+SHAPE_LOG = None         # set to [] to record (B, Cin, H, W, Cout, reverse_taps) of every 3x3 launch (bench.py replays them)
 
 
 def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, relu=False, reverse_taps=False):
@@ -34,6 +35,8 @@ def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, re
     B, cin, H, W = x.shape
     if FLOP_COUNTER is not None:
         FLOP_COUNTER[0] += 2 * B * H * W * cout * 9 * cin
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.append((B, cin, H, W, cout, bool(reverse_taps)))
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
     _lib.check(_lib.load().ud_conv3x3_nhwc_bf16(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin,
