@@ -52,15 +52,15 @@ def _fp32_mode(x):
 
 
 def _fp32_kernel_pays(conv, x):
-    """fp32 mode: MIOpen's assembly implicit-GEMM kernels already run at ~105 TFLOP/s (two thirds of the fp32
-    matrix peak) on the large regular shapes and ours at 90-113 (tools/time_conv2d_f32.py), so the hand-written
-    fp32 kernels are used where they measured faster: mid-size maps (the 90 x 90 trunk level: 1.6x), very wide
-    or very narrow channel counts (head first convs, depth net: 1.06-1.9x); "all" forces them everywhere."""
+    """fp32 mode.  3x3: the straight-line tap kernel with per-launch tile heights measures 103-124 TFLOP/s against
+    MIOpen's 48-108 on every shape of the step but two small ResNet maps where the two are within 3 % (tools/
+    time_conv2d_f32.py), so all stride-1 3x3 convolutions run on it.  1x1: where ours measured faster -- channel counts the
+    library pads (head / depth net) and the wide stage-1 maps; "all" forces the hand-written kernels everywhere."""
     if Conv2d.hip_fp32 == "all":
         return True
     px = x.shape[2] * x.shape[3]
     if conv.kernel_size == (3, 3):
-        return (4000 <= px <= 12000 and conv.in_channels >= 128) or conv.out_channels >= 512 or conv.in_channels >= 512
+        return True
     return conv.out_channels % 64 != 0 or (conv.in_channels <= 64 and px * x.shape[0] >= 65536)
 
 
