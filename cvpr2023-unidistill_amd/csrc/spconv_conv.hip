@@ -145,7 +145,10 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
                                                       float* __restrict__ out, int cout, int Mout,
                                                       const int32_t* __restrict__ order,
                                                       ConvEpilogue ep) {
-  constexpr int LDA = CIN_P + 4;
+  // +8 floats per row: row stride = 8 (mod 64) banks, so the 16 lanes a ds_read_b128 serves together -- rows {0-3, 12-15}
+  // of one 16-byte column and rows {4-11} of the next -- land on 16 distinct 16-byte slots (with +4, rows 11 and 12 of
+  // neighbouring columns shared a slot: SQ_LDS_BANK_CONFLICT was 40 % of the LDS cycles)
+  constexpr int LDA = CIN_P + 8;
   constexpr int NT = COUT_P / 16;
   constexpr int A4 = kTM2 * (CIN_P / 4) / 512;                  // float4 per thread for the A tile
   constexpr int B4 = (COUT_P * (CIN_P / 4) + 511) / 512;        // float4 per thread for the B tile
@@ -1356,7 +1359,7 @@ template <int CIN_P, int COUT_P>
 int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirror, const float* W,
                    WStrides ws, const float* bias, float* out, int cout, int Mout,
                    const int32_t* order, ConvEpilogue ep, hipStream_t stream) {
-  const size_t lds = (size_t)(kTM2 + COUT_P) * (CIN_P + 4) * sizeof(float) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
+  const size_t lds = (size_t)(kTM2 + COUT_P) * (CIN_P + 8) * sizeof(float) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P>,
