@@ -12,8 +12,10 @@ def _cl(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
+# the last three shapes make the per-launch tile-height choice pick 6-row tiles, 8-row tiles and the 8-row narrow tile
 @pytest.mark.parametrize("shape", [(2, 64, 128, 20, 36), (1, 256, 128, 45, 45), (3, 32, 64, 9, 17),
-                                   (1, 128, 76, 33, 40), (2, 512, 64, 24, 24), (1, 64, 2688, 16, 16)])
+                                   (1, 128, 76, 33, 40), (2, 512, 64, 24, 24), (1, 64, 2688, 16, 16),
+                                   (1, 128, 128, 180, 180), (16, 64, 128, 8, 256), (16, 64, 64, 8, 256)])
 def test_conv3x3_f32_forward_and_dgrad(hip_lib, shape):
     from unidistill_amd.ops import conv2d_f32 as c
     B, cin, cout, H, W = shape

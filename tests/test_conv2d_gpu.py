@@ -15,8 +15,12 @@ def _mk(B, Cin, H, W, Cout, seed):
     return x, w, b
 
 
+# the last three shapes make the per-launch tile-height choice (csrc/conv2d.hip: ceil(WGs / 256) x (rows + 1)) pick 6-row
+# tiles (180 x 180), 8-row tiles (256 full-width workgroups) and the 8-row 64-channel-wide tile; the small maps run the
+# 4-row variants
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [(1, 64, 8, 16, 64), (2, 64, 19, 21, 128), (1, 128, 30, 37, 192),
-                                            (2, 256, 9, 5, 64), (1, 128, 180, 180, 128)])
+                                            (2, 256, 9, 5, 64), (1, 128, 180, 180, 128), (16, 64, 8, 256, 128),
+                                            (16, 64, 8, 256, 64)])
 def test_conv3x3_forward_backward(hip_lib, B, Cin, H, W, Cout):
     from unidistill_amd.ops import conv2d as c2
     x, w, b = _mk(B, Cin, H, W, Cout, Cin + Cout + H)
