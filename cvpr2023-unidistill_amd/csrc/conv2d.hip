@@ -684,6 +684,145 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned sho
         if (n < gm.Cout) partial[(((size_t)blockIdx.x * gm.Cout + n) * 9 + tap) * gm.Cin + c] = acc[tap][ti][r];
       }
 }
+// Straight-line version of k_conv3x3_wgrad_dma (same tiling, LDS layout, staging and summation order -> same bits).  SQ
+// counters on that kernel: 6.1 VALU + 1.4 scalar instructions per MFMA (the 26 swizzled fragment addresses of every
+// 32-pixel step and the ten DMA source addresses of every tile rebuilt from scratch), MFMA busy 33 %.  Here
+//   * a dy fragment address is  sd[ti] + 4096 ks (+ 512 for the upper half): the swizzle f(p) uses bits 1 and 3 of the pixel
+//     index, which the 32-pixel step does not touch;
+//   * an x fragment of halo row L + C (L = the lane's row, C = 36 ks + 18 dy + dx (+ 4)) is  sx[C & 15] + 128 C: sixteen
+//     registers cover every (step, tap), the shift goes into the ds_read offset field;
+//   * a DMA source is (tile base: scalar) + (per-lane offset computed once) under four range compares.
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_taps(const unsigned short* __restrict__ x,
+                                                               const unsigned short* __restrict__ dy,
+                                                               float* __restrict__ partial, ConvGeom gm,
+                                                               int c_tiles, int tiles_per_slice) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kXBytes = kHQP * kKC * 2, kDBytes = kTM * kKC * 2, kDOff = 2 * kXBytes;
+  constexpr int kXPer = (kAInstr + 3) / 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int r8 = lane >> 3, slot = lane & 7;
+  const int ct = blockIdx.y % c_tiles, nt = blockIdx.y / c_tiles;
+  const int n0 = nt * 64, c0 = ct * 64;
+  const int per_img = gm.tiles_x * gm.tiles_y, ntiles = gm.B * per_img;
+  const int t_begin = blockIdx.x * tiles_per_slice, t_end = min(ntiles, t_begin + tiles_per_slice);
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
+
+  // DMA pieces of this wave: halo pixel (qy, qx) / tile pixel (py, px) and the element offset from the tile's first pixel
+  int xqy[kXPer], xqx[kXPer], xoff[kXPer], dpy[4], dpx[4], doff[4];
+#pragma unroll
+  for (int i = 0; i < kXPer; ++i) {
+    const int q = (wave + 4 * i) * 8 + r8, qy = q / kHW;
+    xqx[i] = q - qy * kHW;
+    xoff[i] = ((qy - 1) * gm.W + (xqx[i] - 1)) * gm.Cin + c0 + ((slot ^ wg_fsw(q)) << 3);
+    xqy[i] = q < kHQ ? qy : 1 << 20;               // rows past the halo: never valid
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = (wave + 4 * j) * 8 + r8;
+    const int n = n0 + ((slot ^ wg_fsw(p)) << 3);
+    dpy[j] = n < gm.Cout ? p >> 4 : 1 << 20;      // channel pieces past Cout: never valid
+    dpx[j] = p & 15;
+    doff[j] = ((p >> 4) * gm.W + (p & 15)) * gm.Cout + n;
+  }
+  auto stage = [&](int tile, int buf) {
+    const int b = tile / per_img;
+    const int rem = tile - b * per_img;
+    const int ty0 = (rem / gm.tiles_x) * kTH, tx0 = (rem % gm.tiles_x) * kTW;
+    const size_t pix0 = (size_t)(b * gm.H + ty0) * gm.W + tx0;
+    const unsigned short* xb = x + pix0 * gm.Cin;
+    const unsigned short* db = dy + pix0 * gm.Cout;
+#pragma unroll
+    for (int i = 0; i < kXPer; ++i) {
+      if (wave + 4 * i >= kAInstr) continue;
+      const int gy = ty0 + xqy[i] - 1, gx = tx0 + xqx[i] - 1;
+      const unsigned short* src = (gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W) ? xb + xoff[i] : zero;
+      dma16(src, reinterpret_cast<unsigned short*>(smem + buf * kXBytes + (wave + 4 * i) * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned short* src = (ty0 + dpy[j] < gm.H && tx0 + dpx[j] < gm.W) ? db + doff[j] : zero;
+      dma16(src, reinterpret_cast<unsigned short*>(smem + kDOff + buf * kDBytes + (wave + 4 * j) * 1024));
+    }
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses (LDS bytes) of buffer 0
+  const int sub = (li & 3) >> 1, half = (li & 1) << 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned sd[4], sx[16];
+  {
+    const int p0 = 8 * g + (li >> 2);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) sd[ti] = lds0 + kDOff + 2 * (p0 * kKC + (((2 * ti + sub) ^ wg_fsw(p0)) << 3) + half);
+    const int L = (g >> 1) * kHW + 8 * (g & 1) + (li >> 2);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sx[c] = lds0 + 2 * (L * kKC + (((2 * wave + sub) ^ wg_fsw(L + c)) << 3) + half);
+  }
+
+  if (t_begin < t_end) stage(t_begin, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    if (tile + 1 < t_end) stage(tile + 1, buf ^ 1);
+#pragma unroll
+    for (int ks = 0; ks < kTM / 32; ++ks) {
+      v4s al[4], ah[4], bl[9], bh[9];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(al[ti]) : "v"(sd[ti]), "n"(ks * 4096));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ah[ti]) : "v"(sd[ti]), "n"(ks * 4096 + 512));
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int C0 = 2 * ks * kHW + (tap / 3) * kHW + tap % 3, C1 = C0 + 4;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bl[tap]) : "v"(sx[C0 & 15]), "n"(C0 * 128));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bh[tap]) : "v"(sx[C1 & 15]), "n"(C1 * 128));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]));
+      asm volatile("" : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]),
+                        "+v"(bh[3]), "+v"(bl[4]), "+v"(bh[4]));
+      asm volatile("" : "+v"(bl[5]), "+v"(bh[5]), "+v"(bl[6]), "+v"(bh[6]), "+v"(bl[7]), "+v"(bh[7]), "+v"(bl[8]),
+                        "+v"(bh[8]));
+      bf16x8 a[4];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) a[ti] = cat8(al[ti], ah[ti]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bf16x8 bb = cat8(bl[tap], bh[tap]);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          acc[tap][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[tap][ti], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    // the other buffer: toggle the 20 base addresses
+    const int dxb = buf ? -kXBytes : kXBytes, ddb = buf ? -kDBytes : kDBytes;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) sd[ti] += ddb;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sx[c] += dxb;
+    buf ^= 1;
+  }
+  // partial[slice][n][tap][c]; D layout: lane holds column c = li, rows n = 4g + r
+  const int c = c0 + 16 * wave + li;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * ti + 4 * g + r;
+        if (n < gm.Cout) partial[(((size_t)blockIdx.x * gm.Cout + n) * 9 + tap) * gm.Cin + c] = acc[tap][ti][r];
+      }
+}
 constexpr size_t kWgradDmaLds = 2 * ((size_t)kHQP + kTM) * kKC * 2;
 
 // pixel-tile slices of the DMA kernel: <= 2 workgroups per CU over (slices x 64x64 output tiles)
@@ -1053,14 +1192,23 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     int per;
     const int S = wgrad_dma_slices(B, H, W, Cin, Cout, &per);
     static bool set_dma = false;
+    static bool generic = false;     // UD_CONV_GENERIC=1: the runtime-address kernel (A/B timing only)
     if (!set_dma) {
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kWgradDmaLds));
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_taps, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kWgradDmaLds));
+      const char* e = getenv("UD_CONV_GENERIC");
+      generic = e && e[0] == '1';
       set_dma = true;
     }
     UdProfScope prof("conv2d.k_wgrad_dma", stream);
-    k_conv3x3_wgrad_dma<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
-        (const unsigned short*)x, (const unsigned short*)dy, partial, gd, Cin / 64, per);
+    if (generic)
+      k_conv3x3_wgrad_dma<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
+          (const unsigned short*)x, (const unsigned short*)dy, partial, gd, Cin / 64, per);
+    else
+      k_conv3x3_wgrad_taps<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
+          (const unsigned short*)x, (const unsigned short*)dy, partial, gd, Cin / 64, per);
     UD_LAUNCH_CHECK();
     k_wgrad_sum<<<ud_div_up((long long)(n / 4), 64), 256, 0, stream>>>(partial, S, n, dw);
     UD_LAUNCH_CHECK();
