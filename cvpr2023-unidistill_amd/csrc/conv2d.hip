@@ -424,6 +424,104 @@ __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __re
   conv_store_tile<TN, 3, RW, TM>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
 }
 
+// ---- plain 1x1 (no pixel map): straight-line slice loop -------------------------------------------------------------------
+// k_conv3x3_bf16<TN, 1> rebuilds every DMA source through PixMap::off and every fragment address per 64-channel slice; for
+// the unmapped 1x1 convolutions (the ResNet bottleneck convs: most 1x1 launches of the step) everything is affine in the
+// slice index: pointers advance by 128 B per slice, fragment addresses are two registers per operand plus immediates, the
+// slice loop is unrolled by two so the double-buffer index is an immediate as well.  Tile = 128 consecutive pixels; rows past
+// the last pixel re-read pixel P - 1 and channels past Cout re-read channel Cout - 1 (neither is stored).
+template <int TN>
+__global__ __launch_bounds__(256) void k_conv1x1_line(const unsigned short* __restrict__ x,
+                                                      const unsigned short* __restrict__ w,
+                                                      unsigned short* __restrict__ y, ConvGeom gm, ConvEp ep) {
+  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM, NB = TN / 32;
+  constexpr int kABytes = kTM * 128, kBBytes = TN * 128, kBOff = 2 * kABytes;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
+  const int ntiles = gm.tiles_y;
+  const int per = (ntiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int n0 = blockIdx.y * TN;
+
+  f32x4 acc[RW][4];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int r8 = lane >> 3, slot = lane & 7;
+  const unsigned short* pa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 4 * i) * 8 + r8;
+    long long p = (long long)tile * kTM + r;
+    if (p >= gm.npix) p = gm.npix - 1;
+    pa[i] = x + (size_t)p * gm.Cin + ((slot ^ (r & 7)) << 3);
+  }
+  const unsigned short* pb[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave + 4 * j) * 8 + r8;
+    pb[j] = w + (size_t)min(n0 + n, gm.Cout - 1) * gm.Cin + ((slot ^ (n & 7)) << 3);
+  }
+  auto stage = [&](int buf) {      // next 64-channel slice of both operands
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(pa[i], reinterpret_cast<unsigned short*>(smem + buf * kABytes + (wave + 4 * i) * 1024));
+      pa[i] += kKC;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      dma16(pb[j], reinterpret_cast<unsigned short*>(smem + kBOff + buf * kBBytes + (wave + 4 * j) * 1024));
+      pb[j] += kKC;
+    }
+  };
+  unsigned sa[2], sb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    sa[ks] = (RW * wm * 16 + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+    sb[ks] = kBOff + (64 * wn + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+  }
+  auto mma = [&](int buf) {
+    bf16x8 a[2][RW], bb[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int ti = 0; ti < RW; ++ti)
+        a[ks][ti] = *reinterpret_cast<const bf16x8*>(smem + sa[ks] + buf * kABytes + ti * 2048);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+        bb[ks][tj] = *reinterpret_cast<const bf16x8*>(smem + sb[ks] + buf * kBBytes + tj * 2048);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < RW; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][ti], bb[ks][tj], acc[ti][tj], 0, 0, 0);
+  };
+
+  const int nchunks = gm.Cin / kKC;
+  stage(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    if (chunk + 1 < nchunks) stage(1);
+    mma(0);
+    __syncthreads();
+    if (chunk + 1 < nchunks) {
+      if (chunk + 2 < nchunks) stage(0);
+      mma(1);
+      __syncthreads();
+    }
+  }
+  conv_store_tile<TN, 1, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep);
+}
+
 // ---- weight gradient -----------------------------------------------------------------------------
 //   dW[n][tap][c] = sum_p dy[p][n] * x[p + tap][c]           (p over all B*H*W output pixels)
 // A GEMM whose reduction index is the pixel, i.e. both operands are K-STRIDED in their channels-last
@@ -1138,10 +1236,24 @@ static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Ci
   const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
   const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
   unsigned short* ys = reinterpret_cast<unsigned short*>(y);
-  if (Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256)
+  const bool narrow = Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256;
+  static const bool generic = getenv("UD_CONV_GENERIC") && getenv("UD_CONV_GENERIC")[0] == '1';   // A/B timing only
+  if (imap.mode == 0 && omap.mode == 0 && !generic) {
+    static bool line_set = false;
+    if (!line_set) {
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_line<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)conv_smem_bytes(128, 1)));
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)conv_smem_bytes(64, 1)));
+      line_set = true;
+    }
+    if (narrow) k_conv1x1_line<64><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64, 1), stream>>>(xs, ws, ys, gm, ep);
+    else k_conv1x1_line<128><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128, 1), stream>>>(xs, ws, ys, gm, ep);
+  } else if (narrow) {
     k_conv3x3_bf16<64, 1><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64, 1), stream>>>(xs, ws, ys, gm, ep);
-  else
+  } else {
     k_conv3x3_bf16<128, 1><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128, 1), stream>>>(xs, ws, ys, gm, ep);
+  }
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
