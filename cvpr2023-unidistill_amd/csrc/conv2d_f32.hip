@@ -320,6 +320,95 @@ constexpr size_t conv_taps_smem_bytes_f(int tn, int rw) {
   return operands > out ? operands : out;
 }
 
+// Plain 1x1 twin of k_conv_f32_taps: everything is affine in the 32-channel slice index (see k_conv1x1_line in conv2d.hip).
+template <int TN>
+__global__ __launch_bounds__(256) void k_conv1x1_f32_line(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
+  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM, NB = TN / 32;
+  constexpr int kABytes = kTM * 128, kBBytes = TN * 128, kBOff = 2 * kABytes;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
+  const int ntiles = gm.tiles_y;
+  const int per = (ntiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int n0 = blockIdx.y * TN;
+
+  f32x4 acc[RW][4];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int r8 = lane >> 3, slot = lane & 7;
+  const float* pa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 4 * i) * 8 + r8;
+    long long p = (long long)tile * kTM + r;
+    if (p >= gm.npix) p = gm.npix - 1;            // rows past the last pixel re-read it (never stored)
+    pa[i] = x + (size_t)p * gm.Cin + ((slot ^ (r & 7)) << 2);
+  }
+  const float* pb[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave + 4 * j) * 8 + r8;
+    pb[j] = w + (size_t)min(n0 + n, gm.Cout - 1) * gm.Cin + ((slot ^ (n & 7)) << 2);
+  }
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(pa[i], reinterpret_cast<float*>(smem + buf * kABytes + (wave + 4 * i) * 1024));
+      pa[i] += kKC;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      dma16(pb[j], reinterpret_cast<float*>(smem + kBOff + buf * kBBytes + (wave + 4 * j) * 1024));
+      pb[j] += kKC;
+    }
+  };
+  unsigned sa[2], sb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    sa[ks] = (RW * wm * 16 + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+    sb[ks] = kBOff + (64 * wn + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+  }
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 a[RW];
+#pragma unroll
+      for (int ti = 0; ti < RW; ++ti) a[ti] = *reinterpret_cast<const f32x4*>(smem + sa[ks] + buf * kABytes + ti * 2048);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(smem + sb[ks] + buf * kBBytes + tj * 2048);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ti = 0; ti < RW; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti][e], bb[e], acc[ti][tj], 0, 0, 0);
+      }
+    }
+  };
+  const int nchunks = gm.Cin / kKC;
+  stage(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    if (chunk + 1 < nchunks) stage(1);
+    mma(0);
+    __syncthreads();
+    if (chunk + 1 < nchunks) {
+      if (chunk + 2 < nchunks) stage(0);
+      mma(1);
+      __syncthreads();
+    }
+  }
+  store_tile_f32<TN, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep);
+}
+
 template <int KS>
 int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, const ConvEpF& ep, int ntiles,
                const char* name, hipStream_t stream) {
@@ -375,6 +464,22 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
         if (rw == 2) UD_TAPS_LAUNCH(128, 2); else if (rw == 3) UD_TAPS_LAUNCH(128, 3); else UD_TAPS_LAUNCH(128, 4);
       }
 #undef UD_TAPS_LAUNCH
+      UD_LAUNCH_CHECK();
+      return UD_OK;
+    }
+  }
+  if constexpr (KS == 1) {
+    if (!generic) {
+      static bool line_set = false;
+      if (!line_set) {
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)conv_smem_bytes_f(128, 1)));
+        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)conv_smem_bytes_f(64, 1)));
+        line_set = true;
+      }
+      if (narrow) k_conv1x1_f32_line<64><<<grid, 256, conv_smem_bytes_f(64, 1), stream>>>(x, w, y, gm, ep);
+      else k_conv1x1_f32_line<128><<<grid, 256, conv_smem_bytes_f(128, 1), stream>>>(x, w, y, gm, ep);
       UD_LAUNCH_CHECK();
       return UD_OK;
     }
