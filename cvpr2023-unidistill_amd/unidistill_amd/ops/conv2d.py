@@ -182,8 +182,10 @@ def _w1x1_t(weight):
                        w.view(w.shape[0], w.shape[1]).t()))
 
 
-HIP_1X1_MIN_PIXELS = 1025      # per image: maps at least this large run the hand-written 1x1 kernel (forward
-                               # and data gradient); smaller ones the library GEMM (tools/time_conv1x1.py)
+HIP_1X1_MIN_PIXELS = 1         # per image: maps at least this large run the hand-written 1x1 kernel (forward and data
+                               # gradient).  With the straight-line slice loop it is within 3 us of the library GEMM on the
+                               # 8 x 22 / 16 x 44 maps and ahead everywhere else (tools/time_conv1x1.py), so every 1x1 runs
+                               # on it; the GEMM / library branches below only serve channel counts the kernel rejects
 
 
 def _launch1x1(x, w2d, cout, bias=None, scale=None, shift=None, residual=None, relu=False):
