@@ -337,12 +337,13 @@ def timed_steps(trainer, batch, args, world, device):
 
 PRECISION_NOTE = {
     None: "fp32 everywhere (the reference's arithmetic): hand-written HIP for voxelize / sparse convs (fp32 MFMA) / "
-          "lift-splat / target assignment / losses / BatchNorm+ReLU chains / head tail (grouped fp32 kernels) and the "
-          "fp32 MFMA 3x3 / 1x1 convolutions where they beat the library; remaining dense convolutions and all dense "
-          "weight gradients through MIOpen fp32",
+          "lift-splat / target assignment / losses / BatchNorm+ReLU chains / head tail (grouped fp32 kernels), every "
+          "stride-1 3x3 convolution (forward + data gradient) and the 1x1 convolutions where ours beats the library on "
+          "fp32 MFMA kernels; strided / transposed / remaining 1x1 convolutions and all dense weight gradients through "
+          "MIOpen fp32",
     torch.bfloat16: "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the sparse convs "
-                    "(HIP MFMA kernels incl. 1x1 convs and all 3x3 / 1x1 weight gradients; libraries for strided / "
-                    "transposed convs and small-map 1x1 GEMMs); fp32 voxelize/splat/losses; fp32 master weights",
+                    "(HIP MFMA kernels for every convolution of the step -- 3x3, 1x1, strided, transposed: forward, data "
+                    "and weight gradients -- except the frozen 7x7 stem); fp32 voxelize/splat/losses; fp32 master weights",
 }
 
 
