@@ -1,20 +1,25 @@
-// Dense 3x3 / stride 1 / pad 1 convolution on channels-last bf16 tensors: the BEV trunk + head convs
-// of the reference (BaseBEVBackbone, unidistill/layers/blocks_2d/det3d/base_bev_backbone.py:30-110;
-// CenterHead.shared_conv, unidistill/layers/head/det3d/center_head.py:408-420) as a hand-written
-// implicit GEMM on v_mfma_f32_16x16x32_bf16.
+// Dense convolutions on channels-last bf16 tensors as hand-written implicit GEMMs on v_mfma_f32_16x16x32_bf16: the BEV
+// trunk + head convs of the reference (BaseBEVBackbone, unidistill/layers/blocks_2d/det3d/base_bev_backbone.py:30-110;
+// CenterHead.shared_conv, unidistill/layers/head/det3d/center_head.py:408-420), the fusion conv and the ResNet / neck convs
+// (unidistill/layers/blocks_2d/mmdet3d/lss_fpn.py:143-149).
 //
 //   y[b,oy,ox,n] = epilogue( sum_{tap,c} x[b, oy+ty-1, ox+tx-1, c] * w[n, tap, c] )
 //
-// One workgroup (4 waves, each a 64 x 64 sub-tile) owns 8 x 16 output pixels x 128 output channels.
-// Per 64-channel slice of Cin the 10 x 18 input halo is staged ONCE in LDS and serves all nine
-// taps (the gather a library implicit GEMM repeats per tap).  Halo and weight slices travel
-// HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write -- the register
-// staged version spent 31 % of its time in the weight ds_writes); both are double-buffered, the next
-// (tap, slice) weight tile flies while the current one is multiplied: one barrier per 32 MFMAs per
-// wave.  Tiles are unpadded 128-byte rows whose 16-byte slots are XOR-swizzled with the row index on
-// the source address, which keeps every ds_read_b128 fragment load conflict-free; the fp32 result tile is
-// staged through LDS so that bias / folded BatchNorm / residual / ReLU are applied on, and stored as,
-// 16-byte channel pieces.  The data gradient is the same kernel on the flipped, transposed weights.
+// Kernels in this file
+//   k_conv3x3_taps<TN, RW>   3x3 / stride 1 / pad 1, forward and (on transposed weights, taps reversed) data gradient
+//   k_conv1x1_line<TN>       plain 1x1 (pixels as a [P][Cin] matrix)
+//   k_conv1x1_mapped<TN>     1x1 over a PixMap: k = s / stride s, transposed k = s / stride s, 1x1 / stride s, 3x3 / stride 2
+//   k_conv3x3_wgrad_taps, k_conv3x3_wgrad<CT>, k_conv1x1_wgrad_dma<NT, CT>, k_wgrad_sum   weight gradients
+// Common design: one workgroup (4 waves, each a (16 RW) x 64 sub-tile) owns a tile of output pixels x TN output channels.
+// For the 3x3 kernel the (2 RW + 2) x 18 input halo of a 64-channel slice of Cin is staged ONCE in LDS and serves all nine
+// taps (the gather a library implicit GEMM repeats per tap).  Halo and weight slices travel HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write -- the register staged version spent 31 % of its time in the
+// weight ds_writes); both are double-buffered, the next (tap, slice) weight tile flies while the current one is
+// multiplied: one barrier per 32 MFMAs per wave.  Tiles are unpadded 128-byte rows whose 16-byte slots are XOR-swizzled
+// with the row index on the SOURCE address, which keeps every ds_read_b128 fragment load conflict-free; the fp32 result
+// tile is staged through LDS so that bias / folded BatchNorm / residual / ReLU are applied on, and stored as, 16-byte
+// channel pieces.  Loops are straight line: every per-tap / per-slice address is a register computed once plus an
+// instruction immediate (see k_conv3x3_taps for the counters that motivated it).
 #include "ud_common.h"
 #include "ud_prof.h"
 
@@ -88,9 +93,9 @@ struct ConvEp {
   int reverse_taps;   // weights are addressed with tap 8 - t (data gradient on un-flipped weights)
 };
 
-// LDS: two halo slices, two weight slices; the fp32 output tile reuses the space after the K loop.
-constexpr size_t conv_smem_bytes(int tn, int ks = 3) {
-  const size_t operands = 2 * (size_t)(ks == 3 ? kHQP : kTM) * kKC * 2 + 2 * (size_t)tn * kKC * 2;
+// LDS of the 1x1 kernels: two pixel-tile slices, two weight slices; the fp32 output tile reuses the space after the K loop.
+constexpr size_t conv_smem_bytes(int tn) {
+  const size_t operands = 2 * (size_t)kTM * kKC * 2 + 2 * (size_t)tn * kKC * 2;
   const size_t out = (size_t)kTM * (tn + 4) * 4;
   return operands > out ? operands : out;
 }
@@ -166,37 +171,32 @@ __device__ __forceinline__ void conv_store_tile(const f32x4 (&acc)[RW][4], float
   }
 }
 
-// TN = output channels per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64; layers
-// with Cout <= 64 -- the head's shared conv, the data gradient of the packed first head convs -- would
-// waste half of a 128-wide tile).
-// KS = 3 (pad 1) or 1 (no halo: the staged tile is the 8 x 16 pixel tile itself, one "tap").
-template <int TN, int KS>
-__global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __restrict__ x,
-                                                      const unsigned short* __restrict__ w,
-                                                      unsigned short* __restrict__ y, ConvGeom gm,
-                                                      ConvEp ep) {
+// ---- 1x1 over a pixel map (PixMap: strided / transposed / im2col launches) ------------------------------------------------
+// TN = output channels per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64).  The staged tile is the
+// 128-pixel tile itself ([P/16][16] view of the virtual pixel matrix), one 64-channel slice of the virtual K' per step, both
+// operands double-buffered through LDS-DMA; every source address goes through PixMap::off (out-of-tensor pixels read a
+// zero page).  The unmapped launches use k_conv1x1_line below.
+template <int TN>
+__global__ __launch_bounds__(256) void k_conv1x1_mapped(const unsigned short* __restrict__ x,
+                                                        const unsigned short* __restrict__ w,
+                                                        unsigned short* __restrict__ y, ConvGeom gm,
+                                                        ConvEp ep) {
   constexpr int kTN = TN, kBInstr = TN / 8;
   constexpr int WM = TN == 128 ? 2 : 4;          // waves along the pixel dimension
-  constexpr int kTaps = KS * KS, kPad = KS / 2;
-  constexpr int kHW = kTW + 2 * kPad, kHQ = kHW * (kTH + 2 * kPad);   // staged pixels: 18 x 10 or 16 x 8
-  constexpr int kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
-  constexpr int RW = 8 / WM;                     // image rows (of 16 pixels) per wave: 4 or 2
+  constexpr int kAInstr = kTM / 8;               // 1-KiB pieces of a pixel-tile slice
+  constexpr int RW = 8 / WM;                     // rows (of 16 pixels) per wave: 4 or 2
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned short* As = reinterpret_cast<unsigned short*>(smem);          // [2][kHQP][64]
-  unsigned short* Bs = As + 2 * kHQP * kKC;                                // [2][kTN][64]
-  float* Os = reinterpret_cast<float*>(smem);                              // [kTM][kLDO] after the K loop
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);          // [2][kTM][64]
+  unsigned short* Bs = As + 2 * kTM * kKC;                                 // [2][kTN][64]
+  float* Os = reinterpret_cast<float*>(smem);                              // [kTM][kTN + 4] after the K loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
-  // XCD-aware tile order: the 8 XCDs (workgroups are dealt round-robin) each walk a contiguous band
-  // of tiles, so halo rows shared by neighbouring tiles meet in the same L2.
-  const int ntiles = gm.B * gm.tiles_x * gm.tiles_y;
+  const int ntiles = gm.tiles_y;
   const int per = (ntiles + 7) / 8;
-  int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);     // XCD-aware tile order
   if (tile >= ntiles) return;
-  const int b = tile / (gm.tiles_x * gm.tiles_y);
-  tile -= b * gm.tiles_x * gm.tiles_y;
-  const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
+  const int ty0 = tile * kTH;
   const int n0 = blockIdx.y * kTN;
   const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
 
@@ -210,26 +210,23 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
   auto stage_a = [&](int chunk, int buf) {
     for (int piece = wave; piece < kAInstr; piece += 4) {
       const int q = piece * 8 + r8;
-      const int qy = q / kHW, qx = q - qy * kHW;
-      const int gy = ty0 + qy - kPad, gx = tx0 + qx - kPad;
-      const long long pix = (long long)(b * gm.H + gy) * gm.W + gx;
+      const long long pix = (long long)ty0 * kTW + q;
       const unsigned short* src = zero;
-      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && pix < gm.npix) {
-        const int k = chunk * kKC + ((slot ^ (q & 7)) << 3);
-        const size_t o = KS == 1 ? gm.imap.off(pix, k, gm.Cin) : (size_t)pix * gm.Cin + k;
+      if (pix < gm.npix) {
+        const size_t o = gm.imap.off(pix, chunk * kKC + ((slot ^ (q & 7)) << 3), gm.Cin);
         if (o != kNoPixel) src = x + o;
       }
-      dma16(src, As + (buf * kHQP + piece * 8) * kKC);
+      dma16(src, As + (buf * kTM + piece * 8) * kKC);
     }
   };
-  auto stage_b = [&](int chunk, int tap, int buf) {
+  auto stage_b = [&](int chunk, int buf) {
 #pragma unroll
     for (int j = 0; j < kBInstr / 4; ++j) {
       const int piece = wave + 4 * j;
       const int n = piece * 8 + r8;
       const unsigned short* src = zero;
       if (n0 + n < gm.Cout) {
-        if (KS == 1 && gm.imap.mode == 4) {
+        if (gm.imap.mode == 4) {
           // parity-class data gradient: the weights stay in their [C][3][3][N] (tap-major, transposed) layout; slice
           // k = (jy, jx, n) of the class is tap (ty, tx) of that tensor: even coordinate -> 1, odd -> 0 then 2
           const int kk = chunk * kKC + ((slot ^ (n & 7)) << 3);
@@ -238,55 +235,51 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const unsigned short* __re
           const int ty = gm.imap.a ? 2 * jy : 1, tx = gm.imap.b ? 2 * jx : 1;
           src = w + ((size_t)(n0 + n) * 9 + ty * 3 + tx) * gm.imap.C + nn;
         } else {
-          src = w + ((size_t)(n0 + n) * kTaps + (ep.reverse_taps ? kTaps - 1 - tap : tap)) * gm.Cin + chunk * kKC +
-                ((slot ^ (n & 7)) << 3);
+          src = w + (size_t)(n0 + n) * gm.Cin + chunk * kKC + ((slot ^ (n & 7)) << 3);
         }
       }
       dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
     }
   };
 
-  const int nchunks = gm.Cin / kKC, total = nchunks * kTaps;
+  const int nchunks = gm.Cin / kKC;
   stage_a(0, 0);
-  stage_b(0, 0, 0);
+  stage_b(0, 0);
   __syncthreads();                 // drains the DMAs (vmcnt(0)) and publishes the tiles
-  for (int it = 0; it < total; ++it) {
-    const int chunk = it / kTaps, tap = it - chunk * kTaps;
-    // next weight slice (and, at the start of a slice, the next halo) fly while this one is multiplied
-    if (it + 1 < total)
-      stage_b(tap == kTaps - 1 ? chunk + 1 : chunk, tap == kTaps - 1 ? 0 : tap + 1, (it + 1) & 1);
-    if (tap == 0 && chunk + 1 < nchunks) stage_a(chunk + 1, (chunk + 1) & 1);
-    {
-      const unsigned short* bbuf = Bs + (it & 1) * kTN * kKC;
-      const unsigned short* abuf = As + (chunk & 1) * kHQP * kKC;
-      const int q0 = (RW * wm + tap / KS) * kHW + li + tap % KS;  // halo pixel of row tile 0 for this lane
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) {     // the next slice flies while this one is multiplied
+      stage_b(chunk + 1, (chunk + 1) & 1);
+      stage_a(chunk + 1, (chunk + 1) & 1);
+    }
+    const unsigned short* bbuf = Bs + (chunk & 1) * kTN * kKC;
+    const unsigned short* abuf = As + (chunk & 1) * kTM * kKC;
+    const int q0 = RW * wm * kTW + li;
 #pragma unroll
-      for (int ks = 0; ks < kKC / 32; ++ks) {
-        const int cg = 4 * ks + g;                              // logical 16-byte channel group
-        bf16x8 a[RW];
+    for (int ks = 0; ks < kKC / 32; ++ks) {
+      const int cg = 4 * ks + g;                              // logical 16-byte channel group
+      bf16x8 a[RW];
 #pragma unroll
-        for (int ti = 0; ti < RW; ++ti) {
-          const int q = q0 + ti * kHW;
-          a[ti] = *reinterpret_cast<const bf16x8*>(abuf + q * kKC + ((cg ^ (q & 7)) << 3));
-        }
+      for (int ti = 0; ti < RW; ++ti) {
+        const int q = q0 + ti * kTW;
+        a[ti] = *reinterpret_cast<const bf16x8*>(abuf + q * kKC + ((cg ^ (q & 7)) << 3));
+      }
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-          const int n = 64 * wn + 16 * tj + li;
-          const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bbuf + n * kKC + ((cg ^ (n & 7)) << 3));
+      for (int tj = 0; tj < 4; ++tj) {
+        const int n = 64 * wn + 16 * tj + li;
+        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bbuf + n * kKC + ((cg ^ (n & 7)) << 3));
 #pragma unroll
-          for (int ti = 0; ti < RW; ++ti)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
-        }
+        for (int ti = 0; ti < RW; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  conv_store_tile<TN, KS, RW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+  conv_store_tile<TN, 1, RW>(acc, Os, tid, wm, wn, g, li, 0, ty0, 0, n0, y, gm, ep);
 }
 
 // ---- 3x3 forward / data gradient: straight-line tap loop --------------------------------------------------------------
-// Same tiling, LDS layout and DMA staging as k_conv3x3_bf16<TN, 3>, but the nine taps of a 64-channel slice are unrolled so
-// that every per-tap quantity is an instruction immediate.  SQ counters on the generic kernel (tools/pmc_conv.sh, 128 -> 128
+// The nine taps of a 64-channel slice are unrolled so that every per-tap quantity is an instruction immediate.  SQ counters
+// on the round-1 kernel, which looped over (slice, tap) at run time (tools/pmc_kernel.sh, 128 -> 128
 // @180 x 180 x 4): per (tap, slice) a wave issued 32 MFMAs next to 123 other VALU and 93 scalar instructions -- 64-bit
 // multiply-adds and exec-masked branches rebuilding the four weight-piece addresses, the 16 swizzled fragment addresses and
 // the (slice, tap) split of the loop counter -- and MFMA busy was 23 % of the SIMD cycles.  Here
@@ -425,7 +418,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __re
 }
 
 // ---- plain 1x1 (no pixel map): straight-line slice loop -------------------------------------------------------------------
-// k_conv3x3_bf16<TN, 1> rebuilds every DMA source through PixMap::off and every fragment address per 64-channel slice; for
+// k_conv1x1_mapped rebuilds every DMA source through PixMap::off and every fragment address per 64-channel slice; for
 // the unmapped 1x1 convolutions (the ResNet bottleneck convs: most 1x1 launches of the step) everything is affine in the
 // slice index: pointers advance by 128 B per slice, fragment addresses are two registers per operand plus immediates, the
 // slice loop is unrolled by two so the double-buffer index is an immediate as well.  Tile = 128 consecutive pixels; rows past
@@ -678,113 +671,9 @@ __device__ __forceinline__ bf16x8 cat8(v4s lo, v4s hi) {
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned short* __restrict__ x,
-                                                              const unsigned short* __restrict__ dy,
-                                                              float* __restrict__ partial, ConvGeom gm,
-                                                              int c_tiles, int tiles_per_slice) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned short* Xs = reinterpret_cast<unsigned short*>(smem);        // [2][kHQP][64]  x halo
-  unsigned short* Ds = Xs + 2 * kHQP * kKC;                              // [2][kTM][64]   dy tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, li = lane & 15;
-  const int r8 = lane >> 3, slot = lane & 7;
-  const int ct = blockIdx.y % c_tiles, nt = blockIdx.y / c_tiles;
-  const int n0 = nt * 64, c0 = ct * 64;
-  const int per_img = gm.tiles_x * gm.tiles_y, ntiles = gm.B * per_img;
-  const int t_begin = blockIdx.x * tiles_per_slice, t_end = min(ntiles, t_begin + tiles_per_slice);
-  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
-
-  auto stage = [&](int tile, int buf) {
-    const int b = tile / per_img;
-    const int rem = tile - b * per_img;
-    const int ty0 = (rem / gm.tiles_x) * kTH, tx0 = (rem % gm.tiles_x) * kTW;
-    for (int piece = wave; piece < kAInstr; piece += 4) {
-      const int q = piece * 8 + r8;
-      const int qy = q / kHW, qx = q - qy * kHW;
-      const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
-      const unsigned short* src = zero;
-      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W)
-        src = x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + c0 + ((slot ^ wg_fsw(q)) << 3);
-      dma16(src, Xs + (buf * kHQP + piece * 8) * kKC);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int piece = wave + 4 * j;
-      const int p = piece * 8 + r8;
-      const int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
-      const int n = n0 + ((slot ^ wg_fsw(p)) << 3);
-      const unsigned short* src = zero;
-      if (gy < gm.H && gx < gm.W && n < gm.Cout) src = dy + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
-      dma16(src, Ds + (buf * kTM + piece * 8) * kKC);
-    }
-  };
-
-  f32x4 acc[9][4];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (t_begin < t_end) stage(t_begin, 0);
-  __syncthreads();
-  int buf = 0;
-  const int sub = (li & 3) >> 1, half = (li & 1) << 2;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    if (tile + 1 < t_end) stage(tile + 1, buf ^ 1);
-    const unsigned xb = lds0 + buf * (kHQP * kKC * 2);
-    const unsigned db = lds0 + (2 * kHQP + buf * kTM) * (kKC * 2);
-#pragma unroll 1
-    for (int ks = 0; ks < kTM / 32; ++ks) {
-      const int p0 = 32 * ks + 8 * g + (li >> 2), p1 = p0 + 4;
-      v4s al[4], ah[4], bl[9], bh[9];
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        al[ti] = tr_issue(db + 2 * (p0 * kKC + (((2 * ti + sub) ^ wg_fsw(p0)) << 3) + half));
-        ah[ti] = tr_issue(db + 2 * (p1 * kKC + (((2 * ti + sub) ^ wg_fsw(p1)) << 3) + half));
-      }
-      const int qb = (2 * ks + (g >> 1)) * kHW + 8 * (g & 1) + (li >> 2);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int q0 = qb + (tap / 3) * kHW + tap % 3, q1 = q0 + 4;
-        bl[tap] = tr_issue(xb + 2 * (q0 * kKC + (((2 * wave + sub) ^ wg_fsw(q0)) << 3) + half));
-        bh[tap] = tr_issue(xb + 2 * (q1 * kKC + (((2 * wave + sub) ^ wg_fsw(q1)) << 3) + half));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]));
-      asm volatile("" : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]),
-                        "+v"(bh[3]), "+v"(bl[4]), "+v"(bh[4]));
-      asm volatile("" : "+v"(bl[5]), "+v"(bh[5]), "+v"(bl[6]), "+v"(bh[6]), "+v"(bl[7]), "+v"(bh[7]), "+v"(bl[8]),
-                        "+v"(bh[8]));
-      bf16x8 a[4];
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) a[ti] = cat8(al[ti], ah[ti]);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const bf16x8 bb = cat8(bl[tap], bh[tap]);
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-          acc[tap][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[tap][ti], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    buf ^= 1;
-  }
-  // partial[slice][n][tap][c]; D layout: lane holds column c = li, rows n = 4g + r
-  const int c = c0 + 16 * wave + li;
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 16 * ti + 4 * g + r;
-        if (n < gm.Cout) partial[(((size_t)blockIdx.x * gm.Cout + n) * 9 + tap) * gm.Cin + c] = acc[tap][ti][r];
-      }
-}
-// Straight-line version of k_conv3x3_wgrad_dma (same tiling, LDS layout, staging and summation order -> same bits).  SQ
-// counters on that kernel: 6.1 VALU + 1.4 scalar instructions per MFMA (the 26 swizzled fragment addresses of every
-// 32-pixel step and the ten DMA source addresses of every tile rebuilt from scratch), MFMA busy 33 %.  Here
+// Straight-line addressing.  SQ counters on the first version of this kernel, which rebuilt the 26 swizzled fragment
+// addresses of every 32-pixel step and the ten DMA source addresses of every tile from scratch: 6.1 VALU + 1.4 scalar
+// instructions per MFMA, MFMA busy 33 %.  Here
 //   * a dy fragment address is  sd[ti] + 4096 ks (+ 512 for the upper half): the swizzle f(p) uses bits 1 and 3 of the pixel
 //     index, which the 32-pixel step does not touch;
 //   * an x fragment of halo row L + C (L = the lane's row, C = 36 ks + 18 dy + dx (+ 4)) is  sx[C & 15] + 128 C: sixteen
@@ -1137,21 +1026,14 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W, PixMap{}, PixMap{}};
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
   static bool attr_set = false;
-  static bool generic = false;     // UD_CONV_GENERIC=1: the runtime-tap kernel (A/B timing only)
-  static int force_rw = 0;         // UD_CONV_RW=n: pixel rows per wave (A/B timing only)
+  static int force_rw = 0;         // UD_CONV_RW=n: pixel rows per wave (timing experiments only)
   if (!attr_set) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes(128)));
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes(64)));
 #define UD_TAPS_ATTR(TN, RW)                                                                                          \
   UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps<TN, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                  (int)conv_taps_smem_bytes(TN, RW)))
     UD_TAPS_ATTR(128, 4); UD_TAPS_ATTR(128, 3); UD_TAPS_ATTR(128, 2);
     UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
 #undef UD_TAPS_ATTR
-    const char* e = getenv("UD_CONV_GENERIC");
-    generic = e && e[0] == '1';
     if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
     attr_set = true;
   }
@@ -1162,13 +1044,6 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
   // 64-wide output tiles when Cout <= 64, and on small maps where 128-wide tiles would leave CUs idle
   const bool narrow = Cout <= 64 || B * gm.tiles_x * gm.tiles_y * ud_div_up(Cout, 128) <= 256;
   const int ntn = ud_div_up(Cout, narrow ? 64 : 128);
-  if (generic) {
-    const dim3 grid((B * gm.tiles_x * gm.tiles_y + 7) / 8 * 8, ntn);
-    if (narrow) k_conv3x3_bf16<64, 3><<<grid, 256, conv_smem_bytes(64), stream>>>(xs, ws, ys, gm, ep);
-    else k_conv3x3_bf16<128, 3><<<grid, 256, conv_smem_bytes(128), stream>>>(xs, ws, ys, gm, ep);
-    UD_LAUNCH_CHECK();
-    return UD_OK;
-  }
   // Pixel rows per wave (tile height = waves x rows).  A CU works through ceil(workgroups / 256) tiles, two at a time
   // sharing its MFMA pipes, so a launch takes about ceil(WGs / 256) x (rows + 1) -- the +1 is what a tile costs whatever
   // its height (prologue, first DMA round trip, epilogue: ~10 k of the 28 k cycles of an 8-row tile at Cin = 128).  Checked
@@ -1224,10 +1099,14 @@ static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Ci
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, 0};
   static bool attr_set = false;
   if (!attr_set) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes(128, 1)));
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_bf16<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes(64, 1)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(128)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(64)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_line<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(128)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes(64)));
     attr_set = true;
   }
   const int ntiles = gm.tiles_y;
@@ -1236,23 +1115,16 @@ static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Ci
   const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
   const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
   unsigned short* ys = reinterpret_cast<unsigned short*>(y);
+  // 64-wide output tiles when Cout <= 64, and on small maps where 128-wide tiles would leave CUs idle
   const bool narrow = Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256;
-  static const bool generic = getenv("UD_CONV_GENERIC") && getenv("UD_CONV_GENERIC")[0] == '1';   // A/B timing only
-  if (imap.mode == 0 && omap.mode == 0 && !generic) {
-    static bool line_set = false;
-    if (!line_set) {
-      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_line<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)conv_smem_bytes(128, 1)));
-      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)conv_smem_bytes(64, 1)));
-      line_set = true;
-    }
-    if (narrow) k_conv1x1_line<64><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64, 1), stream>>>(xs, ws, ys, gm, ep);
-    else k_conv1x1_line<128><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128, 1), stream>>>(xs, ws, ys, gm, ep);
-  } else if (narrow) {
-    k_conv3x3_bf16<64, 1><<<dim3(gx, ud_div_up(Cout, 64)), 256, conv_smem_bytes(64, 1), stream>>>(xs, ws, ys, gm, ep);
+  const dim3 grid(gx, ud_div_up(Cout, narrow ? 64 : 128));
+  const size_t lds = conv_smem_bytes(narrow ? 64 : 128);
+  if (imap.mode == 0 && omap.mode == 0) {
+    if (narrow) k_conv1x1_line<64><<<grid, 256, lds, stream>>>(xs, ws, ys, gm, ep);
+    else k_conv1x1_line<128><<<grid, 256, lds, stream>>>(xs, ws, ys, gm, ep);
   } else {
-    k_conv3x3_bf16<128, 1><<<dim3(gx, ud_div_up(Cout, 128)), 256, conv_smem_bytes(128, 1), stream>>>(xs, ws, ys, gm, ep);
+    if (narrow) k_conv1x1_mapped<64><<<grid, 256, lds, stream>>>(xs, ws, ys, gm, ep);
+    else k_conv1x1_mapped<128><<<grid, 256, lds, stream>>>(xs, ws, ys, gm, ep);
   }
   UD_LAUNCH_CHECK();
   return UD_OK;
@@ -1304,23 +1176,14 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     int per;
     const int S = wgrad_dma_slices(B, H, W, Cin, Cout, &per);
     static bool set_dma = false;
-    static bool generic = false;     // UD_CONV_GENERIC=1: the runtime-address kernel (A/B timing only)
     if (!set_dma) {
-      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kWgradDmaLds));
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_taps, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kWgradDmaLds));
-      const char* e = getenv("UD_CONV_GENERIC");
-      generic = e && e[0] == '1';
       set_dma = true;
     }
     UdProfScope prof("conv2d.k_wgrad_dma", stream);
-    if (generic)
-      k_conv3x3_wgrad_dma<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
-          (const unsigned short*)x, (const unsigned short*)dy, partial, gd, Cin / 64, per);
-    else
-      k_conv3x3_wgrad_taps<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
-          (const unsigned short*)x, (const unsigned short*)dy, partial, gd, Cin / 64, per);
+    k_conv3x3_wgrad_taps<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
+        (const unsigned short*)x, (const unsigned short*)dy, partial, gd, Cin / 64, per);
     UD_LAUNCH_CHECK();
     k_wgrad_sum<<<ud_div_up((long long)(n / 4), 64), 256, 0, stream>>>(partial, S, n, dw);
     UD_LAUNCH_CHECK();

@@ -38,9 +38,9 @@ struct ConvEpF {
   int reverse_taps;
 };
 
-constexpr size_t conv_smem_bytes_f(int tn, int ks) {
-  const size_t hq = ks == 3 ? ((kTW + 2) * (kTH + 2) + 7) / 8 * 8 : kTM;
-  const size_t operands = 2 * hq * 128 + 2 * (size_t)tn * 128;
+// LDS of the 1x1 kernel: two pixel-tile slices, two weight slices; the output tile reuses the space after the K loop
+constexpr size_t conv_smem_bytes_f(int tn) {
+  const size_t operands = 2 * (size_t)kTM * 128 + 2 * (size_t)tn * 128;
   const size_t out = (size_t)kTM * (tn + 4) * 4;
   return operands > out ? operands : out;
 }
@@ -94,106 +94,9 @@ __device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float*
   }
 }
 
-template <int TN, int KS>
-__global__ __launch_bounds__(256) void k_conv_f32(const float* __restrict__ x, const float* __restrict__ w,
-                                                  float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
-  constexpr int kTN = TN, kBInstr = TN / 8;
-  constexpr int WM = TN == 128 ? 2 : 4;
-  constexpr int kTaps = KS * KS, kPad = KS / 2;
-  constexpr int kHW = kTW + 2 * kPad, kHQ = kHW * (kTH + 2 * kPad);
-  constexpr int kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
-  constexpr int RW = 8 / WM;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);            // [2][kHQP][32]
-  float* Bs = As + 2 * kHQP * kKC;                        // [2][kTN][32]
-  float* Os = reinterpret_cast<float*>(smem);            // [kTM][kLDO] after the K loop
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, li = lane & 15;
-  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
-  const int ntiles = gm.B * gm.tiles_x * gm.tiles_y;
-  const int per = (ntiles + 7) / 8;
-  int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);     // XCD-aware: each XCD walks a contiguous band
-  if (tile >= ntiles) return;
-  const int b = tile / (gm.tiles_x * gm.tiles_y);
-  tile -= b * gm.tiles_x * gm.tiles_y;
-  const int ty0 = (tile / gm.tiles_x) * kTH, tx0 = (tile % gm.tiles_x) * kTW;
-  const int n0 = blockIdx.y * kTN;
-  const float* zero = reinterpret_cast<const float*>(g_zero16f);
-
-  f32x4 acc[RW][4];
-#pragma unroll
-  for (int i = 0; i < RW; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int r8 = lane >> 3, slot = lane & 7;
-  auto stage_a = [&](int chunk, int buf) {
-    for (int piece = wave; piece < kAInstr; piece += 4) {
-      const int q = piece * 8 + r8;
-      const int qy = q / kHW, qx = q - qy * kHW;
-      const int gy = ty0 + qy - kPad, gx = tx0 + qx - kPad;
-      const long long pix = (long long)(b * gm.H + gy) * gm.W + gx;
-      const float* src = zero;
-      if (q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && pix < gm.npix)
-        src = x + (size_t)pix * gm.Cin + chunk * kKC + ((slot ^ (q & 7)) << 2);
-      dma16(src, As + (buf * kHQP + piece * 8) * kKC);
-    }
-  };
-  auto stage_b = [&](int chunk, int tap, int buf) {
-#pragma unroll
-    for (int j = 0; j < kBInstr / 4; ++j) {
-      const int piece = wave + 4 * j;
-      const int n = piece * 8 + r8;
-      const float* src = zero;
-      if (n0 + n < gm.Cout)
-        src = w + ((size_t)(n0 + n) * kTaps + (ep.reverse_taps ? kTaps - 1 - tap : tap)) * gm.Cin + chunk * kKC +
-              ((slot ^ (n & 7)) << 2);
-      dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
-    }
-  };
-
-  const int nchunks = gm.Cin / kKC, total = nchunks * kTaps;
-  stage_a(0, 0);
-  stage_b(0, 0, 0);
-  __syncthreads();
-  for (int it = 0; it < total; ++it) {
-    const int chunk = it / kTaps, tap = it - chunk * kTaps;
-    if (it + 1 < total)
-      stage_b(tap == kTaps - 1 ? chunk + 1 : chunk, tap == kTaps - 1 ? 0 : tap + 1, (it + 1) & 1);
-    if (tap == 0 && chunk + 1 < nchunks) stage_a(chunk + 1, (chunk + 1) & 1);
-    {
-      const float* bbuf = Bs + (it & 1) * kTN * kKC;
-      const float* abuf = As + (chunk & 1) * kHQP * kKC;
-      const int q0 = (RW * wm + tap / KS) * kHW + li + tap % KS;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int cg = 4 * ks + g;                              // 16-byte channel group (4 fp32) of the slice
-        f32x4 a[RW];
-#pragma unroll
-        for (int ti = 0; ti < RW; ++ti) {
-          const int q = q0 + ti * kHW;
-          a[ti] = *reinterpret_cast<const f32x4*>(abuf + q * kKC + ((cg ^ (q & 7)) << 2));
-        }
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-          const int n = 64 * wn + 16 * tj + li;
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(bbuf + n * kKC + ((cg ^ (n & 7)) << 2));
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int ti = 0; ti < RW; ++ti)
-              acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti][e], bb[e], acc[ti][tj], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  store_tile_f32<TN, RW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
-}
-
-// 3x3 only: the nine taps of a 32-channel slice unrolled so that every per-tap quantity is an instruction immediate (see
-// k_conv3x3_taps in conv2d.hip, whose SQ counters motivated it: the runtime-tap loop spends ~220 address / control
-// instructions per (tap, slice) next to the MFMAs).  Same tiling, LDS layout and results as k_conv_f32<TN, 3>.
+// 3x3: the nine taps of a 32-channel slice unrolled so that every per-tap quantity is an instruction immediate (see
+// k_conv3x3_taps in conv2d.hip, whose SQ counters motivated it: a runtime (slice, tap) loop spends ~220 address / control
+// instructions per (tap, slice) next to the MFMAs).
 template <int TN, int RW>
 __global__ __launch_bounds__(256) void k_conv_f32_taps(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
@@ -412,82 +315,64 @@ __global__ __launch_bounds__(256) void k_conv1x1_f32_line(const float* __restric
 template <int KS>
 int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, const ConvEpF& ep, int ntiles,
                const char* name, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32<128, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes_f(128, KS)));
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32<64, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)conv_smem_bytes_f(64, KS)));
-    attr_set = true;
-  }
-  const int gx = (ntiles + 7) / 8 * 8;
   UdProfScope prof(name, stream);
   static const int force64 = getenv("UD_F32_TN64") ? atoi(getenv("UD_F32_TN64")) : 0;
-  static const bool generic = getenv("UD_CONV_GENERIC") && getenv("UD_CONV_GENERIC")[0] == '1';   // A/B timing only
   const bool narrow = force64 || gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256;
-  const dim3 grid(gx, ud_div_up(gm.Cout, narrow ? 64 : 128));
-  if constexpr (KS == 3) {
-    if (!generic) {
-      static bool taps_set = false;
-      static int force_rw = 0;     // UD_CONV_RW=n: pixel rows per wave (A/B timing only)
-      if (!taps_set) {
+  const int ntn = ud_div_up(gm.Cout, narrow ? 64 : 128);
+  if constexpr (KS == 1) {
+    static bool line_set = false;
+    if (!line_set) {
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)conv_smem_bytes_f(128)));
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)conv_smem_bytes_f(64)));
+      line_set = true;
+    }
+    const dim3 grid((ntiles + 7) / 8 * 8, ntn);
+    if (narrow) k_conv1x1_f32_line<64><<<grid, 256, conv_smem_bytes_f(64), stream>>>(x, w, y, gm, ep);
+    else k_conv1x1_f32_line<128><<<grid, 256, conv_smem_bytes_f(128), stream>>>(x, w, y, gm, ep);
+    UD_LAUNCH_CHECK();
+    return UD_OK;
+  } else {
+    static bool taps_set = false;
+    static int force_rw = 0;     // UD_CONV_RW=n: pixel rows per wave (timing experiments only)
+    if (!taps_set) {
 #define UD_TAPS_ATTR(TN, RW)                                                                                          \
   UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32_taps<TN, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                  (int)conv_taps_smem_bytes_f(TN, RW)))
-        UD_TAPS_ATTR(128, 4); UD_TAPS_ATTR(128, 3); UD_TAPS_ATTR(128, 2); UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
+      UD_TAPS_ATTR(128, 4); UD_TAPS_ATTR(128, 3); UD_TAPS_ATTR(128, 2); UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
 #undef UD_TAPS_ATTR
-        if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
-        taps_set = true;
+      if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
+      taps_set = true;
+    }
+    // Tile height = waves x rows per wave.  A CU works through ceil(workgroups / 256) tiles (two at a time, sharing its
+    // MFMA pipes: with a 32-cycle fp32 MFMA a tap is MFMA-bound whatever the height), so the launch takes about
+    // ceil(WGs / 256) x rows: 180 x 180 x 4 at 8 rows = 1 104 tiles -> 5 x 4, at 6 rows 1 440 -> 6 x 3 (measured 104 -> 110
+    // TFLOP/s; 256 -> 256 @90 x 90: 87 -> 113).
+    ConvGeomF g2 = gm;
+    const int wmv = narrow ? 4 : 2;
+    int rw = narrow ? 2 : 4;
+    {
+      double best = -1;
+      for (int r = narrow ? 2 : 4; r >= (narrow ? 1 : 2); --r) {
+        const long long wgs = (long long)gm.B * gm.tiles_x * ud_div_up(gm.H, wmv * r) * ntn;
+        const double cost = (double)((wgs + 255) / 256) * (r + 0.1);
+        if (best < 0 || cost < best) best = cost, rw = r;
       }
-      // Tile height = waves x rows per wave.  A CU works through ceil(workgroups / 256) tiles (two at a time, sharing its
-      // MFMA pipes: with a 32-cycle fp32 MFMA a tap is MFMA-bound whatever the height), so the launch takes about
-      // ceil(WGs / 256) x rows: 180 x 180 x 4 at 8 rows = 1 104 tiles -> 5 x 4, at 6 rows 1 440 -> 6 x 3 (measured 104 -> 110
-      // TFLOP/s; 256 -> 256 @90 x 90: 87 -> 113).
-      ConvGeomF g2 = gm;
-      const int wmv = narrow ? 4 : 2, ntn = ud_div_up(gm.Cout, narrow ? 64 : 128);
-      int rw = narrow ? 2 : 4;
-      {
-        double best = -1;
-        for (int r = narrow ? 2 : 4; r >= (narrow ? 1 : 2); --r) {
-          const long long wgs = (long long)gm.B * gm.tiles_x * ud_div_up(gm.H, wmv * r) * ntn;
-          const double cost = (double)((wgs + 255) / 256) * (r + 0.1);
-          if (best < 0 || cost < best) best = cost, rw = r;
-        }
-        if (force_rw) rw = force_rw < (narrow ? 1 : 2) ? (narrow ? 1 : 2) : force_rw > (narrow ? 2 : 4) ? (narrow ? 2 : 4) : force_rw;
-      }
-      g2.tiles_y = ud_div_up(gm.H, wmv * rw);
-      const dim3 grid2((gm.B * g2.tiles_x * g2.tiles_y + 7) / 8 * 8, ntn);
+      if (force_rw) rw = force_rw < (narrow ? 1 : 2) ? (narrow ? 1 : 2) : force_rw > (narrow ? 2 : 4) ? (narrow ? 2 : 4) : force_rw;
+    }
+    g2.tiles_y = ud_div_up(gm.H, wmv * rw);
+    const dim3 grid2((gm.B * g2.tiles_x * g2.tiles_y + 7) / 8 * 8, ntn);
 #define UD_TAPS_LAUNCH(TN, RW) k_conv_f32_taps<TN, RW><<<grid2, 256, conv_taps_smem_bytes_f(TN, RW), stream>>>(x, w, y, g2, ep)
-      if (narrow) {
-        if (rw == 1) UD_TAPS_LAUNCH(64, 1); else UD_TAPS_LAUNCH(64, 2);
-      } else {
-        if (rw == 2) UD_TAPS_LAUNCH(128, 2); else if (rw == 3) UD_TAPS_LAUNCH(128, 3); else UD_TAPS_LAUNCH(128, 4);
-      }
+    if (narrow) {
+      if (rw == 1) UD_TAPS_LAUNCH(64, 1); else UD_TAPS_LAUNCH(64, 2);
+    } else {
+      if (rw == 2) UD_TAPS_LAUNCH(128, 2); else if (rw == 3) UD_TAPS_LAUNCH(128, 3); else UD_TAPS_LAUNCH(128, 4);
+    }
 #undef UD_TAPS_LAUNCH
-      UD_LAUNCH_CHECK();
-      return UD_OK;
-    }
+    UD_LAUNCH_CHECK();
+    return UD_OK;
   }
-  if constexpr (KS == 1) {
-    if (!generic) {
-      static bool line_set = false;
-      if (!line_set) {
-        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)conv_smem_bytes_f(128, 1)));
-        UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)conv_smem_bytes_f(64, 1)));
-        line_set = true;
-      }
-      if (narrow) k_conv1x1_f32_line<64><<<grid, 256, conv_smem_bytes_f(64, 1), stream>>>(x, w, y, gm, ep);
-      else k_conv1x1_f32_line<128><<<grid, 256, conv_smem_bytes_f(128, 1), stream>>>(x, w, y, gm, ep);
-      UD_LAUNCH_CHECK();
-      return UD_OK;
-    }
-  }
-  if (narrow) k_conv_f32<64, KS><<<grid, 256, conv_smem_bytes_f(64, KS), stream>>>(x, w, y, gm, ep);
-  else k_conv_f32<128, KS><<<grid, 256, conv_smem_bytes_f(128, KS), stream>>>(x, w, y, gm, ep);
-  UD_LAUNCH_CHECK();
-  return UD_OK;
 }
 
 }  // namespace
