@@ -174,31 +174,36 @@ __device__ __forceinline__ void conv_store_tile(const f32x4 (&acc)[RW][4], float
 // ---- 1x1 over a pixel map (PixMap: strided / transposed / im2col launches) ------------------------------------------------
 // TN = output channels per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64).  The staged tile is the
 // 128-pixel tile itself ([P/16][16] view of the virtual pixel matrix), one 64-channel slice of the virtual K' per step, both
-// operands double-buffered through LDS-DMA; every source address goes through PixMap::off (out-of-tensor pixels read a
-// zero page).  The unmapped launches use k_conv1x1_line below.
+// operands double-buffered through LDS-DMA.  For every map the source of (pixel p, slice k0) is
+//     x + base(p) + koff(k0)      valid iff  0 <= py(p) + dy(k0) < H  and  0 <= px(p) + dx(k0) < W   (else the zero page)
+// with base / py / px per lane (computed once) and koff / dy / dx uniform over the workgroup (advanced incrementally per
+// slice: no division in the loop):
+//   mode 1 (space to depth)   base = pixel (s oy, s ox);            koff = row * W C + r      (k0 = row * s C + r); always valid
+//   mode 2 (subsample)        base = pixel (s oy + a, s ox + b);    koff = k0;                                       always valid
+//   mode 3 (3x3 im2col)       base = pixel (s oy, s ox), py / px = its coordinates;  koff = ((ty-1) W + (tx-1)) C + c
+//   mode 4 (parity class)     base = pixel (i, j), py / px = (i, j);  koff = (a (1-jy) W + b (1-jx)) C + c
+// Fragment addresses are registers computed once plus immediates (slice loop unrolled by two: the buffer index is an
+// immediate).  The unmapped launches use k_conv1x1_line below.
 template <int TN>
 __global__ __launch_bounds__(256) void k_conv1x1_mapped(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ w,
                                                         unsigned short* __restrict__ y, ConvGeom gm,
                                                         ConvEp ep) {
-  constexpr int kTN = TN, kBInstr = TN / 8;
-  constexpr int WM = TN == 128 ? 2 : 4;          // waves along the pixel dimension
-  constexpr int kAInstr = kTM / 8;               // 1-KiB pieces of a pixel-tile slice
-  constexpr int RW = 8 / WM;                     // rows (of 16 pixels) per wave: 4 or 2
+  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM, NB = TN / 32;
+  constexpr int kABytes = kTM * 128, kBBytes = TN * 128, kBOff = 2 * kABytes;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned short* As = reinterpret_cast<unsigned short*>(smem);          // [2][kTM][64]
-  unsigned short* Bs = As + 2 * kTM * kKC;                                 // [2][kTN][64]
-  float* Os = reinterpret_cast<float*>(smem);                              // [kTM][kTN + 4] after the K loop
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
   const int ntiles = gm.tiles_y;
   const int per = (ntiles + 7) / 8;
   const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);     // XCD-aware tile order
   if (tile >= ntiles) return;
-  const int ty0 = tile * kTH;
-  const int n0 = blockIdx.y * kTN;
+  const int n0 = blockIdx.y * TN;
   const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
+  const PixMap& im = gm.imap;
+  const int mode = im.mode;
 
   f32x4 acc[RW][4];
 #pragma unroll
@@ -206,75 +211,111 @@ __global__ __launch_bounds__(256) void k_conv1x1_mapped(const unsigned short* __
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int r8 = lane >> 3, slot = lane & 7;      // this lane's row / 16-byte slot inside a 1 KiB piece
-  auto stage_a = [&](int chunk, int buf) {
-    for (int piece = wave; piece < kAInstr; piece += 4) {
-      const int q = piece * 8 + r8;
-      const long long pix = (long long)ty0 * kTW + q;
-      const unsigned short* src = zero;
-      if (pix < gm.npix) {
-        const size_t o = gm.imap.off(pix, chunk * kKC + ((slot ^ (q & 7)) << 3), gm.Cin);
-        if (o != kNoPixel) src = x + o;
-      }
-      dma16(src, As + (buf * kTM + piece * 8) * kKC);
-    }
-  };
-  auto stage_b = [&](int chunk, int buf) {
+  const int r8 = lane >> 3, slot = lane & 7;
+  const unsigned short* pa[4];
+  int py[4], px[4];
 #pragma unroll
-    for (int j = 0; j < kBInstr / 4; ++j) {
-      const int piece = wave + 4 * j;
-      const int n = piece * 8 + r8;
-      const unsigned short* src = zero;
-      if (n0 + n < gm.Cout) {
-        if (gm.imap.mode == 4) {
-          // parity-class data gradient: the weights stay in their [C][3][3][N] (tap-major, transposed) layout; slice
-          // k = (jy, jx, n) of the class is tap (ty, tx) of that tensor: even coordinate -> 1, odd -> 0 then 2
-          const int kk = chunk * kKC + ((slot ^ (n & 7)) << 3);
-          const int tapi = kk / gm.imap.C, nn = kk - tapi * gm.imap.C, nx = 1 + gm.imap.b;
-          const int jy = tapi / nx, jx = tapi - jy * nx;
-          const int ty = gm.imap.a ? 2 * jy : 1, tx = gm.imap.b ? 2 * jx : 1;
-          src = w + ((size_t)(n0 + n) * 9 + ty * 3 + tx) * gm.imap.C + nn;
-        } else {
-          src = w + (size_t)(n0 + n) * gm.Cin + chunk * kKC + ((slot ^ (n & 7)) << 3);
-        }
-      }
-      dma16(src, Bs + (buf * kTN + piece * 8) * kKC);
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 4 * i) * 8 + r8;
+    long long p = (long long)tile * kTM + r;
+    if (p >= gm.npix) p = gm.npix - 1;           // rows past the last pixel re-read it (never stored)
+    py[i] = px[i] = 0;
+    if (mode == 0) {                             // plain input, mapped output (transposed convolution)
+      pa[i] = x + (size_t)p * gm.Cin + ((slot ^ (r & 7)) << 3);
+      continue;
     }
+    const int ox = (int)(p % im.Wo);
+    const long long t = p / im.Wo;
+    const int oy = (int)(t % im.Ho), b = (int)(t / im.Ho);
+    int y0, x0;
+    if (mode == 4) { y0 = oy; x0 = ox; }
+    else if (mode == 2) { y0 = im.s * oy + im.a; x0 = im.s * ox + im.b; }
+    else { y0 = im.s * oy; x0 = im.s * ox; }
+    pa[i] = x + ((size_t)(b * im.H + y0) * im.W + x0) * im.C + ((slot ^ (r & 7)) << 3);
+    if (mode >= 3) { py[i] = y0; px[i] = x0; }
+  }
+  const unsigned short* pb[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave + 4 * j) * 8 + r8;
+    const size_t row = (size_t)min(n0 + n, gm.Cout - 1);     // channels past Cout re-read the last one (never stored)
+    pb[j] = w + (mode == 4 ? row * 9 * im.C : row * gm.Cin) + ((slot ^ (n & 7)) << 3);
+  }
+  // slice state: (seg, c) = (row of the s x s block | tap | class tap, channel offset inside it)
+  const int seg_len = mode == 1 ? im.s * im.C : (mode >= 3 ? im.C : gm.Cin);
+  int seg = 0, c = 0;
+  auto stage = [&](int buf) {
+    long long koff;
+    int dy = 0, dx = 0, wk;
+    if (mode == 1) {
+      koff = (long long)seg * im.W * im.C + c;
+      wk = seg * seg_len + c;
+    } else if (mode == 3) {
+      const int ty = seg / 3, tx = seg - 3 * ty;
+      dy = ty - 1; dx = tx - 1;
+      koff = ((long long)dy * im.W + dx) * im.C + c;
+      wk = seg * seg_len + c;
+    } else if (mode == 4) {
+      const int nx = 1 + im.b, jy = seg / nx, jx = seg - jy * nx;
+      dy = im.a * (1 - jy); dx = im.b * (1 - jx);
+      koff = ((long long)dy * im.W + dx) * im.C + c;
+      const int ty = im.a ? 2 * jy : 1, tx = im.b ? 2 * jx : 1;    // even coordinate -> tap 1, odd -> 0 then 2
+      wk = (ty * 3 + tx) * im.C + c;
+    } else {
+      koff = c;
+      wk = c;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = mode < 3 || ((unsigned)(py[i] + dy) < (unsigned)im.H && (unsigned)(px[i] + dx) < (unsigned)im.W);
+      dma16(ok ? pa[i] + koff : zero, reinterpret_cast<unsigned short*>(smem + buf * kABytes + (wave + 4 * i) * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      dma16(pb[j] + wk, reinterpret_cast<unsigned short*>(smem + kBOff + buf * kBBytes + (wave + 4 * j) * 1024));
+    c += kKC;
+    if (c == seg_len) { c = 0; ++seg; }
+  };
+  unsigned sa[2], sb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    sa[ks] = (RW * wm * 16 + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+    sb[ks] = kBOff + (64 * wn + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+  }
+  auto mma = [&](int buf) {
+    bf16x8 a[2][RW], bb[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int ti = 0; ti < RW; ++ti)
+        a[ks][ti] = *reinterpret_cast<const bf16x8*>(smem + sa[ks] + buf * kABytes + ti * 2048);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+        bb[ks][tj] = *reinterpret_cast<const bf16x8*>(smem + sb[ks] + buf * kBBytes + tj * 2048);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < RW; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][ti], bb[ks][tj], acc[ti][tj], 0, 0, 0);
   };
 
   const int nchunks = gm.Cin / kKC;
-  stage_a(0, 0);
-  stage_b(0, 0);
+  stage(0);
   __syncthreads();                 // drains the DMAs (vmcnt(0)) and publishes the tiles
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    if (chunk + 1 < nchunks) {     // the next slice flies while this one is multiplied
-      stage_b(chunk + 1, (chunk + 1) & 1);
-      stage_a(chunk + 1, (chunk + 1) & 1);
-    }
-    const unsigned short* bbuf = Bs + (chunk & 1) * kTN * kKC;
-    const unsigned short* abuf = As + (chunk & 1) * kTM * kKC;
-    const int q0 = RW * wm * kTW + li;
-#pragma unroll
-    for (int ks = 0; ks < kKC / 32; ++ks) {
-      const int cg = 4 * ks + g;                              // logical 16-byte channel group
-      bf16x8 a[RW];
-#pragma unroll
-      for (int ti = 0; ti < RW; ++ti) {
-        const int q = q0 + ti * kTW;
-        a[ti] = *reinterpret_cast<const bf16x8*>(abuf + q * kKC + ((cg ^ (q & 7)) << 3));
-      }
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) {
-        const int n = 64 * wn + 16 * tj + li;
-        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(bbuf + n * kKC + ((cg ^ (n & 7)) << 3));
-#pragma unroll
-        for (int ti = 0; ti < RW; ++ti)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ti], bb, acc[ti][tj], 0, 0, 0);
-      }
-    }
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    if (chunk + 1 < nchunks) stage(1);
+    mma(0);
     __syncthreads();
+    if (chunk + 1 < nchunks) {
+      if (chunk + 2 < nchunks) stage(0);
+      mma(1);
+      __syncthreads();
+    }
   }
-  conv_store_tile<TN, 1, RW>(acc, Os, tid, wm, wn, g, li, 0, ty0, 0, n0, y, gm, ep);
+  conv_store_tile<TN, 1, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep);
 }
 
 // ---- 3x3 forward / data gradient: straight-line tap loop --------------------------------------------------------------
