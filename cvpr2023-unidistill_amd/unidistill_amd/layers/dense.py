@@ -54,14 +54,15 @@ def _fp32_mode(x):
 def _fp32_kernel_pays(conv, x):
     """fp32 mode.  3x3: the straight-line tap kernel with per-launch tile heights measures 103-124 TFLOP/s against
     MIOpen's 48-108 on every shape of the step but two small ResNet maps where the two are within 3 % (tools/
-    time_conv2d_f32.py), so all stride-1 3x3 convolutions run on it.  1x1: where ours measured faster -- channel counts the
-    library pads (head / depth net) and the wide stage-1 maps; "all" forces the hand-written kernels everywhere."""
+    time_conv2d_f32.py), so all stride-1 3x3 convolutions run on it.  1x1: channel counts the library pads (head / depth
+    net: 2.1x) and every map of at least 1 k pixels (forward + data gradient of a layer together: 0.93-1.07x of the library,
+    94.6 vs 94.9 ms per step); the 16 x 44 / 8 x 22 ResNet maps stay on the library (0.9x); "all" forces ours everywhere."""
     if Conv2d.hip_fp32 == "all":
         return True
     px = x.shape[2] * x.shape[3]
     if conv.kernel_size == (3, 3):
         return True
-    return conv.out_channels % 64 != 0 or (conv.in_channels <= 64 and px * x.shape[0] >= 65536)
+    return conv.out_channels % 64 != 0 or px >= 1024
 
 
 class Conv2d(nn.Conv2d):
