@@ -115,6 +115,10 @@ class Conv2d(nn.Conv2d):
         if (Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x) and x.dtype == torch.bfloat16
                 and self._hip_1x1(x) and torch.is_grad_enabled() and x.requires_grad):
             return hipconv.conv1x1_skip(x, self.weight, self.bias)
+        if (Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x) and _is1x1(self)
+                and hipconv32.supported(x, self.weight, 1) and self.weight.shape[0] % 32 == 0
+                and _fp32_kernel_pays(self, x) and torch.is_grad_enabled() and x.requires_grad):
+            return hipconv32.conv1x1_skip(x, self.weight, self.bias)
         return self(x), x
 
 

@@ -30,18 +30,22 @@ def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False):
     return y
 
 
-def _launch1(x, w, cout, bias=None):
+def _launch1(x, w, cout, bias=None, residual=None):
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     _lib.check(_lib.load().ud_conv1x1_nhwc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), B * H * W, cin, cout,
-                                               _lib.ptr(bias), None, None, None, 0, _lib.stream_of(x)),
+                                               _lib.ptr(bias), None, None, _lib.ptr(residual), 0, _lib.stream_of(x)),
                "ud_conv1x1_nhwc_f32")
     return y
 
 
 class _ConvF32(torch.autograd.Function):
+    """with_skip (1x1 only): the function also returns its input (an alias) for the caller's identity branch, so that the
+    gradient arriving through that branch is added in the data-gradient kernel's epilogue instead of by a separate
+    elementwise add of two full-size tensors (ResNet residual joins; same contract as ops/conv2d.py:_Conv1x1Fn)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, ks):
+    def forward(ctx, x, weight, bias, ks, with_skip=False):
         _lib.require_gpu(x, weight)
         x = _nhwc(x)
         b = None if bias is None else bias.detach().contiguous()
@@ -52,13 +56,15 @@ class _ConvF32(torch.autograd.Function):
             y = _launch1(x, w.reshape(weight.shape[0], weight.shape[1]).contiguous(), weight.shape[0], b)
         ctx.save_for_backward(x, weight)
         ctx.ks, ctx.has_bias = ks, bias is not None
-        return y
+        return (y, x) if with_skip else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, weight = ctx.saved_tensors
         ks = ctx.ks
         gy = _nhwc(gy.float())
+        if gskip is not None:
+            gskip = _nhwc(gskip.float())
         gx = gw = gb = None
         w = weight.detach()
         p = ks // 2
@@ -66,17 +72,20 @@ class _ConvF32(torch.autograd.Function):
             # the data gradient reduces over Cout: not a multiple of the kernel's 32-channel slice -> library
             gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
+            if gskip is not None:
+                gx = gx + gskip
         elif ctx.needs_input_grad[0]:
             if ks == 3:      # un-flipped transposed weights [Cin, 3, 3, Cout], taps walked in reverse
                 gx = _launch3(gy, w.permute(1, 2, 3, 0).contiguous(), weight.shape[1], reverse_taps=True)
             else:
-                gx = _launch1(gy, w.reshape(weight.shape[0], weight.shape[1]).t().contiguous(), weight.shape[1])
+                gx = _launch1(gy, w.reshape(weight.shape[0], weight.shape[1]).t().contiguous(), weight.shape[1],
+                              residual=gskip)
         if ctx.needs_input_grad[1]:
             gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
                                                      [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def conv3x3(x, weight, bias=None):
@@ -85,3 +94,8 @@ def conv3x3(x, weight, bias=None):
 
 def conv1x1(x, weight, bias=None):
     return _ConvF32.apply(x, weight, bias, 1)
+
+
+def conv1x1_skip(x, weight, bias=None):
+    """(conv1x1(x), x'): x' aliases x; a gradient arriving through x' is added inside the data-gradient kernel."""
+    return _ConvF32.apply(x, weight, bias, 1, True)

@@ -1,6 +1,7 @@
 """GPU: the fp32 MFMA convolutions (ud_conv3x3_nhwc_f32 / ud_conv1x1_nhwc_f32: forward + data gradient) against
 plain PyTorch fp32 convolutions of the same tensors.  fp32 products and accumulation on both sides, only the
 summation order differs: tolerance 2e-5 of the output's max."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -83,3 +84,28 @@ def test_fp32_trunk_routes_to_the_fp32_kernels_and_matches_library(hip_lib):
         dense.Conv2d.hip_enabled = True
         dense.Conv2d.hip_fp32 = True
     assert (y - yr).abs().max() <= 1e-4 * yr.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(10, 12), (40, 41)])
+def test_conv1x1_f32_skip_adds_identity_gradient_in_kernel(hip_lib, H, W):
+    """conv1x1_skip (fp32): the gradient of the identity branch is added in the data-gradient epilogue: same result as the
+    convolution followed by a separate residual add (ResNet bottleneck joins of the fp32 mode)."""
+    from unidistill_amd.ops import conv2d_f32 as c
+    torch.manual_seed(H + W)
+    x0 = _cl(torch.randn(2, 64, H, W, device="cuda"))
+    w0 = torch.randn(32, 64, 1, 1, device="cuda") * 0.1
+    w2 = torch.randn(64, 32, 1, 1, device="cuda") * 0.1          # second conv back to the input width: y2 + identity
+    outs = []
+    for skip in (False, True):
+        x = x0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        if skip:
+            y, idt = c.conv1x1_skip(x, w)
+        else:
+            y, idt = c.conv1x1(x, w), x
+        z = torch.nn.functional.conv2d(y, w2) + idt
+        (z * z).sum().backward()
+        outs.append((z.detach(), x.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(b.abs().max()))
