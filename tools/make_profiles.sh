@@ -14,7 +14,7 @@ DB=$(ls /tmp/p_bench/*/*.db | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo;
   echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt; echo '```'; echo;
   echo "## Roofline kernels of the bench legs (rocprofv3 durations; bench.py's own HIP-event figures are in the JSON above)"; echo;
-  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_insert|k_first|k_scan|k_assign|k_gather|k_bin|k_cell|k_fill|k_conv3x3_bf16";
+  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_insert|k_first|k_scan|k_assign|k_gather|k_bin|k_cell|k_fill|k_conv3x3_taps|k_conv1x1_line|k_conv1x1_mapped";
   echo; echo "## Kernels by total time, naive_conv / find-mode kernels excluded"; echo;
   python $T/rocpd_summary.py $DB | grep -v "naive_conv\|MIOpenConvUni\|Im2d2Col\|Col2Im" | head -45; } > $OUT/${R}_bench_kernel_stats.md
 # 2. steady-state training step by category (marker-delimited window): fp32 (headline) and bf16
