@@ -109,3 +109,30 @@ def test_conv1x1_f32_skip_adds_identity_gradient_in_kernel(hip_lib, H, W):
         outs.append((z.detach(), x.grad.clone(), w.grad.clone()))
     for a, b in zip(*outs):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+
+
+@pytest.mark.gpu
+def test_conv_f32_random_shapes_vs_library(hip_lib):
+    """Seeded random shapes through the fp32 3x3 and 1x1 kernels (forward + data gradient) against the library's fp32
+    convolutions: ragged maps, channel counts off the tile widths, every tile-height variant."""
+    from unidistill_amd.ops import conv2d_f32 as c
+    rng = np.random.default_rng(11)
+    for it in range(20):
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        cin = 32 * int(rng.integers(1, 7))
+        cout = 32 * int(rng.integers(1, 9))
+        ks = 3 if it % 3 else 1
+        torch.manual_seed(200 + it)
+        x = _cl(torch.randn(B, cin, H, W, device="cuda")).requires_grad_(True)
+        w = (torch.randn(cout, cin, ks, ks, device="cuda") * (cin * ks * ks) ** -0.5).requires_grad_(True)
+        ref = F.conv2d(x, w, None, 1, ks // 2)
+        gy = _cl(torch.randn_like(ref))
+        gx_ref, = torch.autograd.grad(ref, x, gy)
+        y = c.conv3x3(x, w) if ks == 3 else c.conv1x1(x, w)
+        gx, = torch.autograd.grad(y, x, gy)
+        tag = f"case {it}: B={B} cin={cin} H={H} W={W} cout={cout} k={ks}"
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0,
+                                   atol=3e-5 * float(ref.detach().abs().max()) + 1e-7, err_msg=tag)
+        np.testing.assert_allclose(gx.cpu().numpy(), gx_ref.cpu().numpy(), rtol=0,
+                                   atol=3e-5 * float(gx_ref.abs().max()) + 1e-7, err_msg=tag)

@@ -342,3 +342,37 @@ def test_conv3x3_stride2(hip_lib, cfg):
     _cmp(y, yr, 8e-3, "y")
     _cmp(gx, xr.grad, 2e-2, "dx")
     _cmp(gw, w.grad, 2e-2, "dw")
+
+
+@pytest.mark.gpu
+def test_conv3x3_and_1x1_random_shapes_vs_fp32(hip_lib):
+    """Seeded random shapes (ragged maps, channel counts off the tile widths, one to many slices) through the bf16 3x3 and
+    1x1 kernels, forward and data gradient, against fp32 convolutions of the same bf16-valued tensors: exercises the edge
+    tiles, the clamped rows / channels of the straight-line kernels and every tile-height variant the launcher can pick."""
+    from unidistill_amd.ops import conv2d as c2
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7)
+    for it in range(24):
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        Cin = 64 * int(rng.integers(1, 5))
+        ks = 3 if it % 3 else 1
+        # 3x3: the data gradient reduces over Cout in 64-channel slices (ops.conv2d.supported); 1x1: any multiple of 8
+        Cout = 64 * int(rng.integers(1, 6)) if ks == 3 else 8 * int(rng.integers(1, 40))
+        g = torch.Generator().manual_seed(100 + it)
+        x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+        w = (torch.randn(Cout, Cin, ks, ks, generator=g) * (Cin * ks * ks) ** -0.5).bfloat16().float()
+        xr = x.float().to(dev).requires_grad_(True)
+        wr = w.to(dev)
+        ref = F.conv2d(xr, wr, None, 1, ks // 2)
+        gy = torch.randn(ref.shape, generator=g).bfloat16().float().to(dev)
+        ref.backward(gy)
+        xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd = w.to(dev).requires_grad_(True)
+        y = c2.conv3x3(xd, wd) if ks == 3 else c2.conv1x1(xd, wd)
+        tag = f"case {it}: B={B} Cin={Cin} H={H} W={W} Cout={Cout} k={ks}"
+        np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0,
+                                   atol=8e-3 * float(ref.detach().abs().max()) + 1e-6, err_msg=tag)
+        y.backward(gy.to(torch.bfloat16))
+        np.testing.assert_allclose(xd.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=0,
+                                   atol=8e-3 * float(xr.grad.abs().max()) + 1e-6, err_msg=tag)
