@@ -147,29 +147,37 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const T* __restrict__ 
   }
 }
 
-// one wave per channel: mean / biased variance / invstd, folded scale+shift, running statistics
+// 16 channels per workgroup, 16 slice lanes per channel (a slice row of 16 channels is one 128-byte read): mean / biased
+// variance / invstd, folded scale+shift, running statistics.  Fixed summation order (deterministic); x == nullptr: the
+// partials are unshifted (they come from a convolution epilogue), else shifted by the pivot x[c].
 template <typename T>
-__global__ void k_bn_stats_final(const T* __restrict__ x, const float* __restrict__ partial,
+__global__ __launch_bounds__(256) void k_bn_stats_final(const T* __restrict__ x, const float* __restrict__ partial,
                                  int slices, long long P, int C, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float eps, float* __restrict__ mean,
                                  float* __restrict__ var, float* __restrict__ invstd,
                                  float* __restrict__ scale, float* __restrict__ shift,
                                  float* __restrict__ running_mean, float* __restrict__ running_var,
                                  float momentum, long long* __restrict__ batches_tracked) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  if (batches_tracked && c == 0 && lane == 0) *batches_tracked += 1;   // nn.BatchNorm's step counter
+  __shared__ double red[16][16][2];
+  const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  if (batches_tracked && blockIdx.x == 0 && tid == 0) *batches_tracked += 1;   // nn.BatchNorm's step counter
   double a = 0.0, q = 0.0;
-  for (int s = lane; s < slices; s += 64) {
-    a += partial[((size_t)s * C + c) * 2];
-    q += partial[((size_t)s * C + c) * 2 + 1];
+  for (int s = sl; s < slices; s += 16) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)s * C + c) * 2);
+    a += v.x;
+    q += v.y;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o);
-    q += __shfl_xor(q, o);
+  red[sl][cl][0] = a;
+  red[sl][cl][1] = q;
+  __syncthreads();
+  if (sl != 0) return;
+  a = q = 0.0;
+  for (int k = 0; k < 16; ++k) {
+    a += red[k][cl][0];
+    q += red[k][cl][1];
   }
-  if (lane != 0) return;
-  const double piv = elem_f(x[c]);
+  const double piv = x ? (double)elem_f(x[c]) : 0.0;
   const double m = a / (double)P;
   double v = q / (double)P - m * m;
   if (v < 0.0) v = 0.0;
@@ -328,7 +336,7 @@ int bn_stats_impl(const T* x, long long P, int C, const float* gamma, const floa
   else
     k_bn_stats_partial<16, T><<<dim3(slices, C / 16), 256, 0, stream>>>(x, P, C, w.partial);
   UD_LAUNCH_CHECK();
-  k_bn_stats_final<T><<<C, 64, 0, stream>>>(x, w.partial, slices, P, C, gamma, beta, eps, mean, var, invstd, scale,
+  k_bn_stats_final<T><<<C / 16, 256, 0, stream>>>(x, w.partial, slices, P, C, gamma, beta, eps, mean, var, invstd, scale,
                                             shift, running_mean, running_var, momentum, batches_tracked);
   UD_LAUNCH_CHECK();
   return UD_OK;
@@ -405,6 +413,24 @@ int ud_bn_stats_f32(const float* x, long long P, int C, const float* gamma, cons
                     size_t workspace_bytes, ud_stream_t stream) {
   return bn_stats_impl<float>(x, P, C, gamma, beta, eps, mean, var, invstd, scale, shift, running_mean, running_var,
                               momentum, batches_tracked, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Second pass of the statistics when the first one came out of a convolution epilogue (ud_conv*_bnstats_nhwc_*):
+// partial[slice][C][2] = per-tile (sum, sum of squares) of the P x C tensor, reduced in slice order (deterministic).
+int ud_bn_stats_from_partials(const float* partial, int slices, long long P, int C, const float* gamma,
+                              const float* beta, float eps, float* mean, float* var, float* invstd, float* scale,
+                              float* shift, float* running_mean, float* running_var, float momentum,
+                              long long* batches_tracked, ud_stream_t stream) {
+  if (!partial || slices <= 0 || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || P <= 0 || C <= 0 ||
+      ((running_mean == nullptr) != (running_var == nullptr)))
+    return UD_ERR_INVALID_ARG;
+  UdProfScope prof("bn_act.stats", (hipStream_t)stream);
+  if (C % 16) return UD_ERR_UNSUPPORTED;
+  k_bn_stats_final<float><<<C / 16, 256, 0, (hipStream_t)stream>>>(nullptr, partial, slices, P, C, gamma, beta, eps, mean, var,
+                                                              invstd, scale, shift, running_mean, running_var, momentum,
+                                                              batches_tracked);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
 }
 
 int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,

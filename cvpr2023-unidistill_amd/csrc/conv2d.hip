@@ -91,6 +91,7 @@ struct ConvEp {
   const unsigned short* residual;
   int relu;
   int reverse_taps;   // weights are addressed with tap 8 - t (data gradient on un-flipped weights)
+  float* stats;       // [tiles][Cout][2] per-tile (sum, sum of squares) of the stored outputs, or nullptr (BatchNorm statistics)
 };
 
 // LDS of the 1x1 kernels: two pixel-tile slices, two weight slices; the fp32 output tile reuses the space after the K loop.
@@ -121,11 +122,15 @@ __device__ __forceinline__ void dma16(const unsigned short* src, unsigned short*
 
 // Shared epilogue: accumulators -> fp32 tile in LDS (aliases the operand tiles; the K loop ended on a barrier), then
 // 16-byte channel pieces: bias, folded BN, residual, ReLU, bf16 store.
+// With ep.stats the workgroup also emits, per output channel of its tile, the sum and the sum of squares of the values it
+// stored (the bf16-rounded ones: what a separate statistics pass would read back) -- the first pass of a training-mode
+// BatchNorm that follows the convolution; ud_bn_stats_from_partials reduces the tiles in a fixed order.
 template <int TN, int KS, int RW, int TM = kTM>
 __device__ __forceinline__ void conv_store_tile(const f32x4 (&acc)[RW][4], float* Os, int tid, int wm, int wn, int g,
                                                 int li, int b, int ty0, int tx0, int n0, unsigned short* __restrict__ y,
-                                                const ConvGeom& gm, const ConvEp& ep) {
+                                                const ConvGeom& gm, const ConvEp& ep, int tile_lin = 0) {
   constexpr int kTN = TN, kLDO = TN + 4;
+  float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ti = 0; ti < RW; ++ti)
 #pragma unroll
@@ -165,9 +170,39 @@ __device__ __forceinline__ void conv_store_tile(const f32x4 (&acc)[RW][4], float
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    *reinterpret_cast<uint4*>(y + off) =
-        make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]), ud_pack_bf16x2(v[4], v[5]),
-                   ud_pack_bf16x2(v[6], v[7]));
+    const uint4 pk = make_uint4(ud_pack_bf16x2(v[0], v[1]), ud_pack_bf16x2(v[2], v[3]), ud_pack_bf16x2(v[4], v[5]),
+                                ud_pack_bf16x2(v[6], v[7]));
+    *reinterpret_cast<uint4*>(y + off) = pk;
+    if (ep.stats) {
+      const unsigned pw[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = __uint_as_float(pw[e] << 16), hi = __uint_as_float(pw[e] & 0xFFFF0000u);
+        s1[2 * e] += lo; s2[2 * e] += lo * lo;
+        s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
+      }
+    }
+  }
+  if (ep.stats) {
+    // a thread keeps ONE 8-channel piece over all its rows (256 % (TN / 8) == 0): reduce the row groups through LDS
+    constexpr int kGroups = 256 / (kTN / 8);
+    __syncthreads();                                   // every thread is done reading the output tile
+    const int grp = tid / (kTN / 8), c8 = (tid % (kTN / 8)) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      Os[(grp * kTN + c8 + e) * 2] = s1[e];
+      Os[(grp * kTN + c8 + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    if (tid < kTN && n0 + tid < gm.Cout) {
+      float a = 0.f, q = 0.f;
+      for (int k = 0; k < kGroups; ++k) {
+        a += Os[(k * kTN + tid) * 2];
+        q += Os[(k * kTN + tid) * 2 + 1];
+      }
+      ep.stats[((size_t)tile_lin * gm.Cout + n0 + tid) * 2] = a;
+      ep.stats[((size_t)tile_lin * gm.Cout + n0 + tid) * 2 + 1] = q;
+    }
   }
 }
 
@@ -315,7 +350,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_mapped(const unsigned short* __
       __syncthreads();
     }
   }
-  conv_store_tile<TN, 1, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep);
+  conv_store_tile<TN, 1, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep, tile);
 }
 
 // ---- 3x3 forward / data gradient: straight-line tap loop --------------------------------------------------------------
@@ -349,6 +384,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __re
   const int per = (ntiles + 7) / 8;
   int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
+  const int tile_lin = tile;
   const int b = tile / (gm.tiles_x * gm.tiles_y);
   tile -= b * gm.tiles_x * gm.tiles_y;
   const int ty0 = (tile / gm.tiles_x) * TH, tx0 = (tile % gm.tiles_x) * kTW;
@@ -455,7 +491,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __re
     }
     adelta = -adelta;
   }
-  conv_store_tile<TN, 3, RW, TM>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+  conv_store_tile<TN, 3, RW, TM>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep,
+                                 tile_lin);
 }
 
 // ---- plain 1x1 (no pixel map): straight-line slice loop -------------------------------------------------------------------
@@ -553,7 +590,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_line(const unsigned short* __re
       __syncthreads();
     }
   }
-  conv_store_tile<TN, 1, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep);
+  conv_store_tile<TN, 1, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep, tile);
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------
@@ -1056,16 +1093,17 @@ int wgrad_slices(int Cin, int Cout, long long P, int* ct_width) {
 
 }  // namespace
 
-extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin,
-                                    int Cout, const float* bias, const float* scale,
-                                    const float* shift, const void* residual, int relu,
-                                    ud_stream_t stream_) {
+// stats / stats_bytes / slices_out: optional per-tile BatchNorm partials (see conv_store_tile); the tile count depends on the
+// tile height picked below, so it is reported back
+static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
+                        const float* bias, const float* scale, const float* shift, const void* residual, int relu,
+                        float* stats, size_t stats_bytes, int* slices_out, ud_stream_t stream_) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (Cin % kKC != 0 || Cout % 8 != 0) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W, PixMap{}, PixMap{}};
-  ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1};
+  ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1, stats};
   static bool attr_set = false;
   static int force_rw = 0;         // UD_CONV_RW=n: pixel rows per wave (timing experiments only)
   if (!attr_set) {
@@ -1101,6 +1139,11 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
     if (force_rw) rw = force_rw < (narrow ? 1 : 2) ? (narrow ? 1 : 2) : force_rw > (narrow ? 2 : 4) ? (narrow ? 2 : 4) : force_rw;
   }
   gm.tiles_y = ud_div_up(H, wm * rw);
+  if (stats) {
+    const size_t need = (size_t)B * gm.tiles_x * gm.tiles_y * Cout * 2 * sizeof(float);
+    if (stats_bytes < need || !slices_out) return UD_ERR_WORKSPACE;
+    *slices_out = B * gm.tiles_x * gm.tiles_y;
+  }
   const dim3 grid((B * gm.tiles_x * gm.tiles_y + 7) / 8 * 8, ntn);
 #define UD_TAPS_LAUNCH(TN, RW)                                                                                        \
   k_conv3x3_taps<TN, RW><<<grid, 256, conv_taps_smem_bytes(TN, RW), stream>>>(xs, ws, ys, gm, ep)
@@ -1112,6 +1155,34 @@ extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B
 #undef UD_TAPS_LAUNCH
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+extern "C" int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin,
+                                    int Cout, const float* bias, const float* scale,
+                                    const float* shift, const void* residual, int relu,
+                                    ud_stream_t stream) {
+  return conv3x3_impl(x, w, y, B, H, W, Cin, Cout, bias, scale, shift, residual, relu, nullptr, 0, nullptr, stream);
+}
+
+// Upper bound of the partial-statistics buffer of ud_conv3x3_bnstats_nhwc_* (the smallest tile is 4 rows x 16 pixels).
+extern "C" size_t ud_conv3x3_bnstats_bytes(int B, int H, int W, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  return ud_align_up((size_t)B * ud_div_up(W, kTW) * ud_div_up(H, 4) * Cout * 2 * sizeof(float));
+}
+extern "C" size_t ud_conv1x1_bnstats_bytes(int64_t P, int Cout) {
+  if (P <= 0 || Cout <= 0) return 0;
+  return ud_align_up((size_t)((P + kTM - 1) / kTM) * Cout * 2 * sizeof(float));
+}
+
+// The convolution (+ bias) AND the first pass of the training-mode BatchNorm that follows it: partial[slice][Cout][2] =
+// per-tile (sum, sum of squares) of the stored bf16 values, *slices = number of tiles written (host int).  Finish with
+// ud_bn_stats_from_partials.
+extern "C" int ud_conv3x3_bnstats_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin,
+                                            int Cout, const float* bias, float* partial, size_t partial_bytes,
+                                            int* slices, ud_stream_t stream) {
+  if (!partial || !slices) return UD_ERR_INVALID_ARG;
+  return conv3x3_impl(x, w, y, B, H, W, Cin, Cout, bias, nullptr, nullptr, nullptr, 0, partial, partial_bytes, slices,
+                      stream);
 }
 
 static bool map_from_ints(const int* m, PixMap* out) {
@@ -1129,7 +1200,7 @@ static bool map_from_ints(const int* m, PixMap* out) {
 static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
                         const float* bias, const float* scale, const float* shift,
                         const void* residual, int relu, const PixMap& imap, const PixMap& omap,
-                        ud_stream_t stream_) {
+                        ud_stream_t stream_, float* stats = nullptr, size_t stats_bytes = 0, int* slices_out = nullptr) {
   if (!x || !w || !y || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (Cin % kKC != 0 || Cout % 8 != 0 || P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;
@@ -1137,7 +1208,11 @@ static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Ci
   // pixels as a [ceil(P/16)][16] image: 8 x 16 tiles of 128 consecutive pixels, no halo
   const int H = (int)((P + kTW - 1) / kTW);
   ConvGeom gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P, imap, omap};
-  ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, 0};
+  ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, 0, stats};
+  if (stats) {
+    if (stats_bytes < (size_t)gm.tiles_y * Cout * 2 * sizeof(float) || !slices_out) return UD_ERR_WORKSPACE;
+    *slices_out = gm.tiles_y;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1175,6 +1250,14 @@ extern "C" int ud_conv1x1_nhwc_bf16(const void* x, const void* w, void* y, int64
                                     const float* bias, const float* scale, const float* shift,
                                     const void* residual, int relu, ud_stream_t stream) {
   return conv1x1_impl(x, w, y, P, Cin, Cout, bias, scale, shift, residual, relu, PixMap{}, PixMap{}, stream);
+}
+
+extern "C" int ud_conv1x1_bnstats_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                                            const float* bias, float* partial, size_t partial_bytes, int* slices,
+                                            ud_stream_t stream) {
+  if (!partial || !slices) return UD_ERR_INVALID_ARG;
+  return conv1x1_impl(x, w, y, P, Cin, Cout, bias, nullptr, nullptr, nullptr, 0, PixMap{}, PixMap{}, stream, partial,
+                      partial_bytes, slices);
 }
 
 // 1x1 kernel over a mapped input and / or output (see PixMap): conv k = s / stride s, transposed conv k = s / stride s,

@@ -36,6 +36,7 @@ struct ConvEpF {
   const float* residual;
   int relu;
   int reverse_taps;
+  float* stats;       // [tiles][Cout][2] per-tile (sum, sum of squares) of the stored outputs, or nullptr (BatchNorm statistics)
 };
 
 // LDS of the 1x1 kernel: two pixel-tile slices, two weight slices; the output tile reuses the space after the K loop
@@ -57,8 +58,9 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
 template <int TN, int RW, int TM = kTM>
 __device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float* Os, int tid, int wm, int wn, int g, int li,
                                                int b, int ty0, int tx0, int n0, float* __restrict__ y,
-                                               const ConvGeomF& gm, const ConvEpF& ep) {
+                                               const ConvGeomF& gm, const ConvEpF& ep, int tile_lin = 0) {
   constexpr int kTN = TN, kLDO = TN + 4;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;   // ep.stats: see conv_store_tile in conv2d.hip
 #pragma unroll
   for (int ti = 0; ti < RW; ++ti)
 #pragma unroll
@@ -91,6 +93,32 @@ __device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float*
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     *reinterpret_cast<float4*>(y + off) = v;
+    if (ep.stats) {
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    }
+  }
+  if (ep.stats) {
+    // a thread keeps ONE 4-channel piece over all its rows (256 % (TN / 4) == 0): reduce the row groups through LDS
+    constexpr int kGroups = 256 / (kTN / 4);
+    __syncthreads();                                   // every thread is done reading the output tile
+    const int grp = tid / (kTN / 4), c4 = (tid % (kTN / 4)) * 4;
+    const float a4[4] = {s1.x, s1.y, s1.z, s1.w}, q4[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Os[(grp * kTN + c4 + e) * 2] = a4[e];
+      Os[(grp * kTN + c4 + e) * 2 + 1] = q4[e];
+    }
+    __syncthreads();
+    if (tid < kTN && n0 + tid < gm.Cout) {
+      float a = 0.f, q = 0.f;
+      for (int k = 0; k < kGroups; ++k) {
+        a += Os[(k * kTN + tid) * 2];
+        q += Os[(k * kTN + tid) * 2 + 1];
+      }
+      ep.stats[((size_t)tile_lin * gm.Cout + n0 + tid) * 2] = a;
+      ep.stats[((size_t)tile_lin * gm.Cout + n0 + tid) * 2 + 1] = q;
+    }
   }
 }
 
@@ -113,6 +141,7 @@ __global__ __launch_bounds__(256) void k_conv_f32_taps(const float* __restrict__
   const int per = (ntiles + 7) / 8;
   int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
+  const int tile_lin = tile;
   const int b = tile / (gm.tiles_x * gm.tiles_y);
   tile -= b * gm.tiles_x * gm.tiles_y;
   const int ty0 = (tile / gm.tiles_x) * TH, tx0 = (tile % gm.tiles_x) * kTW;
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(256) void k_conv_f32_taps(const float* __restrict__
     }
     adelta = -adelta;
   }
-  store_tile_f32<TN, RW, TH * kTW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep);
+  store_tile_f32<TN, RW, TH * kTW>(acc, Os, tid, wm, wn, g, li, b, ty0, tx0, n0, y, gm, ep, tile_lin);
 }
 
 constexpr size_t conv_taps_smem_bytes_f(int tn, int rw) {
@@ -309,12 +338,12 @@ __global__ __launch_bounds__(256) void k_conv1x1_f32_line(const float* __restric
       __syncthreads();
     }
   }
-  store_tile_f32<TN, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep);
+  store_tile_f32<TN, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep, tile);
 }
 
 template <int KS>
 int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, const ConvEpF& ep, int ntiles,
-               const char* name, hipStream_t stream) {
+               const char* name, hipStream_t stream, size_t stats_bytes = 0, int* slices_out = nullptr) {
   UdProfScope prof(name, stream);
   static const int force64 = getenv("UD_F32_TN64") ? atoi(getenv("UD_F32_TN64")) : 0;
   const bool narrow = force64 || gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256;
@@ -327,6 +356,10 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)conv_smem_bytes_f(64)));
       line_set = true;
+    }
+    if (ep.stats) {
+      if (stats_bytes < (size_t)ntiles * gm.Cout * 2 * sizeof(float) || !slices_out) return UD_ERR_WORKSPACE;
+      *slices_out = ntiles;
     }
     const dim3 grid((ntiles + 7) / 8 * 8, ntn);
     if (narrow) k_conv1x1_f32_line<64><<<grid, 256, conv_smem_bytes_f(64), stream>>>(x, w, y, gm, ep);
@@ -362,6 +395,11 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
       if (force_rw) rw = force_rw < (narrow ? 1 : 2) ? (narrow ? 1 : 2) : force_rw > (narrow ? 2 : 4) ? (narrow ? 2 : 4) : force_rw;
     }
     g2.tiles_y = ud_div_up(gm.H, wmv * rw);
+    if (ep.stats) {
+      const int nt = gm.B * g2.tiles_x * g2.tiles_y;
+      if (stats_bytes < (size_t)nt * gm.Cout * 2 * sizeof(float) || !slices_out) return UD_ERR_WORKSPACE;
+      *slices_out = nt;
+    }
     const dim3 grid2((gm.B * g2.tiles_x * g2.tiles_y + 7) / 8 * 8, ntn);
 #define UD_TAPS_LAUNCH(TN, RW) k_conv_f32_taps<TN, RW><<<grid2, 256, conv_taps_smem_bytes_f(TN, RW), stream>>>(x, w, y, g2, ep)
     if (narrow) {
@@ -386,6 +424,28 @@ extern "C" int ud_conv3x3_nhwc_f32(const float* x, const float* w, float* y, int
   ConvGeomF gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W};
   ConvEpF ep{bias, scale, shift, residual, flags & 1, (flags >> 1) & 1};
   return launch_f32<3>(x, w, y, gm, ep, B * gm.tiles_x * gm.tiles_y, "conv2d.k_conv3x3_f32", (hipStream_t)stream_);
+}
+
+extern "C" int ud_conv3x3_bnstats_nhwc_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin,
+                                           int Cout, const float* bias, float* partial, size_t partial_bytes,
+                                           int* slices, ud_stream_t stream_) {
+  if (!x || !w || !y || !partial || !slices || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if (Cin % kKC != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;
+  ConvGeomF gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W};
+  ConvEpF ep{bias, nullptr, nullptr, nullptr, 0, 0, partial};
+  return launch_f32<3>(x, w, y, gm, ep, B * gm.tiles_x * gm.tiles_y, "conv2d.k_conv3x3_f32", (hipStream_t)stream_,
+                       partial_bytes, slices);
+}
+
+extern "C" int ud_conv1x1_bnstats_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
+                                           const float* bias, float* partial, size_t partial_bytes, int* slices,
+                                           ud_stream_t stream_) {
+  if (!x || !w || !y || !partial || !slices || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if (Cin % kKC != 0 || Cout % 4 != 0 || P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;
+  const int H = (int)((P + kTW - 1) / kTW);
+  ConvGeomF gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P};
+  ConvEpF ep{bias, nullptr, nullptr, nullptr, 0, 0, partial};
+  return launch_f32<1>(x, w, y, gm, ep, gm.tiles_y, "conv2d.k_conv1x1_f32", (hipStream_t)stream_, partial_bytes, slices);
 }
 
 extern "C" int ud_conv1x1_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,

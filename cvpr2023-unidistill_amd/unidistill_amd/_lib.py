@@ -82,6 +82,12 @@ _SIGS = {
     "ud_conv1x1_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
     "ud_conv3x3_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
     "ud_conv1x1_nhwc_f32": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
+    "ud_conv3x3_bnstats_bytes": (c_size_t, [c_int] * 4),
+    "ud_conv1x1_bnstats_bytes": (c_size_t, [c_i64, c_int]),
+    "ud_conv3x3_bnstats_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 2 + [c_size_t, c_void_p, c_void_p]),
+    "ud_conv1x1_bnstats_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 2 + [c_size_t, c_void_p, c_void_p]),
+    "ud_conv3x3_bnstats_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 2 + [c_size_t, c_void_p, c_void_p]),
+    "ud_conv1x1_bnstats_nhwc_f32": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 2 + [c_size_t, c_void_p, c_void_p]),
     "ud_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_conv3x3_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_points_transform": (c_int, [c_void_p] * 5 + [c_int, c_int, c_i64, c_void_p]),
@@ -109,6 +115,8 @@ _SIGS = {
     "ud_bn_act_workspace_bytes": (c_size_t, [c_int]),
     "ud_bn_stats": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7
                     + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_bn_stats_from_partials": (c_int, [c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7
+                                  + [c_float, c_void_p, c_void_p]),
     "ud_bn_act_fwd": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_int, c_void_p]),
     "ud_bn_act_bwd": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_f32_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),

@@ -70,20 +70,22 @@ class Conv2d(nn.Conv2d):
     # fp32 MFMA kernels for the fp32 (reference) mode: False / True (where they pay) / "all"
     hip_fp32 = {"0": False, "all": "all"}.get(os.environ.get("UD_HIP_FP32_CONV", "1"), True)
 
-    def forward(self, x):
+    def forward(self, x, bn_stats=False):
+        """bn_stats: the caller feeds the result straight into a training-mode BatchNorm (batchnorm_act): the hand-written
+        kernels then emit the BatchNorm's per-tile sums from their epilogue (one pass over the output saved)."""
         if Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x):
             if _is3x3(self, 1):
-                return hipconv.conv3x3(x.to(torch.bfloat16), self.weight, self.bias)
+                return hipconv.conv3x3(x.to(torch.bfloat16), self.weight, self.bias, bn_stats)
             if self._hip_1x1(x):
-                return hipconv.conv1x1(x.to(torch.bfloat16), self.weight, self.bias)
+                return hipconv.conv1x1(x.to(torch.bfloat16), self.weight, self.bias, bn_stats)
             y = self._hip_permutation_conv(x)
             if y is not None:
                 return y
         elif Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x):
             if _is3x3_any(self, 1) and hipconv32.supported(x, self.weight, 3) and _fp32_kernel_pays(self, x):
-                return hipconv32.conv3x3(x, self.weight, self.bias)
+                return hipconv32.conv3x3(x, self.weight, self.bias, bn_stats)
             if _is1x1(self) and hipconv32.supported(x, self.weight, 1) and _fp32_kernel_pays(self, x):
-                return hipconv32.conv1x1(x, self.weight, self.bias)
+                return hipconv32.conv1x1(x, self.weight, self.bias, bn_stats)
         return super().forward(x)
 
     def _hip_permutation_conv(self, x):
@@ -109,17 +111,17 @@ class Conv2d(nn.Conv2d):
         return (_is1x1(self) and self.in_channels % 64 == 0 and self.out_channels % 8 == 0
                 and x.is_contiguous(memory_format=torch.channels_last))
 
-    def forward_with_skip(self, x):
+    def forward_with_skip(self, x, bn_stats=False):
         """(self(x), x'): x' is x, handed back through the convolution's autograd node so that the gradient of
         an identity branch fed from it is added inside the data-gradient kernel (residual blocks)."""
         if (Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x) and x.dtype == torch.bfloat16
                 and self._hip_1x1(x) and torch.is_grad_enabled() and x.requires_grad):
-            return hipconv.conv1x1_skip(x, self.weight, self.bias)
+            return hipconv.conv1x1_skip(x, self.weight, self.bias, bn_stats)
         if (Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x) and _is1x1(self)
                 and hipconv32.supported(x, self.weight, 1) and self.weight.shape[0] % 32 == 0
                 and _fp32_kernel_pays(self, x) and torch.is_grad_enabled() and x.requires_grad):
-            return hipconv32.conv1x1_skip(x, self.weight, self.bias)
-        return self(x), x
+            return hipconv32.conv1x1_skip(x, self.weight, self.bias, bn_stats)
+        return self(x, bn_stats), x
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
@@ -168,6 +170,11 @@ def batchnorm_act(bn, x, residual=None, relu=True):
     return torch.relu(y) if relu else y
 
 
+def _feeds_training_bn(mods, j):
+    """mods[j] is a BatchNorm2d in training mode: the convolution in front of it can hand over its statistics."""
+    return j < len(mods) and isinstance(mods[j], nn.BatchNorm2d) and mods[j].training and _HIP_BN
+
+
 class FusedSequential(nn.Sequential):
     def forward(self, x):
         mods = list(self)
@@ -193,7 +200,7 @@ class FusedSequential(nn.Sequential):
                     and _is3x3_any(mods[i + 1], 0) and hipconv32.supported(x, mods[i + 1].weight, 3) \
                     and _fp32_kernel_pays(mods[i + 1], x):
                 # fp32 mode: ZeroPad2d(1) + unpadded 3x3 conv == the kernel's implicit padding
-                x = hipconv32.conv3x3(x, mods[i + 1].weight, mods[i + 1].bias)
+                x = hipconv32.conv3x3(x, mods[i + 1].weight, mods[i + 1].bias, _feeds_training_bn(mods, i + 2))
                 i += 2
                 continue
             if conv is None:
@@ -202,7 +209,7 @@ class FusedSequential(nn.Sequential):
                     x = batchnorm_act(m, x, None, relu)
                     i += 2 if relu else 1
                     continue
-                x = m(x)
+                x = m(x, _feeds_training_bn(mods, i + 1)) if isinstance(m, Conv2d) else m(x)
                 i += 1
                 continue
             j = i + skip
@@ -214,6 +221,6 @@ class FusedSequential(nn.Sequential):
                                               None, relu)
                 i = j + (2 if relu else 1)
             else:
-                x = hipconv.conv3x3(x.to(torch.bfloat16), conv.weight, conv.bias)
+                x = hipconv.conv3x3(x.to(torch.bfloat16), conv.weight, conv.bias, _feeds_training_bn(mods, j))
                 i = j
         return x

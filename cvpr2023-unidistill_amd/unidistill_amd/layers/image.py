@@ -30,13 +30,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        # each convolution hands the statistics pass of the training-mode BatchNorm behind it over from its epilogue
         if self.downsample is None:
-            y, idt = self.conv1.forward_with_skip(x)      # identity gradient joins inside conv1's data gradient
+            y, idt = self.conv1.forward_with_skip(x, self.bn1.training)   # identity gradient joins inside conv1's dgrad
         else:
-            idt, y = self.downsample(x), self.conv1(x)
+            idt, y = self.downsample(x), self.conv1(x, self.bn1.training)
         y = batchnorm_act(self.bn1, y)
-        y = batchnorm_act(self.bn2, self.conv2(y))
-        return batchnorm_act(self.bn3, self.conv3(y), residual=idt)
+        y = batchnorm_act(self.bn2, self.conv2(y, self.bn2.training))
+        return batchnorm_act(self.bn3, self.conv3(y, self.bn3.training), residual=idt)
 
 
 class ResNet(nn.Module):

@@ -37,7 +37,7 @@ def _workspace(dev, C):
 class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu,
-                tracked=None):
+                tracked=None, partial=None):
         lib = _lib.load()
         _lib.require_gpu(x, gamma, beta)
         f32 = x.dtype == torch.float32
@@ -55,10 +55,18 @@ class _BnActFn(torch.autograd.Function):
             ws = _workspace(dev, C)
             fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
             rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
-            _lib.check(k_stats(x.data_ptr(), P, C, g32.data_ptr(), b32.data_ptr(), float(eps),
-                                       v0, v0 + row, v0 + 2 * row, v0 + 3 * row, v0 + 4 * row,
-                                       _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
-                                       _lib.ptr(tracked), ws.data_ptr(), ws.numel(), stream), "ud_bn_stats")
+            if partial is not None and partial[2] == P:
+                # the producing convolution already reduced every tile (ud_conv*_bnstats_nhwc_*): second pass only
+                _lib.check(lib.ud_bn_stats_from_partials(partial[0].data_ptr(), int(partial[1]), P, C, g32.data_ptr(),
+                                                         b32.data_ptr(), float(eps), v0, v0 + row, v0 + 2 * row,
+                                                         v0 + 3 * row, v0 + 4 * row, _lib.ptr(rm), _lib.ptr(rv),
+                                                         float(momentum or 0.0), _lib.ptr(tracked), stream),
+                           "ud_bn_stats_from_partials")
+            else:
+                _lib.check(k_stats(x.data_ptr(), P, C, g32.data_ptr(), b32.data_ptr(), float(eps),
+                                   v0, v0 + row, v0 + 2 * row, v0 + 3 * row, v0 + 4 * row,
+                                   _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
+                                   _lib.ptr(tracked), ws.data_ptr(), ws.numel(), stream), "ud_bn_stats")
             if running_mean is not None and not fp32_buffers:
                 with torch.no_grad():
                     running_mean.mul_(1 - momentum).add_(vec[0], alpha=momentum)
@@ -102,7 +110,7 @@ class _BnActFn(torch.autograd.Function):
                                      ws.data_ptr(), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd")
         if has_res and ctx.needs_input_grad[3] and dres is None:
             dres = dy
-        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None
 
 
 def bn_act(bn, x, residual=None, relu=True):
@@ -114,5 +122,6 @@ def bn_act(bn, x, residual=None, relu=True):
             tracked = nbt                     # incremented by the statistics kernel (no extra launch)
         else:
             nbt.add_(1)
+    partial = getattr(x, "_ud_bn_partial", None) if bn.training else None    # left by a bn_stats convolution
     return _BnActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.training,
-                          bn.momentum, bn.eps, relu, tracked)
+                          bn.momentum, bn.eps, relu, tracked, partial)

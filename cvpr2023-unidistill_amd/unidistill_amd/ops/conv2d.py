@@ -30,8 +30,16 @@ FLOP_COUNTER = None      # set to [0] to accumulate the multiply-add count of ev
 SHAPE_LOG = None         # set to [] to record (B, Cin, H, W, Cout, reverse_taps) of every 3x3 launch (bench.py replays them)
 
 
-def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, relu=False, reverse_taps=False):
-    """x: [B, Cin, H, W] bf16 channels-last; w_tap: [Cout, 3, 3, Cin] bf16 contiguous."""
+def _bn_partial(nbytes, dev):
+    """Buffer for the per-tile BatchNorm partials a ``*_bnstats`` convolution writes + the host int it reports."""
+    import ctypes
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev), ctypes.c_int(0)
+
+
+def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, relu=False, reverse_taps=False,
+            bn_stats=False):
+    """x: [B, Cin, H, W] bf16 channels-last; w_tap: [Cout, 3, 3, Cin] bf16 contiguous.  bn_stats: also return the
+    per-tile (sum, sum of squares) of the output for the BatchNorm that follows: (y, (partial, slices, rows))."""
     B, cin, H, W = x.shape
     if FLOP_COUNTER is not None:
         FLOP_COUNTER[0] += 2 * B * H * W * cout * 9 * cin
@@ -39,6 +47,15 @@ def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, re
         SHAPE_LOG.append((B, cin, H, W, cout, bool(reverse_taps)))
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
+    if bn_stats:
+        import ctypes
+        lib = _lib.load()
+        part, ns = _bn_partial(lib.ud_conv3x3_bnstats_bytes(B, H, W, cout), x.device)
+        _lib.check(lib.ud_conv3x3_bnstats_nhwc_bf16(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
+                                                    _lib.ptr(bias), _lib.ptr(part), part.numel() * 4,
+                                                    ctypes.addressof(ns), _lib.stream_of(x)),
+                   "ud_conv3x3_bnstats_nhwc_bf16")
+        return y, (part, ns.value, B * H * W)
     _lib.check(_lib.load().ud_conv3x3_nhwc_bf16(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin,
                                                 cout, _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
                                                 _lib.ptr(residual), (1 if relu else 0) | (2 if reverse_taps else 0),
@@ -112,11 +129,14 @@ def weight_grad(x, gy, weight):
 
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, holder=None):
         _lib.require_gpu(x, weight)
         x = _nhwc(x)
         y = _launch(x, tap_major(weight), weight.shape[0],
-                    None if bias is None else bias.detach().float().contiguous())
+                    None if bias is None else bias.detach().float().contiguous(), bn_stats=holder is not None)
+        if holder is not None:
+            y, part = y
+            holder.append(part)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -132,12 +152,24 @@ class _Conv3x3Fn(torch.autograd.Function):
             gw = weight_grad(x, gy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def conv3x3(x, weight, bias=None):
-    """y = conv2d(x, weight, bias, stride=1, padding=1) for bf16 channels-last x (autograd-aware)."""
-    return _Conv3x3Fn.apply(x, weight, bias)
+def _with_partial(y, holder):
+    """Hang the BatchNorm partials of a ``bn_stats`` convolution on its output (ops.bn_act.bn_act picks them up)."""
+    out = y[0] if isinstance(y, tuple) else y
+    if holder:
+        out._ud_bn_partial = holder[0]
+    return y
+
+
+def conv3x3(x, weight, bias=None, bn_stats=False):
+    """y = conv2d(x, weight, bias, stride=1, padding=1) for bf16 channels-last x (autograd-aware).  bn_stats: a
+    training-mode BatchNorm follows -- its statistics pass is folded into the convolution's epilogue."""
+    if not bn_stats:
+        return _Conv3x3Fn.apply(x, weight, bias)
+    holder = []
+    return _with_partial(_Conv3x3Fn.apply(x, weight, bias, holder), holder)
 
 
 def conv3x3_inference(x, weight, bias=None, scale=None, shift=None, residual=None, relu=False):
@@ -188,10 +220,19 @@ HIP_1X1_MIN_PIXELS = 1         # per image: maps at least this large run the han
                                # on it; the GEMM / library branches below only serve channel counts the kernel rejects
 
 
-def _launch1x1(x, w2d, cout, bias=None, scale=None, shift=None, residual=None, relu=False):
+def _launch1x1(x, w2d, cout, bias=None, scale=None, shift=None, residual=None, relu=False, bn_stats=False):
     """x: [B, Cin, H, W] bf16 channels-last; w2d: [Cout, Cin] bf16 contiguous."""
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    if bn_stats:
+        import ctypes
+        lib = _lib.load()
+        part, ns = _bn_partial(lib.ud_conv1x1_bnstats_bytes(B * H * W, cout), x.device)
+        _lib.check(lib.ud_conv1x1_bnstats_nhwc_bf16(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), B * H * W, cin, cout,
+                                                    _lib.ptr(bias), _lib.ptr(part), part.numel() * 4,
+                                                    ctypes.addressof(ns), _lib.stream_of(x)),
+                   "ud_conv1x1_bnstats_nhwc_bf16")
+        return y, (part, ns.value, B * H * W)
     _lib.check(_lib.load().ud_conv1x1_nhwc_bf16(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), B * H * W, cin, cout,
                                                 _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
                                                 _lib.ptr(residual), 1 if relu else 0, _lib.stream_of(x)),
@@ -205,7 +246,7 @@ class _Conv1x1Fn(torch.autograd.Function):
     beta term) instead of by a separate elementwise add of two full-size tensors (ResNet residual joins)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, with_skip=False):
+    def forward(ctx, x, weight, bias, with_skip=False, holder=None):
         _lib.require_gpu(x, weight)
         x = _nhwc(x)
         wb = _w1x1(weight)
@@ -214,7 +255,11 @@ class _Conv1x1Fn(torch.autograd.Function):
         ctx.gemm = H * W <= GEMM_1X1_MAX_PIXELS
         ctx.hip = H * W >= HIP_1X1_MIN_PIXELS
         if ctx.hip:
-            y = _launch1x1(x, wb.view(cout, cin), cout, None if bias is None else bias.detach().float().contiguous())
+            y = _launch1x1(x, wb.view(cout, cin), cout, None if bias is None else bias.detach().float().contiguous(),
+                           bn_stats=holder is not None)
+            if holder is not None:
+                y, part = y
+                holder.append(part)
         elif ctx.gemm:
             # a 1x1 convolution of a channels-last map IS a plain GEMM [pixels, Cin] x [Cin, Cout]: on the
             # small maps of the deep ResNet stages the library GEMM is 1.2-2.5x faster than the conv solver
@@ -254,17 +299,23 @@ class _Conv1x1Fn(torch.autograd.Function):
             gw = weight_grad_1x1(x, gy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
-def conv1x1(x, weight, bias=None):
+def conv1x1(x, weight, bias=None, bn_stats=False):
     """y = conv2d(x, weight, bias) for a 1x1 / stride-1 convolution of a bf16 channels-last map."""
-    return _Conv1x1Fn.apply(x, weight, bias)
+    if not bn_stats:
+        return _Conv1x1Fn.apply(x, weight, bias)
+    holder = []
+    return _with_partial(_Conv1x1Fn.apply(x, weight, bias, False, holder), holder)
 
 
-def conv1x1_skip(x, weight, bias=None):
+def conv1x1_skip(x, weight, bias=None, bn_stats=False):
     """(conv1x1(x), x): use the second value for the identity branch of a residual block (see _Conv1x1Fn)."""
-    return _Conv1x1Fn.apply(x, weight, bias, True)
+    if not bn_stats:
+        return _Conv1x1Fn.apply(x, weight, bias, True)
+    holder = []
+    return _with_partial(_Conv1x1Fn.apply(x, weight, bias, True, holder), holder)
 
 
 # ---- convolutions whose im2col is a permutation: k = s / stride s, transposed k = s / stride s, 1x1 / stride s ----

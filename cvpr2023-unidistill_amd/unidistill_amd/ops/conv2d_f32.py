@@ -20,9 +20,23 @@ def supported(x, weight, ks):
             and x.shape[1] == weight.shape[1])
 
 
-def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False):
+def _bn_partial(nbytes, dev):
+    import ctypes
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev), ctypes.c_int(0)
+
+
+def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False, bn_stats=False):
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if bn_stats:      # + per-tile (sum, sum of squares) for the BatchNorm that follows: (y, (partial, slices, rows))
+        import ctypes
+        lib = _lib.load()
+        part, ns = _bn_partial(lib.ud_conv3x3_bnstats_bytes(B, H, W, cout), x.device)
+        _lib.check(lib.ud_conv3x3_bnstats_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
+                                                   _lib.ptr(bias), _lib.ptr(part), part.numel() * 4,
+                                                   ctypes.addressof(ns), _lib.stream_of(x)),
+                   "ud_conv3x3_bnstats_nhwc_f32")
+        return y, (part, ns.value, B * H * W)
     _lib.check(_lib.load().ud_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
                                                _lib.ptr(bias), None, None, None,
                                                (1 if relu else 0) | (2 if reverse_taps else 0), _lib.stream_of(x)),
@@ -30,9 +44,18 @@ def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False):
     return y
 
 
-def _launch1(x, w, cout, bias=None, residual=None):
+def _launch1(x, w, cout, bias=None, residual=None, bn_stats=False):
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if bn_stats:
+        import ctypes
+        lib = _lib.load()
+        part, ns = _bn_partial(lib.ud_conv1x1_bnstats_bytes(B * H * W, cout), x.device)
+        _lib.check(lib.ud_conv1x1_bnstats_nhwc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), B * H * W, cin, cout,
+                                                   _lib.ptr(bias), _lib.ptr(part), part.numel() * 4,
+                                                   ctypes.addressof(ns), _lib.stream_of(x)),
+                   "ud_conv1x1_bnstats_nhwc_f32")
+        return y, (part, ns.value, B * H * W)
     _lib.check(_lib.load().ud_conv1x1_nhwc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), B * H * W, cin, cout,
                                                _lib.ptr(bias), None, None, _lib.ptr(residual), 0, _lib.stream_of(x)),
                "ud_conv1x1_nhwc_f32")
@@ -45,15 +68,19 @@ class _ConvF32(torch.autograd.Function):
     elementwise add of two full-size tensors (ResNet residual joins; same contract as ops/conv2d.py:_Conv1x1Fn)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, ks, with_skip=False):
+    def forward(ctx, x, weight, bias, ks, with_skip=False, holder=None):
         _lib.require_gpu(x, weight)
         x = _nhwc(x)
         b = None if bias is None else bias.detach().contiguous()
         w = weight.detach()
+        st = holder is not None
         if ks == 3:
-            y = _launch3(x, w.permute(0, 2, 3, 1).contiguous(), weight.shape[0], b)       # [Cout, 3, 3, Cin]
+            y = _launch3(x, w.permute(0, 2, 3, 1).contiguous(), weight.shape[0], b, bn_stats=st)   # [Cout, 3, 3, Cin]
         else:
-            y = _launch1(x, w.reshape(weight.shape[0], weight.shape[1]).contiguous(), weight.shape[0], b)
+            y = _launch1(x, w.reshape(weight.shape[0], weight.shape[1]).contiguous(), weight.shape[0], b, bn_stats=st)
+        if st:
+            y, part = y
+            holder.append(part)
         ctx.save_for_backward(x, weight)
         ctx.ks, ctx.has_bias = ks, bias is not None
         return (y, x) if with_skip else y
@@ -85,17 +112,29 @@ class _ConvF32(torch.autograd.Function):
                                                      [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def conv3x3(x, weight, bias=None):
-    return _ConvF32.apply(x, weight, bias, 3)
+def _apply(x, weight, bias, ks, with_skip, bn_stats):
+    """bn_stats: a training-mode BatchNorm follows -- its statistics pass is folded into the convolution's epilogue and the
+    partials ride on the output tensor (ops.bn_act.bn_act picks them up)."""
+    if not bn_stats:
+        return _ConvF32.apply(x, weight, bias, ks, with_skip)
+    holder = []
+    y = _ConvF32.apply(x, weight, bias, ks, with_skip, holder)
+    if holder:
+        (y[0] if with_skip else y)._ud_bn_partial = holder[0]
+    return y
 
 
-def conv1x1(x, weight, bias=None):
-    return _ConvF32.apply(x, weight, bias, 1)
+def conv3x3(x, weight, bias=None, bn_stats=False):
+    return _apply(x, weight, bias, 3, False, bn_stats)
 
 
-def conv1x1_skip(x, weight, bias=None):
+def conv1x1(x, weight, bias=None, bn_stats=False):
+    return _apply(x, weight, bias, 1, False, bn_stats)
+
+
+def conv1x1_skip(x, weight, bias=None, bn_stats=False):
     """(conv1x1(x), x'): x' aliases x; a gradient arriving through x' is added inside the data-gradient kernel."""
-    return _ConvF32.apply(x, weight, bias, 1, True)
+    return _apply(x, weight, bias, 1, True, bn_stats)

@@ -424,6 +424,26 @@ int ud_conv3x3_nhwc_f32(const float* x, const float* w, float* y, int B, int H, 
 int ud_conv1x1_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
                         const float* bias, const float* scale, const float* shift, const float* residual,
                         int flags, ud_stream_t stream);
+/* Convolution (+ bias) fused with the FIRST pass of the training-mode BatchNorm that follows it in the reference's
+ * Conv2d -> BatchNorm2d -> ReLU links (base_bev_backbone.py:48-66, center_head.py:408-420, the mmdet ResNet
+ * bottlenecks): besides y, every workgroup writes partial[tile][Cout][2] = (sum, sum of squares) of the values it
+ * stored (for bf16 the rounded ones: what a separate statistics pass would read back).  `partial_bytes` >=
+ * ud_conv{3x3,1x1}_bnstats_bytes(...) (an upper bound: the tile height is chosen per launch); *slices (host int) =
+ * number of tiles written.  Finish with ud_bn_stats_from_partials.  Same shape rules as the plain calls. */
+size_t ud_conv3x3_bnstats_bytes(int B, int H, int W, int Cout);
+size_t ud_conv1x1_bnstats_bytes(int64_t P, int Cout);
+int ud_conv3x3_bnstats_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
+                                 const float* bias, float* partial, size_t partial_bytes, int* slices,
+                                 ud_stream_t stream);
+int ud_conv1x1_bnstats_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
+                                 const float* bias, float* partial, size_t partial_bytes, int* slices,
+                                 ud_stream_t stream);
+int ud_conv3x3_bnstats_nhwc_f32(const float* x, const float* w, float* y, int B, int H, int W, int Cin, int Cout,
+                                const float* bias, float* partial, size_t partial_bytes, int* slices,
+                                ud_stream_t stream);
+int ud_conv1x1_bnstats_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
+                                const float* bias, float* partial, size_t partial_bytes, int* slices,
+                                ud_stream_t stream);
 /* Weight gradient of the same convolution: dw [Cout][9][Cin] fp32 = sum over pixels of
  * dy [B][H][W][Cout] (bf16) x shifted x [B][H][W][Cin] (bf16); fp32 accumulation, fixed-order
  * reduction of pixel slices (deterministic).  Cin % 64 == 0, Cout % 8 == 0. */
@@ -512,6 +532,13 @@ int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* sca
                   const float* mean, const float* invstd, void* dx, void* dresidual, float* dgamma,
                   float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
                   ud_stream_t stream);
+/* ud_bn_stats for a tensor whose first statistics pass came out of a convolution epilogue
+ * (ud_conv*_bnstats_nhwc_*): partial [slices][C][2] per-tile (sum, sum of squares) over the P rows, reduced in slice
+ * order (deterministic); outputs and running-statistics update exactly as ud_bn_stats. */
+int ud_bn_stats_from_partials(const float* partial, int slices, long long P, int C, const float* gamma,
+                              const float* beta, float eps, float* mean, float* var, float* invstd, float* scale,
+                              float* shift, float* running_mean, float* running_var, float momentum,
+                              long long* batches_tracked, ud_stream_t stream);
 /* fp32 twins for the fp32 (reference-arithmetic) mode: x / residual / y / dy / dx are FP32 rows, everything
  * else as above (C % 16 == 0). */
 int ud_bn_stats_f32(const float* x, long long P, int C, const float* gamma, const float* beta, float eps,

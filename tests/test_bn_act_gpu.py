@@ -141,3 +141,40 @@ def test_bn_act_fp32_mode(hip_lib, shape, residual, relu):
         _close(rd.grad, rr.grad, 2e-5, "dres")
     _close(bn.running_mean, bn_ref.running_mean, 1e-5, "running_mean")
     _close(bn.running_var, bn_ref.running_var, 1e-5, "running_var")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ks,shape", [(torch.bfloat16, 3, (2, 64, 33, 41, 128)), (torch.bfloat16, 1, (3, 128, 40, 37, 80)),
+                                            (torch.float32, 3, (2, 64, 33, 41, 128)), (torch.float32, 1, (3, 64, 40, 37, 96)),
+                                            (torch.bfloat16, 3, (1, 128, 180, 180, 128))])
+def test_conv_epilogue_statistics_equal_the_separate_pass(hip_lib, dtype, ks, shape):
+    """A convolution launched with bn_stats hands the per-tile (sum, sum of squares) of its output to the BatchNorm behind
+    it (ud_conv*_bnstats_nhwc_* + ud_bn_stats_from_partials): same normalised output, batch statistics, running statistics
+    and gradients as the convolution followed by the stand-alone statistics pass (ud_bn_stats*)."""
+    from unidistill_amd.ops import conv2d as c16, conv2d_f32 as c32, bn_act as hb
+    B, cin, H, W, cout = shape
+    torch.manual_seed(sum(shape) + ks)
+    dev = torch.device("cuda:0")
+    x0 = (torch.randn(B, cin, H, W, device=dev) + 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
+    w0 = torch.randn(cout, cin, ks, ks, device=dev) * (cin * ks * ks) ** -0.5
+    gy = torch.randn(B, cout, H, W, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    mod = c16 if dtype == torch.bfloat16 else c32
+    conv = mod.conv3x3 if ks == 3 else mod.conv1x1
+    outs = []
+    for fused in (False, True):
+        bn = torch.nn.BatchNorm2d(cout).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.copy_(torch.linspace(-0.5, 0.5, cout))
+        x = x0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        y = conv(x, w, None, fused)
+        assert hasattr(y, "_ud_bn_partial") == fused
+        z = hb.bn_act(bn, y, None, True)
+        z.backward(gy)
+        outs.append([t.detach().float() for t in (z, bn.running_mean, bn.running_var, x.grad, w.grad, bn.weight.grad)])
+    for a, b in zip(*outs):
+        tol = (2e-2 if dtype == torch.bfloat16 else 2e-4) * float(a.abs().max()) + 1e-6
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=tol)
+    # the statistics themselves agree far tighter than the bf16 tensors built from them
+    np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(outs[1][2].cpu().numpy(), outs[0][2].cpu().numpy(), rtol=1e-4, atol=1e-6)
