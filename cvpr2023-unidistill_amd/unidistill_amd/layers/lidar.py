@@ -95,7 +95,8 @@ class VoxelResBackBone8x(nn.Module):
         # The site sets of all four down-sampling levels depend on the voxel coordinates only, and sizing each of them costs
         # one host read.  Build the whole pyramid NOW, while only the small index kernels are queued on this stream: a read
         # then waits for microseconds of work instead of for every sparse convolution enqueued in front of the strided
-        # layer that would otherwise trigger it (4.6 ms of host time per step in the distillation benchmark).  The
+        # layer that would otherwise trigger it (LiDAR detector, bf16: 25.4 -> 24.5 ms per step; LiDAR student + fusion teacher:
+        # 38.0 -> 36.7 ms).  The
         # convolutions find their rulebooks in the per-site-set caches.
         sites = x._sites
         for m in self.modules():
