@@ -936,6 +936,94 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in
   }
 }
 
+// ---- weight gradient, fp32, row-major staging ------------------------------------------------------------------------
+// k_wgrad_mfma above transposes both tiles into LDS element by element (one div / mod, one scalar load and one 8-way
+// bank-conflicted ds_write_b32 per element, 64 per thread and tile) and gives every wave single 16 x 16 tiles with no
+// fragment reuse: 4.2 ms per 128-channel layer of the LiDAR detector's fp32 step (6-8 TFLOP/s).  Here the 64 gout rows and
+// the 64 gathered input rows are copied as they lie in memory (16-byte loads and ds_write_b128, rows padded to a stride of
+// 16 mod 32 banks) and the fp32 MFMA's operands are read straight out of the row-major tiles: lane (g, li) of
+// v_mfma_f32_16x16x4_f32 wants A[i = li][k = g] = gout[row 4s + g][n0 + li] -- 16 consecutive floats of each of two rows per
+// half wave, conflict-free at that stride.  Waves form a WN x WC grid over the Cout x Cin tile and reuse their fragments
+// ((TN + TC) reads per TN x TC MFMAs).  Same decomposition (offset k, row chunk) and fixed-order chunk reduction as above.
+template <int P>
+struct WgLd { static constexpr int v = (P % 32 == 0) ? P + 16 : P + 32; };
+
+template <int CIN_P, int COUT_P>
+__global__ __launch_bounds__(256) void k_wgrad_rows(const float* __restrict__ in, int cin,
+                                                    const int32_t* __restrict__ nbr, int K,
+                                                    const float* __restrict__ gout, int cout,
+                                                    float* __restrict__ partial, int Mout,
+                                                    int rows_per_chunk) {
+  constexpr int LDG = WgLd<COUT_P>::v, LDI = WgLd<CIN_P>::v;
+  constexpr int NT = COUT_P / 16, CT = CIN_P / 16;
+  constexpr int WN = NT >= 2 ? 2 : 1, WC = (4 / WN) < CT ? (4 / WN) : CT;   // wave grid (idle waves on the tiny layers)
+  constexpr int TN = NT / WN, TC = CT / WC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Gs = reinterpret_cast<float*>(smem);  // [kTM][LDG]  gout rows
+  float* Is = Gs + kTM * LDG;                   // [kTM][LDI]  gathered input rows (zero where the neighbour is missing)
+  int* s_nbr = reinterpret_cast<int*>(Is + kTM * LDI);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int k = blockIdx.x, chunk = blockIdx.y;
+  const bool active_wave = wave < WN * WC;
+  const int wn = wave / WC, wc = wave % WC;
+  f32x4 acc[TN][TC];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TC; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int r_begin = chunk * rows_per_chunk;
+  const int r_end = min(r_begin + rows_per_chunk, Mout);
+  for (int row0 = r_begin; row0 < r_end; row0 += kTM) {
+    int r = -1;
+    if (tid < kTM && row0 + tid < r_end) r = nbr[(size_t)(row0 + tid) * K + k];
+    if (tid < kTM) s_nbr[tid] = r;
+    if (!__syncthreads_or(r >= 0)) continue;
+    for (int u = tid; u < kTM * (COUT_P / 4); u += 256) {
+      const int o = u / (COUT_P / 4), n4 = (u - o * (COUT_P / 4)) * 4;
+      const int row = row0 + o;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < r_end && n4 < cout) v = *reinterpret_cast<const float4*>(gout + (size_t)row * cout + n4);
+      *reinterpret_cast<float4*>(Gs + o * LDG + n4) = v;
+    }
+    for (int u = tid; u < kTM * (CIN_P / 4); u += 256) {
+      const int o = u / (CIN_P / 4), c4 = (u - o * (CIN_P / 4)) * 4;
+      const int rr = s_nbr[o];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr >= 0 && c4 < cin) v = *reinterpret_cast<const float4*>(in + (size_t)rr * cin + c4);
+      *reinterpret_cast<float4*>(Is + o * LDI + c4) = v;
+    }
+    __syncthreads();
+    if (active_wave) {
+      const float* ga = Gs + g * LDG + wn * TN * 16 + li;
+      const float* ib = Is + g * LDI + wc * TC * 16 + li;
+#pragma unroll 4
+      for (int s4 = 0; s4 < kTM / 4; ++s4) {      // four rows per MFMA
+        float a[TN], b[TC];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) a[t] = ga[s4 * 4 * LDG + t * 16];
+#pragma unroll
+        for (int t = 0; t < TC; ++t) b[t] = ib[s4 * 4 * LDI + t * 16];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tc = 0; tc < TC; ++tc)
+            acc[tn][tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tn], b[tc], acc[tn][tc], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (!active_wave) return;
+  float* p = partial + ((size_t)chunk * K + k) * COUT_P * CIN_P;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        p[(size_t)((wn * TN + tn) * 16 + 4 * g + r) * CIN_P + (wc * TC + tc) * 16 + li] = acc[tn][tc][r];
+}
+
 // ---- weight gradient, bf16 operands (mixed-precision training) --------------------------------------
 // Same decomposition (one workgroup per (offset k, row chunk g), ordered reduction of the chunks), but
 // the products run on v_mfma_f32_16x16x32_bf16 -- 16x the rate of the fp32 matrix instruction the exact
@@ -1453,16 +1541,27 @@ template <int CIN_P, int COUT_P>
 int launch_wgrad(const float* in, int cin, const int32_t* nbr, int K, const float* gout, int cout,
                  float* gW, int Mout, float* partial, int G, int rows_per_chunk,
                  hipStream_t stream) {
-  const size_t lds = (size_t)(CIN_P + COUT_P) * (kTM + 4) * sizeof(float) + kTM * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_mfma<CIN_P, COUT_P>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   dim3 grid(K, G);
-  k_wgrad_mfma<CIN_P, COUT_P><<<grid, 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
-                                                          Mout, rows_per_chunk);
+  if (cin % 4 == 0 && cout % 4 == 0) {        // 16-byte row copies (every layer but the 5-channel input conv)
+    const size_t lds = (size_t)kTM * (WgLd<CIN_P>::v + WgLd<COUT_P>::v) * sizeof(float) + kTM * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_rows<CIN_P, COUT_P>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    k_wgrad_rows<CIN_P, COUT_P><<<grid, 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial, Mout, rows_per_chunk);
+  } else {
+    const size_t lds = (size_t)(CIN_P + COUT_P) * (kTM + 4) * sizeof(float) + kTM * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_mfma<CIN_P, COUT_P>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    k_wgrad_mfma<CIN_P, COUT_P><<<grid, 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
+                                                            Mout, rows_per_chunk);
+  }
   UD_LAUNCH_CHECK();
   k_wgrad_reduce<<<ud_div_up((long long)cout * K * cin, 256), 256, 0, stream>>>(
       partial, G, K, CIN_P, COUT_P, cin, cout, gW);
