@@ -18,7 +18,6 @@ namespace {
 
 constexpr int kHC = 64;                       // channels per group
 constexpr int kTW = 16, kTH = 8, kHW = kTW + 2, kHH = kTH + 2, kHQ = kHW * kHH;   // tile, halo
-constexpr int kLD = 68;                       // LDS row stride of the staged halo (floats)
 constexpr int kKMax = 4;                      // outputs per group
 
 struct GTail {
