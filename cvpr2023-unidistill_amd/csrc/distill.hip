@@ -69,14 +69,6 @@ __device__ __forceinline__ float sample(const MapView& m, int b, int c, const Bi
   return v;
 }
 
-__device__ __forceinline__ void scatter(const MapViewW& m, int b, int c, const Bilin& q, float g) {
-  float* base = m.p + b * m.sb + c * m.sc;
-  if (q.in[0]) atomicAdd(&base[q.y0 * m.sy + q.x0 * m.sx], g * q.w[0]);
-  if (q.in[1]) atomicAdd(&base[q.y0 * m.sy + (q.x0 + 1) * m.sx], g * q.w[1]);
-  if (q.in[2]) atomicAdd(&base[(q.y0 + 1) * m.sy + q.x0 * m.sx], g * q.w[2]);
-  if (q.in[3]) atomicAdd(&base[(q.y0 + 1) * m.sy + (q.x0 + 1) * m.sx], g * q.w[3]);
-}
-
 // 9 key points of a box from its 4 BEV corners: corners, centre, 4 edge mid-points (:200-223)
 __device__ __forceinline__ void key_point(const float* __restrict__ c8, int kp, float& x, float& y) {
   if (kp < 4) {
@@ -133,7 +125,7 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void k_feat(MapView s, MapView t, const float* __restrict__ corners,
                                               const unsigned char* __restrict__ valid, int M, int C,
                                               int H, int W, float* __restrict__ box_loss,
-                                              MapViewW gs, const float* __restrict__ gscale) {
+                                              float* __restrict__ dkp, const float* __restrict__ gscale) {
   __shared__ float s_kp[9];
   const int bm = blockIdx.x, b = bm / M;
   const int lane = ud_lane(), wave = threadIdx.x >> 6;
@@ -152,7 +144,7 @@ __global__ __launch_bounds__(256) void k_feat(MapView s, MapView t, const float*
       const float d = sample(s, b, c, q) - sample(t, b, c, q);
       if (BWD) {
         const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        if (sg != 0.f) scatter(gs, b, c, q, sg * g);
+        dkp[((size_t)bm * 9 + kp) * C + c] = sg * g;       // gradient w.r.t. the sampled value; k_box_scatter spreads it
       } else {
         acc += fabsf(d);
       }
@@ -178,8 +170,8 @@ __global__ __launch_bounds__(256) void k_feat(MapView s, MapView t, const float*
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_rel(MapView s, MapView t, const float* __restrict__ corners,
                                              const unsigned char* __restrict__ valid, int M, int C,
-                                             int H, int W, float* __restrict__ box_loss, MapViewW gs,
-                                             const float* __restrict__ gscale) {
+                                             int H, int W, float* __restrict__ box_loss,
+                                             float* __restrict__ dkp, const float* __restrict__ gscale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Fs = reinterpret_cast<float*>(smem);  // [9][C] student samples (raw, then normalised)
   float* Ft = Fs + 9 * C;                       // [9][C] teacher
@@ -244,9 +236,6 @@ __global__ __launch_bounds__(256) void k_rel(MapView s, MapView t, const float* 
   }
   __syncthreads();
   for (int kp = wave; kp < 9; kp += 4) {
-    float x, y;
-    key_point(c8, kp, x, y);
-    const Bilin q = make_bilin(x, y, H, W);
     const float n = nrm[kp], den = n + 1e-4f;
     // dFhat[kp][c] = sum_j (dG[kp][j] + dG[j][kp]) * Fhat[j][c];  dot = f . dFhat
     float dot = 0.f;
@@ -262,11 +251,77 @@ __global__ __launch_bounds__(256) void k_rel(MapView s, MapView t, const float* 
       float dh = 0.f;
       for (int j = 0; j < 9; ++j)
         dh += (Gd[kp * 9 + j] + Gd[j * 9 + kp]) * (Fs[j * C + c] / (nrm[j] + 1e-4f));
-      const float df = dh / den - Fs[kp * C + c] * k2;
-      if (df != 0.f) scatter(gs, b, c, q, df);
+      dkp[((size_t)bm * 9 + kp) * C + c] = dh / den - Fs[kp * C + c] * k2;
     }
   }
   (void)red;
+}
+
+// ---- deterministic scatter of the key-point gradients -----------------------------------------------------------------
+// d loss / d map[b, c, pixel] = sum over (box m, key point kp, bilinear corner i) of dkp[b, m, kp, c] * w_i.  Footprints
+// overlap (a small box puts all nine key points into one or two BEV cells; neighbouring boxes share pixels), so adding
+// the terms with float atomics -- the first version -- made the sum depend on the arrival order whenever three or more
+// terms met (a run-to-run difference of one ulp in every gradient upstream, seen as a flaky bit-reproducibility test on
+// cold GPUs).  Here every (m, kp, i) term of a sample gets the key (pixel, term index); one workgroup per (sample, 256
+// channels) sorts the <= 2048 keys in LDS (bitonic) and every thread walks the sorted list for its channel, adding the terms
+// of a pixel in term order and storing each pixel once: no atomics, fixed order.
+constexpr int kMaxTerms = 2048;
+__global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ dkp, const float* __restrict__ corners,
+                                                     const unsigned char* __restrict__ valid, int M, int C, int H,
+                                                     int W, MapViewW gs) {
+  __shared__ unsigned keys[kMaxTerms];
+  __shared__ float wts[kMaxTerms];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nterm = M * 36;
+  for (int t = tid; t < kMaxTerms; t += 256) {
+    unsigned key = 0xFFFFFFFFu;
+    float wv = 0.f;
+    if (t < nterm) {
+      const int m = t / 36, kp = (t - m * 36) >> 2, i = t & 3;
+      if (valid[b * M + m]) {
+        float x, y;
+        key_point(corners + (size_t)(b * M + m) * 8, kp, x, y);
+        const Bilin q = make_bilin(x, y, H, W);
+        if (q.in[i]) {
+          const int px = q.x0 + (i & 1), py = q.y0 + (i >> 1);
+          key = ((unsigned)(py * W + px) << 11) | (unsigned)t;
+          wv = q.w[i];
+        }
+      }
+    }
+    keys[t] = key;
+    wts[t] = wv;
+  }
+  __syncthreads();
+  for (int k = 2; k <= kMaxTerms; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < kMaxTerms; t += 256) {
+        const int p = t ^ j;
+        if (p > t) {
+          const unsigned a = keys[t], c2 = keys[p];
+          const bool up = (t & k) == 0;
+          if ((a > c2) == up) { keys[t] = c2; keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  const int c = blockIdx.y * 256 + tid;
+  if (c >= C) return;
+  float* base = gs.p + b * gs.sb + c * gs.sc;
+  float acc = 0.f;
+  int cur = -1;
+  for (int i = 0; i < nterm; ++i) {
+    const unsigned key = keys[i];
+    if (key == 0xFFFFFFFFu) break;
+    const int pix = (int)(key >> 11), t = (int)(key & 2047u);
+    if (pix != cur) {
+      if (cur >= 0) base[(cur / W) * gs.sy + (cur % W) * gs.sx] = acc;
+      cur = pix;
+      acc = 0.f;
+    }
+    acc += dkp[((size_t)(b * M + t / 36) * 9 + ((t % 36) >> 2)) * C + c] * wts[t];
+  }
+  if (cur >= 0) base[(cur / W) * gs.sy + (cur % W) * gs.sx] = acc;
 }
 
 // ---- gaussian box mask ---------------------------------------------------------------------------
@@ -455,11 +510,10 @@ extern "C" int ud_distill_box_fwd(int kind, const float* s, const int64_t* s_str
   if (B <= 0 || M <= 0 || C <= 0 || H <= 0 || W <= 0 || (kind != 0 && kind != 1))
     return UD_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  MapViewW none{nullptr, 0, 0, 0, 0};
   if (kind == 0) {
     UdProfScope prof("distill.k_feat", stream);
     k_feat<false><<<B * M, 256, 0, stream>>>(mv(s, s_strides), mv(t, t_strides), corners_px, valid,
-                                             M, C, H, W, box_loss, none, nullptr);
+                                             M, C, H, W, box_loss, nullptr, nullptr);
   } else {
     const size_t lds = (size_t)(18 * C + 81 + 18 + 4) * sizeof(float);
     if (lds > 160 * 1024) return UD_ERR_UNSUPPORTED;
@@ -468,29 +522,39 @@ extern "C" int ud_distill_box_fwd(int kind, const float* s, const int64_t* s_str
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     UdProfScope prof("distill.k_rel", stream);
     k_rel<false><<<B * M, 256, lds, stream>>>(mv(s, s_strides), mv(t, t_strides), corners_px, valid,
-                                              M, C, H, W, box_loss, none, nullptr);
+                                              M, C, H, W, box_loss, nullptr, nullptr);
   }
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
 
-// Backward w.r.t. the student map: gs (pre-zeroed by the caller, strides gs_strides) +=
+// Backward w.r.t. the student map: gs (pre-zeroed by the caller, strides gs_strides) =
 // d(sum_boxes box_loss * (*gscale))/ds.  gscale is a DEVICE scalar (upstream grad / normaliser),
-// so no host sync is needed between the losses and their backward.
+// so no host sync is needed between the losses and their backward.  Two launches: the per-(box, key point, channel)
+// gradients into `workspace` (ud_distill_box_bwd_workspace_bytes), then their deterministic scatter (k_box_scatter).
+extern "C" size_t ud_distill_box_bwd_workspace_bytes(int B, int M, int C) {
+  if (B <= 0 || M <= 0 || C <= 0) return 0;
+  return ud_align_up((size_t)B * M * 9 * C * sizeof(float));
+}
+
 extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_strides,
                                   const float* t, const int64_t* t_strides,
                                   const float* corners_px, const unsigned char* valid, int B, int M,
                                   int C, int H, int W, const float* gscale, float* gs,
-                                  const int64_t* gs_strides, ud_stream_t stream_) {
+                                  const int64_t* gs_strides, void* workspace, size_t workspace_bytes,
+                                  ud_stream_t stream_) {
   if (!s || !t || !s_strides || !t_strides || !corners_px || !valid || !gscale || !gs || !gs_strides)
     return UD_ERR_INVALID_ARG;
   if (B <= 0 || M <= 0 || C <= 0 || H <= 0 || W <= 0 || (kind != 0 && kind != 1))
     return UD_ERR_INVALID_ARG;
+  if (M * 36 > kMaxTerms || (long long)H * W >= (1 << 21)) return UD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ud_distill_box_bwd_workspace_bytes(B, M, C)) return UD_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
+  float* dkp = reinterpret_cast<float*>(workspace);
   MapViewW g{gs, gs_strides[0], gs_strides[1], gs_strides[2], gs_strides[3]};
   if (kind == 0) {
     k_feat<true><<<B * M, 256, 0, stream>>>(mv(s, s_strides), mv(t, t_strides), corners_px, valid,
-                                            M, C, H, W, nullptr, g, gscale);
+                                            M, C, H, W, nullptr, dkp, gscale);
   } else {
     const size_t lds = (size_t)(18 * C + 81 + 18 + 4) * sizeof(float);
     if (lds > 160 * 1024) return UD_ERR_UNSUPPORTED;
@@ -498,8 +562,10 @@ extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_str
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_rel<true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_rel<true><<<B * M, 256, lds, stream>>>(mv(s, s_strides), mv(t, t_strides), corners_px, valid,
-                                             M, C, H, W, nullptr, g, gscale);
+                                             M, C, H, W, nullptr, dkp, gscale);
   }
+  UD_LAUNCH_CHECK();
+  k_box_scatter<<<dim3(B, ud_div_up(C, 256)), 256, 0, stream>>>(dkp, corners_px, valid, M, C, H, W, g);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

@@ -63,10 +63,12 @@ class _BoxDistill(torch.autograd.Function):
         M = corners.shape[1]
         gscale = (gloss / den).reshape(1).float().contiguous()
         gs = torch.zeros_like(s)
-        _lib.check(_lib.load().ud_distill_box_bwd(ctx.kind, _lib.ptr(s), _strides(s), _lib.ptr(t),
-                                                  _strides(t), _lib.ptr(corners), _lib.ptr(valid_u8),
-                                                  B, M, C, H, W, _lib.ptr(gscale), _lib.ptr(gs),
-                                                  _strides(gs), _lib.stream_of(s)),
+        lib = _lib.load()
+        ws = _lib.workspace(s.device, lib.ud_distill_box_bwd_workspace_bytes(B, M, C), "distill_bwd")
+        _lib.check(lib.ud_distill_box_bwd(ctx.kind, _lib.ptr(s), _strides(s), _lib.ptr(t),
+                                          _strides(t), _lib.ptr(corners), _lib.ptr(valid_u8),
+                                          B, M, C, H, W, _lib.ptr(gscale), _lib.ptr(gs),
+                                          _strides(gs), _lib.ptr(ws), ws.numel(), _lib.stream_of(s)),
                    "ud_distill_box_bwd")
         return None, gs, None, None, None, None
 

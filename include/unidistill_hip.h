@@ -311,18 +311,21 @@ int ud_distill_box_corners(const float* gt, int B, int M, int S, double pc_min_x
  * kind 0 = FeatureDistillLoss (distill_lidar.py:196-245), kind 1 = BEVDistillLoss (:248-323).
  * s / t: student / teacher BEV maps [B,C,H,W] addressed through host element strides
  * int64[4] = (sb, sc, sy, sx).  Forward writes box_loss f32[B,M] (per-box loss, 0 for invalid boxes;
- * the scalar loss is sum(box_loss) / (reduce_mean(n_valid) + 1e-4)).  Backward accumulates
- * (*gscale) * d sum(box_loss)/ds into the pre-zeroed gs (gscale: DEVICE scalar).
+ * the scalar loss is sum(box_loss) / (reduce_mean(n_valid) + 1e-4)).  Backward writes
+ * (*gscale) * d sum(box_loss)/ds into the pre-zeroed gs (gscale: DEVICE scalar): per-(box, key point, channel) gradients
+ * into `workspace` (>= ud_distill_box_bwd_workspace_bytes), then a sorted, atomic-free scatter of the overlapping bilinear
+ * footprints (fixed summation order: bitwise reproducible).  M <= 56.
  */
 int ud_distill_box_fwd(int kind, const float* s, const int64_t* s_strides, const float* t,
                        const int64_t* t_strides, const float* corners_px,
                        const unsigned char* valid, int B, int M, int C, int H, int W,
                        float* box_loss, ud_stream_t stream);
+size_t ud_distill_box_bwd_workspace_bytes(int B, int M, int C);
 int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_strides, const float* t,
                        const int64_t* t_strides, const float* corners_px,
                        const unsigned char* valid, int B, int M, int C, int H, int W,
                        const float* gscale, float* gs, const int64_t* gs_strides,
-                       ud_stream_t stream);
+                       void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* calculate_box_mask_gaussian (distill_lidar.py:100-178) on the device: mask f32[B,H,W]. */
 size_t ud_distill_mask_workspace_bytes(int B, int M);
