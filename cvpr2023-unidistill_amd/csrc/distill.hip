@@ -262,16 +262,20 @@ __global__ __launch_bounds__(256) void k_rel(MapView s, MapView t, const float* 
 // overlap (a small box puts all nine key points into one or two BEV cells; neighbouring boxes share pixels), so adding
 // the terms with float atomics -- the first version -- made the sum depend on the arrival order whenever three or more
 // terms met (a run-to-run difference of one ulp in every gradient upstream, seen as a flaky bit-reproducibility test on
-// cold GPUs).  Here every (m, kp, i) term of a sample gets the key (pixel, term index); one workgroup per (sample, 256
-// channels) sorts the <= 2048 keys in LDS (bitonic) and every thread walks the sorted list for its channel, adding the terms
-// of a pixel in term order and storing each pixel once: no atomics, fixed order.
+// cold GPUs).  Here every (m, kp, i) term of a sample gets the key (pixel, term index); a workgroup sorts the <= 2048 keys of
+// its sample in LDS (bitonic), finds the runs of equal pixels, and its waves take runs in turn: a lane (= channel) adds the
+// terms of a pixel in term order and stores the pixel once -- no atomics, fixed order.  (sample, 64 channels, 1/8 of the runs)
+// per workgroup: the sort is repeated by the workgroups of a sample, which is cheaper than a second launch.
 constexpr int kMaxTerms = 2048;
+constexpr int kRunSplit = 8;                   // workgroups sharing the pixels of one (sample, 64 channels)
 __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ dkp, const float* __restrict__ corners,
                                                      const unsigned char* __restrict__ valid, int M, int C, int H,
                                                      int W, MapViewW gs) {
   __shared__ unsigned keys[kMaxTerms];
   __shared__ float wts[kMaxTerms];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ unsigned short starts[kMaxTerms + 1];     // first sorted index of every pixel's run of terms
+  __shared__ int s_wave[4], s_runs;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nterm = M * 36;
   for (int t = tid; t < kMaxTerms; t += 256) {
     unsigned key = 0xFFFFFFFFu;
@@ -305,23 +309,59 @@ __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ d
       }
       __syncthreads();
     }
-  const int c = blockIdx.y * 256 + tid;
-  if (c >= C) return;
-  float* base = gs.p + b * gs.sb + c * gs.sc;
-  float acc = 0.f;
-  int cur = -1;
-  for (int i = 0; i < nterm; ++i) {
+  // run starts: thread t owns sorted entries [8t, 8t + 8); block-wide exclusive scan of the per-thread start counts
+  int cnt = 0;
+  unsigned flags = 0u;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = tid * 8 + e;
     const unsigned key = keys[i];
-    if (key == 0xFFFFFFFFu) break;
-    const int pix = (int)(key >> 11), t = (int)(key & 2047u);
-    if (pix != cur) {
-      if (cur >= 0) base[(cur / W) * gs.sy + (cur % W) * gs.sx] = acc;
-      cur = pix;
-      acc = 0.f;
-    }
-    acc += dkp[((size_t)(b * M + t / 36) * 9 + ((t % 36) >> 2)) * C + c] * wts[t];
+    const bool st = key != 0xFFFFFFFFu && (i == 0 || (keys[i - 1] >> 11) != (key >> 11));
+    flags |= (unsigned)st << e;
+    cnt += st;
   }
-  if (cur >= 0) base[(cur / W) * gs.sy + (cur % W) * gs.sx] = acc;
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int off = inc - cnt;
+  for (int w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if ((flags >> e) & 1u) starts[off++] = (unsigned short)(tid * 8 + e);
+  if (tid == 255) s_runs = off;                   // total number of runs
+  // number of valid (sorted-to-the-front) entries = end of the last run
+  __syncthreads();
+  const int nruns = s_runs;
+  if (tid == 0) {
+    int n = 0;                                      // binary search for the first invalid key
+    int lo = 0, hi = kMaxTerms;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (keys[mid] == 0xFFFFFFFFu) hi = mid; else lo = mid + 1;
+    }
+    n = lo;
+    starts[nruns] = (unsigned short)n;
+  }
+  __syncthreads();
+  const int c = blockIdx.y * 64 + lane;
+  if (c >= C) return;
+  float* __restrict__ base = gs.p + b * gs.sb + c * gs.sc;
+  const float* __restrict__ dk = dkp + (size_t)b * M * 9 * C + c;
+  for (int r = blockIdx.z + kRunSplit * wave; r < nruns; r += kRunSplit * 4) {
+    const int i0 = starts[r], i1 = starts[r + 1];
+    const int pix = (int)(keys[i0] >> 11);
+    float acc = 0.f;
+    for (int i = i0; i < i1; ++i) {
+      const int t = (int)(keys[i] & 2047u);
+      acc += dk[(size_t)((t / 36) * 9 + ((t % 36) >> 2)) * C] * wts[t];
+    }
+    base[(pix / W) * gs.sy + (pix % W) * gs.sx] = acc;
+  }
 }
 
 // ---- gaussian box mask ---------------------------------------------------------------------------
@@ -565,7 +605,7 @@ extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_str
                                              M, C, H, W, nullptr, dkp, gscale);
   }
   UD_LAUNCH_CHECK();
-  k_box_scatter<<<dim3(B, ud_div_up(C, 256)), 256, 0, stream>>>(dkp, corners_px, valid, M, C, H, W, g);
+  k_box_scatter<<<dim3(B, ud_div_up(C, 64), kRunSplit), 256, 0, stream>>>(dkp, corners_px, valid, M, C, H, W, g);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
