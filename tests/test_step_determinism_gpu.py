@@ -2,7 +2,8 @@
 ("gradient agreement") and reproducible with tools/grad_cosine.py.
 
 Findings the tests pin:
-  * every hand-written kernel is order-deterministic (no fp atomics): with the libraries' strided /
+  * every hand-written kernel is order-deterministic (no fp atomics -- the last one, the scatter of the distillation
+    losses' backward, was replaced by a sorted scatter at the end of round 2): with the libraries' strided /
     transposed convolutions switched to their deterministic algorithms the WHOLE bf16 step -- loss and every
     gradient -- is bitwise reproducible, also with the frozen teacher on a second stream (a race detector);
   * without that switch MIOpen's stride-2 convolutions differ by ~3e-6 from run to run, and the randomly
