@@ -22,6 +22,7 @@
 // instruction immediate (see k_conv3x3_taps for the counters that motivated it).
 #include "ud_common.h"
 #include "ud_prof.h"
+#include "conv_pixmap.h"
 
 namespace {
 
@@ -35,49 +36,6 @@ constexpr int kAInstr = kHQP / 8;            // 1-KiB direct-to-LDS pieces of a 
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// Row p, element k of a VIRTUAL channels-last matrix [P'][K'] -> element offset in the physical tensor.  Lets the 1x1
-// kernels (forward / data gradient / weight gradient) run the convolutions whose im2col is a pure permutation:
-//   mode 0  identity: p * K + k
-//   mode 1  space-to-depth of x[B,H,W,C] with block s (conv k = s, stride s: K' = s*s*C, k = (dy, dx, c); the output
-//           side of a transposed conv k = s, stride s is the same map): p = (b, oy, ox) ->
-//           ((b*H + s*oy + k / (s*C)) * W + s*ox) * C + k % (s*C)
-//   mode 2  spatial subsampling by s (1x1 conv with stride s: K' = C): ((b*H + s*oy) * W + s*ox) * C + k
-//   mode 3  im2col of a 3x3 / pad 1 / stride s convolution (input side only; K' = 9*C, k = (tap, c)):
-//           pixel (s*oy + ty - 1, s*ox + tx - 1), kNoPixel outside the tensor (the kernels read zeros there)
-//   mode 4  data gradient of the same convolution (s = 2) for the input pixels of one parity class (a, b) = (y & 1,
-//           x & 1): row p = (batch, i, j) is input pixel (2i + a, 2j + b); an even coordinate is reached by the centre
-//           tap only, an odd one by taps 0 and 2, so K' = (1 + a)(1 + b) * C with k = (jy, jx, c) and the source
-//           pixel of dy [B,H,W,C] is (i + a*(1 - jy), j + b*(1 - jx)), kNoPixel outside (input side only)
-// Modes 2 and 4 address pixel (s*oy + a, s*ox + b): (a, b) is the class offset (0, 0 for a plain strided 1x1).
-constexpr size_t kNoPixel = ~(size_t)0;
-struct PixMap {
-  int mode, s, Ho, Wo, H, W, C, a, b;
-  __device__ __forceinline__ size_t off(long long p, int k, int K) const {
-    if (mode == 0) return (size_t)p * K + k;
-    const int ox = (int)(p % Wo);
-    const long long t = p / Wo;
-    const int oy = (int)(t % Ho), b = (int)(t / Ho);
-    if (mode == 4) {
-      const int tapi = k / C, c = k - tapi * C, nx = 1 + this->b;
-      const int jy = tapi / nx, jx = tapi - jy * nx;
-      const int sy = oy + a * (1 - jy), sx = ox + this->b * (1 - jx);
-      if (sy >= H || sx >= W) return kNoPixel;
-      return ((size_t)(b * H + sy) * W + sx) * C + c;
-    }
-    if (mode == 3) {
-      const int tap = k / C, c = k - tap * C;
-      const int iy = s * oy + tap / 3 - 1, ix = s * ox + tap % 3 - 1;
-      if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return kNoPixel;
-      return ((size_t)(b * H + iy) * W + ix) * C + c;
-    }
-    if (mode == 1) {
-      const int sc = s * C, dy = k / sc, r = k - dy * sc;
-      return ((size_t)(b * H + s * oy + dy) * W + (size_t)s * ox) * C + r;
-    }
-    return ((size_t)(b * H + s * oy + a) * W + (size_t)s * ox + this->b) * C + k;
-  }
-};
 
 struct ConvGeom {
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
@@ -1185,18 +1143,6 @@ extern "C" int ud_conv3x3_bnstats_nhwc_bf16(const void* x, const void* w, void* 
                       stream);
 }
 
-static bool map_from_ints(const int* m, PixMap* out) {
-  *out = PixMap{};
-  if (!m || m[0] == 0) return true;
-  *out = PixMap{m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]};
-  if (!((m[0] >= 1 && m[0] <= 4) && m[1] >= 1 && m[2] > 0 && m[3] > 0 && m[6] > 0 && m[6] % 8 == 0)) return false;
-  if (m[7] < 0 || m[8] < 0 || m[7] >= m[1] || m[8] >= m[1] || (m[0] != 2 && m[0] != 4 && (m[7] || m[8]))) return false;
-  if (m[0] == 3) return m[6] % 64 == 0 && m[4] > 0 && m[5] > 0;                    // a 64-channel slice inside one tap
-  if (m[0] == 4) return m[1] == 2 && m[6] % 64 == 0 && m[4] > 0 && m[5] > 0;
-  if (m[0] == 1) return m[4] >= m[1] * m[2] && m[5] >= m[1] * m[3];            // every s x s block inside the tensor
-  return m[4] > m[1] * (m[2] - 1) + m[7] && m[5] > m[1] * (m[3] - 1) + m[8];       // every sampled pixel inside
-}
-
 static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
                         const float* bias, const float* scale, const float* shift,
                         const void* residual, int relu, const PixMap& imap, const PixMap& omap,
@@ -1266,7 +1212,8 @@ extern "C" int ud_conv1x1_bnstats_nhwc_bf16(const void* x, const void* w, void* 
 extern "C" int ud_conv1x1_mapped_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
                                            const int* in_map, const int* out_map, ud_stream_t stream) {
   PixMap im, om;
-  if (!map_from_ints(in_map, &im) || !map_from_ints(out_map, &om)) return UD_ERR_INVALID_ARG;
+  if (!map_from_ints(in_map, &im, 64) || !map_from_ints(out_map, &om, 64)) return UD_ERR_INVALID_ARG;
+  if ((im.mode && im.C % 8) || (om.mode && om.C % 8)) return UD_ERR_INVALID_ARG;
   if (im.mode == 1 && (im.s * im.C) % 64 != 0) return UD_ERR_UNSUPPORTED;   // a 64-channel slice must not straddle dy
   if (im.mode == 1 && im.s * im.s * im.C != Cin) return UD_ERR_INVALID_ARG;
   if (im.mode == 2 && im.C != Cin) return UD_ERR_INVALID_ARG;
@@ -1375,7 +1322,8 @@ extern "C" int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, 
                                                  int Cout, const int* x_map, const int* dy_map, void* workspace,
                                                  size_t workspace_bytes, ud_stream_t stream) {
   PixMap xm, ym;
-  if (!map_from_ints(x_map, &xm) || !map_from_ints(dy_map, &ym)) return UD_ERR_INVALID_ARG;
+  if (!map_from_ints(x_map, &xm, 64) || !map_from_ints(dy_map, &ym, 64)) return UD_ERR_INVALID_ARG;
+  if ((xm.mode && xm.C % 8) || (ym.mode && ym.C % 8)) return UD_ERR_INVALID_ARG;
   if (xm.mode == 1 && ((xm.s * xm.C) % 64 != 0 || xm.s * xm.s * xm.C != Cin)) return UD_ERR_UNSUPPORTED;
   if (xm.mode == 2 && xm.C != Cin) return UD_ERR_INVALID_ARG;
   if (xm.mode == 3 && 9 * xm.C != Cin) return UD_ERR_INVALID_ARG;

@@ -16,6 +16,7 @@
 // permutation of the slice's channels that A and B share, so the sum is the same.
 #include "ud_common.h"
 #include "ud_prof.h"
+#include "conv_pixmap.h"
 #include <cstdlib>
 
 namespace {
@@ -28,6 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvGeomF {
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
   long long npix;
+  PixMap imap, omap;   // mapped 1x1 launches only (mode 0 everywhere else)
 };
 struct ConvEpF {
   const float* bias;
@@ -84,7 +86,8 @@ __device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float*
       const float4 sh = *reinterpret_cast<const float4*>(ep.shift + n);
       v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
     }
-    const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+    const size_t off = gm.omap.mode ? gm.omap.off((long long)(b * gm.H + gy) * gm.W + gx, n, gm.Cout)
+                                    : ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
     if (ep.residual) {
       const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
       v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
@@ -341,6 +344,137 @@ __global__ __launch_bounds__(256) void k_conv1x1_f32_line(const float* __restric
   store_tile_f32<TN, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep, tile);
 }
 
+// 1x1 over a pixel map, fp32 twin of k_conv1x1_mapped (conv2d.hip): strided / transposed / im2col launches of the fp32 mode.
+// Source of (pixel p, 32-channel slice k0) = x + base(p) + koff(k0) under a range test, base / py / px per lane (once),
+// koff / dy / dx uniform and advanced incrementally per slice.
+template <int TN>
+__global__ __launch_bounds__(256) void k_conv1x1_mapped_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, ConvGeomF gm, ConvEpF ep) {
+  constexpr int WM = TN == 128 ? 2 : 4, RW = 8 / WM, NB = TN / 32;
+  constexpr int kABytes = kTM * 128, kBBytes = TN * 128, kBOff = 2 * kABytes;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
+  const int ntiles = gm.tiles_y;
+  const int per = (ntiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int n0 = blockIdx.y * TN;
+  const float* zero = reinterpret_cast<const float*>(g_zero16f);
+  const PixMap& im = gm.imap;
+  const int mode = im.mode;
+
+  f32x4 acc[RW][4];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int r8 = lane >> 3, slot = lane & 7;
+  const float* pa[4];
+  int py[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 4 * i) * 8 + r8;
+    long long p = (long long)tile * kTM + r;
+    if (p >= gm.npix) p = gm.npix - 1;           // rows past the last pixel re-read it (never stored)
+    py[i] = px[i] = 0;
+    if (mode == 0) {                             // plain input, mapped output (transposed convolution)
+      pa[i] = x + (size_t)p * gm.Cin + ((slot ^ (r & 7)) << 2);
+      continue;
+    }
+    const int ox = (int)(p % im.Wo);
+    const long long t = p / im.Wo;
+    const int oy = (int)(t % im.Ho), b = (int)(t / im.Ho);
+    int y0, x0;
+    if (mode == 4) { y0 = oy; x0 = ox; }
+    else if (mode == 2) { y0 = im.s * oy + im.a; x0 = im.s * ox + im.b; }
+    else { y0 = im.s * oy; x0 = im.s * ox; }
+    pa[i] = x + ((size_t)(b * im.H + y0) * im.W + x0) * im.C + ((slot ^ (r & 7)) << 2);
+    if (mode >= 3) { py[i] = y0; px[i] = x0; }
+  }
+  const float* pb[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave + 4 * j) * 8 + r8;
+    const size_t row = (size_t)min(n0 + n, gm.Cout - 1);     // channels past Cout re-read the last one (never stored)
+    pb[j] = w + (mode == 4 ? row * 9 * im.C : row * gm.Cin) + ((slot ^ (n & 7)) << 2);
+  }
+  const int seg_len = mode == 1 ? im.s * im.C : (mode >= 3 ? im.C : gm.Cin);
+  int seg = 0, c = 0;
+  auto stage = [&](int buf) {
+    long long koff;
+    int dy = 0, dx = 0, wk;
+    if (mode == 1) {
+      koff = (long long)seg * im.W * im.C + c;
+      wk = seg * seg_len + c;
+    } else if (mode == 3) {
+      const int ty = seg / 3, tx = seg - 3 * ty;
+      dy = ty - 1; dx = tx - 1;
+      koff = ((long long)dy * im.W + dx) * im.C + c;
+      wk = seg * seg_len + c;
+    } else if (mode == 4) {
+      const int nx = 1 + im.b, jy = seg / nx, jx = seg - jy * nx;
+      dy = im.a * (1 - jy); dx = im.b * (1 - jx);
+      koff = ((long long)dy * im.W + dx) * im.C + c;
+      const int ty = im.a ? 2 * jy : 1, tx = im.b ? 2 * jx : 1;
+      wk = (ty * 3 + tx) * im.C + c;
+    } else {
+      koff = c;
+      wk = c;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = mode < 3 || ((unsigned)(py[i] + dy) < (unsigned)im.H && (unsigned)(px[i] + dx) < (unsigned)im.W);
+      dma16(ok ? pa[i] + koff : zero, reinterpret_cast<float*>(smem + buf * kABytes + (wave + 4 * i) * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      dma16(pb[j] + wk, reinterpret_cast<float*>(smem + kBOff + buf * kBBytes + (wave + 4 * j) * 1024));
+    c += kKC;
+    if (c == seg_len) { c = 0; ++seg; }
+  };
+  unsigned sa[2], sb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    sa[ks] = (RW * wm * 16 + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+    sb[ks] = kBOff + (64 * wn + li) * 128 + (((4 * ks + g) ^ (li & 7)) << 4);
+  }
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 a[RW];
+#pragma unroll
+      for (int ti = 0; ti < RW; ++ti) a[ti] = *reinterpret_cast<const f32x4*>(smem + sa[ks] + buf * kABytes + ti * 2048);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(smem + sb[ks] + buf * kBBytes + tj * 2048);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ti = 0; ti < RW; ++ti)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti][e], bb[e], acc[ti][tj], 0, 0, 0);
+      }
+    }
+  };
+  const int nchunks = gm.Cin / kKC;
+  stage(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    if (chunk + 1 < nchunks) stage(1);
+    mma(0);
+    __syncthreads();
+    if (chunk + 1 < nchunks) {
+      if (chunk + 2 < nchunks) stage(0);
+      mma(1);
+      __syncthreads();
+    }
+  }
+  store_tile_f32<TN, RW>(acc, reinterpret_cast<float*>(smem), tid, wm, wn, g, li, 0, tile * kTH, 0, n0, y, gm, ep, tile);
+}
+
 template <int KS>
 int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, const ConvEpF& ep, int ntiles,
                const char* name, hipStream_t stream, size_t stats_bytes = 0, int* slices_out = nullptr) {
@@ -458,4 +592,43 @@ extern "C" int ud_conv1x1_nhwc_f32(const float* x, const float* w, float* y, int
   ConvGeomF gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P};
   ConvEpF ep{bias, scale, shift, residual, flags & 1, 0};
   return launch_f32<1>(x, w, y, gm, ep, gm.tiles_y, "conv2d.k_conv1x1_f32", (hipStream_t)stream_);
+}
+
+// fp32 twin of ud_conv1x1_mapped_nhwc_bf16: 1x1 kernel over a mapped input and / or output (strided, transposed and
+// im2col launches of the fp32 mode; forward and data gradient).  Map channels % 4 == 0, Cin % 32 == 0, Cout % 4 == 0; a
+// 32-channel slice must not straddle a tap / block row.
+extern "C" int ud_conv1x1_mapped_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
+                                          const int* in_map, const int* out_map, ud_stream_t stream_) {
+  if (!x || !w || !y || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  PixMap im, om;
+  if (!map_from_ints(in_map, &im, kKC) || !map_from_ints(out_map, &om, kKC)) return UD_ERR_INVALID_ARG;
+  if (Cin % kKC != 0 || Cout % 4 != 0 || P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;
+  if (im.mode == 1 && (im.s * im.C) % kKC != 0) return UD_ERR_UNSUPPORTED;
+  if (im.mode == 1 && im.s * im.s * im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (im.mode == 2 && im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (im.mode == 3 && 9 * im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (im.mode == 4 && (1 + im.a) * (1 + im.b) * im.C != Cin) return UD_ERR_INVALID_ARG;
+  if (om.mode >= 3) return UD_ERR_UNSUPPORTED;
+  if (om.mode == 1 && om.s * om.s * om.C != Cout) return UD_ERR_INVALID_ARG;
+  if (om.mode == 2 && om.C != Cout) return UD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = (int)((P + kTW - 1) / kTW);
+  ConvGeomF gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P, im, om};
+  ConvEpF ep{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+  static bool attr_set = false;
+  if (!attr_set) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped_f32<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes_f(128)));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)conv_smem_bytes_f(64)));
+    attr_set = true;
+  }
+  const int ntiles = gm.tiles_y;
+  UdProfScope prof("conv2d.k_conv1x1_f32", stream);
+  const bool narrow = Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256;
+  const dim3 grid((ntiles + 7) / 8 * 8, ud_div_up(Cout, narrow ? 64 : 128));
+  if (narrow) k_conv1x1_mapped_f32<64><<<grid, 256, conv_smem_bytes_f(64), stream>>>(x, w, y, gm, ep);
+  else k_conv1x1_mapped_f32<128><<<grid, 256, conv_smem_bytes_f(128), stream>>>(x, w, y, gm, ep);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
 }

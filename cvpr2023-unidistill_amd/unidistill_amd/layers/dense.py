@@ -65,6 +65,14 @@ def _fp32_kernel_pays(conv, x):
     return conv.out_channels % 64 != 0 or px >= 1024
 
 
+# fp32 mode: strided / transposed convolutions on the fp32 mapped kernel (forward + data gradient; weight gradient: library)
+_FP32_MAPPED = os.environ.get("UD_FP32_MAPPED", "1") != "0"
+
+
+def _fp32_mapped(x):
+    return _FP32_MAPPED and Conv2d.hip_fp32 and _fp32_mode(x)
+
+
 class Conv2d(nn.Conv2d):
     hip_enabled = True          # class-wide switch (tests / A-B timing)
     # fp32 MFMA kernels for the fp32 (reference) mode: False / True (where they pay) / "all"
@@ -86,6 +94,10 @@ class Conv2d(nn.Conv2d):
                 return hipconv32.conv3x3(x, self.weight, self.bias, bn_stats)
             if _is1x1(self) and hipconv32.supported(x, self.weight, 1) and _fp32_kernel_pays(self, x):
                 return hipconv32.conv1x1(x, self.weight, self.bias, bn_stats)
+            if _FP32_MAPPED:
+                y = self._hip_permutation_conv(x)       # strided convolutions: fp32 twin of the mapped 1x1 kernel
+                if y is not None:
+                    return y
         return super().forward(x)
 
     def _hip_permutation_conv(self, x):
@@ -136,7 +148,7 @@ class ConvTranspose2d(nn.ConvTranspose2d):
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0
                 and x.is_contiguous(memory_format=torch.channels_last)):
             return hipconv.conv1x1(x.to(torch.bfloat16), self.weight.permute(1, 0, 2, 3), self.bias)
-        if (Conv2d.hip_enabled and output_size is None and x.dim() == 4 and _mixed_precision(x)
+        if (Conv2d.hip_enabled and output_size is None and x.dim() == 4 and (_mixed_precision(x) or _fp32_mapped(x))
                 and self.kernel_size[0] == self.kernel_size[1] == self.stride[0] == self.stride[1] and self.stride[0] >= 2
                 and self.padding == (0, 0) and self.output_padding == (0, 0) and self.dilation == (1, 1)
                 and self.groups == 1 and hipconv.supported_patch(x, self.weight, self.stride[0], transposed=True)):
@@ -188,7 +200,7 @@ class FusedSequential(nn.Sequential):
                     conv, skip = mods[i + 1], 2
                 elif _is3x3(m, 1):
                     conv, skip = m, 1
-            if conv is None and Conv2d.hip_enabled and x.dim() == 4 and _mixed_precision(x) \
+            if conv is None and Conv2d.hip_enabled and x.dim() == 4 and (_mixed_precision(x) or _fp32_mapped(x)) \
                     and isinstance(m, nn.ZeroPad2d) and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < n \
                     and _is3x3_s2(mods[i + 1], 0) and hipconv.supported_3x3_s2(x, mods[i + 1].weight):
                 # ZeroPad2d(1) + unpadded 3x3 / stride 2 (first conv of BaseBEVBackbone's second level) == pad-1 conv

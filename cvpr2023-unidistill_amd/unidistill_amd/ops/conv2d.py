@@ -330,8 +330,25 @@ def _pmap(mode, s, Ho, Wo, H, W, C, a=0, b=0):
 
 
 def _mapped(x, w2d, y, P, K, N, imap, omap):
+    """1x1 kernel over pixel maps; bf16 or (the reference's arithmetic) fp32 by the dtype of x."""
+    if x.dtype == torch.float32:
+        _lib.check(_lib.load().ud_conv1x1_mapped_nhwc_f32(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), P, K, N, imap, omap,
+                                                          _lib.stream_of(x)), "ud_conv1x1_mapped_nhwc_f32")
+        return
     _lib.check(_lib.load().ud_conv1x1_mapped_nhwc_bf16(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), P, K, N, imap, omap,
                                                        _lib.stream_of(x)), "ud_conv1x1_mapped_nhwc_bf16")
+
+
+def _cdt(x):
+    """Compute dtype of the mapped convolutions: fp32 tensors outside autocast stay fp32 (fp32 MFMA kernels; their weight
+    gradient goes through the library), everything else runs in bf16."""
+    return torch.float32 if (x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")) else torch.bfloat16
+
+
+def _lib_wgrad(x, gy, weight, stride, padding, transposed=False):
+    """fp32 mode: weight gradient of the strided / transposed convolution through the library (MIOpen fp32)."""
+    return torch.ops.aten.convolution_backward(gy, x, weight.detach(), None, [stride, stride], [padding, padding], [1, 1],
+                                               transposed, [0, 0], 1, [False, True, False])[1]
 
 
 def _mapped_wgrad(x, gy, P, K, N, xmap, ymap):
@@ -344,8 +361,8 @@ def _mapped_wgrad(x, gy, P, K, N, xmap, ymap):
     return dw
 
 
-def _bf16_cl_empty(shape, dev, zero=False):
-    t = torch.empty(shape, dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+def _bf16_cl_empty(shape, dev, zero=False, dtype=torch.bfloat16):
+    t = torch.empty(shape, dtype=dtype, device=dev, memory_format=torch.channels_last)
     return t.zero_() if zero else t
 
 
@@ -364,14 +381,15 @@ class _ConvPatchFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, s):
         _lib.require_gpu(x, weight)
-        x = _nhwc(x.to(torch.bfloat16))
+        dt = _cdt(x)
+        x = _nhwc(x.to(dt))
         B, C, H, W = x.shape
         cout = weight.shape[0]
         Ho, Wo = H // s, W // s
         K, P = s * s * C, B * Ho * Wo
-        w2 = _cached(weight, "_ud_patch", lambda w: torch.empty((w.shape[0], s, s, w.shape[1]), dtype=torch.bfloat16,
-                                                                  device=w.device).copy_(w.permute(0, 2, 3, 1)))
-        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device)
+        w2 = _cached(weight, "_ud_patch" + str(dt), lambda w: torch.empty((w.shape[0], s, s, w.shape[1]), dtype=dt,
+                                                                            device=w.device).copy_(w.permute(0, 2, 3, 1)))
+        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device, dtype=dt)
         _mapped(x, w2, y, P, K, cout, _pmap(1, s, Ho, Wo, H, W, C), None)
         ctx.save_for_backward(x, weight)
         ctx.s = s
@@ -381,7 +399,8 @@ class _ConvPatchFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         s = ctx.s
-        gy = _nhwc(gy.to(torch.bfloat16))
+        dt = x.dtype
+        gy = _nhwc(gy.to(dt))
         B, C, H, W = x.shape
         cout = weight.shape[0]
         Ho, Wo = H // s, W // s
@@ -389,16 +408,19 @@ class _ConvPatchFn(torch.autograd.Function):
         pm = _pmap(1, s, Ho, Wo, H, W, C)
         gx = gw = None
         if ctx.needs_input_grad[0] and cout % 64 == 0:
-            wt = _cached(weight, "_ud_patch_t", lambda w: torch.empty((s, s, w.shape[1], w.shape[0]), dtype=torch.bfloat16,
-                                                                        device=w.device).copy_(w.permute(2, 3, 1, 0)))
-            gx = _bf16_cl_empty((B, C, H, W), x.device, zero=(H % s != 0 or W % s != 0))
+            wt = _cached(weight, "_ud_patch_t" + str(dt), lambda w: torch.empty((s, s, w.shape[1], w.shape[0]), dtype=dt,
+                                                                                  device=w.device).copy_(w.permute(2, 3, 1, 0)))
+            gx = _bf16_cl_empty((B, C, H, W), x.device, zero=(H % s != 0 or W % s != 0), dtype=dt)
             _mapped(gy, wt, gx, P, cout, K, None, pm)          # [P][Cout] x [K][Cout]^T -> rows scattered by the map
         elif ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, weight.detach().to(torch.bfloat16), None, [s, s], [0, 0], [1, 1],
+            gx = torch.ops.aten.convolution_backward(gy, x, weight.detach().to(dt), None, [s, s], [0, 0], [1, 1],
                                                      False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = _mapped_wgrad(x, gy, P, K, cout, pm, None)    # [Cout][s][s][C]
-            gw = dw.view(cout, s, s, C).permute(0, 3, 1, 2).to(weight.dtype)
+            if dt == torch.float32:
+                gw = _lib_wgrad(x, gy, weight, s, 0)
+            else:
+                dw = _mapped_wgrad(x, gy, P, K, cout, pm, None)    # [Cout][s][s][C]
+                gw = dw.view(cout, s, s, C).permute(0, 3, 1, 2).to(weight.dtype)
         return gx, gw, None
 
 
@@ -408,13 +430,14 @@ class _ConvTPatchFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, s):
         _lib.require_gpu(x, weight)
-        x = _nhwc(x.to(torch.bfloat16))
+        dt = _cdt(x)
+        x = _nhwc(x.to(dt))
         B, cin, H, W = x.shape
         cout = weight.shape[1]
         N, P = s * s * cout, B * H * W
-        wt = _cached(weight, "_ud_tpatch", lambda w: torch.empty((s, s, w.shape[1], w.shape[0]), dtype=torch.bfloat16,
-                                                                   device=w.device).copy_(w.permute(2, 3, 1, 0)))
-        y = _bf16_cl_empty((B, cout, H * s, W * s), x.device)
+        wt = _cached(weight, "_ud_tpatch" + str(dt), lambda w: torch.empty((s, s, w.shape[1], w.shape[0]), dtype=dt,
+                                                                             device=w.device).copy_(w.permute(2, 3, 1, 0)))
+        y = _bf16_cl_empty((B, cout, H * s, W * s), x.device, dtype=dt)
         _mapped(x, wt, y, P, cin, N, None, _pmap(1, s, H, W, H * s, W * s, cout))
         ctx.save_for_backward(x, weight)
         ctx.s = s
@@ -424,20 +447,24 @@ class _ConvTPatchFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         s = ctx.s
-        gy = _nhwc(gy.to(torch.bfloat16))
+        dt = x.dtype
+        gy = _nhwc(gy.to(dt))
         B, cin, H, W = x.shape
         cout = weight.shape[1]
         N, P = s * s * cout, B * H * W
         pm = _pmap(1, s, H, W, H * s, W * s, cout)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            w2 = _cached(weight, "_ud_tpatch_t", lambda w: torch.empty((w.shape[0], s, s, w.shape[1]), dtype=torch.bfloat16,
-                                                                         device=w.device).copy_(w.permute(0, 2, 3, 1)))
-            gx = _bf16_cl_empty((B, cin, H, W), x.device)
+            w2 = _cached(weight, "_ud_tpatch_t" + str(dt), lambda w: torch.empty((w.shape[0], s, s, w.shape[1]), dtype=dt,
+                                                                                   device=w.device).copy_(w.permute(0, 2, 3, 1)))
+            gx = _bf16_cl_empty((B, cin, H, W), x.device, dtype=dt)
             _mapped(gy, w2, gx, P, N, cin, pm, None)            # rows of dy gathered by the map: [P][N] x [Cin][N]^T
         if ctx.needs_input_grad[1]:
-            dw = _mapped_wgrad(x, gy, P, cin, N, None, pm)      # [s][s][Cout][Cin]
-            gw = dw.view(s, s, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
+            if dt == torch.float32:
+                gw = _lib_wgrad(x, gy, weight, s, 0, transposed=True)
+            else:
+                dw = _mapped_wgrad(x, gy, P, cin, N, None, pm)      # [s][s][Cout][Cin]
+                gw = dw.view(s, s, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
         return gx, gw, None
 
 
@@ -447,12 +474,14 @@ class _Conv1x1StrideFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, s):
         _lib.require_gpu(x, weight)
-        x = _nhwc(x.to(torch.bfloat16))
+        dt = _cdt(x)
+        x = _nhwc(x.to(dt))
         B, cin, H, W = x.shape
         cout = weight.shape[0]
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
-        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device)
-        _mapped(x, _w1x1(weight).view(cout, cin), y, B * Ho * Wo, cin, cout, _pmap(2, s, Ho, Wo, H, W, cin), None)
+        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device, dtype=dt)
+        w2 = weight.detach().reshape(cout, cin).contiguous() if dt == torch.float32 else _w1x1(weight).view(cout, cin)
+        _mapped(x, w2, y, B * Ho * Wo, cin, cout, _pmap(2, s, Ho, Wo, H, W, cin), None)
         ctx.save_for_backward(x, weight)
         ctx.s = s
         return y
@@ -461,7 +490,8 @@ class _Conv1x1StrideFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         s = ctx.s
-        gy = _nhwc(gy.to(torch.bfloat16))
+        dt = x.dtype
+        gy = _nhwc(gy.to(dt))
         B, cin, H, W = x.shape
         cout = weight.shape[0]
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
@@ -469,10 +499,14 @@ class _Conv1x1StrideFn(torch.autograd.Function):
         pm = _pmap(2, s, Ho, Wo, H, W, cin)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _bf16_cl_empty((B, cin, H, W), x.device, zero=True)      # only the sampled pixels receive gradient
-            _mapped(gy, _w1x1_t(weight), gx, P, cout, cin, None, pm)
+            gx = _bf16_cl_empty((B, cin, H, W), x.device, zero=True, dtype=dt)   # only the sampled pixels receive gradient
+            wt = weight.detach().reshape(cout, cin).t().contiguous() if dt == torch.float32 else _w1x1_t(weight)
+            _mapped(gy, wt, gx, P, cout, cin, None, pm)
         if ctx.needs_input_grad[1]:
-            gw = _mapped_wgrad(x, gy, P, cin, cout, pm, None).view(cout, cin, 1, 1).to(weight.dtype)
+            if dt == torch.float32:
+                gw = _lib_wgrad(x, gy, weight, s, 0)
+            else:
+                gw = _mapped_wgrad(x, gy, P, cin, cout, pm, None).view(cout, cin, 1, 1).to(weight.dtype)
         return gx, gw, None
 
 
@@ -497,26 +531,30 @@ class _Conv3x3S2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         _lib.require_gpu(x, weight)
-        x = _nhwc(x.to(torch.bfloat16))
+        dt = _cdt(x)
+        x = _nhwc(x.to(dt))
         B, C, H, W = x.shape
         cout = weight.shape[0]
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device)
-        _mapped(x, tap_major(weight), y, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)
+        y = _bf16_cl_empty((B, cout, Ho, Wo), x.device, dtype=dt)
+        wt = weight.detach().permute(0, 2, 3, 1).contiguous() if dt == torch.float32 else tap_major(weight)
+        _mapped(x, wt, y, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)
         ctx.save_for_backward(x, weight)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gy = _nhwc(gy.to(torch.bfloat16))
+        dt = x.dtype
+        gy = _nhwc(gy.to(dt))
         B, C, H, W = x.shape
         cout = weight.shape[0]
         Ho, Wo = gy.shape[2], gy.shape[3]
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            wtt = tap_major_transposed(weight)        # [C][3][3][Cout]: the kernel picks each class's taps from it
-            gx = _bf16_cl_empty((B, C, H, W), x.device)
+            # [C][3][3][Cout]: the kernel picks each class's taps from it
+            wtt = weight.detach().permute(1, 2, 3, 0).contiguous() if dt == torch.float32 else tap_major_transposed(weight)
+            gx = _bf16_cl_empty((B, C, H, W), x.device, dtype=dt)
             for a in (0, 1):
                 for b in (0, 1):
                     Hc, Wc = (H - a + 1) // 2, (W - b + 1) // 2
@@ -526,8 +564,11 @@ class _Conv3x3S2Fn(torch.autograd.Function):
                     _mapped(gy, wtt, gx, B * Hc * Wc, K, C, _pmap(4, 2, Hc, Wc, Ho, Wo, cout, a, b),
                             _pmap(2, 2, Hc, Wc, H, W, C, a, b))
         if ctx.needs_input_grad[1]:
-            dw = _mapped_wgrad(x, gy, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)   # [Cout][9][C]
-            gw = dw.view(cout, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype)
+            if dt == torch.float32:
+                gw = _lib_wgrad(x, gy, weight, 2, 1)
+            else:
+                dw = _mapped_wgrad(x, gy, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)   # [Cout][9][C]
+                gw = dw.view(cout, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype)
         return gx, gw
 
 

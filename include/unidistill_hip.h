@@ -481,6 +481,10 @@ int ud_conv1x1_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t
  * ud_conv1x1_wgrad_mapped_nhwc_bf16 with the map on x or dy.  w / dw as in the unmapped calls: [Cout][K] / [Cout][Cin]. */
 int ud_conv1x1_mapped_nhwc_bf16(const void* x, const void* w, void* y, int64_t P, int Cin, int Cout,
                                 const int* in_map, const int* out_map, ud_stream_t stream);
+/* fp32 twin (the reference's arithmetic): forward and data gradient of the strided / transposed convolutions of the fp32
+ * mode on v_mfma_f32_16x16x4_f32; map channels % 4 == 0, Cin % 32 == 0, Cout % 4 == 0, a 32-channel slice inside one tap. */
+int ud_conv1x1_mapped_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
+                               const int* in_map, const int* out_map, ud_stream_t stream);
 int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
                                       const int* x_map, const int* dy_map, void* workspace,
                                       size_t workspace_bytes, ud_stream_t stream);

@@ -136,3 +136,42 @@ def test_conv_f32_random_shapes_vs_library(hip_lib):
                                    atol=3e-5 * float(ref.detach().abs().max()) + 1e-7, err_msg=tag)
         np.testing.assert_allclose(gx.cpu().numpy(), gx_ref.cpu().numpy(), rtol=0,
                                    atol=3e-5 * float(gx_ref.abs().max()) + 1e-7, err_msg=tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,cfg", [("patch", (2, 256, 128, 4, 16, 44)), ("patch", (1, 64, 64, 2, 10, 18)),
+                                      ("tpatch", (2, 256, 256, 2, 12, 20)), ("tpatch", (1, 64, 64, 2, 5, 9)),
+                                      ("s1x1", (2, 256, 512, 2, 16, 44)), ("s1x1", (1, 64, 128, 2, 9, 7)),
+                                      ("s3x3", (2, 128, 128, 2, 32, 88)), ("s3x3", (1, 128, 256, 2, 45, 45)),
+                                      ("s3x3", (2, 64, 64, 2, 9, 7))])
+def test_fp32_strided_and_transposed_convs_on_the_mapped_kernel(hip_lib, kind, cfg):
+    """fp32 mode: conv k = s / stride s, transposed conv k = s / stride s, 1x1 / stride s and 3x3 / stride 2 / pad 1 run
+    forward and data gradient on ud_conv1x1_mapped_nhwc_f32 (weight gradient: library): same numbers as the library's
+    fp32 convolutions up to summation order."""
+    from unidistill_amd.ops import conv2d as c
+    B, cin, cout, s, H, W = cfg
+    torch.manual_seed(sum(cfg))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda")).requires_grad_(True)
+    if kind == "tpatch":
+        w = (torch.randn(cin, cout, s, s, device="cuda") * 0.05).requires_grad_(True)
+        ref = F.conv_transpose2d(x, w, None, s)
+        y = c.conv_transpose_patch(x, w, s)
+    elif kind == "patch":
+        w = (torch.randn(cout, cin, s, s, device="cuda") * 0.05).requires_grad_(True)
+        ref = F.conv2d(x, w, None, s)
+        y = c.conv_patch(x, w, s)
+    elif kind == "s1x1":
+        w = (torch.randn(cout, cin, 1, 1, device="cuda") * 0.05).requires_grad_(True)
+        ref = F.conv2d(x, w, None, s)
+        y = c.conv1x1_strided(x, w, s)
+    else:
+        w = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+        ref = F.conv2d(x, w, None, 2, 1)
+        y = c.conv3x3_stride2(x, w)
+    assert y.dtype == torch.float32 and y.shape == ref.shape
+    gy = _cl(torch.randn_like(ref))
+    gx_ref, gw_ref = torch.autograd.grad(ref, (x, w), gy)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    for a, b, name in ((y, ref, "y"), (gx, gx_ref, "dx"), (gw, gw_ref, "dw")):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=0,
+                                   atol=5e-5 * float(b.detach().abs().max()) + 1e-7, err_msg=f"{kind} {cfg} {name}")
