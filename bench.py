@@ -237,7 +237,10 @@ def voxelize_leg(device):
     big = cases[-1]
     return {"bound": "hbm", "kernel": "ud_voxelize (reference op boundary: voxels[M,10,5] + coords + num), whole op",
             "achieved": big["op_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big["frac_op"],
-            "traffic": None, "cases": cases,
+            # PMC bytes of the four kernels at this size (profiles/r02_pmc_voxelize.md, max = the 1.19 M-point case: FETCH_SIZE x 2
+            # (gfx950 correction) + WRITE_SIZE, KB): 4.7x the algorithmic bytes -- the random 8-byte hash-table accesses of
+            # k_insert / k_first move whole sectors
+            "traffic": 602.7e6 if big["points"] > 1000000 else None, "cases": cases,
             "note": "op-level (memset + 5 launches); per-kernel times are HIP-event brackets incl. ~6 us dispatch. "
                     "The op is bound by random 8-byte hash-table accesses (k_insert), not by streaming bytes: see DESIGN.md"}
 
