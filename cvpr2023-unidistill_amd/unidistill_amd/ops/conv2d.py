@@ -7,6 +7,8 @@ kernels.  ``conv1x1`` covers the 1x1 / stride-1 convolutions of the ResNet bottl
 ud_conv1x1_nhwc_bf16 on maps above 1 k pixels and from the library GEMM below, the weight gradient -- a
 pixel-reduced GEMM that BLAS libraries run on a handful of CUs -- is ud_conv1x1_wgrad_nhwc_bf16.
 """
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -32,7 +34,6 @@ SHAPE_LOG = None         # set to [] to record (B, Cin, H, W, Cout, reverse_taps
 
 def _bn_partial(nbytes, dev):
     """Buffer for the per-tile BatchNorm partials a ``*_bnstats`` convolution writes + the host int it reports."""
-    import ctypes
     return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev), ctypes.c_int(0)
 
 
@@ -48,7 +49,6 @@ def _launch(x, w_tap, cout, bias=None, scale=None, shift=None, residual=None, re
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
     if bn_stats:
-        import ctypes
         lib = _lib.load()
         part, ns = _bn_partial(lib.ud_conv3x3_bnstats_bytes(B, H, W, cout), x.device)
         _lib.check(lib.ud_conv3x3_bnstats_nhwc_bf16(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
@@ -225,7 +225,6 @@ def _launch1x1(x, w2d, cout, bias=None, scale=None, shift=None, residual=None, r
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     if bn_stats:
-        import ctypes
         lib = _lib.load()
         part, ns = _bn_partial(lib.ud_conv1x1_bnstats_bytes(B * H * W, cout), x.device)
         _lib.check(lib.ud_conv1x1_bnstats_nhwc_bf16(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), B * H * W, cin, cout,

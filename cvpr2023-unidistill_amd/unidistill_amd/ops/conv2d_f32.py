@@ -4,6 +4,8 @@ trunk, head, fusion conv and the ResNet / neck convs (base_bev_backbone.py:30-11
 BEVFusion_nuscenes_base_exp.py:107-135, lss_fpn.py:143-149).  Forward and data gradient are hand-written;
 the weight gradient of the fp32 mode goes through aten.convolution_backward.
 """
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -21,7 +23,6 @@ def supported(x, weight, ks):
 
 
 def _bn_partial(nbytes, dev):
-    import ctypes
     return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev), ctypes.c_int(0)
 
 
@@ -29,7 +30,6 @@ def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False, bn_stats
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if bn_stats:      # + per-tile (sum, sum of squares) for the BatchNorm that follows: (y, (partial, slices, rows))
-        import ctypes
         lib = _lib.load()
         part, ns = _bn_partial(lib.ud_conv3x3_bnstats_bytes(B, H, W, cout), x.device)
         _lib.check(lib.ud_conv3x3_bnstats_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
@@ -48,7 +48,6 @@ def _launch1(x, w, cout, bias=None, residual=None, bn_stats=False):
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if bn_stats:
-        import ctypes
         lib = _lib.load()
         part, ns = _bn_partial(lib.ud_conv1x1_bnstats_bytes(B * H * W, cout), x.device)
         _lib.check(lib.ud_conv1x1_bnstats_nhwc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), B * H * W, cin, cout,
