@@ -61,6 +61,13 @@ def _launch1(x, w, cout, bias=None, residual=None, bn_stats=False):
     return y
 
 
+def weight_grad(x, gy, w, ks):
+    """dW of a stride-1 'same' convolution; x, gy channels-last fp32, w [Cout, Cin, ks, ks]."""
+    p = ks // 2
+    return torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+                                               [False, True, False])[1]
+
+
 class _ConvF32(torch.autograd.Function):
     """with_skip (1x1 only): the function also returns its input (an alias) for the caller's identity branch, so that the
     gradient arriving through that branch is added in the data-gradient kernel's epilogue instead of by a separate
@@ -107,8 +114,7 @@ class _ConvF32(torch.autograd.Function):
                 gx = _launch1(gy, w.reshape(weight.shape[0], weight.shape[1]).t().contiguous(), weight.shape[1],
                               residual=gskip)
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            gw = weight_grad(x, gy, w, ks)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
         return gx, gw, gb, None, None, None

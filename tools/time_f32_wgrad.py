@@ -1,0 +1,49 @@
+"""fp32 mode: which weight gradients does one distillation step run, and what does each cost?
+
+Logs the (B, Cin, H, W, Cout, ks) of every ops.conv2d_f32.weight_grad call of one step, then times each distinct shape
+alone (HIP events, 10 repeats after 3 warm-ups) and prints time, count per step and TFLOP/s.
+"""
+import os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]
+import torch
+from unidistill_amd import train
+from unidistill_amd.ops import conv2d_f32 as cf
+
+B = int(os.environ.get("B", 4))
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+step = train.DistillStep(os.environ.get("WL", "camera_exp_distill_lidar"))
+batch = train.synthetic_batch(dev, B)
+tr = train.Trainer(step, device=dev, autocast_dtype=None, channels_last=True)
+for _ in range(2):
+    tr.step(batch)
+log = []
+orig = cf.weight_grad
+def logged(x, gy, w, ks):
+    log.append((x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], ks))
+    return orig(x, gy, w, ks)
+cf.weight_grad = logged
+tr.step(batch)
+cf.weight_grad = orig
+torch.cuda.synchronize()
+cnt = collections.Counter(log)
+fn = orig
+tot = 0.0
+print(f"{'B':>3} {'Cin':>5} {'H':>4} {'W':>4} {'Cout':>5} ks  calls    ms   TFLOP/s   ms/step")
+for (b, cin, h, w_, cout, ks), n in sorted(cnt.items(), key=lambda kv: -kv[1]):
+    x = torch.randn(b, cin, h, w_, device=dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(b, cout, h, w_, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, ks, ks, device=dev)
+    for _ in range(3):
+        fn(x, gy, w, ks)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn(x, gy, w, ks)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    fl = 2.0 * b * h * w_ * cin * cout * ks * ks
+    tot += ms * n
+    print(f"{b:3d} {cin:5d} {h:4d} {w_:4d} {cout:5d} {ks:2d} {n:6d} {ms:7.3f} {fl / ms / 1e9:8.1f} {ms * n:8.3f}")
+print(f"total {tot:.2f} ms/step over {sum(cnt.values())} calls")
