@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
 //   * MFMAs are issued round-robin over the accumulators (no back-to-back dependent pairs).
 constexpr int kTM2 = 128;
 
-template <int CIN_P, int COUT_P>
+template <int CIN_P, int COUT_P, bool VA, bool VB>   // VA: cin % 4 == 0 (16-byte row pieces); VB: VA and channel-contiguous weights
 __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ in, int cin,
                                                       const int32_t* __restrict__ nbr, int K,
                                                       int mirror, const float* __restrict__ W,
@@ -198,49 +198,63 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool vecA = (cin & 3) == 0;
-  const bool vecB = (ws.sc == 1) && vecA;
-  float4 ra[A4];
+  float4 ra[A4], rb[VB ? B4 : 1];
+  // thread <-> (row or weight row r0 + RPP j, 16-byte channel piece c4): the same piece for every j
+  constexpr int PER = CIN_P / 4, RPP = 512 / PER;
+  const int r0 = tid / PER, c4 = (tid % PER) * 4;
+  const bool cok = c4 < cin;
+  const float* in_c = in + (cok ? c4 : 0);
+  const float* w_c = W + (cok ? c4 : 0);
 
-  // A (gathered rows, DRAM/L2 latency) is prefetched into registers one offset ahead;
-  // W[:,k,:] is L2-resident and goes global -> registers -> LDS inside the commit step.
-  auto fetch = [&](int k) {
-#pragma unroll
-    for (int j = 0; j < A4; ++j) {
-      const int u = tid + 512 * j;
-      const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
-      const int rr = s_nbr[k * kTM2 + row];
+  // The gathered rows AND W[:,k,:] of the next active offset are fetched into registers during the MFMA phase of the
+  // current one and written to LDS after it.  Every load is unconditional (rows without a neighbour read row 0, weight
+  // rows past cout re-read the last one; the zeros go in at commit time), and the vector / scalar variants are template
+  // parameters: chosen at run time (round 1) the 128 x 128 instance needed 256 VGPRs and spilled 95 SGPRs, and its
+  // weights were loaded synchronously inside the commit.
+  auto fetch_a = [&](int k, int j) {
+    const int rr = s_nbr[k * kTM2 + r0 + RPP * j];
+    if constexpr (VA) {
+      ra[j] = *reinterpret_cast<const float4*>(in_c + (size_t)(rr < 0 ? 0 : rr) * cin);
+    } else {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (rr >= 0) {
         const float* src = in + (size_t)rr * cin + c4;
-        if (vecA) {
-          if (c4 < cin) v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (c4 + 0 < cin) v.x = src[0];
-          if (c4 + 1 < cin) v.y = src[1];
-          if (c4 + 2 < cin) v.z = src[2];
-          if (c4 + 3 < cin) v.w = src[3];
-        }
+        if (c4 + 0 < cin) v.x = src[0];
+        if (c4 + 1 < cin) v.y = src[1];
+        if (c4 + 2 < cin) v.z = src[2];
+        if (c4 + 3 < cin) v.w = src[3];
       }
       ra[j] = v;
     }
   };
+  auto fetch_b = [&](int k, int j) {
+    if constexpr (VB) {
+      const int n = r0 + RPP * j;
+      if (n < COUT_P)
+        rb[j] = *reinterpret_cast<const float4*>(w_c + (size_t)k * ws.sk + (size_t)(n < cout ? n : cout - 1) * ws.sn);
+    }
+  };
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < A4; ++j) fetch_a(k, j);
+#pragma unroll
+    for (int j = 0; j < B4; ++j) fetch_b(k, j);
+  };
   auto commit = [&](int k) {
+    // component-wise selects: `ok ? ra[j] : zero4` on the float4 structs becomes a select of two ADDRESSES, which sends the
+    // register arrays to scratch memory
+    auto keep = [](bool ok, const float4& v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
 #pragma unroll
     for (int j = 0; j < A4; ++j) {
-      const int u = tid + 512 * j;
-      const int row = u / (CIN_P / 4), c4 = (u - row * (CIN_P / 4)) * 4;
-      *reinterpret_cast<float4*>(As + row * LDA + c4) = ra[j];
+      const int row = r0 + RPP * j;
+      const bool ok = !VA || (cok && s_nbr[k * kTM2 + row] >= 0);
+      *reinterpret_cast<float4*>(As + row * LDA + c4) = keep(ok, ra[j]);
     }
-    if (vecB) {
+    if constexpr (VB) {
 #pragma unroll
       for (int j = 0; j < B4; ++j) {
-        const int u = tid + 512 * j;
-        if (u >= BU) break;
-        const int n = u / (CIN_P / 4), c4 = (u - n * (CIN_P / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < cout && c4 < cin) v = *reinterpret_cast<const float4*>(W + n * ws.sn + k * ws.sk + c4);
-        *reinterpret_cast<float4*>(Bs + n * LDA + c4) = v;
+        const int n = r0 + RPP * j;
+        if (n < COUT_P) *reinterpret_cast<float4*>(Bs + n * LDA + c4) = keep(cok && n < cout, rb[j]);
       }
     } else {
       // strided weights (dgrad: n is the fast axis in memory): thread <-> (c, 4 consecutive n)
@@ -273,11 +287,21 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
     commit(k);
     __syncthreads();
     const int knext = todo ? (__ffs((int)todo) - 1) : -1;
-    if (knext >= 0) fetch(knext);  // in flight during the MFMA phase
+    // The next offset's loads are issued BETWEEN the matrix steps, one row piece (and at most one weight piece) per
+    // 16-channel step: issued in one burst after the barrier, the eight waves' 128 KB of requests took 4 600 cycles to
+    // get into the memory pipeline with the MFMA pipes idle (in-kernel cycle stamps).
+    constexpr int CB = CIN_P / 16;
+    static_assert(A4 == CB, "one gathered-row piece per 16-channel step");
     if ((wmask >> k) & 1u) {
       const float* arow = As + (wave * 16 + li) * LDA + 4 * g;
-#pragma unroll 1
-      for (int cb = 0; cb < CIN_P / 16; ++cb) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        if (knext >= 0) {
+          fetch_a(knext, cb);
+#pragma unroll
+          for (int j = 0; j < B4; ++j)
+            if (j * CB / B4 == cb) fetch_b(knext, j);
+        }
         const float4 a = *reinterpret_cast<const float4*>(arow + cb * 16);
         float4 b[NT];
 #pragma unroll
@@ -292,6 +316,8 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
       }
+    } else if (knext >= 0) {
+      fetch(knext);
     }
     __syncthreads();
     k = knext;
@@ -1451,12 +1477,25 @@ int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirr
   const size_t lds = (size_t)(kTM2 + COUT_P) * (CIN_P + 8) * sizeof(float) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P>,
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P, true, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P, true, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P, false, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  k_conv_mfma_v2<CIN_P, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(
-      in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep);
+  const bool va = (cin & 3) == 0, vb = va && ws.sc == 1;
+  const dim3 grid(ud_div_up(Mout, kTM2));
+  if (vb)
+    k_conv_mfma_v2<CIN_P, COUT_P, true, true><<<grid, 512, lds, stream>>>(in, cin, nbr, K, mirror, W, ws, bias, out, cout,
+                                                                          Mout, order, ep);
+  else if (va)
+    k_conv_mfma_v2<CIN_P, COUT_P, true, false><<<grid, 512, lds, stream>>>(in, cin, nbr, K, mirror, W, ws, bias, out, cout,
+                                                                           Mout, order, ep);
+  else
+    k_conv_mfma_v2<CIN_P, COUT_P, false, false><<<grid, 512, lds, stream>>>(in, cin, nbr, K, mirror, W, ws, bias, out,
+                                                                            cout, Mout, order, ep);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
