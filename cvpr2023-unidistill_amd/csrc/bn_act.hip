@@ -92,14 +92,16 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const T* __restrict__ x, con
 }
 
 // mask source: y (the saved output) when a residual took part, else recomputed from x.
-__device__ __forceinline__ void masked_grad(const float* xv, const float* yv, const float* dyv,
+// has_y is a flag, not a null yv: `y ? yv : nullptr` at the call site is a select of two addresses, which forces the yv
+// register array into scratch memory (48 bytes per lane written and re-read per pixel in two HBM-bound kernels)
+__device__ __forceinline__ void masked_grad(const float* xv, const float* yv, bool has_y, const float* dyv,
                                             const float* s, const float* t, int relu, float* dr) {
   if (!relu) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dr[e] = dyv[e];
     return;
   }
-  if (yv) {
+  if (has_y) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dr[e] = yv[e] > 0.f ? dyv[e] : 0.f;
   } else {
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ x, 
     ld8(x + off, xv);
     ld8(dy + off, dyv);
     if (y) ld8(y + off, yv);
-    masked_grad(xv, y ? yv : nullptr, dyv, s, t, relu, dr);
+    masked_grad(xv, yv, y != nullptr, dyv, s, t, relu, dr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       s1[e] += dr[e];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const T* __restrict__ x, cons
     ld8(x + off, xv);
     ld8(dy + off, dyv);
     if (y) ld8(y + off, yv);
-    masked_grad(xv, y ? yv : nullptr, dyv, s, t, relu, dr);
+    masked_grad(xv, yv, y != nullptr, dyv, s, t, relu, dr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = fmaf(s[e], dr[e], fmaf(a2[e], xv[e], a0[e]));
     st8(dx + off, o);

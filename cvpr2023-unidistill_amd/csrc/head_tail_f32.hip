@@ -35,7 +35,7 @@ __device__ __forceinline__ void tile_origin(const GTail& t, int tile, int& b, in
 // Sum over each ROW of 16 lanes with DPP adds (VALU rate; a shuffle butterfly goes through the LDS pipe): row_shr
 // 1/2/4/8 with zero fill; lane 15 of every row holds its row's total.
 __device__ __forceinline__ float dpp_row_sum_to_lane15(float v) {
-#define UD_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false))
+#define UD_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
   UD_DPP_ADD(0x111);   // row_shr:1
   UD_DPP_ADD(0x112);   // row_shr:2
   UD_DPP_ADD(0x114);   // row_shr:4
@@ -58,13 +58,24 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b, float ac
 // ~19 instructions per output pixel and wave.  (Earlier formulations, all 1.7-2.1 ms at B = 4: halo in LDS with a
 // thread per pixel; lane = channel with nine row reads per pixel and shuffle reductions; lane = channel with a register
 // halo and 64-lane DPP reductions -- instruction-bound: 140 instructions per pixel.)
+__device__ __attribute__((aligned(16))) unsigned int g_zero_f4[4];
 template <int KM>
 __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, float* __restrict__ z, GTail t) {
+                                                   const float* __restrict__ bias, float* __restrict__ z, GTail t,
+                                                   int strip_rows, int strips) {
   // groups vary fastest over the grid: the workgroups running together consume whole pixel rows
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int b, ty0, tx0;
-  tile_origin(t, blockIdx.y, b, ty0, tx0);
+  // A workgroup walks a 16-pixel-wide strip of `strip_rows` rows (a multiple of kTH): the window keeps sliding across the
+  // 8-row blocks, so the lane's 9 * KM weight quads (27 KB per wave, more than a block's input) and the two halo rows are
+  // fetched once per strip instead of once per block.  With one 8-row block per workgroup (the first version) a workgroup
+  // lived ~4 us, about half of it the latency of its weight and first-row loads, with only two workgroups per CU
+  // (252 VGPRs) to hide it: 1.0 ms for the 1.39 GB tensor; fetching rows further ahead changed nothing.
+  int bidx = blockIdx.y;
+  const int tx = bidx % t.tiles_x;
+  bidx /= t.tiles_x;
+  const int strip = bidx % strips, b = bidx / strips;
+  const int tx0 = tx * kTW, ty0 = strip * strip_rows;
+  const int y_end = min(t.H, ty0 + strip_rows);
   const int Ct = t.G * kHC, Zt = t.G * KM;
   const int ps = lane >> 4, cq = lane & 15;
   float4 wr[KM][9];
@@ -76,45 +87,63 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
   const int gx = tx0 + 4 * wave + ps;
   if (tx0 + 4 * wave >= t.W) return;
   const float* ab = a + (size_t)b * t.H * t.W * Ct + g * kHC + 4 * cq;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_row = [&](int yy, float4* r) {        // the three pieces (gx-1, gx, gx+1) of image row yy
+  // out-of-image pieces read a zero page: `ok ? *p : zero4` on float4 structs is compiled as a load through a select of
+  // two addresses (one of them a scratch copy of zero4), i.e. flat loads
+  const float* zero = reinterpret_cast<const float*>(g_zero_f4);
+  // The three pieces (gx-1, gx, gx+1) of the next input row: pointers stepped by one image row per call.  (Rebuilding
+  // ((yy * W + xx) * Ct) per piece cost ten quarter-rate 32 / 64-bit multiplies per row -- as many issue cycles as the
+  // row's 71 FMA instructions.)
+  const float* pp[3];
+  bool xok[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int xx = gx - 1 + d;
+    xok[d] = xx >= 0 && xx < t.W;
+    pp[d] = ab + ((long long)(ty0 - 1) * t.W + (xok[d] ? xx : 0)) * Ct;
+  }
+  const size_t rstride = (size_t)t.W * Ct;
+  int yy_next = ty0 - 1;
+  auto load_next = [&](float4* r) {
+    const bool yok = yy_next >= 0 && yy_next < t.H;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const int xx = gx - 1 + d;
-      r[d] = (yy >= 0 && yy < t.H && xx >= 0 && xx < t.W)
-                 ? *reinterpret_cast<const float4*>(ab + ((size_t)yy * t.W + xx) * Ct) : zero4;
+      r[d] = *reinterpret_cast<const float4*>((yok && xok[d]) ? pp[d] : zero);
+      pp[d] += rstride;
     }
+    ++yy_next;
   };
-  float4 win[4][3];                                // rows y-1, y, y+1 and the prefetched y+2
-  load_row(ty0 - 1, win[0]);
-  load_row(ty0, win[1]);
-  load_row(ty0 + 1, win[2]);
+  constexpr int PD = KM >= 4 ? 2 : 3;              // rows fetched ahead of their first use
+  float4 rows[kTH + 2 + PD][3];                    // rows[r] = input row (block's first row) - 1 + r
+#pragma unroll
+  for (int r = 0; r < 2 + PD; ++r) load_next(rows[r]);
   float bv[KM];
 #pragma unroll
   for (int k = 0; k < KM; ++k) bv[k] = bias ? bias[g * KM + k] : 0.f;
+  float* zo = z + ((size_t)(b * t.H + ty0) * t.W + gx) * Zt + g * KM;      // this lane's output pixel, stepped per row
+  const size_t zstride = (size_t)t.W * Zt;
+  for (int y0 = ty0; y0 < y_end; y0 += kTH) {
 #pragma unroll
-  for (int y = 0; y < kTH; ++y) {
-    const int gy = ty0 + y;
-    if (y + 1 < kTH) load_row(gy + 2, win[3]);     // two rows ahead: its latency hides behind two pixels of FMAs
-    float acc[KM];
+    for (int y = 0; y < kTH; ++y) {
+      const int gy = y0 + y;
+      load_next(rows[y + 2 + PD]);
+      float acc[KM];
 #pragma unroll
-    for (int k = 0; k < KM; ++k) {
-      float s = 0.f;
+      for (int k = 0; k < KM; ++k) {
+        float s = 0.f;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) s = dot4(win[tap / 3][tap % 3], wr[k][tap], s);
-      acc[k] = dpp_row_sum_to_lane15(s);
+        for (int tap = 0; tap < 9; ++tap) s = dot4(rows[y + tap / 3][tap % 3], wr[k][tap], s);
+        acc[k] = dpp_row_sum_to_lane15(s);
+      }
+      if (cq == 15 && gy < y_end && gx < t.W) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k) zo[k] = acc[k] + bv[k];
+      }
+      zo += zstride;
     }
-    if (cq == 15 && gy < t.H && gx < t.W) {
-      float* o = z + ((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * KM;
 #pragma unroll
-      for (int k = 0; k < KM; ++k) o[k] = acc[k] + bv[k];
-    }
+    for (int r = 0; r < 2 + PD; ++r)
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      win[0][d] = win[1][d];
-      win[1][d] = win[2][d];
-      win[2][d] = win[3][d];
-    }
+      for (int d = 0; d < 3; ++d) rows[r][d] = rows[r + kTH][d];
   }
 }
 
@@ -240,12 +269,16 @@ extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float*
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_fwd", stream);
-  const dim3 grid(G, B * t.tiles_x * t.tiles_y);
+  // strips of up to 48 rows, shorter when that leaves fewer than ~8 workgroups per CU
+  int strip_rows = 48;
+  while (strip_rows > kTH && (long long)G * B * t.tiles_x * ud_div_up(H, strip_rows) < 2048) strip_rows -= kTH;
+  const int strips = ud_div_up(H, strip_rows);
+  const dim3 grid(G, B * t.tiles_x * strips);
   switch (KM) {
-    case 1: k_gtail_fwd<1><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
-    case 2: k_gtail_fwd<2><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
-    case 3: k_gtail_fwd<3><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
-    default: k_gtail_fwd<4><<<grid, 256, 0, stream>>>(a, w, bias, z, t); break;
+    case 1: k_gtail_fwd<1><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
+    case 2: k_gtail_fwd<2><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
+    case 3: k_gtail_fwd<3><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
+    default: k_gtail_fwd<4><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
   }
   UD_LAUNCH_CHECK();
   return UD_OK;

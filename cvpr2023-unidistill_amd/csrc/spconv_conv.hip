@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
   const int r0 = tid / PER, c4 = (tid % PER) * 4;
   const bool cok = c4 < cin;
   const float* in_c = in + (cok ? c4 : 0);
-  const float* w_c = W + (cok ? c4 : 0);
+  const int wc4 = cok ? c4 : 0;
 
   // The gathered rows AND W[:,k,:] of the next active offset are fetched into registers during the MFMA phase of the
   // current one and written to LDS after it.  Every load is unconditional (rows without a neighbour read row 0, weight
@@ -230,8 +230,10 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
   auto fetch_b = [&](int k, int j) {
     if constexpr (VB) {
       const int n = r0 + RPP * j;
+      // 32-bit offset from the (uniform) weight pointer: eight 64-bit row pointers would be hoisted out of the offset loop
+      // and spilled
       if (n < COUT_P)
-        rb[j] = *reinterpret_cast<const float4*>(w_c + (size_t)k * ws.sk + (size_t)(n < cout ? n : cout - 1) * ws.sn);
+        rb[j] = *reinterpret_cast<const float4*>(W + (unsigned)(k * (int)ws.sk + (n < cout ? n : cout - 1) * (int)ws.sn + wc4));
     }
   };
   auto fetch = [&](int k) {
@@ -284,7 +286,9 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
   if (k >= 0) fetch(k);
   while (k >= 0) {
     todo &= todo - 1;
+    __builtin_amdgcn_sched_barrier(0);     // the phases stay apart too (same reason as between the matrix steps below)
     commit(k);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     const int knext = todo ? (__ffs((int)todo) - 1) : -1;
     // The next offset's loads are issued BETWEEN the matrix steps, one row piece (and at most one weight piece) per
@@ -315,6 +319,9 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+        // keep the steps apart: with the loop unrolled the scheduler hoists the fragment reads of several steps to the top
+        // (256 VGPRs, 24 of them spilled in the 128 x 128 instance)
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else if (knext >= 0) {
       fetch(knext);
