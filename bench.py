@@ -178,6 +178,10 @@ def mfma_leg(trainer, batch, steps=3):
             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
             "launches": len(log), "avg_kernel_us": rp_ms / len(log) * 1e3, "algorithmic_flops_per_step": rp_flops,
             "kernel_ms_per_step": rp_ms, "traffic": None,
+            # what an MFMA-only loop sustains on the same machine with the instruction this kernel uses
+            # (tools/mfma_peak.hip, profiles/r02_mfma_peak.md): the nominal 2 517 is not reachable with 16x16x32
+            "mfma_only_loop": {"v_mfma_f32_16x16x32_bf16": 1330.0, "v_mfma_f32_32x32x16_bf16": 2350.0, "unit": "TFLOP/s",
+                               "frac_of_16x16x32_loop": achieved / 1330.0, "source": "profiles/r02_mfma_peak.md"},
             "in_step_events": {"achieved": in_step, "frac": in_step / MFMA_PEAK_TFLOPS, "launches": calls,
                                "avg_kernel_us": ms / calls * 1e3, "kernel_ms_per_step": ms / steps,
                                "algorithmic_flops_per_step": flops / steps},
