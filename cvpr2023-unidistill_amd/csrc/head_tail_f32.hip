@@ -5,32 +5,24 @@
 // B = 4) and the second layer is a GROUPED 3x3 convolution with 64 inputs and k <= 4 outputs per group: 19
 // GFLOP that the libraries run either as a block-diagonal dense conv (42x the FLOPs: 6.2 ms forward, 19 ms
 // forward+backward) or as a 42-group conv (slower still).  It is HBM-bound by construction, so these are
-// streaming VALU kernels (exact fp32 FMAs), one workgroup per (8 x 16 pixel tile, group):
-//   k_gtail_fwd    the 10 x 18 x 64 halo of the group in LDS, thread = pixel: 9 x 64 x k FMAs
-//   k_gtail_dgrad  da[q, c] = sum_{tap,k} dz[q - tap, k] * w[k, tap, c]: dz halo in LDS, lane = channel, the
-//                  group's 27-36 weights of a lane's channel in registers, coalesced 256-byte row stores
-//   k_gtail_wgrad  dW[k, tap, c] = sum_q a[q, c] * dz[q - tap, k]: lane = channel, 36 accumulators in registers,
-//                  a workgroup walks a slice of the tiles; slices are summed in a fixed order (deterministic)
+// streaming VALU kernels (exact fp32 FMAs), one workgroup per (16-pixel-wide strip of up to 48 rows, group):
+//   k_gtail_fwd    no LDS: lane = (pixel column of a 4-wide strip, channel quad), 3 x 3 register window walking down a strip
+//   k_gtail_dgrad  da[q, c] = sum_{tap,k} dz[q - tap, k] * w[k, tap, c]: same lane map, dz window in registers, 16-byte stores
+//   k_gtail_wgrad  dW[k, tap, c] = sum_q a[q, c] * dz[q - tap, k]: the forward's lane map and strip walk, 9 * KM 4-channel accumulators,
+//                  a workgroup walks a slice of the strips; slices are summed in a fixed order (deterministic)
 #include "ud_common.h"
 #include "ud_prof.h"
 
 namespace {
 
 constexpr int kHC = 64;                       // channels per group
-constexpr int kTW = 16, kTH = 8, kHW = kTW + 2, kHH = kTH + 2, kHQ = kHW * kHH;   // tile, halo
+constexpr int kTW = 16, kTH = 8, kHW = kTW + 2;   // strip width, rows per unrolled block, halo width
 constexpr int kKMax = 4;                      // outputs per group
+constexpr int kStripMax = 48;                 // rows a workgroup of the strip-walking kernels covers
 
 struct GTail {
   int B, H, W, G, KM, tiles_x, tiles_y;
 };
-
-__device__ __forceinline__ void tile_origin(const GTail& t, int tile, int& b, int& ty0, int& tx0) {
-  const int per = t.tiles_x * t.tiles_y;
-  b = tile / per;
-  tile -= b * per;
-  ty0 = (tile / t.tiles_x) * kTH;
-  tx0 = (tile % t.tiles_x) * kTW;
-}
 
 // Sum over each ROW of 16 lanes with DPP adds (VALU rate; a shuffle butterfly goes through the LDS pipe): row_shr
 // 1/2/4/8 with zero fill; lane 15 of every row holds its row's total.
@@ -148,100 +140,195 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
 }
 
 // da[q, g*64 + c] = sum_{tap, k} dz[q - (tap - 1), g*KM + k] * w[g][k][tap][c]
+template <int KM>
 __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ dz, const float* __restrict__ w,
-                                                     float* __restrict__ da, GTail t) {
-  __shared__ float s_z[kHQ][kKMax];
+                                                     float* __restrict__ da, GTail t, int strip_rows, int strips) {
+  // Lane map and strip walk of k_gtail_fwd / k_gtail_wgrad: lane = (pixel column of a 4-wide strip, channel quad); the
+  // lane's 9 * KM weight quads stay in registers, the 3 x 3 window of dz values slides down the strip (dz halo of the strip
+  // staged once in LDS), one 16-byte store per pixel and lane.  (First version: lane = channel, a pixel per wave step, nine
+  // broadcast LDS reads + 36 FMAs + the pixel's address arithmetic for a 4-byte store: 530 us.)
+  __shared__ float4 s_z[(kStripMax + 2) * kHW];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // groups fastest (see k_gtail_fwd)
-  int b, ty0, tx0;
-  tile_origin(t, blockIdx.y, b, ty0, tx0);
-  const int Zt = t.G * t.KM, Ct = t.G * kHC;
-  for (int i = tid; i < kHQ * kKMax; i += 256) {
-    const int q = i / kKMax, k = i - q * kKMax;
-    const int gy = ty0 + q / kHW - 1, gx = tx0 + q % kHW - 1;
-    float v = 0.f;
-    if (k < t.KM && gy >= 0 && gy < t.H && gx >= 0 && gx < t.W)
-      v = dz[((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * t.KM + k];
-    s_z[q][k] = v;
-  }
-  float wr[kKMax][9];                                           // this lane's channel: w[g][k][tap][lane]
+  const int ps = lane >> 4, cq = lane & 15;
+  int r = blockIdx.y;
+  const int tx = r % t.tiles_x;
+  r /= t.tiles_x;
+  const int strip = r % strips, b = r / strips;
+  const int tx0 = tx * kTW, ty0 = strip * strip_rows, y_end = min(t.H, ty0 + strip_rows);
+  const int Zt = t.G * KM, Ct = t.G * kHC;
+  const int nz = ((y_end - ty0 + kTH - 1) / kTH * kTH + 2) * kHW;
+  for (int i = tid; i < nz; i += 256) {
+    const int zr = i / kHW, zc = i - zr * kHW;
+    const int gy = ty0 - 1 + zr, gx = tx0 - 1 + zc;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gy >= 0 && gy < t.H && gx >= 0 && gx < t.W) {
+      const float* src = dz + ((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * KM;
 #pragma unroll
-  for (int k = 0; k < kKMax; ++k)
+      for (int k = 0; k < KM; ++k) v[k] = src[k];
+    }
+    s_z[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  float4 wr[KM][9];
+#pragma unroll
+  for (int k = 0; k < KM; ++k)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
-      wr[k][tap] = (k < t.KM) ? w[((size_t)(g * t.KM + k) * 9 + tap) * kHC + lane] : 0.f;
+      wr[k][tap] = *reinterpret_cast<const float4*>(w + ((size_t)(g * KM + k) * 9 + tap) * kHC + 4 * cq);
   __syncthreads();
-  for (int p = wave; p < kTW * kTH; p += 4) {
-    const int py = p >> 4, px = p & 15;
-    const int gy = ty0 + py, gx = tx0 + px;
-    if (gy >= t.H || gx >= t.W) continue;
-    float acc = 0.f;
+  if (tx0 + 4 * wave >= t.W) return;
+  const int px = 4 * wave + ps, gx = tx0 + px;
+  float* po = da + ((size_t)(b * t.H + ty0) * t.W + gx) * Ct + g * kHC + 4 * cq;
+  const size_t rstride = (size_t)t.W * Ct;
+  float4 zw[kTH + 2][3];                              // zw[r][d]: dz of output pixel (block row - 1 + r, px - 1 + d)
+  const float4* zp = s_z + px;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // output pixel that used input q through this tap: q - (tap - 1)  -> halo index (py + 2 - ty, px + 2 - tx)
-      const float4 zv = *reinterpret_cast<const float4*>(&s_z[(py + 2 - tap / 3) * kHW + px + 2 - tap % 3][0]);
-      acc = fmaf(zv.x, wr[0][tap], acc);
-      acc = fmaf(zv.y, wr[1][tap], acc);
-      acc = fmaf(zv.z, wr[2][tap], acc);
-      acc = fmaf(zv.w, wr[3][tap], acc);
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) zw[i][d] = zp[i * kHW + d];
+  zp += 2 * kHW;
+  for (int y0 = ty0; y0 < y_end; y0 += kTH) {
+#pragma unroll
+    for (int y = 0; y < kTH; ++y) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) zw[y + 2][d] = zp[d];
+      zp += kHW;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // the output pixel that read this input through tap (ty, tx) is (row - (ty - 1), column - (tx - 1))
+        const float4 zv = zw[y + 2 - tap / 3][2 - tap % 3];
+        const float zk[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+          o.x = fmaf(zk[k], wr[k][tap].x, o.x);
+          o.y = fmaf(zk[k], wr[k][tap].y, o.y);
+          o.z = fmaf(zk[k], wr[k][tap].z, o.z);
+          o.w = fmaf(zk[k], wr[k][tap].w, o.w);
+        }
+      }
+      if (y0 + y < y_end && gx < t.W) *reinterpret_cast<float4*>(po) = o;
+      po += rstride;
     }
-    da[((size_t)(b * t.H + gy) * t.W + gx) * Ct + g * kHC + lane] = acc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) zw[i][d] = zw[i + kTH][d];
   }
 }
 
 // partial[slice][g][k][tap][c] = sum over the slice's tiles of a[q, c] * dz[q - (tap - 1), k]
+template <int KM>
 __global__ __launch_bounds__(256) void k_gtail_wgrad(const float* __restrict__ a, const float* __restrict__ dz,
-                                                     float* __restrict__ partial, GTail t, int ntiles,
-                                                     int tiles_per_slice) {
-  __shared__ float s_z[kHQ][kKMax];
-  __shared__ float s_red[4][kKMax * 9][kHC];
-  const int g = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Zt = t.G * t.KM, Ct = t.G * kHC;
-  float acc[kKMax][9];
+                                                     float* __restrict__ partial, GTail t, int strip_rows, int strips,
+                                                     int nstrips, int S) {
+  // Same lane map and strip walk as k_gtail_fwd: lane = (pixel column ps of a 4-wide strip, channel quad cq), the wave walks
+  // down its strip with the 3 x 3 window of dz values (KM <= 4 floats per pixel, staged once per strip in LDS) in
+  // registers; per row one 16-byte load of the hidden tensor and 9 * KM packed FMAs on 4-channel accumulators.  The first
+  // version (lane = channel, one pixel per wave step: a 4-byte load, nine broadcast LDS reads, 36 FMAs and the pixel's
+  // address arithmetic per step) issued ~3.4 x the instructions: 1.05 ms for the 1.39 GB tensor.
+  __shared__ float4 s_z[(kStripMax + 2) * kHW];
+  __shared__ float s_red[4][KM * 9][kHC];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ps = lane >> 4, cq = lane & 15;
+  const int Zt = t.G * KM, Ct = t.G * kHC;
+  const float* zero = reinterpret_cast<const float*>(g_zero_f4);
+  float4 acc[KM][9];
 #pragma unroll
-  for (int k = 0; k < kKMax; ++k)
+  for (int k = 0; k < KM; ++k)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) acc[k][tap] = 0.f;
-  const int t0 = slice * tiles_per_slice, t1 = min(ntiles, t0 + tiles_per_slice);
-  for (int tile = t0; tile < t1; ++tile) {
-    int b, ty0, tx0;
-    tile_origin(t, tile, b, ty0, tx0);
-    __syncthreads();
-    for (int i = tid; i < kHQ * kKMax; i += 256) {
-      const int q = i / kKMax, k = i - q * kKMax;
-      const int gy = ty0 + q / kHW - 1, gx = tx0 + q % kHW - 1;
-      float v = 0.f;
-      if (k < t.KM && gy >= 0 && gy < t.H && gx >= 0 && gx < t.W)
-        v = dz[((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * t.KM + k];
-      s_z[q][k] = v;
-    }
-    __syncthreads();
-    float avs[kTW * kTH / 4];                                   // this wave's 32 pixels: all loads in flight at once
+    for (int tap = 0; tap < 9; ++tap) acc[k][tap] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int st = blockIdx.y; st < nstrips; st += S) {
+    int r = st;
+    const int tx = r % t.tiles_x;
+    r /= t.tiles_x;
+    const int strip = r % strips, b = r / strips;
+    const int tx0 = tx * kTW, ty0 = strip * strip_rows, y_end = min(t.H, ty0 + strip_rows);
+    __syncthreads();                                    // the previous strip's window reads are done
+    // whole 8-row blocks (+ halo): rows past the strip only meet zero inputs, but must hold finite values
+    const int nz = ((y_end - ty0 + kTH - 1) / kTH * kTH + 2) * kHW;
+    for (int i = tid; i < nz; i += 256) {
+      const int zr = i / kHW, zc = i - zr * kHW;
+      const int gy = ty0 - 1 + zr, gx = tx0 - 1 + zc;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < t.H && gx >= 0 && gx < t.W) {
+        const float* src = dz + ((size_t)(b * t.H + gy) * t.W + gx) * Zt + g * KM;
 #pragma unroll
-    for (int j = 0; j < kTW * kTH / 4; ++j) {
-      const int p = wave + 4 * j, gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
-      avs[j] = (gy < t.H && gx < t.W) ? a[((size_t)(b * t.H + gy) * t.W + gx) * Ct + g * kHC + lane] : 0.f;
-    }
-#pragma unroll 4
-    for (int j = 0; j < kTW * kTH / 4; ++j) {
-      const int p = wave + 4 * j, py = p >> 4, px = p & 15;
-      const float av = avs[j];                                   // 0 outside the image: contributes nothing
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const float4 zv = *reinterpret_cast<const float4*>(&s_z[(py + 2 - tap / 3) * kHW + px + 2 - tap % 3][0]);
-        acc[0][tap] = fmaf(av, zv.x, acc[0][tap]);
-        acc[1][tap] = fmaf(av, zv.y, acc[1][tap]);
-        acc[2][tap] = fmaf(av, zv.z, acc[2][tap]);
-        acc[3][tap] = fmaf(av, zv.w, acc[3][tap]);
+        for (int k = 0; k < KM; ++k) v[k] = src[k];
       }
+      s_z[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    if (tx0 + 4 * wave >= t.W) continue;                // wave-uniform (the barriers above are reached by every wave)
+    const int px = 4 * wave + ps, gx = tx0 + px;
+    const bool xok = gx < t.W;
+    const float* pa = a + ((size_t)(b * t.H + ty0) * t.W + (xok ? gx : 0)) * Ct + g * kHC + 4 * cq;
+    const size_t rstride = (size_t)t.W * Ct;
+    constexpr int PD = 3;                               // rows of the hidden tensor in flight ahead of their use
+    float4 av[kTH + PD];
+    int yn = ty0;
+    auto load_next = [&](float4& dst) {
+      dst = *reinterpret_cast<const float4*>((xok && yn < y_end) ? pa : zero);
+      pa += rstride;
+      ++yn;
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i) load_next(av[i]);
+    float4 zw[kTH + 2][3];                              // zw[r][d]: dz of output pixel (block row - 1 + r, px - 1 + d)
+    const float4* zp = s_z + px;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) zw[i][d] = zp[i * kHW + d];
+    zp += 2 * kHW;
+    for (int y0 = ty0; y0 < y_end; y0 += kTH) {
+#pragma unroll
+      for (int y = 0; y < kTH; ++y) {
+        load_next(av[y + PD]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) zw[y + 2][d] = zp[d];
+        zp += kHW;
+        const float4 x4 = av[y];                         // 0 outside the image / strip: contributes nothing
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          // the output pixel that read this input through tap (ty, tx) is (row - (ty - 1), column - (tx - 1))
+          const float4 zv = zw[y + 2 - tap / 3][2 - tap % 3];
+          const float zk[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+          for (int k = 0; k < KM; ++k) {
+            acc[k][tap].x = fmaf(x4.x, zk[k], acc[k][tap].x);
+            acc[k][tap].y = fmaf(x4.y, zk[k], acc[k][tap].y);
+            acc[k][tap].z = fmaf(x4.z, zk[k], acc[k][tap].z);
+            acc[k][tap].w = fmaf(x4.w, zk[k], acc[k][tap].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PD; ++i) av[i] = av[i + kTH];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) zw[i][d] = zw[i + kTH][d];
     }
   }
+  // sum over the four pixel columns of the wave (fixed order), then over the four waves
 #pragma unroll
-  for (int k = 0; k < kKMax; ++k)
+  for (int k = 0; k < KM; ++k)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) s_red[wave][k * 9 + tap][lane] = acc[k][tap];
+    for (int tap = 0; tap < 9; ++tap) {
+      float v[4] = {acc[k][tap].x, acc[k][tap].y, acc[k][tap].z, acc[k][tap].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += __shfl_xor(v[e], 16);
+        v[e] += __shfl_xor(v[e], 32);
+      }
+      if (ps == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_red[wave][k * 9 + tap][4 * cq + e] = v[e];
+      }
+    }
   __syncthreads();
-  float* out = partial + ((size_t)slice * t.G + g) * t.KM * 9 * kHC;
-  for (int i = tid; i < t.KM * 9 * kHC; i += 256) {
+  float* out = partial + ((size_t)blockIdx.y * t.G + g) * KM * 9 * kHC;
+  for (int i = tid; i < KM * 9 * kHC; i += 256) {
     const int kt = i / kHC, c = i - kt * kHC;
     out[i] = ((s_red[0][kt][c] + s_red[1][kt][c]) + s_red[2][kt][c]) + s_red[3][kt][c];
   }
@@ -270,7 +357,7 @@ extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float*
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_fwd", stream);
   // strips of up to 48 rows, shorter when that leaves fewer than ~8 workgroups per CU
-  int strip_rows = 48;
+  int strip_rows = kStripMax;
   while (strip_rows > kTH && (long long)G * B * t.tiles_x * ud_div_up(H, strip_rows) < 2048) strip_rows -= kTH;
   const int strips = ud_div_up(H, strip_rows);
   const dim3 grid(G, B * t.tiles_x * strips);
@@ -290,7 +377,16 @@ extern "C" int ud_head_tail_f32_dgrad(const float* dz, const float* w, float* da
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_dgrad", stream);
-  k_gtail_dgrad<<<dim3(G, B * t.tiles_x * t.tiles_y), 256, 0, stream>>>(dz, w, da, t);
+  int strip_rows = kStripMax;
+  while (strip_rows > kTH && (long long)G * B * t.tiles_x * ud_div_up(H, strip_rows) < 2048) strip_rows -= kTH;
+  const int strips = ud_div_up(H, strip_rows);
+  const dim3 grid(G, B * t.tiles_x * strips);
+  switch (KM) {
+    case 1: k_gtail_dgrad<1><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
+    case 2: k_gtail_dgrad<2><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
+    case 3: k_gtail_dgrad<3><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
+    default: k_gtail_dgrad<4><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
+  }
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -307,10 +403,19 @@ extern "C" int ud_head_tail_f32_wgrad(const float* a, const float* dz, float* dw
   if (!workspace || workspace_bytes < ud_head_tail_f32_wgrad_workspace_bytes(B, H, W, G, KM)) return UD_ERR_WORKSPACE;
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
-  const int ntiles = B * t.tiles_x * t.tiles_y, S = gtail_slices(ntiles), per = ud_div_up(ntiles, S);
+  int strip_rows = kStripMax;
+  while (strip_rows > kTH && B * t.tiles_x * ud_div_up(H, strip_rows) < 32) strip_rows -= kTH;
+  const int strips = ud_div_up(H, strip_rows), nstrips = B * t.tiles_x * strips;
+  const int S = gtail_slices(nstrips);          // <= the slice count the workspace was sized for (strips <= tiles)
   float* partial = reinterpret_cast<float*>(workspace);
   UdProfScope prof("head_tail.k_gtail_wgrad", stream);
-  k_gtail_wgrad<<<dim3(G, S), 256, 0, stream>>>(a, dz, partial, t, ntiles, per);
+  const dim3 grid(G, S);
+  switch (KM) {
+    case 1: k_gtail_wgrad<1><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
+    case 2: k_gtail_wgrad<2><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
+    case 3: k_gtail_wgrad<3><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
+    default: k_gtail_wgrad<4><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
+  }
   UD_LAUNCH_CHECK();
   const long long n = (long long)G * KM * 9 * kHC;
   k_gtail_wsum<<<ud_div_up(n, 256), 256, 0, stream>>>(partial, S, n, dw);
