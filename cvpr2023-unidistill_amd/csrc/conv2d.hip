@@ -872,8 +872,17 @@ __global__ __launch_bounds__(256) void k_wgrad_sum(const float* __restrict__ par
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i4 < n4) {
     const int per = (slices + 3) / 4, s0 = wave * per, s1 = min(slices, s0 + per);
-    for (int s = s0; s < s1; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)s * n + 4 * i4);
+    auto ld = [&](int s) { return *reinterpret_cast<const float4*>(partial + (size_t)s * n + 4 * i4); };
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {          // four loads in flight per trip; the additions keep the ascending order
+      const float4 v0 = ld(s), v1 = ld(s + 1), v2 = ld(s + 2), v3 = ld(s + 3);
+      a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+      a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+      a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+      a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+    }
+    for (; s < s1; ++s) {
+      const float4 v = ld(s);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
   }

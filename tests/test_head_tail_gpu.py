@@ -109,7 +109,10 @@ def test_packed_heads_fused_tail_matches_library_path(hip_lib):
         assert torch.allclose(a, b, rtol=0, atol=4e-2 * float(b.detach().abs().max()) + 1e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 20, 36, 5, 3), (1, 17, 9, 42, 3), (2, 8, 16, 3, 4), (1, 33, 40, 2, 1)])
+# the last shape is large enough for the 48-row strips of the real head (several 8-row blocks per workgroup, a partial last
+# strip of 4 rows, a partial last column tile); the small ones run 8-row strips
+@pytest.mark.parametrize("shape", [(2, 20, 36, 5, 3), (1, 17, 9, 42, 3), (2, 8, 16, 3, 4), (1, 33, 40, 2, 1),
+                                   (2, 100, 140, 42, 3)])
 def test_fp32_group_tail_vs_grouped_conv(hip_lib, shape):
     """fp32 mode: ud_head_tail_f32_fwd / _dgrad / _wgrad == torch's grouped 3x3 convolution (fp32), forward,
     input gradient, weight and bias gradients; 2e-5 of the max (summation order only)."""
