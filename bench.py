@@ -183,6 +183,9 @@ def mfma_leg(trainer, batch, steps=3):
             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
             "launches": len(log), "avg_kernel_us": rp_ms / len(log) * 1e3, "algorithmic_flops_per_step": rp_flops,
             "kernel_ms_per_step": rp_ms, "traffic": None,
+            # PMC bytes of ONE shape (the replay mixes 65): FETCH_SIZE x 2 + WRITE_SIZE, profiles/r02_pmc_conv3x3.md
+            "traffic_trunk_256_128_180x180x4": {"hbm_bytes": 110.6e6, "algorithmic_bytes": 100.1e6,
+                                                "source": "profiles/r02_pmc_conv3x3.md"},
             # what an MFMA-only loop sustains on the same machine with the instruction this kernel uses
             # (tools/mfma_peak.hip, profiles/r02_mfma_peak.md): the nominal 2 517 is not reachable with 16x16x32
             "mfma_only_loop": {"v_mfma_f32_16x16x32_bf16": 1330.0, "v_mfma_f32_32x32x16_bf16": 2350.0, "unit": "TFLOP/s",
