@@ -31,6 +31,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "cvpr2023-unidistill_amd")
+os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic benchmark: random weights of the reference architecture
 for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)

@@ -262,44 +262,53 @@ __global__ __launch_bounds__(256) void k_rel(MapView s, MapView t, const float* 
 // overlap (a small box puts all nine key points into one or two BEV cells; neighbouring boxes share pixels), so adding
 // the terms with float atomics -- the first version -- made the sum depend on the arrival order whenever three or more
 // terms met (a run-to-run difference of one ulp in every gradient upstream, seen as a flaky bit-reproducibility test on
-// cold GPUs).  Here every (m, kp, i) term of a sample gets the key (pixel, term index); a workgroup sorts the <= 2048 keys of
-// its sample in LDS (bitonic), finds the runs of equal pixels, and its waves take runs in turn: a lane (= channel) adds the
-// terms of a pixel in term order and stores the pixel once -- no atomics, fixed order.  (sample, 64 channels, 1/8 of the runs)
-// per workgroup: the sort is repeated by the workgroups of a sample, which is cheaper than a second launch.
-constexpr int kMaxTerms = 2048;
+// cold GPUs).  Here every (m, kp, i) term of a sample gets the key (pixel, term index); the keys of a sample are sorted,
+// runs of equal pixels are found, and a lane (= channel) adds the terms of a pixel in term order and stores the pixel
+// once -- no atomics, fixed order.  Two sorters, chosen by the number of terms T = 36 * M (M = padded box count):
+//   * T <= 16384 (M <= 455): bitonic sort in LDS (dynamic, 10 bytes per term), repeated by the (64 channels, 1/8 of the
+//     runs) workgroups of a sample, which is cheaper than a second launch;
+//   * larger: rank sort through the workspace (every key is unique, so its rank = the number of smaller keys; O(T^2)
+//     compares, no size limit), then one pass over the sorted keys.
+constexpr int kMinTerms = 2048;                // 8 sorted entries per thread at least
+constexpr int kMaxLdsTerms = 16384;            // 160 KB of LDS would hold 16384 * 10 bytes
 constexpr int kRunSplit = 8;                   // workgroups sharing the pixels of one (sample, 64 channels)
+
+__device__ __forceinline__ bool term_pixel(const float* __restrict__ corners, const unsigned char* __restrict__ valid,
+                                           int b, int M, int t, int H, int W, int& pix, float& wv) {
+  const int m = t / 36, kp = (t - m * 36) >> 2, i = t & 3;
+  if (!valid[b * M + m]) return false;
+  float x, y;
+  key_point(corners + (size_t)(b * M + m) * 8, kp, x, y);
+  const Bilin q = make_bilin(x, y, H, W);
+  if (!q.in[i]) return false;
+  pix = (q.y0 + (i >> 1)) * W + q.x0 + (i & 1);
+  wv = q.w[i];
+  return true;
+}
+
 __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ dkp, const float* __restrict__ corners,
                                                      const unsigned char* __restrict__ valid, int M, int C, int H,
-                                                     int W, MapViewW gs) {
-  __shared__ unsigned keys[kMaxTerms];
-  __shared__ float wts[kMaxTerms];
-  __shared__ unsigned short starts[kMaxTerms + 1];     // first sorted index of every pixel's run of terms
+                                                     int W, MapViewW gs, int T, int tbits) {
+  extern __shared__ __attribute__((aligned(16))) char smem_sc[];
+  unsigned* keys = reinterpret_cast<unsigned*>(smem_sc);                    // [T]
+  float* wts = reinterpret_cast<float*>(keys + T);                          // [T]
+  unsigned short* starts = reinterpret_cast<unsigned short*>(wts + T);      // [T + 1] first sorted index of every run
   __shared__ int s_wave[4], s_runs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nterm = M * 36;
-  for (int t = tid; t < kMaxTerms; t += 256) {
+  const unsigned tmask = (1u << tbits) - 1u;
+  for (int t = tid; t < T; t += 256) {
     unsigned key = 0xFFFFFFFFu;
     float wv = 0.f;
-    if (t < nterm) {
-      const int m = t / 36, kp = (t - m * 36) >> 2, i = t & 3;
-      if (valid[b * M + m]) {
-        float x, y;
-        key_point(corners + (size_t)(b * M + m) * 8, kp, x, y);
-        const Bilin q = make_bilin(x, y, H, W);
-        if (q.in[i]) {
-          const int px = q.x0 + (i & 1), py = q.y0 + (i >> 1);
-          key = ((unsigned)(py * W + px) << 11) | (unsigned)t;
-          wv = q.w[i];
-        }
-      }
-    }
+    int pix;
+    if (t < nterm && term_pixel(corners, valid, b, M, t, H, W, pix, wv)) key = ((unsigned)pix << tbits) | (unsigned)t;
     keys[t] = key;
-    wts[t] = wv;
+    wts[t] = (key != 0xFFFFFFFFu) ? wv : 0.f;
   }
   __syncthreads();
-  for (int k = 2; k <= kMaxTerms; k <<= 1)
+  for (int k = 2; k <= T; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < kMaxTerms; t += 256) {
+      for (int t = tid; t < T; t += 256) {
         const int p = t ^ j;
         if (p > t) {
           const unsigned a = keys[t], c2 = keys[p];
@@ -309,15 +318,15 @@ __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ d
       }
       __syncthreads();
     }
-  // run starts: thread t owns sorted entries [8t, 8t + 8); block-wide exclusive scan of the per-thread start counts
+  // run starts: thread t owns sorted entries [E t, E t + E); block-wide exclusive scan of the per-thread start counts
+  const int E = T >> 8;                                // 8 .. 64
   int cnt = 0;
-  unsigned flags = 0u;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int i = tid * 8 + e;
+  unsigned long long flags = 0ull;
+  for (int e = 0; e < E; ++e) {
+    const int i = tid * E + e;
     const unsigned key = keys[i];
-    const bool st = key != 0xFFFFFFFFu && (i == 0 || (keys[i - 1] >> 11) != (key >> 11));
-    flags |= (unsigned)st << e;
+    const bool st = key != 0xFFFFFFFFu && (i == 0 || (keys[i - 1] >> tbits) != (key >> tbits));
+    flags |= (unsigned long long)st << e;
     cnt += st;
   }
   int inc = cnt;
@@ -330,22 +339,19 @@ __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ d
   __syncthreads();
   int off = inc - cnt;
   for (int w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
-#pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if ((flags >> e) & 1u) starts[off++] = (unsigned short)(tid * 8 + e);
+  for (int e = 0; e < E; ++e)
+    if ((flags >> e) & 1ull) starts[off++] = (unsigned short)(tid * E + e);
   if (tid == 255) s_runs = off;                   // total number of runs
   // number of valid (sorted-to-the-front) entries = end of the last run
   __syncthreads();
   const int nruns = s_runs;
   if (tid == 0) {
-    int n = 0;                                      // binary search for the first invalid key
-    int lo = 0, hi = kMaxTerms;
+    int lo = 0, hi = T;                             // binary search for the first invalid key
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (keys[mid] == 0xFFFFFFFFu) hi = mid; else lo = mid + 1;
     }
-    n = lo;
-    starts[nruns] = (unsigned short)n;
+    starts[nruns] = (unsigned short)lo;
   }
   __syncthreads();
   const int c = blockIdx.y * 64 + lane;
@@ -354,13 +360,79 @@ __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ d
   const float* __restrict__ dk = dkp + (size_t)b * M * 9 * C + c;
   for (int r = blockIdx.z + kRunSplit * wave; r < nruns; r += kRunSplit * 4) {
     const int i0 = starts[r], i1 = starts[r + 1];
-    const int pix = (int)(keys[i0] >> 11);
+    const int pix = (int)(keys[i0] >> tbits);
     float acc = 0.f;
     for (int i = i0; i < i1; ++i) {
-      const int t = (int)(keys[i] & 2047u);
+      const int t = (int)(keys[i] & tmask);
       acc += dk[(size_t)((t / 36) * 9 + ((t % 36) >> 2)) * C] * wts[t];
     }
     base[(pix / W) * gs.sy + (pix % W) * gs.sx] = acc;
+  }
+}
+
+// -- the rank-sort path (T > kMaxLdsTerms).  Keys are 64-bit (pixel << 32 | term), invalid terms sort to the end.
+__global__ __launch_bounds__(256) void k_terms_make(const float* __restrict__ corners,
+                                                    const unsigned char* __restrict__ valid, int M, int H, int W,
+                                                    int T, unsigned long long* __restrict__ keys,
+                                                    float* __restrict__ wts) {
+  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  int pix = 0;
+  float wv = 0.f;
+  const bool ok = term_pixel(corners, valid, b, M, t, H, W, pix, wv);
+  keys[(size_t)b * T + t] = ((unsigned long long)(ok ? (unsigned)pix : 0xFFFFFFFFu) << 32) | (unsigned)t;
+  wts[(size_t)b * T + t] = ok ? wv : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_terms_rank(const unsigned long long* __restrict__ keys, int T,
+                                                    unsigned long long* __restrict__ sorted) {
+  __shared__ unsigned long long tile[256];
+  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long* kb = keys + (size_t)b * T;
+  const unsigned long long mine = (t < T) ? kb[t] : ~0ull;
+  int rank = 0;
+  for (int j0 = 0; j0 < T; j0 += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = (j0 + threadIdx.x < T) ? kb[j0 + threadIdx.x] : ~0ull;
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < 256; ++j) rank += tile[j] < mine;
+  }
+  if (t < T) sorted[(size_t)b * T + rank] = mine;
+}
+
+// one wave per 64 sorted entries; a lane is a channel.  The wave visits the run starts among its entries in order and
+// follows each run to its end (possibly into the next wave's entries).
+__global__ __launch_bounds__(256) void k_box_scatter_sorted(const float* __restrict__ dkp,
+                                                            const unsigned long long* __restrict__ sorted,
+                                                            const float* __restrict__ wts, int M, int C, int W,
+                                                            int T, MapViewW gs) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long* sk = sorted + (size_t)b * T;
+  const float* wt = wts + (size_t)b * T;
+  const int i = (blockIdx.z * 4 + wave) * 64 + lane;
+  bool st = false;
+  if (i < T) {
+    const unsigned pix = (unsigned)(sk[i] >> 32);
+    st = pix != 0xFFFFFFFFu && (i == 0 || (unsigned)(sk[i - 1] >> 32) != pix);
+  }
+  unsigned long long todo = __ballot(st);
+  const int c = blockIdx.y * 64 + lane;
+  if (c >= C) return;
+  float* __restrict__ base = gs.p + b * gs.sb + c * gs.sc;
+  const float* __restrict__ dk = dkp + (size_t)b * M * 9 * C + c;
+  const int i_base = (blockIdx.z * 4 + wave) * 64;
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    int j = i_base + first;
+    const unsigned pix = (unsigned)(sk[j] >> 32);
+    float acc = 0.f;
+    for (; j < T && (unsigned)(sk[j] >> 32) == pix; ++j) {
+      const int t = (int)(unsigned)sk[j];
+      acc += dk[(size_t)((t / 36) * 9 + ((t % 36) >> 2)) * C] * wt[t];
+    }
+    base[((int)pix / W) * gs.sy + ((int)pix % W) * gs.sx] = acc;
   }
 }
 
@@ -574,7 +646,9 @@ extern "C" int ud_distill_box_fwd(int kind, const float* s, const int64_t* s_str
 // gradients into `workspace` (ud_distill_box_bwd_workspace_bytes), then their deterministic scatter (k_box_scatter).
 extern "C" size_t ud_distill_box_bwd_workspace_bytes(int B, int M, int C) {
   if (B <= 0 || M <= 0 || C <= 0) return 0;
-  return ud_align_up((size_t)B * M * 9 * C * sizeof(float));
+  // key-point gradients + (rank-sort path only, but sized always: 20 bytes per term) keys, sorted keys, weights
+  return ud_align_up((size_t)B * M * 9 * C * sizeof(float)) +
+         2 * ud_align_up((size_t)B * M * 36 * sizeof(unsigned long long)) + ud_align_up((size_t)B * M * 36 * sizeof(float));
 }
 
 extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_strides,
@@ -587,7 +661,7 @@ extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_str
     return UD_ERR_INVALID_ARG;
   if (B <= 0 || M <= 0 || C <= 0 || H <= 0 || W <= 0 || (kind != 0 && kind != 1))
     return UD_ERR_INVALID_ARG;
-  if (M * 36 > kMaxTerms || (long long)H * W >= (1 << 21)) return UD_ERR_UNSUPPORTED;
+  if ((long long)H * W >= (1ll << 31) || (long long)M * 36 >= (1ll << 31)) return UD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < ud_distill_box_bwd_workspace_bytes(B, M, C)) return UD_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* dkp = reinterpret_cast<float*>(workspace);
@@ -605,7 +679,35 @@ extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_str
                                              M, C, H, W, nullptr, dkp, gscale);
   }
   UD_LAUNCH_CHECK();
-  k_box_scatter<<<dim3(B, ud_div_up(C, 64), kRunSplit), 256, 0, stream>>>(dkp, corners_px, valid, M, C, H, W, g);
+  const int nterm = M * 36;
+  int T = kMinTerms, tbits = 11;
+  while (T < nterm) { T <<= 1; ++tbits; }
+  if (T <= kMaxLdsTerms && (long long)H * W < (1ll << (32 - tbits))) {
+    const size_t lds = (size_t)T * 10 + 16;
+    if (lds > 64 * 1024)
+      UD_HIP_TRY(hipFuncSetAttribute((const void*)k_box_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_box_scatter<<<dim3(B, ud_div_up(C, 64), kRunSplit), 256, lds, stream>>>(dkp, corners_px, valid, M, C, H, W, g,
+                                                                                 T, tbits);
+    UD_LAUNCH_CHECK();
+    return UD_OK;
+  }
+  // rank-sort path
+  const size_t need = ud_align_up((size_t)B * M * 9 * C * sizeof(float)) +
+                      2 * ud_align_up((size_t)B * nterm * sizeof(unsigned long long)) +
+                      ud_align_up((size_t)B * nterm * sizeof(float));
+  if (workspace_bytes < need) return UD_ERR_WORKSPACE;
+  UdArena a(workspace, workspace_bytes);
+  a.take<float>((size_t)B * M * 9 * C);
+  unsigned long long* keys = a.take<unsigned long long>((size_t)B * nterm);
+  unsigned long long* sorted = a.take<unsigned long long>((size_t)B * nterm);
+  float* wts = a.take<float>((size_t)B * nterm);
+  const dim3 gt_(ud_div_up(nterm, 256), B);
+  k_terms_make<<<gt_, 256, 0, stream>>>(corners_px, valid, M, H, W, nterm, keys, wts);
+  UD_LAUNCH_CHECK();
+  k_terms_rank<<<gt_, 256, 0, stream>>>(keys, nterm, sorted);
+  UD_LAUNCH_CHECK();
+  k_box_scatter_sorted<<<dim3(B, ud_div_up(C, 64), ud_div_up(nterm, 256)), 256, 0, stream>>>(dkp, sorted, wts, M, C, W,
+                                                                                            nterm, g);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

@@ -15,6 +15,24 @@ from torch import nn
 from .dense import Conv2d, ConvTranspose2d, FusedSequential, batchnorm_act
 
 
+def _resolve_checkpoint(spec):
+    """mmcv's Pretrained initialiser resolves ``torchvision://resnet50`` through the network; here: a local file,
+    the UD_RESNET50_CKPT environment variable, or torch hub's checkpoint cache.  -> path or None."""
+    import glob
+    import os
+    if os.path.isfile(spec):
+        return spec
+    if spec.startswith("torchvision://"):
+        env = os.environ.get("UD_RESNET50_CKPT", "")
+        if os.path.isfile(env):
+            return env
+        name = spec[len("torchvision://"):]
+        hits = sorted(glob.glob(os.path.join(torch.hub.get_dir(), "checkpoints", name + "-*.pth")))
+        if hits:
+            return hits[0]
+    return None
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -88,21 +106,32 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         cfg = self.init_cfg or {}
+        self.pretrained_loaded = False
         if cfg.get("type") == "Pretrained":
-            # mmcv's Pretrained initialiser: torchvision://resnet50 needs the network; a local file works
             import os
             import warnings
-            path = str(cfg.get("checkpoint", ""))
-            if os.path.isfile(path):
-                state = torch.load(path, map_location="cpu")
+            spec = str(cfg.get("checkpoint", ""))
+            path = _resolve_checkpoint(spec)
+            if path is not None:
+                state = torch.load(path, map_location="cpu", weights_only=True)
                 state = state.get("state_dict", state)
                 missing = self.load_state_dict(state, strict=False)
                 if missing.missing_keys:
                     warnings.warn(f"ResNet init_cfg: {len(missing.missing_keys)} keys missing in {path}")
+                self.pretrained_loaded = True
+            elif os.environ.get("UD_RANDOM_INIT", "0") == "1":
+                # benchmark / test mode (synthetic data, random weights of the reference architecture): keep the
+                # reference's freeze pattern -- its compute graph -- on the Kaiming initialisation
+                warnings.warn(f"ResNet init_cfg checkpoint {spec!r} not found: UD_RANDOM_INIT=1 keeps the Kaiming "
+                              "initialisation (benchmark mode; the reference starts from ImageNet weights)")
+            elif self.frozen_stages >= 0:
+                # a frozen, randomly initialised stem can never be trained: refuse instead of training on it silently
+                raise FileNotFoundError(
+                    f"ResNet init_cfg checkpoint {spec!r} not found and frozen_stages={self.frozen_stages} freezes "
+                    "the stem: point UD_RESNET50_CKPT (or init_cfg['checkpoint']) at a local torchvision ResNet-50 "
+                    "state_dict, or set UD_RANDOM_INIT=1 for synthetic benchmarks / tests")
             else:
-                warnings.warn(f"ResNet init_cfg checkpoint {path!r} is not a local file (no network here): "
-                              "the backbone keeps its Kaiming initialisation, unlike the reference's "
-                              "ImageNet start")
+                warnings.warn(f"ResNet init_cfg checkpoint {spec!r} not found: Kaiming initialisation kept")
 
     def forward(self, x):
         x = self.maxpool(batchnorm_act(self.bn1, self.conv1(x)))

@@ -23,11 +23,13 @@ from .image import build_backbone, build_neck
 class LSSFPN(nn.Module):
     def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, downsample_factor,
                  output_channels, img_backbone_conf, img_neck_conf, depth_net_conf,
-                 timestamp_net_conf=None, materialise=False, inverse="exact"):
+                 timestamp_net_conf=None, materialise=False, inverse="torch"):
         super().__init__()
-        # "exact": correctly rounded 4x4 inverses inside the matrix kernel (default: no solver launch,
-        # no sync).  "torch": torch.linalg.inv_ex on the device, i.e. the reference's own
-        # ida_mat.inverse() / torch.inverse(intrin_mat) call with that backend's rounding.
+        # "torch" (default = the reference's behaviour, index work is exact): torch.linalg.inv_ex on the device,
+        # i.e. the reference's own ida_mat.inverse() / torch.inverse(intrin_mat) calls (lss_fpn.py:222,233) with
+        # that backend's rounding -- two tiny solver launches, no host sync.  "exact": correctly rounded 4x4
+        # inverses inside the matrix kernel (no solver launch; differs from the LAPACK LU in the last bit, which
+        # can move a point sitting on a bin edge).
         assert inverse in ("exact", "torch")
         self.inverse = inverse
         self.downsample_factor = downsample_factor

@@ -10,6 +10,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("UD_RANDOM_INIT", "1")   # tests build the reference architecture on random weights
 
 
 def pytest_configure(config):

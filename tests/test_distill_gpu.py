@@ -106,3 +106,34 @@ def test_box_losses_full_size_vs_torch(relation, C):
     ref.backward()
     np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
     np.testing.assert_allclose(s.grad.cpu().numpy(), s2.grad.cpu().numpy(), rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,Mmax", [(150, 160), (470, 500)])
+def test_box_losses_many_boxes(M, Mmax):
+    """the deterministic scatter of the backward used to refuse more than 56 (padded) boxes per sample.
+    M=150 -> 8192-term LDS sort; Mmax=500 -> 18000 terms -> the rank-sort path.  Also bitwise reproducible."""
+    from unidistill_amd.ops import distill as ds
+    from unidistill_amd import synthetic as syn
+    B, C = 2, 64
+    boxes, _ = syn.gt_boxes(syn.rng(7), B, M, Mmax=Mmax)
+    boxes[:, :, :2] *= 0.3            # crowd the boxes so that footprints overlap heavily
+    gt = torch.from_numpy(boxes).cuda()
+    corners, valid = ds.box_corners_bev(gt, syn.POINT_CLOUD_RANGE, syn.VOXEL_SIZE, 8)
+    assert corners.shape[1] == Mmax and valid.sum().item() == B * M
+    torch.manual_seed(1)
+    t = torch.randn(B, C, 180, 180, device="cuda")
+    for relation in (False, True):
+        fn = ds.BEVDistillLoss if relation else ds.FeatureDistillLoss
+        grads = []
+        for _ in range(2):
+            s = torch.randn(B, C, 180, 180, device="cuda", generator=torch.Generator("cuda").manual_seed(3),
+                            requires_grad=True)
+            loss = fn(s, t, corners, valid)
+            loss.backward()
+            grads.append(s.grad.clone())
+        assert torch.equal(grads[0], grads[1])
+        s2 = s.detach().clone().requires_grad_(True)
+        ref = _torch_feature_loss(s2, t, corners, valid, relation)
+        ref.backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+        np.testing.assert_allclose(grads[0].cpu().numpy(), s2.grad.cpu().numpy(), rtol=2e-3, atol=2e-7)

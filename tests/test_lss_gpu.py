@@ -82,6 +82,32 @@ def test_lssfpn_torch_inverse_mode_matches_exact_mode():
     assert (b0 != b1).any(-1).float().mean().item() < 1e-3
 
 
+def test_lssfpn_default_is_the_reference_inverse():
+    """the module default takes its 4x4 inverses from torch.linalg.inv_ex like the reference
+    (lss_fpn.py:222,233); bins of the default module == bins computed with those inverses passed explicitly, on the
+    BASELINE rig, bit for bit.  The in-kernel exact inverse is the opt-in variant."""
+    import inspect
+    from unidistill_amd import config as C, synthetic as syn
+    from unidistill_amd.layers.lss_fpn import LSSFPN
+    from unidistill_amd.ops import lss
+    assert inspect.signature(LSSFPN.__init__).parameters["inverse"].default == "torch"
+    cfg = dict(C.CAMERA_ENCODER)
+    m = LSSFPN(**cfg).cuda()
+    assert m.inverse == "torch"
+    s2e, intr, ida, bda = (torch.from_numpy(a).cuda() for a in syn.camera_rig(syn.rng(5), 2, 6, bda_aug=True))
+    bins, _ = m.get_geometry_bins(s2e[:, 0], intr[:, 0], ida[:, 0], bda)
+    ai, ki = torch.linalg.inv_ex(ida[:, 0]).inverse, torch.linalg.inv_ex(intr[:, 0]).inverse
+    fu, fv, fd = m._frustum_axes()
+    ref, _ = lss.geometry(lss.prepare_mats(s2e[:, 0], intr[:, 0], ida[:, 0], bda, ai, ki), fu, fv, fd, 2, 6,
+                          m._lo, m._size)
+    assert torch.equal(bins, ref)
+    m.inverse = "exact"
+    alt, _ = m.get_geometry_bins(s2e[:, 0], intr[:, 0], ida[:, 0], bda)
+    flips = (alt != bins).any(-1).float().mean().item()
+    print(f"exact-inverse opt-in variant: {flips:.2e} of the frustum points change bin")
+    assert flips < 1e-3
+
+
 def test_lift_matches_reference_golden(golden):
     from unidistill_amd.ops import lss
     g = golden("lss_lift")

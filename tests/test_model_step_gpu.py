@@ -74,7 +74,7 @@ def test_lssfpn_forward_single_sweep_vs_reference(golden, hip_lib):
         B, ncam = g["sensor2ego"].shape[:2]
         bins, _ = lss.geometry(mats, fu, fv, fd, B, ncam, enc._lo, enc._size)
         assert int((bins.cpu().numpy().reshape(g["lss_geom_xyz"].shape) != g["lss_geom_xyz"]).sum()) == 0
-        # the module, end to end (fused lift+splat; in-kernel correctly rounded inverses)
+        # the module, end to end (fused lift+splat; inverses from torch.linalg.inv_ex on the device, the module default)
         bev, depth = enc._forward_single_sweep(0, b["imgs"], b["mats_dict"], is_return_depth=True)
         _close(depth, g["lss_depth"], what="depth distribution")
         _close(bev, g["lss_bev"], what="pooled BEV map")
