@@ -76,8 +76,9 @@ def _distill_step_checks(workload, batch_size, sweeps, ac, ncam=6):
 
 
 def test_cfg4_lidar_student_fusion_teacher_three_loss_step():
-    """BASELINE configs[3]: LiDAR student + fusion teacher, full 3-loss distillation (batch 2 here, fp32)."""
-    step, out = _distill_step_checks("lidar_exp_distill_fusion", batch_size=2, sweeps=1, ac=None)
+    """BASELINE configs[3]: LiDAR student + fusion teacher, full 3-loss distillation at its stated batch of 4 per GPU,
+    fp32 (the reference's arithmetic)."""
+    step, out = _distill_step_checks("lidar_exp_distill_fusion", batch_size=4, sweeps=1, ac=None)
     assert step.teacher_model.fusion_encoder is not None and step.teacher_model.camera_encoder is not None
     assert step.model.camera_encoder is None and step.model.lidar_encoder is not None
     e = step.exp
