@@ -1,0 +1,319 @@
+// fp32 weight gradients of the dense convolutions (the reference's arithmetic: it trains in fp32, base_cli.py:40-45) --
+// BEV trunk (base_bev_backbone.py:38-115), CenterHead shared / first SepHead convs (center_head.py:58-99,311-355), the
+// fusion conv and the ResNet / neck convolutions (lss_fpn.py:143-149) -- on v_mfma_f32_16x16x4_f32 (exact fp32
+// products, fp32 accumulation).  Deterministic: pixel slices keep private partial sums that k_wgrad_sum adds in a fixed
+// order (the library's split-K kernels use atomics).
+//
+//   3x3 / stride 1 / pad 1:   dW[n][tap][c] = sum_p dy[p][n] * x[p + tap][c]
+//   1x1 over pixel maps:      dW[n][k]      = sum_p dy'[p][n] * x'[p][k]     (plain, strided, transposed, patch, im2col)
+//
+// The reduction index of the MFMA is the PIXEL: A[i][k] = dy[pixel k][channel i], B[k][j] = x[pixel k][channel j], one
+// fp32 register per operand, so channels-last rows are MFMA fragments as they lie in LDS -- no transposition:
+//   A: ds_read_b32   lane (li, g) reads dy[p0 + g][n0 + 16 wave + li]
+//   B: ds_read_b128  lane (li, g) reads x[p0 + g (+ tap shift)][4 li .. 4 li + 3]; element e feeds MFMA e, whose column
+//      j = li then stands for channel 4 li + e (a permutation of the 64 channels that only the epilogue has to know).
+// 3x3: a workgroup owns a 64 (dy channels) x 64 (x channels) tile of dW for ALL nine taps and walks a slice of the
+// 8 x 16 pixel tiles; the x halo (10 x 18 pixels) and the dy tile are staged once per pixel tile by LDS-DMA and serve
+// the nine shifted GEMMs: per 4-pixel step a wave issues 1 + 9 LDS reads for 36 MFMAs (1 152 MFMA cycles) -- the kernel
+// is MFMA-bound by construction.  LDS is single-buffered (78 KB) and TWO workgroups share a CU: one multiplies while the
+// other one's DMA is in flight, which is the double buffering of the bf16 twin without its bookkeeping.
+#include "ud_common.h"
+#include "ud_prof.h"
+#include "conv_pixmap.h"
+#include "wgrad_sum.h"
+
+namespace {
+
+constexpr int kTW = 16, kTH = 8, kTM = kTW * kTH;
+constexpr int kHW = kTW + 2, kHQ = kHW * (kTH + 2), kHQP = (kHQ + 3) / 4 * 4;   // 180 halo pixels, staged 4 rows per DMA
+constexpr int kRowB = 256;                                                       // 64 fp32 channels per LDS row
+constexpr int kXBytes = kHQP * kRowB, kDBytes = kTM * kRowB;                     // 46 080 + 32 768
+constexpr int kXPieces = kHQP / 4, kDPieces = kTM / 4;                           // 1-KiB DMA pieces: 45, 32
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16w[4];
+
+__device__ __forceinline__ void dma16(const float* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct WgGeom {
+  int B, H, W, Cin, Cout, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ partial, WgGeom gm, int c_tiles,
+                                                              int tiles_per_slice) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int ct = blockIdx.y % c_tiles, nt = blockIdx.y / c_tiles;
+  const int n0 = nt * 64, c0 = ct * 64;
+  const int per_img = gm.tiles_x * gm.tiles_y, ntiles = gm.B * per_img;
+  const int t_begin = blockIdx.x * tiles_per_slice, t_end = min(ntiles, t_begin + tiles_per_slice);
+  const float* zero = reinterpret_cast<const float*>(g_zero16w);
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // DMA: a piece = 4 LDS rows x 256 B; lane -> (row g, 16-byte slot li).  x rows are stored as they are; dy rows have
+  // their slots XOR-ed with 4 on odd pixels (on the SOURCE address: the DMA's LDS pattern is fixed), which puts the
+  // two pixel rows a half-wave's ds_read_b32 touches on different bank halves.
+  const bool xc_ok = c0 + 4 * li < gm.Cin;
+  const int dslot = li ^ ((g & 1) << 2);
+  const bool dn_ok = n0 + 4 * dslot < gm.Cout;
+  auto stage = [&](int tile) {
+    const int b = tile / per_img;
+    const int rem = tile - b * per_img;
+    const int ty0 = (rem / gm.tiles_x) * kTH, tx0 = (rem % gm.tiles_x) * kTW;
+    for (int piece = wave; piece < kXPieces; piece += 4) {
+      const int q = piece * 4 + g, qy = q / kHW, qx = q - qy * kHW;
+      const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
+      const bool ok = xc_ok && q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
+      dma16(ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + c0 + 4 * li : zero, smem + piece * 1024);
+    }
+    for (int piece = wave; piece < kDPieces; piece += 4) {
+      const int p = piece * 4 + g, gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+      const bool ok = dn_ok && gy < gm.H && gx < gm.W;
+      dma16(ok ? dy + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n0 + 4 * dslot : zero,
+            smem + kXBytes + piece * 1024);
+    }
+  };
+  // fragment addresses of step (row 0, columns 0..3); a step adds an immediate
+  const int aslot = 4 * wave + (li >> 2);
+  const char* pa = smem + kXBytes + g * kRowB + ((aslot ^ ((g & 1) << 2)) << 4) + (li & 3) * 4;
+  const char* pb = smem + g * kRowB + li * 16;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    stage(tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < kTH; ++r) {
+      const char* par = pa + r * (kTW * kRowB);
+      const char* pbr = pb + r * (kHW * kRowB);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = *reinterpret_cast<const float*>(par + 4 * q * kRowB);
+        f32x4 bb[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+          bb[tap] = *reinterpret_cast<const f32x4*>(pbr + ((tap / 3) * kHW + 4 * q + tap % 3) * kRowB);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[tap][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[tap][e], acc[tap][e], 0, 0, 0);
+      }
+    }
+    __syncthreads();            // everybody is done reading before the next tile's DMA lands
+  }
+  // partial[slice][n][tap][c]; D layout: lane holds rows n = 4 g + r, column li = channels 4 li + e of MFMA e
+  const int c = c0 + 4 * li;
+  if (c < gm.Cin) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * wave + 4 * g + r;
+        if (n < gm.Cout)
+          *reinterpret_cast<float4*>(partial + (((size_t)blockIdx.x * gm.Cout + n) * 9 + tap) * gm.Cin + c) =
+              make_float4(acc[tap][0][r], acc[tap][1][r], acc[tap][2][r], acc[tap][3][r]);
+      }
+  }
+}
+
+constexpr size_t kWg3Lds = (size_t)kXBytes + kDBytes;
+
+// pixel-tile slices: (slices x 64x64 output tiles) <= 512 workgroups = two per CU, all resident
+int wg3_slices(int B, int H, int W, int Cin, int Cout, int* tiles_per_slice) {
+  const int ntiles = B * ud_div_up(W, kTW) * ud_div_up(H, kTH);
+  const int combos = ud_div_up(Cout, 64) * ud_div_up(Cin, 64);
+  int s = 512 / combos;
+  if (s > ntiles) s = ntiles;
+  if (s < 1) s = 1;
+  const int per = (ntiles + s - 1) / s;
+  *tiles_per_slice = per;
+  return (ntiles + per - 1) / per;
+}
+
+// ---- 1x1 over pixel maps ---------------------------------------------------------------------------------------------
+// (pixel slice) x (NT x 64 output tile) workgroups, 64-pixel steps staged by LDS-DMA (single buffer, 48 / 32 KB: three /
+// four workgroups per CU overlap each other's DMA), wave w owns NT / 4 dy channels x 64 x channels.
+template <int NT>
+__global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ partial, long long P, int Cin, int Cout,
+                                                           int c_tiles, int steps_per_slice, PixMap xmap, PixMap ymap) {
+  constexpr int TI = NT / 64;                    // 16-channel dy fragments per wave
+  constexpr int kDRow = NT * 4;                  // bytes per dy row (512 / 256)
+  constexpr int kDSlots = NT / 4;                // 16-byte slots per dy row
+  constexpr int kDRowsPer = 1024 / kDRow;        // dy rows per DMA piece (2 / 4)
+  constexpr int kDTile = 64 * kDRow;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int ct = blockIdx.y % c_tiles, nt = blockIdx.y / c_tiles;
+  const int n0 = nt * NT, c0 = ct * 64;
+  const int steps = (int)((P + 63) / 64);
+  const int s_begin = blockIdx.x * steps_per_slice, s_end = min(steps, s_begin + steps_per_slice);
+  const float* zero = reinterpret_cast<const float*>(g_zero16w);
+
+  f32x4 acc[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int step) {
+    const long long p0 = (long long)step * 64;
+    for (int piece = wave; piece < 64 / kDRowsPer; piece += 4) {       // dy: slots XOR 4 on odd pixels (see the 3x3 kernel)
+      const int r = piece * kDRowsPer + lane / kDSlots, slot = lane % kDSlots;
+      const int n = n0 + 4 * (slot ^ ((r & 1) << 2));
+      const long long p = p0 + r;
+      dma16((p < P && n < Cout) ? dy + ymap.off(p, n, Cout) : zero, smem + piece * 1024);
+    }
+    for (int piece = wave; piece < 16; piece += 4) {
+      const int r = piece * 4 + g;
+      const long long p = p0 + r;
+      const float* src = zero;
+      if (p < P && c0 + 4 * li < Cin) {
+        const size_t o = xmap.off(p, c0 + 4 * li, Cin);
+        if (o != kNoPixel) src = x + o;
+      }
+      dma16(src, smem + kDTile + piece * 1024);
+    }
+  };
+  const char* pa[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    const int slot = 4 * (TI * wave + ti) + (li >> 2);
+    pa[ti] = smem + g * kDRow + ((slot ^ ((g & 1) << 2)) << 4) + (li & 3) * 4;
+  }
+  const char* pb = smem + kDTile + g * kRowB + li * 16;
+
+  for (int step = s_begin; step < s_end; ++step) {
+    stage(step);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(pb + 4 * ks * kRowB);
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        const float a = *reinterpret_cast<const float*>(pa[ti] + 4 * ks * kDRow);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[ti][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[e], acc[ti][e], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int c = c0 + 4 * li;
+  if (c < Cin) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * (TI * wave + ti) + 4 * g + r;
+        if (n < Cout)
+          *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * Cout + n) * Cin + c) =
+              make_float4(acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]);
+      }
+  }
+}
+
+struct Wg1Plan {
+  int nt, n_tiles, c_tiles, slices, steps_per_slice;
+};
+Wg1Plan wg1_plan(long long P, int Cin, int Cout) {
+  Wg1Plan pl;
+  pl.nt = Cout > 64 ? 128 : 64;
+  pl.n_tiles = ud_div_up(Cout, pl.nt);
+  pl.c_tiles = ud_div_up(Cin, 64);
+  const int steps = (int)((P + 63) / 64);
+  int s = 768 / (pl.n_tiles * pl.c_tiles);           // three workgroups per CU, all resident
+  if (s > steps) s = steps;
+  if (s < 1) s = 1;
+  pl.steps_per_slice = (steps + s - 1) / s;
+  pl.slices = (steps + pl.steps_per_slice - 1) / pl.steps_per_slice;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t ud_conv3x3_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  int per;
+  return ud_align_up((size_t)wg3_slices(B, H, W, Cin, Cout, &per) * Cout * 9 * Cin * sizeof(float));
+}
+
+// x [B][H][W][Cin], dy [B][H][W][Cout] fp32 channels-last -> dw [Cout][3][3][Cin] fp32.  Cin % 4 == 0, Cout % 4 == 0.
+extern "C" int ud_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin,
+                                         int Cout, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  if (!x || !dy || !dw || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if (Cin % 4 != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < ud_conv3x3_wgrad_f32_workspace_bytes(B, H, W, Cin, Cout)) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* partial = reinterpret_cast<float*>(workspace);
+  WgGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH)};
+  int per;
+  const int S = wg3_slices(B, H, W, Cin, Cout, &per);
+  static bool set = false;
+  if (!set) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kWg3Lds));
+    set = true;
+  }
+  const int c_tiles = ud_div_up(Cin, 64);
+  {
+    UdProfScope prof("conv2d.k_wgrad_f32", stream);
+    k_conv3x3_wgrad_f32<<<dim3(S, ud_div_up(Cout, 64) * c_tiles), 256, kWg3Lds, stream>>>(x, dy, partial, gm, c_tiles, per);
+    UD_LAUNCH_CHECK();
+  }
+  return ud_wgrad_sum(partial, S, (size_t)Cout * 9 * Cin, dw, stream);
+}
+
+extern "C" size_t ud_conv1x1_wgrad_f32_workspace_bytes(int64_t P, int Cin, int Cout) {
+  if (P <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const Wg1Plan pl = wg1_plan(P, Cin, Cout);
+  return ud_align_up((size_t)pl.slices * Cout * Cin * sizeof(float));
+}
+
+// dW[n][k] = sum_p dy'[p][n] * x'[p][k], either operand optionally read through a PixMap (NULL = plain [P][C] rows):
+// the weight gradients of every convolution ud_conv1x1_nhwc_f32 / ud_conv1x1_mapped_nhwc_f32 run.
+extern "C" int ud_conv1x1_wgrad_mapped_nhwc_f32(const float* x, const float* dy, float* dw, int64_t P, int Cin, int Cout,
+                                                const int* x_map, const int* dy_map, void* workspace,
+                                                size_t workspace_bytes, ud_stream_t stream_) {
+  if (!x || !dy || !dw || P <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  PixMap xm, ym;
+  if (!map_from_ints(x_map, &xm, 4) || !map_from_ints(dy_map, &ym, 4)) return UD_ERR_INVALID_ARG;
+  if (Cin % 4 != 0 || Cout % 4 != 0 || P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;
+  if (xm.mode == 1 && xm.s * xm.s * xm.C != Cin) return UD_ERR_INVALID_ARG;
+  if (xm.mode == 2 && xm.C != Cin) return UD_ERR_INVALID_ARG;
+  if (xm.mode == 3 && 9 * xm.C != Cin) return UD_ERR_INVALID_ARG;
+  if (xm.mode == 4 || ym.mode >= 3) return UD_ERR_UNSUPPORTED;
+  if (ym.mode == 1 && ym.s * ym.s * ym.C != Cout) return UD_ERR_INVALID_ARG;
+  if (ym.mode == 2 && ym.C != Cout) return UD_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < ud_conv1x1_wgrad_f32_workspace_bytes(P, Cin, Cout)) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const Wg1Plan pl = wg1_plan(P, Cin, Cout);
+  float* partial = reinterpret_cast<float*>(workspace);
+  {
+    UdProfScope prof("conv2d.k_wgrad_1x1_f32", stream);
+    const dim3 grid(pl.slices, pl.n_tiles * pl.c_tiles);
+    if (pl.nt == 128)
+      k_conv1x1_wgrad_f32<128><<<grid, 256, 64 * 512 + 64 * 256, stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
+                                                                          pl.steps_per_slice, xm, ym);
+    else
+      k_conv1x1_wgrad_f32<64><<<grid, 256, 64 * 256 + 64 * 256, stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
+                                                                         pl.steps_per_slice, xm, ym);
+    UD_LAUNCH_CHECK();
+  }
+  return ud_wgrad_sum(partial, pl.slices, (size_t)Cout * Cin, dw, stream);
+}

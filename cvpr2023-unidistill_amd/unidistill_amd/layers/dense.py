@@ -65,7 +65,7 @@ def _fp32_kernel_pays(conv, x):
     return conv.out_channels % 64 != 0 or px >= 1024
 
 
-# fp32 mode: strided / transposed convolutions on the fp32 mapped kernel (forward + data gradient; weight gradient: library)
+# fp32 mode: strided / transposed convolutions on the fp32 mapped kernels (forward, data and weight gradient)
 _FP32_MAPPED = os.environ.get("UD_FP32_MAPPED", "1") != "0"
 
 
@@ -148,6 +148,12 @@ class ConvTranspose2d(nn.ConvTranspose2d):
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0
                 and x.is_contiguous(memory_format=torch.channels_last)):
             return hipconv.conv1x1(x.to(torch.bfloat16), self.weight.permute(1, 0, 2, 3), self.bias)
+        if (Conv2d.hip_enabled and Conv2d.hip_fp32 and output_size is None and x.dim() == 4 and _fp32_mode(x)
+                and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                and self.output_padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1
+                and hipconv32.supported(x, self.weight.permute(1, 0, 2, 3), 1)):
+            # fp32 mode: the same 1x1 convolution on the fp32 MFMA kernels (all three passes)
+            return hipconv32.conv1x1(x, self.weight.permute(1, 0, 2, 3), self.bias)
         if (Conv2d.hip_enabled and output_size is None and x.dim() == 4 and (_mixed_precision(x) or _fp32_mapped(x))
                 and self.kernel_size[0] == self.kernel_size[1] == self.stride[0] == self.stride[1] and self.stride[0] >= 2
                 and self.padding == (0, 0) and self.output_padding == (0, 0) and self.dilation == (1, 1)

@@ -339,18 +339,16 @@ def _mapped(x, w2d, y, P, K, N, imap, omap):
 
 
 def _cdt(x):
-    """Compute dtype of the mapped convolutions: fp32 tensors outside autocast stay fp32 (fp32 MFMA kernels; their weight
-    gradient goes through the library), everything else runs in bf16."""
+    """Compute dtype of the mapped convolutions: fp32 tensors outside autocast stay fp32 (fp32 MFMA kernels, all three
+    passes), everything else runs in bf16."""
     return torch.float32 if (x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")) else torch.bfloat16
 
 
-def _lib_wgrad(x, gy, weight, stride, padding, transposed=False):
-    """fp32 mode: weight gradient of the strided / transposed convolution through the library (MIOpen fp32)."""
-    return torch.ops.aten.convolution_backward(gy, x, weight.detach(), None, [stride, stride], [padding, padding], [1, 1],
-                                               transposed, [0, 0], 1, [False, True, False])[1]
-
-
 def _mapped_wgrad(x, gy, P, K, N, xmap, ymap):
+    """Weight gradient through pixel maps; bf16 or (the reference's arithmetic) fp32 by the dtype of x."""
+    if x.dtype == torch.float32:
+        from . import conv2d_f32
+        return conv2d_f32.wgrad_mapped(x, gy, P, K, N, xmap, ymap)
     lib = _lib.load()
     ws = _lib.workspace(x.device, lib.ud_conv1x1_wgrad_workspace_bytes(P, K, N), "conv_wgrad")
     dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
@@ -415,11 +413,8 @@ class _ConvPatchFn(torch.autograd.Function):
             gx = torch.ops.aten.convolution_backward(gy, x, weight.detach().to(dt), None, [s, s], [0, 0], [1, 1],
                                                      False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            if dt == torch.float32:
-                gw = _lib_wgrad(x, gy, weight, s, 0)
-            else:
-                dw = _mapped_wgrad(x, gy, P, K, cout, pm, None)    # [Cout][s][s][C]
-                gw = dw.view(cout, s, s, C).permute(0, 3, 1, 2).to(weight.dtype)
+            dw = _mapped_wgrad(x, gy, P, K, cout, pm, None)    # [Cout][s][s][C]
+            gw = dw.view(cout, s, s, C).permute(0, 3, 1, 2).to(weight.dtype)
         return gx, gw, None
 
 
@@ -459,11 +454,8 @@ class _ConvTPatchFn(torch.autograd.Function):
             gx = _bf16_cl_empty((B, cin, H, W), x.device, dtype=dt)
             _mapped(gy, w2, gx, P, N, cin, pm, None)            # rows of dy gathered by the map: [P][N] x [Cin][N]^T
         if ctx.needs_input_grad[1]:
-            if dt == torch.float32:
-                gw = _lib_wgrad(x, gy, weight, s, 0, transposed=True)
-            else:
-                dw = _mapped_wgrad(x, gy, P, cin, N, None, pm)      # [s][s][Cout][Cin]
-                gw = dw.view(s, s, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
+            dw = _mapped_wgrad(x, gy, P, cin, N, None, pm)      # [s][s][Cout][Cin]
+            gw = dw.view(s, s, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
         return gx, gw, None
 
 
@@ -502,10 +494,7 @@ class _Conv1x1StrideFn(torch.autograd.Function):
             wt = weight.detach().reshape(cout, cin).t().contiguous() if dt == torch.float32 else _w1x1_t(weight)
             _mapped(gy, wt, gx, P, cout, cin, None, pm)
         if ctx.needs_input_grad[1]:
-            if dt == torch.float32:
-                gw = _lib_wgrad(x, gy, weight, s, 0)
-            else:
-                gw = _mapped_wgrad(x, gy, P, cin, cout, pm, None).view(cout, cin, 1, 1).to(weight.dtype)
+            gw = _mapped_wgrad(x, gy, P, cin, cout, pm, None).view(cout, cin, 1, 1).to(weight.dtype)
         return gx, gw, None
 
 
@@ -563,11 +552,8 @@ class _Conv3x3S2Fn(torch.autograd.Function):
                     _mapped(gy, wtt, gx, B * Hc * Wc, K, C, _pmap(4, 2, Hc, Wc, Ho, Wo, cout, a, b),
                             _pmap(2, 2, Hc, Wc, H, W, C, a, b))
         if ctx.needs_input_grad[1]:
-            if dt == torch.float32:
-                gw = _lib_wgrad(x, gy, weight, 2, 1)
-            else:
-                dw = _mapped_wgrad(x, gy, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)   # [Cout][9][C]
-                gw = dw.view(cout, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype)
+            dw = _mapped_wgrad(x, gy, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)   # [Cout][9][C]
+            gw = dw.view(cout, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype)
         return gx, gw
 
 

@@ -1,8 +1,8 @@
 """fp32 3x3 / stride-1 / pad-1 and 1x1 convolutions on channels-last fp32 tensors (ud_conv3x3_nhwc_f32,
 ud_conv1x1_nhwc_f32: exact fp32 products on the fp32 MFMA pipe) -- the reference's own arithmetic for the BEV
 trunk, head, fusion conv and the ResNet / neck convs (base_bev_backbone.py:30-110, center_head.py:311-420,
-BEVFusion_nuscenes_base_exp.py:107-135, lss_fpn.py:143-149).  Forward and data gradient are hand-written;
-the weight gradient of the fp32 mode goes through aten.convolution_backward.
+BEVFusion_nuscenes_base_exp.py:107-135, lss_fpn.py:143-149).  Forward, data gradient and weight gradient are
+hand-written (csrc/conv2d_f32.hip, csrc/conv2d_f32_wgrad.hip).
 """
 import ctypes
 
@@ -61,11 +61,44 @@ def _launch1(x, w, cout, bias=None, residual=None, bn_stats=False):
     return y
 
 
+USE_HIP_WGRAD = True       # False: aten.convolution_backward (MIOpen fp32 split-K kernels, atomics) for A/B timing
+
+
+def wgrad_supported(x, gy):
+    return (x.is_cuda and x.dtype == torch.float32 and gy.dtype == torch.float32 and x.shape[1] % 4 == 0
+            and gy.shape[1] % 4 == 0)
+
+
 def weight_grad(x, gy, w, ks):
-    """dW of a stride-1 'same' convolution; x, gy channels-last fp32, w [Cout, Cin, ks, ks]."""
-    p = ks // 2
-    return torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
-                                               [False, True, False])[1]
+    """dW of a stride-1 'same' convolution; x, gy channels-last fp32, w [Cout, Cin, ks, ks].  Hand-written fp32 MFMA
+    kernels with a fixed-order slice reduction (ud_conv3x3_wgrad_nhwc_f32 / ud_conv1x1_wgrad_mapped_nhwc_f32); the
+    result comes back in the parameter's channels-last strides (a [Cout, ks, ks, Cin] buffer viewed as [Cout, Cin, ks, ks])."""
+    cout, cin = w.shape[0], w.shape[1]
+    if not (USE_HIP_WGRAD and wgrad_supported(x, gy)):
+        p = ks // 2
+        return torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
+                                                   [False, True, False])[1]
+    lib = _lib.load()
+    B, _, H, W = x.shape
+    if ks == 3:
+        ws = _lib.workspace(x.device, lib.ud_conv3x3_wgrad_f32_workspace_bytes(B, H, W, cin, cout), "conv_wgrad")
+        dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ud_conv3x3_wgrad_nhwc_f32(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), B, H, W, cin, cout,
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+                   "ud_conv3x3_wgrad_nhwc_f32")
+        return dw.permute(0, 3, 1, 2)
+    return wgrad_mapped(x, gy, B * H * W, cin, cout, None, None).view(cout, cin, 1, 1)
+
+
+def wgrad_mapped(x, gy, P, K, N, xmap, ymap):
+    """dW [N][K] = sum_p dy'[p][N] x'[p][K] with pixel maps (ops/conv2d.py:_pmap) on x and / or dy; fp32."""
+    lib = _lib.load()
+    ws = _lib.workspace(x.device, lib.ud_conv1x1_wgrad_f32_workspace_bytes(P, K, N), "conv_wgrad")
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ud_conv1x1_wgrad_mapped_nhwc_f32(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), P, K, N, xmap, ymap,
+                                                    _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+               "ud_conv1x1_wgrad_mapped_nhwc_f32")
+    return dw
 
 
 class _ConvF32(torch.autograd.Function):

@@ -488,6 +488,19 @@ int ud_conv1x1_mapped_nhwc_f32(const float* x, const float* w, float* y, int64_t
 int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
                                       const int* x_map, const int* dy_map, void* workspace,
                                       size_t workspace_bytes, ud_stream_t stream);
+/* fp32 weight gradients (the reference's arithmetic; replaces nn.Conv2d's backward-weights pass of the BEV trunk,
+ * base_bev_backbone.py:38-115, the CenterHead convolutions, center_head.py:58-99,311-355, and the image branch) on
+ * v_mfma_f32_16x16x4_f32, exact fp32 products; pixel slices reduced in a fixed order (deterministic, no atomics).
+ *   3x3 / stride 1 / pad 1: x [B][H][W][Cin], dy [B][H][W][Cout] -> dw [Cout][3][3][Cin];
+ *   1x1 over pixel maps (NULL = plain rows; maps as above, on x or dy): dw [Cout][Cin'].
+ * Cin % 4 == 0, Cout % 4 == 0 (and map channels % 4 == 0), else UD_ERR_UNSUPPORTED. */
+size_t ud_conv3x3_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ud_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                              void* workspace, size_t workspace_bytes, ud_stream_t stream);
+size_t ud_conv1x1_wgrad_f32_workspace_bytes(int64_t P, int Cin, int Cout);
+int ud_conv1x1_wgrad_mapped_nhwc_f32(const float* x, const float* dy, float* dw, int64_t P, int Cin, int Cout,
+                                     const int* x_map, const int* dy_map, void* workspace, size_t workspace_bytes,
+                                     ud_stream_t stream);
 
 /* ---- LiDAR input side ------------------------------------------------------------------
  * Replaces the numpy point transforms of the reference's data pipeline:
