@@ -15,8 +15,7 @@
 // 3x3: a workgroup owns a 64 (dy channels) x 64 (x channels) tile of dW for ALL nine taps and walks a slice of the
 // 8 x 16 pixel tiles; the x halo (10 x 18 pixels) and the dy tile are staged once per pixel tile by LDS-DMA and serve
 // the nine shifted GEMMs: per 4-pixel step a wave issues 1 + 9 LDS reads for 36 MFMAs (1 152 MFMA cycles) -- the kernel
-// is MFMA-bound by construction.  LDS is single-buffered (78 KB) and TWO workgroups share a CU: one multiplies while the
-// other one's DMA is in flight, which is the double buffering of the bf16 twin without its bookkeeping.
+// is MFMA-bound by construction.  LDS is double-buffered (2 x 77 KB), one workgroup per CU.
 #include "ud_common.h"
 #include "ud_prof.h"
 #include "conv_pixmap.h"
@@ -29,6 +28,7 @@ constexpr int kHW = kTW + 2, kHQ = kHW * (kTH + 2), kHQP = (kHQ + 3) / 4 * 4;   
 constexpr int kRowB = 256;                                                       // 64 fp32 channels per LDS row
 constexpr int kXBytes = kHQP * kRowB, kDBytes = kTM * kRowB;                     // 46 080 + 32 768
 constexpr int kXPieces = kHQP / 4, kDPieces = kTM / 4;                           // 1-KiB DMA pieces: 45, 32
+constexpr int kBufBytes = kXBytes + kDBytes;                                     // 78 848 per buffer, two buffers
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -43,7 +43,7 @@ struct WgGeom {
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ partial, WgGeom gm, int c_tiles,
                                                               int tiles_per_slice) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_f32(const float* __res
   const bool xc_ok = c0 + 4 * li < gm.Cin;
   const int dslot = li ^ ((g & 1) << 2);
   const bool dn_ok = n0 + 4 * dslot < gm.Cout;
-  auto stage = [&](int tile) {
+  auto stage = [&](int tile, int buf) {
+    char* sb = smem + buf * kBufBytes;
     const int b = tile / per_img;
     const int rem = tile - b * per_img;
     const int ty0 = (rem / gm.tiles_x) * kTH, tx0 = (rem % gm.tiles_x) * kTW;
@@ -76,44 +77,74 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_f32(const float* __res
       const int q = piece * 4 + g, qy = q / kHW, qx = q - qy * kHW;
       const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
       const bool ok = xc_ok && q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
-      dma16(ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + c0 + 4 * li : zero, smem + piece * 1024);
+      dma16(ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + c0 + 4 * li : zero, sb + piece * 1024);
     }
     for (int piece = wave; piece < kDPieces; piece += 4) {
       const int p = piece * 4 + g, gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
       const bool ok = dn_ok && gy < gm.H && gx < gm.W;
       dma16(ok ? dy + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n0 + 4 * dslot : zero,
-            smem + kXBytes + piece * 1024);
+            sb + kXBytes + piece * 1024);
     }
   };
-  // fragment addresses of step (row 0, columns 0..3); a step adds an immediate
+  // Fragment addresses of step (row 0, columns 0..3); a step adds an immediate.  The fragment reads are inline asm with
+  // explicit lgkmcnt waits: left to itself the compiler re-used ONE register quad for all nine B fragments of a step
+  // (ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, nine times: an exposed LDS round trip per 128 MFMA cycles, 99-105 TFLOP/s);
+  // here the ten reads of step s + 1 are in flight while the 36 MFMAs of step s issue.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int aslot = 4 * wave + (li >> 2);
-  const char* pa = smem + kXBytes + g * kRowB + ((aslot ^ ((g & 1) << 2)) << 4) + (li & 3) * 4;
-  const char* pb = smem + g * kRowB + li * 16;
+  unsigned pa = lds0 + kXBytes + g * kRowB + ((aslot ^ ((g & 1) << 2)) << 4) + (li & 3) * 4;
+  unsigned pb = lds0 + g * kRowB + li * 16;
+  float fa[2];
+  f32x4 fb[2][9];
+#define UD_WG_LOADS(BUF, R, Q)                                                                                          \
+  do {                                                                                                                  \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[BUF]) : "v"(pa), "n"(((R) * kTW + 4 * (Q)) * kRowB) : "memory"); \
+    _Pragma("unroll") for (int tap = 0; tap < 9; ++tap)                                                                 \
+      asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                      \
+                   : "=v"(fb[BUF][tap])                                                                                 \
+                   : "v"(pb), "n"((((R) + tap / 3) * kHW + 4 * (Q) + tap % 3) * kRowB)                                 \
+                   : "memory");                                                                                         \
+  } while (0)
+#define UD_WG_WAIT(BUF, N)                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                              \
+               : "+v"(fa[BUF]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]), "+v"(fb[BUF][3]), "+v"(fb[BUF][4]), \
+                 "+v"(fb[BUF][5]), "+v"(fb[BUF][6]), "+v"(fb[BUF][7]), "+v"(fb[BUF][8]))
 
+  // two LDS buffers, ONE workgroup per CU (one wave per SIMD: the 36 MFMAs of a step are independent, and the fragment
+  // reads run a step ahead): tile t + 1 lands while tile t is multiplied, one barrier per tile.  (First version: one
+  // buffer and two workgroups per CU to overlap each other's DMA -- but identical workgroups that start together stay in
+  // phase, both wait for their DMA at the same time: 99-109 TFLOP/s.)
+  if (t_begin < t_end) stage(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
   for (int tile = t_begin; tile < t_end; ++tile) {
-    stage(tile);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < kTH; ++r) {
-      const char* par = pa + r * (kTW * kRowB);
-      const char* pbr = pb + r * (kHW * kRowB);
+    if (tile + 1 < t_end) stage(tile + 1, buf ^ 1);
+    UD_WG_LOADS(0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float a = *reinterpret_cast<const float*>(par + 4 * q * kRowB);
-        f32x4 bb[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-          bb[tap] = *reinterpret_cast<const f32x4*>(pbr + ((tap / 3) * kHW + 4 * q + tap % 3) * kRowB);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[tap][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[tap][e], acc[tap][e], 0, 0, 0);
+    for (int st = 0; st < 4 * kTH; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < 4 * kTH) {
+        if (cur == 0) UD_WG_LOADS(1, (st + 1) >> 2, (st + 1) & 3); else UD_WG_LOADS(0, (st + 1) >> 2, (st + 1) & 3);
+        if (cur == 0) UD_WG_WAIT(0, 10); else UD_WG_WAIT(1, 10);
+      } else {
+        if (cur == 0) UD_WG_WAIT(0, 0); else UD_WG_WAIT(1, 0);
       }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[tap][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur], fb[cur][tap][e], acc[tap][e], 0, 0, 0);
     }
-    __syncthreads();            // everybody is done reading before the next tile's DMA lands
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();            // the next tile has landed; everybody is done reading this one
+    const unsigned d = buf ? (unsigned)-kBufBytes : (unsigned)kBufBytes;
+    pa += d;
+    pb += d;
+    buf ^= 1;
   }
+#undef UD_WG_LOADS
+#undef UD_WG_WAIT
   // partial[slice][n][tap][c]; D layout: lane holds rows n = 4 g + r, column li = channels 4 li + e of MFMA e
   const int c = c0 + 4 * li;
   if (c < gm.Cin) {
@@ -129,13 +160,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_f32(const float* __res
   }
 }
 
-constexpr size_t kWg3Lds = (size_t)kXBytes + kDBytes;
+constexpr size_t kWg3Lds = 2 * (size_t)kBufBytes;
 
-// pixel-tile slices: (slices x 64x64 output tiles) <= 512 workgroups = two per CU, all resident
+// pixel-tile slices: (slices x 64x64 output tiles) <= 256 workgroups = one per CU, all resident
 int wg3_slices(int B, int H, int W, int Cin, int Cout, int* tiles_per_slice) {
   const int ntiles = B * ud_div_up(W, kTW) * ud_div_up(H, kTH);
   const int combos = ud_div_up(Cout, 64) * ud_div_up(Cin, 64);
-  int s = 512 / combos;
+  int s = 256 / combos;
   if (s > ntiles) s = ntiles;
   if (s < 1) s = 1;
   const int per = (ntiles + s - 1) / s;
@@ -144,8 +175,10 @@ int wg3_slices(int B, int H, int W, int Cin, int Cout, int* tiles_per_slice) {
 }
 
 // ---- 1x1 over pixel maps ---------------------------------------------------------------------------------------------
-// (pixel slice) x (NT x 64 output tile) workgroups, 64-pixel steps staged by LDS-DMA (single buffer, 48 / 32 KB: three /
-// four workgroups per CU overlap each other's DMA), wave w owns NT / 4 dy channels x 64 x channels.
+// (pixel slice) x (NT x 64 output tile) workgroups, 32-pixel steps staged by LDS-DMA into two buffers (2 x 24 / 16 KB:
+// three workgroups per CU), wave w owns NT / 4 dy channels x 64 x channels.  These layers have few channels (64 <-> 256
+// ...), i.e. 21-32 flops per byte streamed: the kernel runs at the HBM / L2 rate as much as at the MFMA rate.
+constexpr int kPS = 32;                          // pixels per step
 template <int NT>
 __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ partial, long long P, int Cin, int Cout,
@@ -154,14 +187,14 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
   constexpr int kDRow = NT * 4;                  // bytes per dy row (512 / 256)
   constexpr int kDSlots = NT / 4;                // 16-byte slots per dy row
   constexpr int kDRowsPer = 1024 / kDRow;        // dy rows per DMA piece (2 / 4)
-  constexpr int kDTile = 64 * kDRow;
+  constexpr int kDTile = kPS * kDRow, kBuf = kDTile + kPS * kRowB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int ct = blockIdx.y % c_tiles, nt = blockIdx.y / c_tiles;
   const int n0 = nt * NT, c0 = ct * 64;
-  const int steps = (int)((P + 63) / 64);
+  const int steps = (int)((P + kPS - 1) / kPS);
   const int s_begin = blockIdx.x * steps_per_slice, s_end = min(steps, s_begin + steps_per_slice);
   const float* zero = reinterpret_cast<const float*>(g_zero16w);
 
@@ -171,15 +204,16 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[i][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto stage = [&](int step) {
-    const long long p0 = (long long)step * 64;
-    for (int piece = wave; piece < 64 / kDRowsPer; piece += 4) {       // dy: slots XOR 4 on odd pixels (see the 3x3 kernel)
+  auto stage = [&](int step, int buf) {
+    char* sb = smem + buf * kBuf;
+    const long long p0 = (long long)step * kPS;
+    for (int piece = wave; piece < kPS / kDRowsPer; piece += 4) {      // dy: slots XOR 4 on odd pixels (see the 3x3 kernel)
       const int r = piece * kDRowsPer + lane / kDSlots, slot = lane % kDSlots;
       const int n = n0 + 4 * (slot ^ ((r & 1) << 2));
       const long long p = p0 + r;
-      dma16((p < P && n < Cout) ? dy + ymap.off(p, n, Cout) : zero, smem + piece * 1024);
+      dma16((p < P && n < Cout) ? dy + ymap.off(p, n, Cout) : zero, sb + piece * 1024);
     }
-    for (int piece = wave; piece < 16; piece += 4) {
+    for (int piece = wave; piece < kPS / 4; piece += 4) {
       const int r = piece * 4 + g;
       const long long p = p0 + r;
       const float* src = zero;
@@ -187,32 +221,57 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
         const size_t o = xmap.off(p, c0 + 4 * li, Cin);
         if (o != kNoPixel) src = x + o;
       }
-      dma16(src, smem + kDTile + piece * 1024);
+      dma16(src, sb + kDTile + piece * 1024);
     }
   };
-  const char* pa[TI];
+  // fragment reads as inline asm, one 4-pixel step ahead of the MFMAs (see the 3x3 kernel)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned pa[TI];
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) {
     const int slot = 4 * (TI * wave + ti) + (li >> 2);
-    pa[ti] = smem + g * kDRow + ((slot ^ ((g & 1) << 2)) << 4) + (li & 3) * 4;
+    pa[ti] = lds0 + g * kDRow + ((slot ^ ((g & 1) << 2)) << 4) + (li & 3) * 4;
   }
-  const char* pb = smem + kDTile + g * kRowB + li * 16;
+  unsigned pb = lds0 + kDTile + g * kRowB + li * 16;
+  float fa[2][TI];
+  f32x4 fb[2];
+  auto loads = [&](int b2, int ks) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[b2]) : "v"(pb + 4 * ks * kRowB) : "memory");
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+      asm volatile("ds_read_b32 %0, %1" : "=v"(fa[b2][ti]) : "v"(pa[ti] + 4 * ks * kDRow) : "memory");
+  };
 
+  if (s_begin < s_end) stage(s_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
   for (int step = s_begin; step < s_end; ++step) {
-    stage(step);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (step + 1 < s_end) stage(step + 1, buf ^ 1);
+    loads(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(pb + 4 * ks * kRowB);
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti) {
-        const float a = *reinterpret_cast<const float*>(pa[ti] + 4 * ks * kDRow);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[ti][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[e], acc[ti][e], 0, 0, 0);
+    for (int ks = 0; ks < kPS / 4; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < kPS / 4) {
+        loads(cur ^ 1, ks + 1);
+        if (TI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[cur]), "+v"(fa[cur][0]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));
       }
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[ti][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][ti], fb[cur][e], acc[ti][e], 0, 0, 0);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();            // the next step has landed; everybody is done reading this one
+    const unsigned d = buf ? (unsigned)-kBuf : (unsigned)kBuf;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) pa[ti] += d;
+    pb += d;
+    buf ^= 1;
   }
   const int c = c0 + 4 * li;
   if (c < Cin) {
@@ -236,7 +295,7 @@ Wg1Plan wg1_plan(long long P, int Cin, int Cout) {
   pl.nt = Cout > 64 ? 128 : 64;
   pl.n_tiles = ud_div_up(Cout, pl.nt);
   pl.c_tiles = ud_div_up(Cin, 64);
-  const int steps = (int)((P + 63) / 64);
+  const int steps = (int)((P + kPS - 1) / kPS);
   int s = 768 / (pl.n_tiles * pl.c_tiles);           // three workgroups per CU, all resident
   if (s > steps) s = steps;
   if (s < 1) s = 1;
@@ -308,11 +367,11 @@ extern "C" int ud_conv1x1_wgrad_mapped_nhwc_f32(const float* x, const float* dy,
     UdProfScope prof("conv2d.k_wgrad_1x1_f32", stream);
     const dim3 grid(pl.slices, pl.n_tiles * pl.c_tiles);
     if (pl.nt == 128)
-      k_conv1x1_wgrad_f32<128><<<grid, 256, 64 * 512 + 64 * 256, stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
-                                                                          pl.steps_per_slice, xm, ym);
+      k_conv1x1_wgrad_f32<128><<<grid, 256, 2 * kPS * (512 + 256), stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
+                                                                            pl.steps_per_slice, xm, ym);
     else
-      k_conv1x1_wgrad_f32<64><<<grid, 256, 64 * 256 + 64 * 256, stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
-                                                                         pl.steps_per_slice, xm, ym);
+      k_conv1x1_wgrad_f32<64><<<grid, 256, 2 * kPS * (256 + 256), stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
+                                                                           pl.steps_per_slice, xm, ym);
     UD_LAUNCH_CHECK();
   }
   return ud_wgrad_sum(partial, pl.slices, (size_t)Cout * Cin, dw, stream);

@@ -94,10 +94,10 @@ class BEVFusionCenterHead(nn.Module):
     with_camera_encoder = property(lambda self: self.camera_encoder is not None)
     with_fusion_encoder = property(lambda self: self.fusion_encoder is not None)
 
-    def extract_bev(self, lidar_points, cameras_imgs, metas):
+    def extract_bev(self, lidar_points, cameras_imgs, metas, lidar_prepared=None):
         lidar_out = camera_out = None
         if self.with_lidar_encoder:
-            lidar_out = self.lidar_encoder(lidar_points)
+            lidar_out = self.lidar_encoder(lidar_points, lidar_prepared)
         if self.with_camera_encoder:
             camera_out = self.camera_encoder(cameras_imgs, metas)
         if self.with_fusion_encoder:
@@ -105,10 +105,11 @@ class BEVFusionCenterHead(nn.Module):
         return camera_out if camera_out is not None else lidar_out
 
     def forward(self, lidar_points=None, cameras_imgs=None, metas=None, gt_boxes=None,
-                return_feature=False, targets=None, loss_norm=None, **_):
+                return_feature=False, targets=None, loss_norm=None, lidar_prepared=None, **_):
         """targets / loss_norm: optional precomputed FCOS targets and globally reduced loss
-        normalisers (train.py computes them up front so the network pass holds no collective)."""
-        bev = self.extract_bev(lidar_points, cameras_imgs, metas)
+        normalisers (train.py computes them up front so the network pass holds no collective);
+        lidar_prepared: LidarEncoder.prepare(lidar_points), when the caller ran it ahead of time."""
+        bev = self.extract_bev(lidar_points, cameras_imgs, metas, lidar_prepared)
         trunk, _ = self.bev_encoder(bev)
         ret = self.det_head(trunk, gt_boxes, targets=targets)
         if return_feature:

@@ -107,9 +107,15 @@ class DistillStep(nn.Module):
         return prep
 
     @torch.no_grad()
-    def teacher(self, batch, prep):
+    def teacher(self, batch, prep, lidar_prepared=None):
         return self.teacher_model(self._points(batch), batch.get("imgs"), batch.get("mats_dict"),
-                                  prep["gt"], return_feature=True)
+                                  prep["gt"], return_feature=True, lidar_prepared=lidar_prepared)
+
+    @torch.no_grad()
+    def teacher_geometry(self, batch):
+        """The part of a LiDAR / fusion teacher's pass that reads sizes back to the host (voxel and site counts)."""
+        enc = self.teacher_model.lidar_encoder
+        return None if enc is None else enc.prepare(self._points(batch))
 
     def student_loss(self, batch, prep, teacher_out, join=None):
         e = self.exp
@@ -136,6 +142,7 @@ class DistillStep(nn.Module):
         return {"loss": loss, "tb": tb}
 
     overlap_teacher = True      # frozen teacher on a second HIP stream, concurrent with the student forward
+    XX
     teacher_first = os.environ.get("UD_TEACHER_FIRST", "0") == "1"   # enqueue order of the two forwards (see forward())
 
     def forward(self, batch):
@@ -152,11 +159,13 @@ class DistillStep(nn.Module):
         if side is None or side.device != gt.device:
             side = self._teacher_stream = torch.cuda.Stream(gt.device)
         ready = cur.record_event()                 # the batch and the GT-side tensors are ready from here on
+        side.wait_event(ready)
+        with torch.cuda.stream(side), _lib.workspace_scope("teacher_stream"):
+            lidar_prepared = self.teacher_geometry(batch) if self.hoist_teacher_geometry else None
 
         def run_teacher():
-            side.wait_event(ready)
             with torch.cuda.stream(side), _lib.workspace_scope("teacher_stream"):
-                tout = self.teacher(batch, prep)
+                tout = self.teacher(batch, prep, lidar_prepared)
             for part in tout:
                 for t in _tensors_in(part):
                     t.record_stream(cur)

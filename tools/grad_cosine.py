@@ -5,6 +5,7 @@ Runs the same step (same seed, same batch) several times and prints, in forward 
   * per-parameter gradient cosine: bf16 vs bf16 (same seed), fp32 vs fp32, bf16 vs fp32.
     WL=camera_exp_distill_lidar B=1 python tools/grad_cosine.py
 """
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

@@ -1,4 +1,5 @@
 """Run a few training steps of a workload (for rocprofv3 / timing breakdowns)."""
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

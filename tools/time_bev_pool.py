@@ -1,4 +1,5 @@
 """Quick GPU timing of bev_pool fwd/bwd at the BASELINE shape with a synthetic 6-camera rig."""
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

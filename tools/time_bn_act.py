@@ -1,4 +1,5 @@
 """BatchNorm(+ReLU) streaming kernels (csrc/bn_act.hip) against their HBM bounds, at the step's big shapes."""
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

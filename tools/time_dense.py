@@ -1,5 +1,6 @@
 """SparseConvTensor.dense() (HeightCompression, a4) in fp32: ud_sparse_to_dense / ud_dense_to_sparse at the encoder's
 output shape [B, 128, 2, 180, 180] with a synthetic occupancy; algorithmic bytes per SURVEY 8d."""
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

@@ -3,6 +3,7 @@
 Logs the (B, Cin, H, W, Cout, ks) of every ops.conv2d_f32.weight_grad call of one step, then times each distinct shape
 alone (HIP events, 10 repeats after 3 warm-ups) and prints time, count per step and TFLOP/s.
 """
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

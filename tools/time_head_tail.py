@@ -1,4 +1,5 @@
 """Head tail (BN -> ReLU -> 42 per-head convs) at the nuScenes BEV size: HIP kernels vs the library path."""
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

@@ -1,4 +1,5 @@
 """fp32 head tail (grouped 3x3 64->3, 42 groups) at B=4, 180x180: per-kernel times vs the library formulations."""
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]

@@ -1,4 +1,5 @@
 """ud_points_transform at the BASELINE batch (4 samples x 10 sweeps x ~30 k points, D=5) vs numpy on the host."""
+import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]
