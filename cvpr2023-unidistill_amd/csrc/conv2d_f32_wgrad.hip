@@ -23,12 +23,15 @@
 
 namespace {
 
-constexpr int kTW = 16, kTH = 8, kTM = kTW * kTH;
-constexpr int kHW = kTW + 2, kHQ = kHW * (kTH + 2), kHQP = (kHQ + 3) / 4 * 4;   // 180 halo pixels, staged 4 rows per DMA
 constexpr int kRowB = 256;                                                       // 64 fp32 channels per LDS row
-constexpr int kXBytes = kHQP * kRowB, kDBytes = kTM * kRowB;                     // 46 080 + 32 768
-constexpr int kXPieces = kHQP / 4, kDPieces = kTM / 4;                           // 1-KiB DMA pieces: 45, 32
-constexpr int kBufBytes = kXBytes + kDBytes;                                     // 78 848 per buffer, two buffers
+// pixel tile TW x TH (16 x 8 or 20 x 6: the second one tiles the 180 x 180 BEV maps without a wasted pixel)
+template <int TW, int TH>
+struct WgTile {
+  static constexpr int kTM = TW * TH, kHW = TW + 2, kHQ = kHW * (TH + 2), kHQP = (kHQ + 3) / 4 * 4;   // halo staged 4 rows per DMA
+  static constexpr int kXBytes = kHQP * kRowB, kDBytes = kTM * kRowB;
+  static constexpr int kXPieces = kHQP / 4, kDPieces = kTM / 4;                // 1-KiB DMA pieces
+  static constexpr int kBufBytes = kXBytes + kDBytes;                          // 78 848 / 75 776 per buffer, two buffers
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -43,9 +46,13 @@ struct WgGeom {
   int B, H, W, Cin, Cout, tiles_x, tiles_y;
 };
 
+template <int kTW, int kTH>
 __global__ __launch_bounds__(256) void k_conv3x3_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ partial, WgGeom gm, int c_tiles,
-                                                              int tiles_per_slice) {
+                                                           float* __restrict__ partial, WgGeom gm, int c_tiles,
+                                                           int tiles_per_slice) {
+  using T = WgTile<kTW, kTH>;
+  constexpr int kHW = T::kHW, kHQ = T::kHQ, kXBytes = T::kXBytes, kXPieces = T::kXPieces, kDPieces = T::kDPieces,
+                kBufBytes = T::kBufBytes;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_f32(const float* __restri
       dma16(ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + c0 + 4 * li : zero, sb + piece * 1024);
     }
     for (int piece = wave; piece < kDPieces; piece += 4) {
-      const int p = piece * 4 + g, gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+      const int p = piece * 4 + g, gy = ty0 + p / kTW, gx = tx0 + p % kTW;
       const bool ok = dn_ok && gy < gm.H && gx < gm.W;
       dma16(ok ? dy + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n0 + 4 * dslot : zero,
             sb + kXBytes + piece * 1024);
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_f32(const float* __restri
   unsigned pb = lds0 + g * kRowB + li * 16;
   float fa[2];
   f32x4 fb[2][9];
+  constexpr int kQ = kTW / 4, kSteps = kTH * kQ;      // 4-pixel steps per tile row / per tile
 #define UD_WG_LOADS(BUF, R, Q)                                                                                          \
   do {                                                                                                                  \
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[BUF]) : "v"(pa), "n"(((R) * kTW + 4 * (Q)) * kRowB) : "memory"); \
@@ -122,10 +130,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_f32(const float* __restri
     if (tile + 1 < t_end) stage(tile + 1, buf ^ 1);
     UD_WG_LOADS(0, 0, 0);
 #pragma unroll
-    for (int st = 0; st < 4 * kTH; ++st) {
+    for (int st = 0; st < kSteps; ++st) {
       const int cur = st & 1;
-      if (st + 1 < 4 * kTH) {
-        if (cur == 0) UD_WG_LOADS(1, (st + 1) >> 2, (st + 1) & 3); else UD_WG_LOADS(0, (st + 1) >> 2, (st + 1) & 3);
+      if (st + 1 < kSteps) {
+        if (cur == 0) UD_WG_LOADS(1, (st + 1) / kQ, (st + 1) % kQ); else UD_WG_LOADS(0, (st + 1) / kQ, (st + 1) % kQ);
         if (cur == 0) UD_WG_WAIT(0, 10); else UD_WG_WAIT(1, 10);
       } else {
         if (cur == 0) UD_WG_WAIT(0, 0); else UD_WG_WAIT(1, 0);
@@ -160,11 +168,14 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_f32(const float* __restri
   }
 }
 
-constexpr size_t kWg3Lds = 2 * (size_t)kBufBytes;
-
+// tile shape with the smaller padded area (ties: 16 x 8)
+bool wg3_wide(int H, int W) {
+  return (long long)ud_div_up(W, 20) * 20 * ud_div_up(H, 6) * 6 < (long long)ud_div_up(W, 16) * 16 * ud_div_up(H, 8) * 8;
+}
 // pixel-tile slices: (slices x 64x64 output tiles) <= 256 workgroups = one per CU, all resident
 int wg3_slices(int B, int H, int W, int Cin, int Cout, int* tiles_per_slice) {
-  const int ntiles = B * ud_div_up(W, kTW) * ud_div_up(H, kTH);
+  const bool wide = wg3_wide(H, W);
+  const int ntiles = B * ud_div_up(W, wide ? 20 : 16) * ud_div_up(H, wide ? 6 : 8);
   const int combos = ud_div_up(Cout, 64) * ud_div_up(Cin, 64);
   int s = 256 / combos;
   if (s > ntiles) s = ntiles;
@@ -320,19 +331,23 @@ extern "C" int ud_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float*
   if (!workspace || workspace_bytes < ud_conv3x3_wgrad_f32_workspace_bytes(B, H, W, Cin, Cout)) return UD_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* partial = reinterpret_cast<float*>(workspace);
-  WgGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH)};
+  const bool wide = wg3_wide(H, W);
+  WgGeom gm{B, H, W, Cin, Cout, ud_div_up(W, wide ? 20 : 16), ud_div_up(H, wide ? 6 : 8)};
   int per;
   const int S = wg3_slices(B, H, W, Cin, Cout, &per);
+  constexpr int lds16 = 2 * WgTile<16, 8>::kBufBytes, lds20 = 2 * WgTile<20, 6>::kBufBytes;
   static bool set = false;
   if (!set) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)kWg3Lds));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_f32<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16));
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_f32<20, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds20));
     set = true;
   }
   const int c_tiles = ud_div_up(Cin, 64);
   {
     UdProfScope prof("conv2d.k_wgrad_f32", stream);
-    k_conv3x3_wgrad_f32<<<dim3(S, ud_div_up(Cout, 64) * c_tiles), 256, kWg3Lds, stream>>>(x, dy, partial, gm, c_tiles, per);
+    const dim3 grid(S, ud_div_up(Cout, 64) * c_tiles);
+    if (wide) k_conv3x3_wgrad_f32<20, 6><<<grid, 256, lds20, stream>>>(x, dy, partial, gm, c_tiles, per);
+    else k_conv3x3_wgrad_f32<16, 8><<<grid, 256, lds16, stream>>>(x, dy, partial, gm, c_tiles, per);
     UD_LAUNCH_CHECK();
   }
   return ud_wgrad_sum(partial, S, (size_t)Cout * 9 * Cin, dw, stream);

@@ -56,7 +56,9 @@ def _fp32_kernel_pays(conv, x):
     MIOpen's 48-108 on every shape of the step but two small ResNet maps where the two are within 3 % (tools/
     time_conv2d_f32.py), so all stride-1 3x3 convolutions run on it.  1x1: channel counts the library pads (head / depth
     net: 2.1x) and every map of at least 1 k pixels (forward + data gradient of a layer together: 0.93-1.07x of the library,
-    94.6 vs 94.9 ms per step); the 16 x 44 / 8 x 22 ResNet maps stay on the library (0.9x); "all" forces ours everywhere."""
+    94.6 vs 94.9 ms per step); on the 16 x 44 / 8 x 22 ResNet maps the library is ~1.1x faster per layer, which does not show
+    in the step (89.5 vs 90.1 ms), so the default is "all": every convolution of the fp32 step but the frozen 7 x 7 stem is
+    hand-written and deterministic; UD_HIP_FP32_CONV=pays restores the per-shape routing."""
     if Conv2d.hip_fp32 == "all":
         return True
     px = x.shape[2] * x.shape[3]
@@ -76,7 +78,7 @@ def _fp32_mapped(x):
 class Conv2d(nn.Conv2d):
     hip_enabled = True          # class-wide switch (tests / A-B timing)
     # fp32 MFMA kernels for the fp32 (reference) mode: False / True (where they pay) / "all"
-    hip_fp32 = {"0": False, "all": "all"}.get(os.environ.get("UD_HIP_FP32_CONV", "1"), True)
+    hip_fp32 = {"0": False, "pays": True}.get(os.environ.get("UD_HIP_FP32_CONV", "all"), "all")
 
     def forward(self, x, bn_stats=False):
         """bn_stats: the caller feeds the result straight into a training-mode BatchNorm (batchnorm_act): the hand-written

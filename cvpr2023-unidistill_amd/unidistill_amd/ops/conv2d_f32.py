@@ -135,11 +135,22 @@ class _ConvF32(torch.autograd.Function):
         w = weight.detach()
         p = ks // 2
         if ctx.needs_input_grad[0] and weight.shape[0] % 32 != 0:
-            # the data gradient reduces over Cout: not a multiple of the kernel's 32-channel slice -> library
-            gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
-            if gskip is not None:
-                gx = gx + gskip
+            # the data gradient reduces over Cout in 32-channel slices: zero-pad dy and the transposed weights to the next
+            # multiple (depth net 512 -> 368: one 25 MB copy) instead of leaving the hand-written path
+            cout, pad = weight.shape[0], (-weight.shape[0]) % 32
+            gyp = torch.zeros((gy.shape[0], cout + pad, gy.shape[2], gy.shape[3]), dtype=gy.dtype, device=gy.device,
+                              memory_format=torch.channels_last)
+            gyp[:, :cout] = gy
+            if ks == 3:
+                wt = torch.zeros((weight.shape[1], 3, 3, cout + pad), dtype=w.dtype, device=w.device)
+                wt[..., :cout] = w.permute(1, 2, 3, 0)
+                gx = _launch3(gyp, wt, weight.shape[1], reverse_taps=True)
+                if gskip is not None:
+                    gx = gx + gskip
+            else:
+                wt = torch.zeros((weight.shape[1], cout + pad), dtype=w.dtype, device=w.device)
+                wt[:, :cout] = w.reshape(cout, weight.shape[1]).t()
+                gx = _launch1(gyp, wt, weight.shape[1], residual=gskip)
         elif ctx.needs_input_grad[0]:
             if ks == 3:      # un-flipped transposed weights [Cin, 3, 3, Cout], taps walked in reverse
                 gx = _launch3(gy, w.permute(1, 2, 3, 0).contiguous(), weight.shape[1], reverse_taps=True)

@@ -58,6 +58,28 @@ def test_conv1x1_f32_forward_and_dgrad(hip_lib, shape):
     assert (gw - w.grad).abs().max() <= 1e-4 * w.grad.abs().max()
 
 
+def test_conv_f32_dgrad_pads_cout_off_the_slice_width(hip_lib):
+    """Cout = 368 (the depth net) / 40: the data gradient reduces over Cout in 32-channel slices, so dy and the transposed
+    weights are zero-padded to the next multiple -- still the hand-written kernels (profile counter), same numbers."""
+    from unidistill_amd import _lib
+    from unidistill_amd.ops import conv2d_f32 as c
+    for ks, (B, cin, cout, H, W) in ((1, (2, 64, 368, 9, 20)), (3, (1, 32, 40, 13, 17))):
+        torch.manual_seed(cout)
+        x = _cl(torch.randn(B, cin, H, W, device="cuda")).requires_grad_(True)
+        w = (torch.randn(cout, cin, ks, ks, device="cuda") * 0.05).requires_grad_(True)
+        name = "conv2d.k_conv3x3_f32" if ks == 3 else "conv2d.k_conv1x1_f32"
+        _lib.prof_read(name, reset=True)
+        _lib.prof_enable(True)
+        y = c.conv3x3(x, w) if ks == 3 else c.conv1x1(x, w)
+        gy = _cl(torch.randn_like(y))
+        gx, = torch.autograd.grad(y, x, gy)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        assert _lib.prof_read(name)[1] == 2          # forward + data gradient
+        gx_ref, = torch.autograd.grad(F.conv2d(x, w, None, 1, ks // 2), x, gy)
+        assert (gx - gx_ref).abs().max() <= 2e-5 * gx_ref.abs().max()
+
+
 def test_fp32_trunk_routes_to_the_fp32_kernels_and_matches_library(hip_lib):
     """BaseBEVBackbone in fp32 mode: ZeroPad + unpadded conv folding, stride-1 convs on ud_conv3x3_nhwc_f32."""
     from unidistill_amd import _lib
@@ -82,7 +104,7 @@ def test_fp32_trunk_routes_to_the_fp32_kernels_and_matches_library(hip_lib):
         yr, _ = m(x)
     finally:
         dense.Conv2d.hip_enabled = True
-        dense.Conv2d.hip_fp32 = True
+        dense.Conv2d.hip_fp32 = "all"
     assert (y - yr).abs().max() <= 1e-4 * yr.abs().max()
 
 
