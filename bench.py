@@ -18,7 +18,10 @@ After the timed region (never counted in `value`) further legs run:
   * roofline (rank 0): the reference-boundary bev_pool forward (BASELINE.json: "bev_pool+voxelize HBM GB/s")
     at the BASELINE shape, its dominant kernel timed with HIP events on its launch stream, plus the
     op-level and counter-byte fractions; roofline_voxelize: ud_voxelize at 30 k and 4 x 300 k points;
-    roofline_mfma: the 3x3 conv kernel family inside the bf16 step;
+    roofline_mfma_f32: the fp32 3x3 conv kernel family of the HEADLINE step (peak 157.3 TFLOP/s);
+    roofline_spconv: the fp32 sparse encoder pass (pairs / flops / bytes per layer, SURVEY 8d);
+    roofline_mfma: the 3x3 conv kernel family inside the bf16 step (labelled second);
+    HBM-traffic figures come from profiles/traffic.json (PMC passes, tools/make_profiles.sh), never from constants here;
   * cpu_baseline (rank 0, N=1): BASELINE configs[0] (camera-only student, 1 camera, batch 1, fwd+bwd) end to end
     on the host cores -- torch CPU ops + the CPU oracle for the native ops (oracle/cpu_step.py), all cores and
     one thread -- with the GPU timed on the same configuration beside it.
@@ -41,6 +44,16 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def profile_figures():
+    """profiles/traffic.json: HBM bytes per launch from the PMC counter passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate
+    passes as MI355X_MICROARCH.md prescribes) and the MFMA-only loop rates, written by tools/make_profiles.sh.  Counters
+    cannot be read from inside this process; a missing file or a shape mismatch yields None (never a stale constant)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return {}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: camera student + LiDAR teacher, 6-cam nuScenes shape
@@ -106,6 +119,8 @@ def roofline_leg(device, batch):
     k_ms, k_calls = _lib.prof_read("bev_pool.k_pool")
     alg = B * N * (12 + C * 4 + 12) + B * ny * nx * C * 4          # SURVEY 8d bev_pool fwd row
     k_us = k_ms / max(k_calls, 1) * 1e3
+    pf = profile_figures().get("bev_pool.k_pool", {})
+    traffic = pf.get("hbm_bytes") if pf.get("shape") == {"C": C, "nx": nx, "ny": ny, "N": N, "B": B} else None
     achieved = alg / (k_us * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": "bev_pool.k_pool (ud_bev_pool_fwd, reference op boundary)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -114,39 +129,41 @@ def roofline_leg(device, batch):
             # whole op (memset + k_bin + scan + k_fill + k_pool) against the same algorithmic bytes
             "frac_op": alg / (op_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # the kernel against the HBM bytes it really moves (PMC traffic below: out-of-grid rows are never read)
-            "frac_counter_bytes": (406.8e6 / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
-            if (C, nx, ny, N) == (256, 180, 180, 473088) else None,
-            # HBM bytes per launch from the PMC passes of the same op at the same shape
-            # (profiles/r01_pmc_k_pool.md: FETCH_SIZE 182401 KB x2 (gfx950) + WRITE_SIZE 32400 KB);
-            # counters cannot be read from inside this process, so the committed figure is reported.
-            "traffic": 406.8e6 if (C, nx, ny, N) == (256, 180, 180, 473088) else None,
+            "frac_counter_bytes": (traffic / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            # HBM bytes per launch from the PMC passes of the same op at the same shape (profiles/traffic.json)
+            "traffic": traffic, "traffic_source": pf.get("source") if traffic else None,
             "note": "measured after the timed region; HIP events bracket each launch, so avg_kernel_us carries "
                     "the ~6 us dispatch latency that rocprofv3's kernel duration (profiles/) does not; op_avg_us is "
                     "timed in a separate pass without those brackets; the "
                     "training step itself uses the fused lift+splat (no [B,N,C] tensor), see DESIGN.md"}
 
 
-MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+MFMA_PEAK_TFLOPS_F32 = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD)
 
 
-def mfma_leg(trainer, batch, steps=3):
-    """The dense trunk / head / image-branch 3x3 convolutions (ud_conv3x3_nhwc_bf16: forward + data gradient, the largest
-    kernel family of the bf16 step).  Two measurements of the SAME launches:
+def mfma_leg(trainer, batch, fp32, steps=3):
+    """The dense trunk / head / image-branch 3x3 convolutions of a training step (forward + data gradient: the largest
+    kernel family of the step) -- ud_conv3x3_nhwc_f32 for the fp32 HEADLINE step, ud_conv3x3_nhwc_bf16 for the bf16 leg.
+    Two measurements of the SAME launches:
       * replay (-> achieved / frac): every 3x3 launch of one training step is logged (shape, direction) and the whole
         list is replayed back to back inside ONE HIP-event bracket -- per-launch kernel time without the ~6 us that an
         event pair around a single short launch adds; this is the figure rocprofv3's kernel durations agree with;
       * in_step_events: HIP events around every launch inside real training steps (other streams running, cold L2,
         event overhead included) -- the pessimistic bound."""
     from unidistill_amd import _lib
-    from unidistill_amd.ops import conv2d as c2
+    from unidistill_amd.ops import conv2d as c16, conv2d_f32 as c32
+    c2 = c32 if fp32 else c16
+    prof_name = "conv2d.k_conv3x3_f32" if fp32 else "conv2d.k_conv3x3"
+    peak = MFMA_PEAK_TFLOPS_F32 if fp32 else MFMA_PEAK_TFLOPS
     c2.FLOP_COUNTER = [0]
-    _lib.prof_read("conv2d.k_conv3x3", reset=True)
+    _lib.prof_read(prof_name, reset=True)
     _lib.prof_enable(True)
     for _ in range(steps):
         trainer.step(batch)
     torch.cuda.synchronize()
     _lib.prof_enable(False)
-    ms, calls = _lib.prof_read("conv2d.k_conv3x3")
+    ms, calls = _lib.prof_read(prof_name)
     flops, c2.FLOP_COUNTER = c2.FLOP_COUNTER[0], None
     if not calls or ms <= 0:
         return None
@@ -156,21 +173,23 @@ def mfma_leg(trainer, batch, steps=3):
     log, c2.SHAPE_LOG = c2.SHAPE_LOG, None
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev).manual_seed(3)
+    dt = torch.float32 if fp32 else torch.bfloat16
     ops, cache = [], {}
     for (B, cin, H, W, cout, rev) in log:
         key = (B, cin, H, W, cout)
         if key not in cache:
-            x = torch.randn(B, cin, H, W, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            w = (torch.randn(cout, 3, 3, cin, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+            x = torch.randn(B, cin, H, W, device=dev, generator=g).to(dt).contiguous(memory_format=torch.channels_last)
+            w = (torch.randn(cout, 3, 3, cin, device=dev, generator=g) * 0.02).to(dt)
             cache[key] = (x, w)
         ops.append((cache[key], cout, rev))
+    launch = c32._launch3 if fp32 else c16._launch
 
     def replay():
         for (x, w), cout, rev in ops:
-            c2._launch(x, w, cout, reverse_taps=rev)
+            launch(x, w, cout, reverse_taps=rev)
     replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = 3 if fp32 else 5
     e0.record()
     for _ in range(reps):
         replay()
@@ -180,23 +199,106 @@ def mfma_leg(trainer, batch, steps=3):
     rp_flops = sum(2 * B * H * W * cout * 9 * cin for (B, cin, H, W, cout, _) in log)
     achieved = rp_flops / (rp_ms * 1e-3) / 1e12
     in_step = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv2d.k_conv3x3 (ud_conv3x3_nhwc_bf16: BEV trunk, head, ResNet 3x3 convs; fwd + dgrad)",
-            "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-            "launches": len(log), "avg_kernel_us": rp_ms / len(log) * 1e3, "algorithmic_flops_per_step": rp_flops,
-            "kernel_ms_per_step": rp_ms, "traffic": None,
-            # PMC bytes of ONE shape (the replay mixes 65): FETCH_SIZE x 2 + WRITE_SIZE, profiles/r02_pmc_conv3x3.md
-            "traffic_trunk_256_128_180x180x4": {"hbm_bytes": 110.6e6, "algorithmic_bytes": 100.1e6,
-                                                "source": "profiles/r02_pmc_conv3x3.md"},
-            # what an MFMA-only loop sustains on the same machine with the instruction this kernel uses
-            # (tools/mfma_peak.hip, profiles/r02_mfma_peak.md): the nominal 2 517 is not reachable with 16x16x32
-            "mfma_only_loop": {"v_mfma_f32_16x16x32_bf16": 1330.0, "v_mfma_f32_32x32x16_bf16": 2350.0, "unit": "TFLOP/s",
-                               "frac_of_16x16x32_loop": achieved / 1330.0, "source": "profiles/r02_mfma_peak.md"},
-            "in_step_events": {"achieved": in_step, "frac": in_step / MFMA_PEAK_TFLOPS, "launches": calls,
-                               "avg_kernel_us": ms / calls * 1e3, "kernel_ms_per_step": ms / steps,
-                               "algorithmic_flops_per_step": flops / steps},
-            "note": "achieved = flops of one training step's %d conv3x3 launches / their time replayed back to back in one "
-                    "HIP-event bracket (%d repetitions); in_step_events = HIP events around every launch inside %d real "
-                    "steps (adds ~6 us per launch and the second stream's contention)" % (len(log), reps, steps)}
+    pf = profile_figures()
+    loop = pf.get("mfma_only_loop_tflops", {})
+    instr = "v_mfma_f32_16x16x4_f32" if fp32 else "v_mfma_f32_16x16x32_bf16"
+    out = {"bound": "mfma",
+           "kernel": ("conv2d_f32.k_conv_f32_taps (ud_conv3x3_nhwc_f32" if fp32 else "conv2d.k_conv3x3_taps (ud_conv3x3_nhwc_bf16")
+                     + ": BEV trunk, head, ResNet 3x3 convs; fwd + dgrad)",
+           "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "dtype": "f32" if fp32 else "bf16",
+           "launches": len(log), "avg_kernel_us": rp_ms / len(log) * 1e3, "algorithmic_flops_per_step": rp_flops,
+           "kernel_ms_per_step": rp_ms, "traffic": None,
+           # what an MFMA-only loop sustains on the same machine with the instruction this kernel uses (tools/mfma_peak.hip;
+           # profiles/traffic.json): informational, `frac` stays priced against the guide's nominal peak
+           "mfma_only_loop": ({"instruction": instr, "TFLOP/s": loop[instr], "frac_of_loop": achieved / loop[instr],
+                               "source": loop.get("source")} if instr in loop else None),
+           "in_step_events": {"achieved": in_step, "frac": in_step / peak, "launches": calls,
+                              "avg_kernel_us": ms / calls * 1e3, "kernel_ms_per_step": ms / steps,
+                              "algorithmic_flops_per_step": flops / steps},
+           "note": "achieved = flops of one training step's %d conv3x3 launches / their time replayed back to back in one "
+                   "HIP-event bracket (%d repetitions); in_step_events = HIP events around every launch inside %d real "
+                   "steps (adds ~6 us per launch and the second stream's contention)" % (len(log), reps, steps)}
+    if not fp32:
+        t = pf.get("conv3x3_bf16_trunk_256_128_180x180x4")
+        out["traffic_trunk_256_128_180x180x4"] = t      # PMC bytes of ONE shape (the replay mixes 65)
+    else:
+        # the fp32 weight gradients of the same step (ud_conv3x3_wgrad_nhwc_f32 + ud_conv1x1_wgrad_mapped_nhwc_f32): in-step HIP events
+        w3, n3 = _lib.prof_read("conv2d.k_wgrad_f32")
+        w1, n1 = _lib.prof_read("conv2d.k_wgrad_1x1_f32")
+        out["weight_gradients_in_step_events"] = {"k_wgrad_f32": {"ms_per_step": w3 / steps, "launches_per_step": n3 / steps},
+                                                  "k_wgrad_1x1_f32": {"ms_per_step": w1 / steps, "launches_per_step": n1 / steps}}
+    return out
+
+
+def spconv_leg(device, batch):
+    """SURVEY 8d sparse-conv row: one fp32 pass of the LiDAR encoder (VoxelResBackBone8x, spconv_backbone.py:259-341) on the
+    batch's clouds -- per layer rows, pairs (measured from the rulebook), flops = 2 pairs Cin Cout, bytes = pairs (Cin + Cout)
+    4 + |W| -- with the pass's `spconv.k_conv` launches timed by HIP events.  MFMA-bound fraction reported on the 128-channel
+    layers (v_mfma_f32_16x16x4_f32, peak 157.3), HBM gather/scatter fraction on the narrower ones."""
+    from unidistill_amd import _lib, config as C
+    from unidistill_amd.layers.lidar import LidarEncoder
+    from unidistill_amd.ops import spconv as sp
+    torch.manual_seed(7)
+    enc = LidarEncoder(C.LIDAR_ENCODER).to(device).eval()
+    pts = [p for p in batch["points"]]
+    with torch.no_grad():
+        for _ in range(2):
+            enc(pts)
+        sp.CONV_LOG = []
+        enc(pts)
+        log, sp.CONV_LOG = sp.CONV_LOG, None
+        pairs = {}
+        for nbr, _, _, _ in log:
+            if id(nbr) not in pairs:
+                pairs[id(nbr)] = int((nbr >= 0).sum())
+        _lib.prof_read("spconv.k_conv", reset=True)      # HIP events around every conv launch of one whole pass
+        _lib.prof_enable(True)
+        enc(pts)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        tot_ms, tot_n = _lib.prof_read("spconv.k_conv")
+        # per-layer split: replay each layer's conv alone (same rulebook, random features), HIP events around 5 launches
+        layers = []
+        g = torch.Generator(device=device).manual_seed(1)
+        for i, (nbr, cin, cout, kind) in enumerate(log):
+            M, K = nbr.shape
+            feat = torch.randn(int(nbr.max().item()) + 1, cin, device=device, generator=g)
+            w = torch.randn(cout, K, cin, device=device, generator=g) * 0.05
+            for _ in range(2):
+                sp._conv(feat, nbr, w, (K * cin, cin, 1), False, None, cin, cout, 0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                sp._conv(feat, nbr, w, (K * cin, cin, 1), False, None, cin, cout, 0)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 5 * 1e3
+            pr = pairs[id(nbr)]
+            fl = 2.0 * pr * cin * cout
+            by = pr * (cin + cout) * 4.0 + cout * K * cin * 4.0
+            layers.append({"rows": M, "K": K, "cin": cin, "cout": cout, "pairs": pr, "flops": fl, "bytes": by, "us": us,
+                           "TFLOP/s": fl / us / 1e6, "GB/s": by / us / 1e3})
+    wide = [l for l in layers if l["cin"] == 128 and l["cout"] == 128]
+    narrow = [l for l in layers if l["cin"] <= 64]
+    fl_w, us_w = sum(l["flops"] for l in wide), sum(l["us"] for l in wide)
+    by_n, us_n = sum(l["bytes"] for l in narrow), sum(l["us"] for l in narrow)
+    fl_all, us_all = sum(l["flops"] for l in layers), sum(l["us"] for l in layers)
+    ach = fl_w / us_w / 1e6 if us_w else 0.0
+    return {"bound": "mfma", "kernel": "spconv_conv.k_conv_mfma_v2<128,128> (ud_spconv_conv, fp32: the 128-channel layers of "
+                                       "VoxelResBackBone8x; narrower layers are gather/scatter-bound, see hbm_layers)",
+            "achieved": ach, "peak": MFMA_PEAK_TFLOPS_F32, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_F32,
+            "launches": len(wide), "avg_kernel_us": us_w / max(len(wide), 1), "traffic": None,
+            "hbm_layers": {"bound": "hbm", "achieved": by_n / us_n / 1e3 if us_n else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": (by_n / us_n / 1e3 / HBM_PEAK_GBS) if us_n else 0.0, "launches": len(narrow),
+                           "note": "layers with Cin <= 64: SURVEY 8d bytes = pairs (Cin + Cout) 4 + |W| (gather + scatter traffic "
+                                   "of a pair-list formulation; the output-stationary kernel writes each row once)"},
+            "encoder_pass": {"conv_launches": len(layers), "pairs": sum(l["pairs"] for l in layers), "flops": fl_all,
+                             "sum_of_layer_us": us_all, "TFLOP/s": fl_all / us_all / 1e6,
+                             "in_pass_events": {"ms": tot_ms, "launches": tot_n}},
+            "layers": layers,
+            "note": "clouds of the bench batch (%d x %d points); per-layer times: each layer's launch replayed alone on its real "
+                    "rulebook (HIP events around 5 launches); in_pass_events: HIP events around every launch inside one encoder pass"
+                    % (len(pts), pts[0].shape[0])}
 
 
 def voxelize_leg(device):
@@ -248,12 +350,15 @@ def voxelize_leg(device):
                       "op_GBps": alg / op_us / 1e3, "frac_op": alg / op_us / 1e3 / HBM_PEAK_GBS,
                       "kernel_us": kern, "dominant_kernel": "voxelize." + dom})
     big = cases[-1]
+    pv = profile_figures().get("voxelize", {})
+    sh = pv.get("shape", {})
+    vox_traffic = pv.get("hbm_bytes") if abs(big["points"] - sh.get("points", -10 ** 9)) <= sh.get("tolerance", 0) else None
     return {"bound": "hbm", "kernel": "ud_voxelize (reference op boundary: voxels[M,10,5] + coords + num), whole op",
             "achieved": big["op_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big["frac_op"],
             # PMC bytes of the four kernels at this size (profiles/r02_pmc_voxelize.md, max = the 1.19 M-point case: FETCH_SIZE x 2
             # (gfx950 correction) + WRITE_SIZE, KB): 4.7x the algorithmic bytes -- the random 8-byte hash-table accesses of
             # k_insert / k_first move whole sectors
-            "traffic": 602.7e6 if big["points"] > 1000000 else None, "cases": cases,
+            "traffic": vox_traffic, "traffic_source": pv.get("source") if vox_traffic else None, "cases": cases,
             "note": "op-level (memset + 5 launches); per-kernel times are HIP-event brackets incl. ~6 us dispatch. "
                     "The op is bound by random 8-byte hash-table accesses (k_insert), not by streaming bytes: see DESIGN.md"}
 
@@ -298,9 +403,9 @@ def cpu_baseline_leg(device):
         return ts
     prev = torch.get_num_threads()
     torch.set_num_threads(ncores)
-    t_all = timed(3, 1)
+    t_all = timed(10, 2)            # 2 warm-up + 10 timed iterations
     torch.set_num_threads(1)
-    t_one = timed(1, 0)
+    t_one = timed(3, 1)             # one thread: 1 + 3 (a step takes ~7 s there; keeps the default run within minutes)
     torch.set_num_threads(prev)
     # the product path on the same configuration (camera detector, 1 camera, batch 1, fp32, fwd+bwd+AdamW)
     torch.manual_seed(1234)
@@ -322,9 +427,12 @@ def cpu_baseline_leg(device):
     return {"value": 1.0 / med, "unit": "samples/s", "cores": ncores, "kind": "port",
             "sample": "BASELINE configs[0]: camera-only student, 1 camera 256x704, batch 1, random weights, "
                       "forward+backward; torch CPU ops (image branch, BEV trunk, head, target assignment, loss) + "
-                      "CPU oracle (geometry, lift, voxel pooling fwd/bwd); median of 3 iterations after 1 warm-up",
-            "seconds_per_step_all_cores": {"median": med, "min": min(t_all)},
-            "one_thread": {"value": 1.0 / t_one[0], "seconds_per_step": t_one[0], "iterations": 1},
+                      "CPU oracle (geometry, lift, voxel pooling fwd/bwd); median of 10 iterations after 2 warm-ups on the "
+                      f"{ncores} cores this process may use (affinity mask capped by the cgroup CPU quota; the host has "
+                      f"{os.cpu_count()}); one thread: median of 3 after 1 warm-up",
+            "seconds_per_step_all_cores": {"median": med, "min": min(t_all), "iterations": 10, "warmup": 2},
+            "one_thread": {"value": 1.0 / sorted(t_one)[1], "seconds_per_step": sorted(t_one)[1], "min": min(t_one),
+                           "iterations": 3, "warmup": 1},
             "cpu_model": cpu_name,
             "gpu_same_config": {"value": 1.0 / gpu_s, "ms_per_step": gpu_s * 1e3, "dtype": "f32",
                                 "note": "unidistill_amd camera detector, 1 camera, batch 1, fwd+bwd+AdamW on 1 MI355X"}}
@@ -354,9 +462,8 @@ def timed_steps(trainer, batch, args, world, device):
 PRECISION_NOTE = {
     None: "fp32 everywhere (the reference's arithmetic): hand-written HIP for voxelize / sparse convs (fp32 MFMA) / "
           "lift-splat / target assignment / losses / BatchNorm+ReLU chains / head tail (grouped fp32 kernels), every "
-          "stride-1 3x3 convolution (forward + data gradient) and the 1x1 convolutions where ours beats the library on "
-          "fp32 MFMA kernels; strided / transposed / remaining 1x1 convolutions and all dense weight gradients through "
-          "MIOpen fp32",
+          "convolution of the step but the frozen 7x7 stem -- 3x3, 1x1, strided, transposed: forward, data and weight "
+          "gradient -- on fp32 MFMA kernels (v_mfma_f32_16x16x4_f32), deterministic",
     torch.bfloat16: "bf16 operands / fp32 accumulate on dense convs, BatchNorm chains, head tail and the sparse convs "
                     "(HIP MFMA kernels for every convolution of the step -- 3x3, 1x1, strided, transposed: forward, data "
                     "and weight gradients -- except the frozen 7x7 stem); fp32 voxelize/splat/losses; fp32 master weights",
@@ -397,8 +504,10 @@ def main():
     ac = torch.bfloat16 if args.autocast == "bf16" else None
     trainer = train.Trainer(step, device=device, autocast_dtype=ac, channels_last=not args.nchw)
     dt, loss = timed_steps(trainer, batch, args, world, device)
-    # second precision + the MFMA leg take extra (collective) training steps: EVERY rank runs them
-    bf16, mfma = None, None
+    # second precision + the MFMA legs take extra (collective) training steps: EVERY rank runs them
+    bf16, mfma, mfma32 = None, None, None
+    if ac is None and not args.no_roofline:
+        mfma32 = mfma_leg(trainer, batch, fp32=True)
     if ac is None and not args.no_bf16_leg:
         del trainer
         torch.manual_seed(1234)
@@ -411,9 +520,10 @@ def main():
                 "note": "same workload, batch and step as the headline under bf16 autocast + channels-last "
                         "(BASELINE.json configs[4]-style mixed precision; NOT the headline: the reference trains in fp32)"}
         if not args.no_roofline:
-            mfma = mfma_leg(trainer16, batch)
+            mfma = mfma_leg(trainer16, batch, fp32=False)
+        del trainer16
     elif ac is not None and not args.no_roofline:
-        mfma = mfma_leg(trainer, batch)
+        mfma = mfma_leg(trainer, batch, fp32=False)
     if rank == 0:
         samples = args.batch * world * args.steps
         line = {
@@ -436,6 +546,10 @@ def main():
         if not args.no_roofline:
             line["roofline"] = roofline_leg(device, 1)
             line["roofline_voxelize"] = voxelize_leg(device)
+            if mfma32 is not None:
+                line["roofline_mfma_f32"] = mfma32
+            if "points" in batch:
+                line["roofline_spconv"] = spconv_leg(device, batch)
             if mfma is not None:
                 line["roofline_mfma"] = mfma
         if world == 1 and not args.no_cpu_baseline:

@@ -26,8 +26,16 @@ def _bn_partial(nbytes, dev):
     return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev), ctypes.c_int(0)
 
 
+FLOP_COUNTER = None      # set to [0] to accumulate the multiply-add count of every 3x3 launch (bench.py)
+SHAPE_LOG = None         # set to [] to record (B, Cin, H, W, Cout, reverse_taps) of every 3x3 launch (bench.py replays them)
+
+
 def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False, bn_stats=False):
     B, cin, H, W = x.shape
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER[0] += 2 * B * H * W * cout * 9 * cin
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.append((B, cin, H, W, cout, bool(reverse_taps)))
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if bn_stats:      # + per-tile (sum, sum of squares) for the BatchNorm that follows: (y, (partial, slices, rows))
         lib = _lib.load()

@@ -143,9 +143,14 @@ def mask_order(nbr, mirror=False):
     return None if order is False else order
 
 
+CONV_LOG = None          # set to [] to record (rulebook, Cin, Cout, "f32" | "bf16") of every conv launch (bench.py)
+
+
 def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0, scale=None, shift=None,
           residual=None, relu=False):
     Mout, K = nbr.shape
+    if CONV_LOG is not None:
+        CONV_LOG.append((nbr, cin, cout, "f32"))
     out = torch.empty((Mout, cout), dtype=torch.float32, device=feat.device)
     order = mask_order(nbr, mirror) if algo in (0, 3) else None
     _lib.check(_lib.load().ud_spconv_conv(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(weight),
@@ -187,6 +192,8 @@ def _conv_bf16io(feat, nbr, weight, bias, cin, cout, scale=None, shift=None, res
     [cout, K, cin] bf16 (or fp32 when cin % 4 != 0), output (and residual) bf16 [Mout, cout].
     ``mirror`` reads rulebook column K-1-k for weight offset k (submanifold data gradient)."""
     Mout, K = nbr.shape
+    if CONV_LOG is not None:
+        CONV_LOG.append((nbr, cin, cout, "bf16"))
     io = 2 | (4 if weight.dtype == torch.bfloat16 else 0)
     if feat.dtype == torch.bfloat16 and cin % 4 == 0:
         io |= 1
