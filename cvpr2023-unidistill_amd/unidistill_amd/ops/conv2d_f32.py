@@ -146,9 +146,10 @@ class _ConvF32(torch.autograd.Function):
             # the data gradient reduces over Cout in 32-channel slices: zero-pad dy and the transposed weights to the next
             # multiple (depth net 512 -> 368: one 25 MB copy) instead of leaving the hand-written path
             cout, pad = weight.shape[0], (-weight.shape[0]) % 32
-            gyp = torch.zeros((gy.shape[0], cout + pad, gy.shape[2], gy.shape[3]), dtype=gy.dtype, device=gy.device,
+            gyp = torch.empty((gy.shape[0], cout + pad, gy.shape[2], gy.shape[3]), dtype=gy.dtype, device=gy.device,
                               memory_format=torch.channels_last)
             gyp[:, :cout] = gy
+            gyp[:, cout:] = 0
             if ks == 3:
                 wt = torch.zeros((weight.shape[1], 3, 3, cout + pad), dtype=w.dtype, device=w.device)
                 wt[..., :cout] = w.permute(1, 2, 3, 0)
