@@ -242,6 +242,8 @@ def test_fp32_training_step_has_no_library_weight_gradient(hip_lib):
                 if isinstance(mod, torch.nn.BatchNorm2d):
                     mod.reset_running_stats()
             m.zero_grad(set_to_none=True)
+            for nm in ("conv2d.k_wgrad_f32", "conv2d.k_wgrad_1x1_f32"):
+                _lib.prof_read(nm, reset=True)
             _lib.prof_enable(hip)
             y, _ = m(x)
             y.square().mean().backward()
