@@ -318,12 +318,13 @@ def voxelize_leg(device):
         vox = torch.empty(cap, P, F, device=device)
         coords = torch.empty(cap, 4, dtype=torch.int32, device=device)
         num = torch.empty(cap, dtype=torch.int32, device=device)
-        m = torch.empty(B + 1, dtype=torch.int32, device=device)
+        m = torch.empty(B + 2, dtype=torch.int32, device=device)
+        ALGO = 0       # hash partition + LDS sort (no global atomics); the synthetic clouds never overflow a partition
         vs, rg, st = _f3(syn.VOXEL_SIZE), _f3(syn.POINT_CLOUD_RANGE), _lib.stream_of(pts)
 
         def run():
             _lib.check(lib.ud_voxelize(_lib.ptr(pts), B, N, F, vs, rg, P, maxM, _lib.ptr(vox), _lib.ptr(coords),
-                                       _lib.ptr(num), None, _lib.ptr(m), _lib.ptr(ws), ws.numel(), st), "ud_voxelize")
+                                       _lib.ptr(num), None, _lib.ptr(m), _lib.ptr(ws), ws.numel(), ALGO, st), "ud_voxelize")
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -9,7 +9,27 @@
 //   voxels are numbered in order of first appearance in the point list, per sample, and no new
 //   voxel is created once a sample has max_voxels; a voxel keeps its first P points in input
 //   order; num = min(#points, P); coords are emitted (b, z, y, x).
-// The GPU gets the same result without any order-dependent race, in five launches + one memset:
+// Two algorithms behind ud_voxelize, same bits:
+//
+// algo 0 (default) -- NO global atomics.  Measured on MI355X (tools/atomic_rate.hip): a device-scope atomic on a random
+// word costs the same whatever its flavour (returning or not, 32 or 64 bit, 1 MB or 42 MB table): 24.7 G ops/s, i.e.
+// 48 us per pass over 1.19 M points -- they execute at the memory side.  Plain random stores / loads run 3-5 x faster,
+// LDS atomics are free in comparison.  So the points are PARTITIONED by a hash of their voxel key and every partition is
+// voxelized inside one workgroup's LDS:
+//   k_vp_partition  a workgroup per 2 048-point chunk: voxel key per point, bucket = hash(key) (all points of a voxel share
+//                   a bucket), LDS histogram + ranks, the chunk's (key, point id) pairs leave grouped by bucket
+//   k_vp_bucket     a workgroup per bucket: gathers its ~2-4 k pairs from the chunks' segments, bitonic-sorts them by
+//                   (key, point id) in LDS -> runs of equal keys are voxels, a run's ids are already in input order (first
+//                   P = the kept points, first id = the voxel's first appearance); emits one record per voxel, the sorted
+//                   id list, and a byte flag at the first point id
+//   k_vp_flags      flags -> bitmap over the points by wave ballots + in-block popcount prefixes; k_scan (one workgroup)
+//                   scans the block totals: first-appearance rank = a three-term lookup, per-sample counts and caps
+//   k_vp_emit       a wave per 64 voxel records: rank -> output row (dropped beyond max_voxels), coords / num, and the
+//                   point rows gathered through the sorted id lists (voxels[M,P,F] and / or the MeanVFE mean)
+// One global atomic per BUCKET (record slots).  A bucket that exceeds the LDS sort (8 192 pairs: thousands of points in
+// one voxel, e.g. long zero-padded tails) sets the overflow word m_out[B + 1]; the caller then repeats with algo 1.
+//
+// algo 1 -- open-addressing hash with device-scope atomics (round 1-2 design; any input), five launches + one memset:
 //   k_insert   open-addressing hash over 64-bit entries (key << 32 | first point id): one word per
 //              voxel, so a point touches ONE random cache line (a plain load settles points whose voxel
 //              already holds a smaller id without any atomic; otherwise CAS on the empty slot / a 64-bit
@@ -342,6 +362,313 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, V
   }
 }
 
+
+// ---- algo 0: hash partition + LDS sort (see the header) -------------------------------------------------------------
+constexpr int kCH = 2048;        // points per partition chunk
+constexpr int kCap = 8192;       // pairs per bucket the LDS sort takes
+constexpr int kMaxNB = 1024;     // buckets
+
+__device__ __forceinline__ bool point_key(const float* __restrict__ q, const VoxParams& p, long long gid, unsigned& key) {
+  int c[3];
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float f = floorf(__fdiv_rn(__fsub_rn(q[a], p.lo[a]), p.vs[a]));
+    ok = ok && (f >= 0.0f) && (f < (float)p.grid[a]);  // false for NaN
+    c[a] = ok ? (int)f : 0;
+  }
+  const int b = (int)(gid / p.N);
+  key = (unsigned)(((b * p.grid[2] + c[2]) * p.grid[1] + c[1])) * (unsigned)p.grid[0] + (unsigned)c[0];
+  return ok;
+}
+
+// tab[bucket][chunk] = (offset of the bucket's segment inside the chunk's pair list) << 16 | its length
+__global__ __launch_bounds__(256) void k_vp_partition(const float* __restrict__ pts, VoxParams p, int NB, int lgNB,
+                                                      int nchunks, unsigned long long* __restrict__ pairs,
+                                                      unsigned* __restrict__ tab, unsigned char* __restrict__ flags) {
+  __shared__ unsigned s_hist[kMaxNB];
+  __shared__ unsigned long long s_pairs[kCH];
+  __shared__ unsigned s_w[4];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long total = (long long)p.B * p.N, base = (long long)c * kCH;
+  for (int i = tid; i < NB; i += 256) s_hist[i] = 0u;
+  *reinterpret_cast<unsigned long long*>(flags + base + tid * 8) = 0ull;     // this chunk's first-point flags (kCH bytes)
+  __syncthreads();
+  unsigned key[kCH / 256], rk[kCH / 256];
+  int bkt[kCH / 256];
+#pragma unroll
+  for (int i = 0; i < kCH / 256; ++i) {
+    const long long gid = base + tid + 256 * i;
+    bkt[i] = -1;
+    if (gid < total && point_key(pts + gid * p.F, p, gid, key[i])) {
+      bkt[i] = lgNB ? (int)((key[i] * 2654435761u) >> (32 - lgNB)) : 0;
+      rk[i] = atomicAdd(&s_hist[bkt[i]], 1u);            // LDS atomic: rank inside (chunk, bucket); any order will do
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the NB counters: thread t owns counters [t * per, t * per + per)
+  const int per = NB > 256 ? NB / 256 : 1;
+  unsigned v[kMaxNB / 256], sum = 0u;
+#pragma unroll
+  for (int k = 0; k < kMaxNB / 256; ++k) {
+    const int idx = tid * per + k;
+    v[k] = (k < per && idx < NB) ? s_hist[idx] : 0u;
+    sum += v[k];
+  }
+  unsigned inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned a = __shfl_up(inc, o);
+    if (lane >= o) inc += a;
+  }
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  unsigned off = inc - sum;
+  for (int k = 0; k < wv; ++k) off += s_w[k];
+  const unsigned nvalid = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+#pragma unroll
+  for (int k = 0; k < kMaxNB / 256; ++k) {
+    const int idx = tid * per + k;
+    if (k < per && idx < NB) {
+      s_hist[idx] = off;
+      tab[(size_t)idx * nchunks + c] = (off << 16) | v[k];
+      off += v[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kCH / 256; ++i)
+    if (bkt[i] >= 0)
+      s_pairs[s_hist[bkt[i]] + rk[i]] = ((unsigned long long)key[i] << 32) | (unsigned long long)(unsigned)(base + tid + 256 * i);
+  __syncthreads();
+  for (unsigned i = tid; i < nvalid; i += 256) pairs[base + i] = s_pairs[i];
+}
+
+struct VoxRec {
+  unsigned key, first, count, list;      // voxel key, first point id, #points, index of its sorted id list in spid
+};
+
+__global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __restrict__ pairs,
+                                                    const unsigned* __restrict__ tab, int nchunks,
+                                                    unsigned* __restrict__ spid, VoxRec* __restrict__ rec,
+                                                    unsigned* __restrict__ nrec, unsigned char* __restrict__ flags,
+                                                    int32_t* __restrict__ ovf) {
+  __shared__ unsigned long long s_k[kCap];
+  __shared__ unsigned short s_st[kCap + 1];
+  __shared__ int s_ws[16];
+  __shared__ unsigned s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // 1. segment offsets (exclusive scan of the chunk counts of this bucket) + gather into LDS
+  int run = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += 1024) {
+    const int c = c0 + tid;
+    const unsigned meta = c < nchunks ? tab[(size_t)b * nchunks + c] : 0u;
+    const int len = (int)(meta & 0xFFFFu), off = (int)(meta >> 16);
+    int inc = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int a = __shfl_up(inc, o);
+      if (lane >= o) inc += a;
+    }
+    if (lane == 63) s_ws[wv] = inc;
+    __syncthreads();
+    int pos = run + inc - len, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int t = s_ws[k];
+      if (k < wv) pos += t;
+      tot += t;
+    }
+    if (pos + len <= kCap) {
+      const unsigned long long* src = pairs + (size_t)c * kCH + off;
+      for (int k = 0; k < len; ++k) s_k[pos + k] = src[k];
+    }
+    run += tot;
+    __syncthreads();
+  }
+  const int n = run;
+  if (n > kCap) {                      // uniform: this bucket does not fit the LDS sort -> the caller falls back to algo 1
+    if (tid == 0) *ovf = 1;
+    return;
+  }
+  if (n == 0) return;
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  for (int i = n + tid; i < np2; i += 1024) s_k[i] = ~0ull;
+  __syncthreads();
+  // 2. bitonic sort by (key, point id)
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (np2 >> 1); t += 1024) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;     // the pair (lo, lo ^ j) with bit j clear in lo
+        const unsigned long long a = s_k[lo], c2 = s_k[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > c2) == up) { s_k[lo] = c2; s_k[hi] = a; }
+      }
+      __syncthreads();
+    }
+  // 3. runs of equal keys = voxels; compact the run starts (ascending)
+  int nruns = 0;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool st = i < n && (i == 0 || (unsigned)(s_k[i - 1] >> 32) != (unsigned)(s_k[i] >> 32));
+    const unsigned long long bal = __ballot(st);
+    if (lane == 0) s_ws[wv] = __popcll(bal);
+    __syncthreads();
+    int pre = nruns, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int t = s_ws[k];
+      if (k < wv) pre += t;
+      tot += t;
+    }
+    if (st) s_st[pre + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+    nruns += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    s_st[nruns] = (unsigned short)n;          // n <= 8192 fits
+    s_base = atomicAdd(nrec, (unsigned)nruns);  // the ONE global atomic of this workgroup
+  }
+  __syncthreads();
+  const unsigned rbase = s_base, lbase = (unsigned)b * kCap;
+  for (int j = tid; j < nruns; j += 1024) {
+    const int i0 = s_st[j], i1 = s_st[j + 1];
+    const unsigned long long e = s_k[i0];
+    VoxRec r;
+    r.key = (unsigned)(e >> 32);
+    r.first = (unsigned)e;
+    r.count = (unsigned)(i1 - i0);
+    r.list = lbase + (unsigned)i0;
+    *reinterpret_cast<uint4*>(rec + rbase + j) = *reinterpret_cast<const uint4*>(&r);
+    flags[r.first] = 1;
+  }
+  for (int i = tid; i < n; i += 1024) spid[lbase + i] = (unsigned)s_k[i];
+}
+
+// first-point byte flags -> bitmap + in-block popcount prefixes (the layout k_scan / rank_of read)
+__global__ __launch_bounds__(256) void k_vp_flags(const unsigned char* __restrict__ flags, VoxParams p,
+                                                  unsigned long long* __restrict__ bitmap,
+                                                  unsigned short* __restrict__ wlocal, int* __restrict__ part) {
+  __shared__ int s_cnt[16];
+  const long long total = (long long)p.B * p.N;
+  const int lane = ud_lane(), wv = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * kFirstTile;
+  unsigned char f[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long g = base + k * 256 + threadIdx.x;
+    f[k] = (g < total) ? flags[g] : (unsigned char)0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long bits = __ballot(f[k] != 0);
+    if (lane == 0) {
+      const long long w = (base >> 6) + k * 4 + wv;
+      if (w * 64 < total) bitmap[w] = bits;
+      s_cnt[k * 4 + wv] = __popcll(bits);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    int pre = 0;
+    for (int i = 0; i < 16; ++i) pre += (i < (int)threadIdx.x) ? s_cnt[i] : 0;
+    const long long w = (base >> 6) + threadIdx.x;
+    if (w * 64 < total) wlocal[w] = (unsigned short)pre;
+    if (threadIdx.x == 15) part[blockIdx.x] = pre + s_cnt[15];
+  }
+}
+
+// A wave per 64 voxel records: rank -> output row; the rows are written through the sorted id lists.  Same element walk
+// as k_gather (64 elements of (row, point slot, feature) at a time, independent iterations), rows land where their rank says.
+__global__ __launch_bounds__(256) void k_vp_emit(const float* __restrict__ pts, VoxParams p, const VoxRec* __restrict__ rec,
+                                                 const unsigned* __restrict__ nrec, const unsigned* __restrict__ spid,
+                                                 const unsigned long long* __restrict__ bitmap,
+                                                 const int* __restrict__ bprefix, const unsigned short* __restrict__ wlocal,
+                                                 const int* __restrict__ samp_rank, float* __restrict__ voxels,
+                                                 int32_t* __restrict__ coords, int32_t* __restrict__ num,
+                                                 float* __restrict__ mean) {
+  __shared__ unsigned s_id[4][64 * kGatherPMax];
+  __shared__ int s_n[4][64], s_row[4][64];
+  __shared__ unsigned s_list[4][64];
+  const int lane = ud_lane(), wv = threadIdx.x >> 6;
+  const unsigned r0 = (unsigned)(blockIdx.x * 4 + wv) * 64u, NR = *nrec;
+  if (r0 >= NR) return;
+  const int rows = (int)min(64u, NR - r0);
+  const int P = p.P, F = p.F, E = P * F;
+  int row = -1, n_l = 0;
+  unsigned list = 0u;
+  if (lane < rows) {
+    const uint4 q = *reinterpret_cast<const uint4*>(rec + r0 + lane);
+    unsigned t = q.x;
+    const int x = (int)(t % (unsigned)p.grid[0]);
+    t /= (unsigned)p.grid[0];
+    const int y = (int)(t % (unsigned)p.grid[1]);
+    t /= (unsigned)p.grid[1];
+    const int z = (int)(t % (unsigned)p.grid[2]), b = (int)(t / (unsigned)p.grid[2]);
+    const int r = rank_of(q.y, bitmap, bprefix, wlocal) - samp_rank[b];
+    if (r < p.maxM) {
+      row = sample_row_base(samp_rank, b, p.maxM) + r;
+      n_l = min((int)q.z, P);
+      list = q.w;
+      *reinterpret_cast<int4*>(coords + (size_t)row * 4) = make_int4(b, z, y, x);
+      if (num) num[row] = n_l;
+    }
+  }
+  s_n[wv][lane] = n_l;
+  s_row[wv][lane] = row;
+  s_list[wv][lane] = list;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+  const bool staged = P <= kGatherPMax;
+  const float invF = 1.0f / (float)F, invE = 1.0f / (float)E, invP = 1.0f / (float)P;
+  if (staged) {
+    for (int i = lane; i < rows * P; i += 64) {
+      const int r = (int)(((float)i + 0.5f) * invP), j = i - r * P;
+      s_id[wv][i] = (j < s_n[wv][r]) ? spid[s_list[wv][r] + j] : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+  if (voxels) {
+    const int total = rows * E;
+    for (int e = lane; e < total; e += 64) {
+      const int r = (int)(((float)e + 0.5f) * invE);
+      const int rem = e - r * E;
+      const int j = (int)(((float)rem + 0.5f) * invF);
+      const int f = rem - j * F;
+      const int orow = s_row[wv][r];
+      if (orow < 0) continue;
+      float v = 0.0f;
+      if (j < s_n[wv][r]) {
+        const unsigned pid = staged ? s_id[wv][r * P + j] : spid[s_list[wv][r] + j];
+        v = pts[(size_t)pid * F + f];
+      }
+      __builtin_nontemporal_store(v, &voxels[(size_t)orow * E + rem]);
+    }
+  }
+  if (mean) {
+    const int total = rows * F;
+    for (int e = lane; e < total; e += 64) {
+      const int r = (int)(((float)e + 0.5f) * invF);
+      const int f = e - r * F;
+      const int orow = s_row[wv][r];
+      if (orow < 0) continue;
+      const int n = s_n[wv][r];
+      float acc = 0.0f;
+      for (int j = 0; j < P; ++j) {
+        float v = 0.0f;
+        if (j < n) {
+          const unsigned pid = staged ? s_id[wv][r * P + j] : spid[s_list[wv][r] + j];
+          v = pts[(size_t)pid * F + f];
+        }
+        acc = __fadd_rn(acc, v);
+      }
+      mean[(size_t)orow * F + f] = __fdiv_rn(acc, (float)max(n, 1));
+    }
+  }
+}
+
 struct VoxWs {
   unsigned long long* table;  // ---- 0xFF-initialised block: hash entries, top lists, counts - 1, ticket
   unsigned* top;
@@ -394,6 +721,52 @@ VoxWs carve(void* ws, int B, int N, int P, int maxM) {
   return w;
 }
 
+struct VpWs {
+  unsigned long long* pairs;   // [nchunks * kCH]
+  unsigned* tab;               // [NB][nchunks]
+  unsigned char* flags;        // [nchunks * kCH]
+  unsigned* spid;              // [NB * kCap] (only the first n_b entries of a bucket are touched)
+  VoxRec* rec;                 // [B * N]
+  unsigned* nrec;
+  unsigned long long* bitmap;
+  unsigned short* wlocal;
+  int* part;
+  int* bprefix;
+  int* samp_rank;
+  size_t total_bytes;
+  int nchunks, NB, lgNB, nwords, ntile;
+};
+
+VpWs carve_vp(void* ws, int B, int N) {
+  UdArena a(ws, (size_t)-1);
+  VpWs w;
+  const size_t total = (size_t)B * N;
+  w.nchunks = (int)((total + kCH - 1) / kCH);
+  // buckets: a power of two with ~2-3 k points each (sorts of 2 048 / 4 096 pairs), at most kMaxNB
+  int nb = 1, lg = 0;
+  while (nb < kMaxNB && (size_t)nb * 3000 < total) {
+    nb <<= 1;
+    ++lg;
+  }
+  w.NB = nb;
+  w.lgNB = lg;
+  w.nwords = (int)((total + 63) / 64);
+  w.ntile = (int)((total + kFirstTile - 1) / kFirstTile);
+  w.pairs = a.take<unsigned long long>((size_t)w.nchunks * kCH);
+  w.tab = a.take<unsigned>((size_t)w.NB * w.nchunks);
+  w.flags = a.take<unsigned char>((size_t)w.nchunks * kCH);
+  w.spid = a.take<unsigned>((size_t)w.NB * kCap);
+  w.rec = a.take<VoxRec>(total);
+  w.nrec = a.take<unsigned>(4);
+  w.bitmap = a.take<unsigned long long>(w.nwords);
+  w.wlocal = a.take<unsigned short>(w.nwords);
+  w.part = a.take<int>(w.ntile);
+  w.bprefix = a.take<int>(w.ntile);
+  w.samp_rank = a.take<int>(B + 1);
+  w.total_bytes = a.used;
+  return w;
+}
+
 bool vox_sizes_ok(int B, int N, int F, int P, int maxM, const int* grid) {
   if (B <= 0 || N <= 0 || F < 3 || P <= 0 || P > 64 || maxM <= 0) return false;
   if ((long long)B * N >= (1ll << 30)) return false;
@@ -409,7 +782,7 @@ bool vox_sizes_ok(int B, int N, int F, int P, int maxM, const int* grid) {
 
 extern "C" size_t ud_voxelize_workspace_bytes(int B, int N, int P, int max_voxels) {
   if (!vox_sizes_ok(B, N, 3, P, max_voxels, nullptr)) return 0;
-  return carve(nullptr, B, N, P, max_voxels).total_bytes;
+  return std::max(carve(nullptr, B, N, P, max_voxels).total_bytes, carve_vp(nullptr, B, N).total_bytes);
 }
 
 extern "C" int ud_voxelize_capacity(int B, int N, int max_voxels) {
@@ -421,9 +794,9 @@ extern "C" int ud_voxelize_capacity(int B, int N, int max_voxels) {
 extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float* voxel_size,
                            const float* range, int P, int max_voxels, float* voxels,
                            int32_t* coords, int32_t* num_points, float* mean_feats,
-                           int32_t* m_out, void* workspace, size_t workspace_bytes,
+                           int32_t* m_out, void* workspace, size_t workspace_bytes, int algo,
                            ud_stream_t stream_) {
-  if (!points || !voxel_size || !range || !coords || !m_out) return UD_ERR_INVALID_ARG;
+  if (!points || !voxel_size || !range || !coords || !m_out || (algo != 0 && algo != 1)) return UD_ERR_INVALID_ARG;
   VoxParams p;
   for (int a = 0; a < 3; ++a) {
     p.lo[a] = range[a];
@@ -433,17 +806,52 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
     p.grid[a] = (int)llround(((double)range[a + 3] - (double)range[a]) / (double)voxel_size[a]);
   }
   if (!vox_sizes_ok(B, N, F, P, max_voxels, p.grid)) return UD_ERR_INVALID_ARG;
-  VoxWs w = carve(workspace, B, N, P, max_voxels);
-  if (!workspace || workspace_bytes < w.total_bytes) return UD_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < ud_voxelize_workspace_bytes(B, N, P, max_voxels)) return UD_ERR_WORKSPACE;
   p.F = F;
   p.P = P;
   p.maxM = max_voxels;
   p.B = B;
   p.N = N;
-  p.tmask = w.T - 1;
-  p.tshift = w.tshift;
+  p.tmask = 0;
+  p.tshift = 0;
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * N;
+  if (algo == 0) {
+    VpWs v = carve_vp(workspace, B, N);
+    const int cap = ud_voxelize_capacity(B, N, max_voxels);
+    (void)cap;
+    // record counter + the overflow word (m_out[B + 1]) start at zero
+    UD_HIP_TRY(hipMemsetAsync(v.nrec, 0, 16, stream));
+    UD_HIP_TRY(hipMemsetAsync(m_out + B + 1, 0, sizeof(int32_t), stream));
+    {
+      UdProfScope prof("voxelize.k_partition", stream);
+      k_vp_partition<<<v.nchunks, 256, 0, stream>>>(points, p, v.NB, v.lgNB, v.nchunks, v.pairs, v.tab, v.flags);
+      UD_LAUNCH_CHECK();
+    }
+    {
+      UdProfScope prof("voxelize.k_bucket", stream);
+      k_vp_bucket<<<v.NB, 1024, 0, stream>>>(v.pairs, v.tab, v.nchunks, v.spid, v.rec, v.nrec, v.flags, m_out + B + 1);
+      UD_LAUNCH_CHECK();
+    }
+    {
+      UdProfScope prof("voxelize.k_flags", stream);
+      k_vp_flags<<<v.ntile, 256, 0, stream>>>(v.flags, p, v.bitmap, v.wlocal, v.part);
+      UD_LAUNCH_CHECK();
+      k_scan<<<1, 256, 0, stream>>>(v.part, v.ntile, p, v.bitmap, v.wlocal, v.bprefix, v.samp_rank, m_out);
+      UD_LAUNCH_CHECK();
+    }
+    {
+      UdProfScope prof("voxelize.k_emit", stream);
+      k_vp_emit<<<ud_div_up(total, 256), 256, 0, stream>>>(points, p, v.rec, v.nrec, v.spid, v.bitmap, v.bprefix, v.wlocal,
+                                                           v.samp_rank, voxels, coords, num_points, mean_feats);
+      UD_LAUNCH_CHECK();
+    }
+    return UD_OK;
+  }
+  VoxWs w = carve(workspace, B, N, P, max_voxels);
+  p.tmask = w.T - 1;
+  p.tshift = w.tshift;
+  UD_HIP_TRY(hipMemsetAsync(m_out + B + 1, 0, sizeof(int32_t), stream));
   UD_HIP_TRY(hipMemsetAsync(w.table, 0xFF, w.ff_bytes, stream));
   {
     UdProfScope prof("voxelize.k_insert", stream);

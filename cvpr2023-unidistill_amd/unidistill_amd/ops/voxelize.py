@@ -17,11 +17,15 @@ def _f3(v):
     return (ctypes.c_float * len(v))(*[float(x) for x in v])
 
 
+ALGO = None      # None: partition + LDS sort, hash fallback on overflow; 0 / 1: force one algorithm (tests, timing)
+
+
 def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_voxels=True,
-                   want_mean=True):
+                   want_mean=True, algo=None):
     """points f32[B,N,F] (cuda) -> (voxels[M,P,F] | None, coords i32[M,4] (b,z,y,x), num i32[M],
     mean f32[M,F] | None, per_sample i32[B]).  One host read of the voxel count sizes the views
-    (spconv's PointToVoxel has the same sync)."""
+    (spconv's PointToVoxel has the same sync); the same read carries the fast path's overflow word, and an
+    overflowing input (thousands of points in one voxel) is voxelized again by the hash path."""
     _lib.require_gpu(points)
     if points.dtype != torch.float32:
         raise TypeError("points must be float32")
@@ -40,12 +44,18 @@ def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_vo
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
     mean = torch.empty((cap, F), dtype=torch.float32, device=dev) if want_mean else None
-    m_out = torch.empty((B + 1,), dtype=torch.int32, device=dev)
-    _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range),
-                               int(max_points), int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords),
-                               _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m_out), _lib.ptr(ws),
-                               ws.numel(), _lib.stream_of(points)), "ud_voxelize")
-    m_host = m_out.cpu()
+    m_out = torch.empty((B + 2,), dtype=torch.int32, device=dev)
+    algo = ALGO if algo is None else algo
+    for a in ((0, 1) if algo is None else (algo,)):
+        _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range),
+                                   int(max_points), int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords),
+                                   _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m_out), _lib.ptr(ws),
+                                   ws.numel(), a, _lib.stream_of(points)), "ud_voxelize")
+        m_host = m_out.cpu()
+        if int(m_host[B + 1]) == 0:
+            break
+    else:
+        raise RuntimeError("ud_voxelize: a hash partition overflowed (algo 0 forced)")
     M = int(m_host[B])
     return (voxels[:M] if want_voxels else None, coords[:M], num[:M],
             mean[:M] if want_mean else None, m_host[:B])

@@ -176,7 +176,11 @@ int ud_lss_lift_bwd(const float* gsrc, const int32_t* pos, const float* prob, co
  *   voxels      f32[cap,P,F] zero padded, or NULL to skip materialising it (fused path)
  *   coords      i32[cap,4]  (b, z, y, x)
  *   num_points  i32[cap] or NULL;  mean_feats f32[cap,F] or NULL (sum over slots / max(num,1))
- *   m_out       i32[B+1]    voxels per sample, then the total (device memory)
+ *   m_out       i32[B+2]    voxels per sample, then the total, then the overflow word (device memory)
+ *   algo        0: hash partition + per-partition LDS sort, no global atomics (the fast path; if one partition
+ *                  receives more than 8 192 points -- thousands of points in a single voxel -- it sets the overflow
+ *                  word m_out[B+1] = 1, the outputs are then invalid and the call must be repeated with algo 1);
+ *               1: open-addressing hash with device-scope atomics (any input).  Both give the same bits.
  * Deterministic: voxel order = first appearance in the point list, kept points = the first P in
  * input order, no voxel created beyond max_voxels per sample (oracle/ud_oracle.c:oracle_voxelize).
  */
@@ -185,7 +189,7 @@ int ud_voxelize_capacity(int B, int N, int max_voxels);
 int ud_voxelize(const float* points, int B, int N, int F, const float* voxel_size,
                 const float* range, int P, int max_voxels, float* voxels, int32_t* coords,
                 int32_t* num_points, float* mean_feats, int32_t* m_out, void* workspace,
-                size_t workspace_bytes, ud_stream_t stream);
+                size_t workspace_bytes, int algo, ud_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Sparse 3-D convolution (spconv boundary) + densify                        */

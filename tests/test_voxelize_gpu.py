@@ -1,4 +1,6 @@
-"""GPU parity: HIP voxelize(+MeanVFE) through the C ABI vs the CPU oracle (bit-exact indices)."""
+"""GPU parity: HIP voxelize(+MeanVFE) through the C ABI vs the CPU oracle (bit-exact indices), for both algorithms behind
+ud_voxelize: 0 = hash partition + per-partition LDS sort (no global atomics; reports an overflow when one partition gets more
+than 8 192 points), 1 = atomic open-addressing hash; None = the product default (0, falling back to 1 on overflow)."""
 import numpy as np
 import pytest
 import torch
@@ -10,34 +12,59 @@ pytestmark = pytest.mark.gpu
 VS, RG = syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE
 
 
-def _gpu(points, P=10, maxM=120000, want_voxels=True, vs=VS, rg=RG):
+ALGOS = [None, 1]          # every check runs the default path (0 with fallback) and the atomic hash
+
+
+def _gpu(points, P=10, maxM=120000, want_voxels=True, vs=VS, rg=RG, algo=None):
     from unidistill_amd.ops.voxelize import voxelize_batch
     t = torch.from_numpy(points).cuda()
-    vox, coords, num, mean, m = voxelize_batch(t, vs, rg, P, maxM, want_voxels=want_voxels)
+    vox, coords, num, mean, m = voxelize_batch(t, vs, rg, P, maxM, want_voxels=want_voxels, algo=algo)
     torch.cuda.synchronize()
     return (None if vox is None else vox.cpu().numpy(), coords.cpu().numpy(), num.cpu().numpy(),
             mean.cpu().numpy(), m.numpy())
 
 
-def _check(points, P=10, maxM=120000, vs=VS, rg=RG):
+def _check(points, P=10, maxM=120000, vs=VS, rg=RG, algos=ALGOS):
     ref = oracle.voxelize(points, vs, rg, P, maxM)
-    vox, coords, num, mean, m = _gpu(points, P, maxM, True, vs, rg)
-    np.testing.assert_array_equal(m, ref["m"][:-1])
-    np.testing.assert_array_equal(coords, ref["coords"])          # same voxels, same ORDER
-    np.testing.assert_array_equal(num, ref["num"])
-    np.testing.assert_array_equal(vox, ref["voxels"])             # same points in the same slots
-    np.testing.assert_array_equal(mean, ref["mean"])              # same add order -> bit exact
-    vox2, coords2, num2, mean2, _ = _gpu(points, P, maxM, False, vs, rg)   # fused (no [M,P,F])
-    assert vox2 is None
-    np.testing.assert_array_equal(coords2, coords)
-    np.testing.assert_array_equal(mean2, mean)
+    for algo in algos:
+        vox, coords, num, mean, m = _gpu(points, P, maxM, True, vs, rg, algo)
+        np.testing.assert_array_equal(m, ref["m"][:-1], err_msg=f"algo {algo}")
+        np.testing.assert_array_equal(coords, ref["coords"], err_msg=f"algo {algo}")   # same voxels, same ORDER
+        np.testing.assert_array_equal(num, ref["num"], err_msg=f"algo {algo}")
+        np.testing.assert_array_equal(vox, ref["voxels"], err_msg=f"algo {algo}")      # same points in the same slots
+        np.testing.assert_array_equal(mean, ref["mean"], err_msg=f"algo {algo}")       # same add order -> bit exact
+        vox2, coords2, num2, mean2, _ = _gpu(points, P, maxM, False, vs, rg, algo)   # fused (no [M,P,F])
+        assert vox2 is None
+        np.testing.assert_array_equal(coords2, coords)
+        np.testing.assert_array_equal(mean2, mean)
     return ref
 
 
 def test_single_sweep_cloud():
     pts = syn.lidar_cloud(syn.rng(), 30000, 1)
-    ref = _check(pts[None])
+    ref = _check(pts[None], algos=[None, 0, 1])
     assert ref["m"][0] > 20000
+
+
+def test_four_ten_sweep_clouds_on_the_partition_path():
+    """BASELINE configs[3]/[4] size: 1.19 M points, 480 k voxels (every sample at its 120 000 cap); algo 0 forced -- no
+    partition may overflow on these clouds (the zero-padded tails are a few hundred points)."""
+    g = syn.rng(21)
+    pts = syn.pad_clouds([syn.lidar_cloud(g, 30000, 10) for _ in range(4)])
+    ref = _check(pts, algos=[0])
+    assert ref["m"][:4].tolist() == [120000] * 4
+
+
+def test_partition_overflow_is_reported_and_falls_back():
+    """20 000 points in ONE voxel overflow a partition's 8 192-pair LDS sort: algo 0 reports it (the wrapper raises when it
+    is forced), the default path repeats with the atomic hash and still matches the oracle."""
+    from unidistill_amd.ops.voxelize import voxelize_batch
+    g = syn.rng(9)
+    pts = syn.lidar_cloud(g, 30000, 1)
+    pts[5000:25000, :3] = (1.0, 2.0, 0.5)
+    with pytest.raises(RuntimeError, match="overflow"):
+        voxelize_batch(torch.from_numpy(pts[None]).cuda(), VS, RG, 10, 120000, algo=0)
+    _check(pts[None], algos=[None])
 
 
 def test_ten_sweeps_batch2_hits_per_voxel_cap():

@@ -9,6 +9,7 @@ from unidistill_amd.ops.voxelize import _f3
 
 lib = _lib.load()
 d = torch.device("cuda:0")
+ALGO = int(os.environ.get("ALGO", "0"))      # 0: partition + LDS sort, 1: atomic hash
 def bench(B, sweeps, fused):
     g = syn.rng()
     pts = torch.from_numpy(syn.pad_clouds([syn.lidar_cloud(g, 30000, sweeps) for _ in range(B)])).to(d)
@@ -18,12 +19,12 @@ def bench(B, sweeps, fused):
     ws = _lib.workspace(d, lib.ud_voxelize_workspace_bytes(B, N, P, maxM), "vox")
     vox = None if fused else torch.empty(cap, P, F, device=d)
     coords = torch.empty(cap, 4, dtype=torch.int32, device=d); num = torch.empty(cap, dtype=torch.int32, device=d)
-    mean = torch.empty(cap, F, device=d); m = torch.empty(B + 1, dtype=torch.int32, device=d)
+    mean = torch.empty(cap, F, device=d); m = torch.empty(B + 2, dtype=torch.int32, device=d)
     vs, rg = _f3(syn.VOXEL_SIZE), _f3(syn.POINT_CLOUD_RANGE)
     st = _lib.stream_of(pts)
     def run():
         _lib.check(lib.ud_voxelize(_lib.ptr(pts), B, N, F, vs, rg, P, maxM, _lib.ptr(vox), _lib.ptr(coords),
-                                   _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m), _lib.ptr(ws), ws.numel(), st), "vox")
+                                   _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m), _lib.ptr(ws), ws.numel(), ALGO, st), "vox")
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -37,7 +38,7 @@ def bench(B, sweeps, fused):
     for _ in range(10): run()
     torch.cuda.synchronize(); _lib.prof_enable(False)
     parts = []
-    for k in ("k_insert", "k_first", "k_assign", "k_gather"):
+    for k in (("k_partition", "k_bucket", "k_flags", "k_emit") if ALGO == 0 else ("k_insert", "k_first", "k_assign", "k_gather")):
         ms, n = _lib.prof_read("voxelize." + k)
         parts.append(f"{k} {ms / max(n, 1) * 1e3:.1f}")
     print("    per-kernel us (HIP events, incl. ~6 us dispatch each): " + ", ".join(parts))
