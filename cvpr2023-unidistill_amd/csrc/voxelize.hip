@@ -18,16 +18,17 @@
 // voxelized inside one workgroup's LDS:
 //   k_vp_partition  a workgroup per 2 048-point chunk: voxel key per point, bucket = hash(key) (all points of a voxel share
 //                   a bucket), LDS histogram + ranks, the chunk's (key, point id) pairs leave grouped by bucket
-//   k_vp_bucket     a workgroup per bucket: gathers its ~2-4 k pairs from the chunks' segments, bitonic-sorts them by
-//                   (key, point id) in LDS -> runs of equal keys are voxels, a run's ids are already in input order (first
-//                   P = the kept points, first id = the voxel's first appearance); emits one record per voxel, the sorted
-//                   id list, and a byte flag at the first point id
+//   k_vp_bucket     a workgroup per bucket, all in LDS with LDS atomics: gathers its ~2 k pairs from the chunks' segments,
+//                   hashes the keys (slot = voxel), counting-sorts the point ids by slot, and a thread per voxel selects
+//                   its P smallest ids in ascending order (= the kept points; the smallest = the voxel's first appearance);
+//                   emits one record + id list per voxel and a byte flag at the first point id
 //   k_vp_flags      flags -> bitmap over the points by wave ballots + in-block popcount prefixes; k_scan (one workgroup)
 //                   scans the block totals: first-appearance rank = a three-term lookup, per-sample counts and caps
-//   k_vp_emit       a wave per 64 voxel records: rank -> output row (dropped beyond max_voxels), coords / num, and the
-//                   point rows gathered through the sorted id lists (voxels[M,P,F] and / or the MeanVFE mean)
-// One global atomic per BUCKET (record slots).  A bucket that exceeds the LDS sort (8 192 pairs: thousands of points in
-// one voxel, e.g. long zero-padded tails) sets the overflow word m_out[B + 1]; the caller then repeats with algo 1.
+//   k_vp_rows       rank -> output row of every record (dropped beyond max_voxels); coords, count and id list in row order
+//   k_gather        (shared with algo 1) a wave per 64 consecutive output rows: num and the point rows gathered through
+//                   the id lists (voxels[M,P,F] and / or the MeanVFE mean), contiguous 256-byte stores
+// One global atomic per BUCKET (record slots).  A bucket that receives more than 3 072 points (thousands of points in one
+// voxel, e.g. long zero-padded tails) sets the overflow word m_out[B + 1]; the caller then repeats with algo 1.
 //
 // algo 1 -- open-addressing hash with device-scope atomics (round 1-2 design; any input), five launches + one memset:
 //   k_insert   open-addressing hash over 64-bit entries (key << 32 | first point id): one word per
@@ -49,6 +50,7 @@
 #include "ud_prof.h"
 #include <limits.h>
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, V
 
 // ---- algo 0: hash partition + LDS sort (see the header) -------------------------------------------------------------
 constexpr int kCH = 2048;        // points per partition chunk
-constexpr int kCap = 8192;       // pairs per bucket the LDS sort takes
+constexpr int kCap = 3072;       // pairs per bucket that fit the LDS tables (3/4 of the hash slots)
 constexpr int kMaxNB = 1024;     // buckets
 
 __device__ __forceinline__ bool point_key(const float* __restrict__ q, const VoxParams& p, long long gid, unsigned& key) {
@@ -445,20 +447,40 @@ __global__ __launch_bounds__(256) void k_vp_partition(const float* __restrict__ 
 }
 
 struct VoxRec {
-  unsigned key, first, count, list;      // voxel key, first point id, #points, index of its sorted id list in spid
+  unsigned key, first, count, pad;       // voxel key, first point id, #points
 };
 
+// A workgroup per bucket, everything in LDS with LDS atomics (which cost nothing next to the 24.7 G/s of a device-scope
+// atomic): gather the bucket's pairs; open-addressing hash of the keys (CAS) + per-slot counts and ranks; exclusive scan
+// of the counts; counting-sort the point ids into per-voxel segments; a thread per voxel then selects its P smallest ids in
+// ascending order (segments average 2-3 ids) and writes the voxel's record, id list and first-point flag.
+// (First version: bitonic sort of the (key, id) pairs -- 78 barrier-separated stages, 35 us per workgroup.)
+constexpr int kLgTab = 12, kTab = 1 << kLgTab;      // hash slots: load factor <= 0.75 at the cap, ~0.25-0.5 typically
+static_assert(kCap * 4 == kTab * 3, "kCap = 3/4 kTab");
+
 __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __restrict__ pairs,
-                                                    const unsigned* __restrict__ tab, int nchunks,
-                                                    unsigned* __restrict__ spid, VoxRec* __restrict__ rec,
+                                                    const unsigned* __restrict__ tab, int nchunks, int P,
+                                                    unsigned* __restrict__ vtop, VoxRec* __restrict__ rec,
                                                     unsigned* __restrict__ nrec, unsigned char* __restrict__ flags,
-                                                    int32_t* __restrict__ ovf) {
-  __shared__ unsigned long long s_k[kCap];
-  __shared__ unsigned short s_st[kCap + 1];
+                                                    int32_t* __restrict__ ovf, int dbg) {
+  __shared__ unsigned s_key[kCap];        // keys of the gathered pairs; later the ids grouped by voxel
+  __shared__ unsigned s_pid[kCap];
+  __shared__ unsigned short s_slot[kCap];
+  __shared__ unsigned s_tkey[kTab];
+  __shared__ unsigned s_tcnt[kTab + 1];    // counts, then exclusive offsets
   __shared__ int s_ws[16];
-  __shared__ unsigned s_base;
+  __shared__ unsigned s_cpos[1024], s_csrc[1024];
+  __shared__ unsigned s_nv, s_ctr, s_base, s_nheavy;
+  __shared__ unsigned s_heavy[kCap / 9 + 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // 1. segment offsets (exclusive scan of the chunk counts of this bucket) + gather into LDS
+  for (int i = tid; i < kTab; i += 1024) {
+    s_tkey[i] = kEmpty;
+    s_tcnt[i] = 0u;
+  }
+  if (tid == 0) s_nv = s_ctr = s_nheavy = 0u;
+  // 1. segment offsets (exclusive scan of the chunk counts of this bucket) + gather into LDS.  The copy is FLAT over the
+  //    pairs (pair i -> its chunk by binary search in the offsets): a thread-per-chunk copy loop waits for its longest
+  //    segment, one memory round trip per pair (12 of them for a Poisson(4) maximum: most of the first version's 19 us).
   int run = 0;
   for (int c0 = 0; c0 < nchunks; c0 += 1024) {
     const int c = c0 + tid;
@@ -467,83 +489,170 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
     int inc = len;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const int a = __shfl_up(inc, o);
-      if (lane >= o) inc += a;
+      const int a2 = __shfl_up(inc, o);
+      if (lane >= o) inc += a2;
     }
     if (lane == 63) s_ws[wv] = inc;
     __syncthreads();
-    int pos = run + inc - len, tot = 0;
+    int pos = inc - len, tot = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int t = s_ws[k];
       if (k < wv) pos += t;
       tot += t;
     }
-    if (pos + len <= kCap) {
-      const unsigned long long* src = pairs + (size_t)c * kCH + off;
-      for (int k = 0; k < len; ++k) s_k[pos + k] = src[k];
+    s_cpos[tid] = (unsigned)pos;                                  // exclusive offset inside this pass
+    s_csrc[tid] = (unsigned)((size_t)c * kCH + off);              // pair index of the segment (total < 2^30 points)
+    __syncthreads();
+    for (int i = tid; i < tot && run + i < kCap; i += 1024) {
+      int lo = 0, hi = 1023;                                      // last chunk t with cpos[t] <= i
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_cpos[mid] <= (unsigned)i) lo = mid; else hi = mid - 1;
+      }
+      const unsigned long long e = pairs[(size_t)s_csrc[lo] + (i - (int)s_cpos[lo])];
+      s_key[run + i] = (unsigned)(e >> 32);
+      s_pid[run + i] = (unsigned)e;
     }
     run += tot;
     __syncthreads();
   }
   const int n = run;
-  if (n > kCap) {                      // uniform: this bucket does not fit the LDS sort -> the caller falls back to algo 1
+  if (n > kCap) {                      // uniform: this bucket does not fit in LDS -> the caller falls back to algo 1
     if (tid == 0) *ovf = 1;
     return;
   }
-  if (n == 0) return;
-  int np2 = 2;
-  while (np2 < n) np2 <<= 1;
-  for (int i = n + tid; i < np2; i += 1024) s_k[i] = ~0ull;
-  __syncthreads();
-  // 2. bitonic sort by (key, point id)
-  for (int k = 2; k <= np2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (np2 >> 1); t += 1024) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;     // the pair (lo, lo ^ j) with bit j clear in lo
-        const unsigned long long a = s_k[lo], c2 = s_k[hi];
-        const bool up = (lo & k) == 0;
-        if ((a > c2) == up) { s_k[lo] = c2; s_k[hi] = a; }
-      }
-      __syncthreads();
-    }
-  // 3. runs of equal keys = voxels; compact the run starts (ascending)
-  int nruns = 0;
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    const int i = i0 + tid;
-    const bool st = i < n && (i == 0 || (unsigned)(s_k[i - 1] >> 32) != (unsigned)(s_k[i] >> 32));
-    const unsigned long long bal = __ballot(st);
-    if (lane == 0) s_ws[wv] = __popcll(bal);
-    __syncthreads();
-    int pre = nruns, tot = 0;
+  if (n == 0 || dbg == 1) return;
+  // 2. hash the keys: slot per pair, rank of the pair inside its voxel (arrival order: any will do)
+  unsigned rk[kCap / 1024];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int t = s_ws[k];
-      if (k < wv) pre += t;
-      tot += t;
+  for (int u = 0; u < kCap / 1024; ++u) {
+    const int i = tid + 1024 * u;
+    if (i < n) {
+      const unsigned key = s_key[i];
+      // NOT the partition's multiplicative hash again: the keys of a bucket agree in exactly its top bits
+      unsigned h = (key ^ (key >> 16)) * 0x7FEB352Du;
+      h ^= h >> 15;
+      h = (h * 0x846CA68Bu) >> (32 - kLgTab);
+      while (true) {
+        const unsigned old = atomicCAS(&s_tkey[h], kEmpty, key);
+        if (old == kEmpty || old == key) break;
+        h = (h + 1) & (kTab - 1);
+      }
+      s_slot[i] = (unsigned short)h;
+      rk[u] = atomicAdd(&s_tcnt[h], 1u);
     }
-    if (st) s_st[pre + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
-    nruns += tot;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    s_st[nruns] = (unsigned short)n;          // n <= 8192 fits
-    s_base = atomicAdd(nrec, (unsigned)nruns);  // the ONE global atomic of this workgroup
   }
   __syncthreads();
-  const unsigned rbase = s_base, lbase = (unsigned)b * kCap;
-  for (int j = tid; j < nruns; j += 1024) {
-    const int i0 = s_st[j], i1 = s_st[j + 1];
-    const unsigned long long e = s_k[i0];
-    VoxRec r;
-    r.key = (unsigned)(e >> 32);
-    r.first = (unsigned)e;
-    r.count = (unsigned)(i1 - i0);
-    r.list = lbase + (unsigned)i0;
-    *reinterpret_cast<uint4*>(rec + rbase + j) = *reinterpret_cast<const uint4*>(&r);
-    flags[r.first] = 1;
+  if (dbg == 2) return;
+  // 3. exclusive scan of the slot counts (thread t owns slots [8 t, 8 t + 8)); occupied slots = voxels
+  {
+    unsigned v[kTab / 1024], sum = 0u, occ = 0u;
+#pragma unroll
+    for (int k = 0; k < kTab / 1024; ++k) {
+      v[k] = s_tcnt[tid * (kTab / 1024) + k];
+      sum += v[k];
+      occ += v[k] != 0u;
+    }
+    unsigned inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned a2 = __shfl_up(inc, o);
+      if (lane >= o) inc += a2;
+    }
+    if (lane == 63) s_ws[wv] = (int)inc;
+    occ = (unsigned)ud_wave_sum_i((int)occ);
+    if (lane == 0 && occ) atomicAdd(&s_nv, occ);
+    __syncthreads();
+    unsigned off = inc - sum;
+    for (int k = 0; k < wv; ++k) off += (unsigned)s_ws[k];
+#pragma unroll
+    for (int k = 0; k < kTab / 1024; ++k) {
+      s_tcnt[tid * (kTab / 1024) + k] = off;
+      off += v[k];
+    }
+    if (tid == 1023) s_tcnt[kTab] = off;
   }
-  for (int i = tid; i < n; i += 1024) spid[lbase + i] = (unsigned)s_k[i];
+  __syncthreads();
+  if (tid == 0) s_base = atomicAdd(nrec, s_nv);      // the ONE global atomic of this workgroup
+  // 4. ids grouped by voxel (s_key is free: the keys live in the table now)
+#pragma unroll
+  for (int u = 0; u < kCap / 1024; ++u) {
+    const int i = tid + 1024 * u;
+    if (i < n) s_key[s_tcnt[s_slot[i]] + rk[u]] = s_pid[i];
+  }
+  __syncthreads();
+  if (dbg == 4) return;
+  // 5. a thread per occupied slot: the P smallest ids in ascending order (ids are unique), record, first-point flag
+  const unsigned rbase = s_base;
+#pragma unroll 1
+  for (int k = 0; k < kTab / 1024; ++k) {
+    const int h = tid + 1024 * k;
+    const unsigned key = s_tkey[h];
+    if (key == kEmpty) continue;
+    const unsigned o0 = s_tcnt[h], cnt = s_tcnt[h + 1] - o0;
+    const unsigned j_rec = rbase + atomicAdd(&s_ctr, 1u);
+    unsigned* top = vtop + (size_t)j_rec * P;
+    unsigned first;
+    if (cnt <= 8u) {
+      // the common case (2-3 ids per voxel): all reads independent, position of an id = number of smaller ids
+      unsigned v[8];
+#pragma unroll
+      for (int a2 = 0; a2 < 8; ++a2) v[a2] = (unsigned)a2 < cnt ? s_key[o0 + a2] : kEmpty;
+      first = kEmpty;
+#pragma unroll
+      for (int a2 = 0; a2 < 8; ++a2) {
+        unsigned r2 = 0u;
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) r2 += v[c2] < v[a2];
+        if ((unsigned)a2 < cnt && r2 < (unsigned)P) top[r2] = v[a2];
+        first = min(first, v[a2]);
+      }
+    } else {
+      const unsigned e = atomicAdd(&s_nheavy, 1u);      // <= kCap / 9 = 341 such voxels in a bucket
+      s_heavy[e] = (unsigned)h | ((j_rec - rbase) << 16);
+      continue;
+    }
+    VoxRec r;
+    r.key = key;
+    r.first = first;
+    r.count = cnt;
+    r.pad = 0u;
+    *reinterpret_cast<uint4*>(rec + j_rec) = *reinterpret_cast<const uint4*>(&r);
+    flags[first] = 1;
+  }
+  // voxels with more than 8 points (zero-padded tails, coarse grids): a WAVE per voxel -- every lane scans a strided part of
+  // the segment, the wave takes the minimum; P rounds.  (Left to one thread, a 400-point voxel kept its whole workgroup --
+  // and with it the kernel -- busy for 50 us.)
+  __syncthreads();
+  const unsigned nheavy = s_nheavy;
+  for (unsigned e = wv; e < nheavy; e += 16) {
+    const unsigned h = s_heavy[e] & 0xFFFFu, j_rec = rbase + (s_heavy[e] >> 16);
+    const unsigned o0 = s_tcnt[h], cnt = s_tcnt[h + 1] - o0, keep = min(cnt, (unsigned)P);
+    unsigned* top = vtop + (size_t)j_rec * P;
+    unsigned last = 0u, first = 0u;
+    for (unsigned j = 0; j < keep; ++j) {
+      unsigned m = kEmpty;
+      for (unsigned t = lane; t < cnt; t += 64) {
+        const unsigned v = s_key[o0 + t];
+        if ((j == 0 || v > last) && v < m) m = v;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+      if (lane == 0) top[j] = m;
+      last = m;
+      if (j == 0) first = m;
+    }
+    if (lane == 0) {
+      VoxRec r;
+      r.key = s_tkey[h];
+      r.first = first;
+      r.count = cnt;
+      r.pad = 0u;
+      *reinterpret_cast<uint4*>(rec + j_rec) = *reinterpret_cast<const uint4*>(&r);
+      flags[first] = 1;
+    }
+  }
 }
 
 // first-point byte flags -> bitmap + in-block popcount prefixes (the layout k_scan / rank_of read)
@@ -579,94 +688,33 @@ __global__ __launch_bounds__(256) void k_vp_flags(const unsigned char* __restric
   }
 }
 
-// A wave per 64 voxel records: rank -> output row; the rows are written through the sorted id lists.  Same element walk
-// as k_gather (64 elements of (row, point slot, feature) at a time, independent iterations), rows land where their rank says.
-__global__ __launch_bounds__(256) void k_vp_emit(const float* __restrict__ pts, VoxParams p, const VoxRec* __restrict__ rec,
-                                                 const unsigned* __restrict__ nrec, const unsigned* __restrict__ spid,
+// Records -> row order: rank -> output row of every voxel record (dropped beyond max_voxels); the row's coordinates, its
+// point count (as count - 1, k_gather's convention) and its kept ids land in row-indexed arrays, so that the final pass is
+// the same k_gather as algo 1's (a wave per 64 consecutive rows, contiguous stores).
+__global__ __launch_bounds__(256) void k_vp_rows(VoxParams p, const VoxRec* __restrict__ rec,
+                                                 const unsigned* __restrict__ nrec, const unsigned* __restrict__ vtop,
                                                  const unsigned long long* __restrict__ bitmap,
                                                  const int* __restrict__ bprefix, const unsigned short* __restrict__ wlocal,
-                                                 const int* __restrict__ samp_rank, float* __restrict__ voxels,
-                                                 int32_t* __restrict__ coords, int32_t* __restrict__ num,
-                                                 float* __restrict__ mean) {
-  __shared__ unsigned s_id[4][64 * kGatherPMax];
-  __shared__ int s_n[4][64], s_row[4][64];
-  __shared__ unsigned s_list[4][64];
-  const int lane = ud_lane(), wv = threadIdx.x >> 6;
-  const unsigned r0 = (unsigned)(blockIdx.x * 4 + wv) * 64u, NR = *nrec;
-  if (r0 >= NR) return;
-  const int rows = (int)min(64u, NR - r0);
-  const int P = p.P, F = p.F, E = P * F;
-  int row = -1, n_l = 0;
-  unsigned list = 0u;
-  if (lane < rows) {
-    const uint4 q = *reinterpret_cast<const uint4*>(rec + r0 + lane);
-    unsigned t = q.x;
-    const int x = (int)(t % (unsigned)p.grid[0]);
-    t /= (unsigned)p.grid[0];
-    const int y = (int)(t % (unsigned)p.grid[1]);
-    t /= (unsigned)p.grid[1];
-    const int z = (int)(t % (unsigned)p.grid[2]), b = (int)(t / (unsigned)p.grid[2]);
-    const int r = rank_of(q.y, bitmap, bprefix, wlocal) - samp_rank[b];
-    if (r < p.maxM) {
-      row = sample_row_base(samp_rank, b, p.maxM) + r;
-      n_l = min((int)q.z, P);
-      list = q.w;
-      *reinterpret_cast<int4*>(coords + (size_t)row * 4) = make_int4(b, z, y, x);
-      if (num) num[row] = n_l;
-    }
-  }
-  s_n[wv][lane] = n_l;
-  s_row[wv][lane] = row;
-  s_list[wv][lane] = list;
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
-  const bool staged = P <= kGatherPMax;
-  const float invF = 1.0f / (float)F, invE = 1.0f / (float)E, invP = 1.0f / (float)P;
-  if (staged) {
-    for (int i = lane; i < rows * P; i += 64) {
-      const int r = (int)(((float)i + 0.5f) * invP), j = i - r * P;
-      s_id[wv][i] = (j < s_n[wv][r]) ? spid[s_list[wv][r] + j] : 0u;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-  }
-  if (voxels) {
-    const int total = rows * E;
-    for (int e = lane; e < total; e += 64) {
-      const int r = (int)(((float)e + 0.5f) * invE);
-      const int rem = e - r * E;
-      const int j = (int)(((float)rem + 0.5f) * invF);
-      const int f = rem - j * F;
-      const int orow = s_row[wv][r];
-      if (orow < 0) continue;
-      float v = 0.0f;
-      if (j < s_n[wv][r]) {
-        const unsigned pid = staged ? s_id[wv][r * P + j] : spid[s_list[wv][r] + j];
-        v = pts[(size_t)pid * F + f];
-      }
-      __builtin_nontemporal_store(v, &voxels[(size_t)orow * E + rem]);
-    }
-  }
-  if (mean) {
-    const int total = rows * F;
-    for (int e = lane; e < total; e += 64) {
-      const int r = (int)(((float)e + 0.5f) * invF);
-      const int f = e - r * F;
-      const int orow = s_row[wv][r];
-      if (orow < 0) continue;
-      const int n = s_n[wv][r];
-      float acc = 0.0f;
-      for (int j = 0; j < P; ++j) {
-        float v = 0.0f;
-        if (j < n) {
-          const unsigned pid = staged ? s_id[wv][r * P + j] : spid[s_list[wv][r] + j];
-          v = pts[(size_t)pid * F + f];
-        }
-        acc = __fadd_rn(acc, v);
-      }
-      mean[(size_t)orow * F + f] = __fdiv_rn(acc, (float)max(n, 1));
-    }
-  }
+                                                 const int* __restrict__ samp_rank, unsigned* __restrict__ top,
+                                                 unsigned* __restrict__ cnt, int32_t* __restrict__ coords) {
+  const unsigned j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= *nrec) return;
+  const uint4 q = *reinterpret_cast<const uint4*>(rec + j);
+  unsigned t = q.x;
+  const int x = (int)(t % (unsigned)p.grid[0]);
+  t /= (unsigned)p.grid[0];
+  const int y = (int)(t % (unsigned)p.grid[1]);
+  t /= (unsigned)p.grid[1];
+  const int z = (int)(t % (unsigned)p.grid[2]), b = (int)(t / (unsigned)p.grid[2]);
+  const int r = rank_of(q.y, bitmap, bprefix, wlocal) - samp_rank[b];
+  if (r >= p.maxM) return;
+  const size_t row = (size_t)sample_row_base(samp_rank, b, p.maxM) + r;
+  *reinterpret_cast<int4*>(coords + row * 4) = make_int4(b, z, y, x);
+  cnt[row] = q.z - 1u;
+  const int keep = min((int)q.z, p.P);
+  const unsigned* src = vtop + (size_t)j * p.P;
+  unsigned* dst = top + row * p.P;
+  for (int k = 0; k < keep; ++k) dst[k] = src[k];
 }
 
 struct VoxWs {
@@ -725,7 +773,9 @@ struct VpWs {
   unsigned long long* pairs;   // [nchunks * kCH]
   unsigned* tab;               // [NB][nchunks]
   unsigned char* flags;        // [nchunks * kCH]
-  unsigned* spid;              // [NB * kCap] (only the first n_b entries of a bucket are touched)
+  unsigned* vtop;              // [B * N][P] kept point ids per voxel record (ascending)
+  unsigned* top;               // [cap][P] the same lists in output-row order
+  unsigned* cnt;               // [cap]    points per row - 1
   VoxRec* rec;                 // [B * N]
   unsigned* nrec;
   unsigned long long* bitmap;
@@ -737,14 +787,14 @@ struct VpWs {
   int nchunks, NB, lgNB, nwords, ntile;
 };
 
-VpWs carve_vp(void* ws, int B, int N) {
+VpWs carve_vp(void* ws, int B, int N, int P, int maxM) {
   UdArena a(ws, (size_t)-1);
   VpWs w;
   const size_t total = (size_t)B * N;
   w.nchunks = (int)((total + kCH - 1) / kCH);
-  // buckets: a power of two with ~2-3 k points each (sorts of 2 048 / 4 096 pairs), at most kMaxNB
+  // buckets: a power of two with <= ~2.4 k points each on average (capacity 4 096), at most kMaxNB
   int nb = 1, lg = 0;
-  while (nb < kMaxNB && (size_t)nb * 3000 < total) {
+  while (nb < kMaxNB && (size_t)nb * 2400 < total) {
     nb <<= 1;
     ++lg;
   }
@@ -755,7 +805,10 @@ VpWs carve_vp(void* ws, int B, int N) {
   w.pairs = a.take<unsigned long long>((size_t)w.nchunks * kCH);
   w.tab = a.take<unsigned>((size_t)w.NB * w.nchunks);
   w.flags = a.take<unsigned char>((size_t)w.nchunks * kCH);
-  w.spid = a.take<unsigned>((size_t)w.NB * kCap);
+  w.vtop = a.take<unsigned>(total * P);
+  const size_t cap = (size_t)B * maxM < total ? (size_t)B * maxM : total;
+  w.top = a.take<unsigned>(cap * P);
+  w.cnt = a.take<unsigned>(cap);
   w.rec = a.take<VoxRec>(total);
   w.nrec = a.take<unsigned>(4);
   w.bitmap = a.take<unsigned long long>(w.nwords);
@@ -782,7 +835,7 @@ bool vox_sizes_ok(int B, int N, int F, int P, int maxM, const int* grid) {
 
 extern "C" size_t ud_voxelize_workspace_bytes(int B, int N, int P, int max_voxels) {
   if (!vox_sizes_ok(B, N, 3, P, max_voxels, nullptr)) return 0;
-  return std::max(carve(nullptr, B, N, P, max_voxels).total_bytes, carve_vp(nullptr, B, N).total_bytes);
+  return std::max(carve(nullptr, B, N, P, max_voxels).total_bytes, carve_vp(nullptr, B, N, P, max_voxels).total_bytes);
 }
 
 extern "C" int ud_voxelize_capacity(int B, int N, int max_voxels) {
@@ -817,9 +870,8 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * N;
   if (algo == 0) {
-    VpWs v = carve_vp(workspace, B, N);
+    VpWs v = carve_vp(workspace, B, N, P, max_voxels);
     const int cap = ud_voxelize_capacity(B, N, max_voxels);
-    (void)cap;
     // record counter + the overflow word (m_out[B + 1]) start at zero
     UD_HIP_TRY(hipMemsetAsync(v.nrec, 0, 16, stream));
     UD_HIP_TRY(hipMemsetAsync(m_out + B + 1, 0, sizeof(int32_t), stream));
@@ -830,7 +882,8 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
     }
     {
       UdProfScope prof("voxelize.k_bucket", stream);
-      k_vp_bucket<<<v.NB, 1024, 0, stream>>>(v.pairs, v.tab, v.nchunks, v.spid, v.rec, v.nrec, v.flags, m_out + B + 1);
+      static const int dbg = getenv("UD_VOX_DBG") ? atoi(getenv("UD_VOX_DBG")) : 0;
+      k_vp_bucket<<<v.NB, 1024, 0, stream>>>(v.pairs, v.tab, v.nchunks, P, v.vtop, v.rec, v.nrec, v.flags, m_out + B + 1, dbg);
       UD_LAUNCH_CHECK();
     }
     {
@@ -842,8 +895,13 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
     }
     {
       UdProfScope prof("voxelize.k_emit", stream);
-      k_vp_emit<<<ud_div_up(total, 256), 256, 0, stream>>>(points, p, v.rec, v.nrec, v.spid, v.bitmap, v.bprefix, v.wlocal,
-                                                           v.samp_rank, voxels, coords, num_points, mean_feats);
+      k_vp_rows<<<ud_div_up(total, 256), 256, 0, stream>>>(p, v.rec, v.nrec, v.vtop, v.bitmap, v.bprefix, v.wlocal,
+                                                           v.samp_rank, v.top, v.cnt, coords);
+      UD_LAUNCH_CHECK();
+    }
+    {
+      UdProfScope prof("voxelize.k_gather", stream);
+      k_gather<<<ud_div_up(cap, 256), 256, 0, stream>>>(points, p, v.top, v.cnt, m_out, voxels, num_points, mean_feats);
       UD_LAUNCH_CHECK();
     }
     return UD_OK;

@@ -178,7 +178,7 @@ int ud_lss_lift_bwd(const float* gsrc, const int32_t* pos, const float* prob, co
  *   num_points  i32[cap] or NULL;  mean_feats f32[cap,F] or NULL (sum over slots / max(num,1))
  *   m_out       i32[B+2]    voxels per sample, then the total, then the overflow word (device memory)
  *   algo        0: hash partition + per-partition LDS sort, no global atomics (the fast path; if one partition
- *                  receives more than 8 192 points -- thousands of points in a single voxel -- it sets the overflow
+ *                  receives more than 3 072 points -- thousands of points in a single voxel -- it sets the overflow
  *                  word m_out[B+1] = 1, the outputs are then invalid and the call must be repeated with algo 1);
  *               1: open-addressing hash with device-scope atomics (any input).  Both give the same bits.
  * Deterministic: voxel order = first appearance in the point list, kept points = the first P in

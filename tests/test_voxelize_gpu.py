@@ -56,7 +56,7 @@ def test_four_ten_sweep_clouds_on_the_partition_path():
 
 
 def test_partition_overflow_is_reported_and_falls_back():
-    """20 000 points in ONE voxel overflow a partition's 8 192-pair LDS sort: algo 0 reports it (the wrapper raises when it
+    """20 000 points in ONE voxel overflow a partition's 4 096-point LDS tables: algo 0 reports it (the wrapper raises when it
     is forced), the default path repeats with the atomic hash and still matches the oracle."""
     from unidistill_amd.ops.voxelize import voxelize_batch
     g = syn.rng(9)
