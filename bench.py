@@ -341,7 +341,7 @@ def voxelize_leg(device):
         torch.cuda.synchronize()
         _lib.prof_enable(False)
         kern = {}
-        for k in ("k_insert", "k_first", "k_assign", "k_gather"):
+        for k in ("k_partition", "k_bucket", "k_flags", "k_emit", "k_gather"):
             ms, n = _lib.prof_read("voxelize." + k)
             kern[k] = ms / max(n, 1) * 1e3
         M = int(m[B])
@@ -360,8 +360,9 @@ def voxelize_leg(device):
             # (gfx950 correction) + WRITE_SIZE, KB): 4.7x the algorithmic bytes -- the random 8-byte hash-table accesses of
             # k_insert / k_first move whole sectors
             "traffic": vox_traffic, "traffic_source": pv.get("source") if vox_traffic else None, "cases": cases,
-            "note": "op-level (memset + 5 launches); per-kernel times are HIP-event brackets incl. ~6 us dispatch. "
-                    "The op is bound by random 8-byte hash-table accesses (k_insert), not by streaming bytes: see DESIGN.md"}
+            "note": "op-level, algo 0 (hash partition + per-partition LDS hash / counting sort: no global atomics; 7 launches); "
+                    "per-kernel times are HIP-event brackets incl. ~6 us dispatch.  Random-access bound (gathers of 20-byte "
+                    "points, 4-16-byte scattered stores), not streaming-bound: see DESIGN.md"}
 
 
 def usable_cores():

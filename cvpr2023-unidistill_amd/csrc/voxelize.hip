@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_assign(const float* __restrict__ pts, V
 constexpr int kGatherPMax = 16;  // ids staged in LDS up to this many slots per voxel
 
 __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, VoxParams p,
-                                                const unsigned* __restrict__ top,
+                                                const unsigned* __restrict__ top, int TS,
                                                 const unsigned* __restrict__ cnt,
                                                 const int32_t* __restrict__ m_out,
                                                 float* __restrict__ voxels,
@@ -320,28 +320,37 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, V
     if (num) num[row0 + lane] = n_l;
   }
   s_n[wv][lane] = n_l;
-  const bool staged = P <= kGatherPMax;
-  const unsigned* trow = top + (size_t)row0 * P;
+  const bool staged = TS <= kGatherPMax;
+  const unsigned* trow = top + (size_t)row0 * TS;      // id lists, TS words per row (TS = P, or P rounded up to 4)
   if (staged)
-    for (int i = lane; i < rows * P; i += 64) s_id[wv][i] = trow[i];
+    for (int i = lane; i < rows * TS; i += 64) s_id[wv][i] = trow[i];
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
   const float invF = 1.0f / (float)F, invE = 1.0f / (float)E;
   if (voxels) {
-    float* vrow = voxels + (size_t)row0 * E;
+    float* vrow = voxels + (size_t)row0 * E;       // 64 * E * 4 bytes per wave: 16-byte aligned
     const int total = rows * E;
-    for (int e = lane; e < total; e += 64) {
-      int r = (int)(((float)e + 0.5f) * invE);
+    auto element = [&](int e) -> float {
+      const int r = (int)(((float)e + 0.5f) * invE);
       const int rem = e - r * E;
       const int j = (int)(((float)rem + 0.5f) * invF);
       const int f = rem - j * F;
-      float v = 0.0f;
-      if (j < s_n[wv][r]) {
-        const unsigned pid = staged ? s_id[wv][r * P + j] : trow[r * P + j];
-        v = pts[(size_t)pid * F + f];
-      }
-      __builtin_nontemporal_store(v, &vrow[e]);
+      if (j >= s_n[wv][r]) return 0.0f;
+      const unsigned pid = staged ? s_id[wv][r * TS + j] : trow[r * TS + j];
+      return pts[(size_t)pid * F + f];
+    };
+    // 16-byte stores: four gathered elements per lane and store instruction (a quarter of the 4-byte version's store
+    // instructions; the walk over the 12.5 KB block stays contiguous)
+    const int total4 = total >> 2;
+    for (int q = lane; q < total4; q += 64) {
+      ud_vf4 v4;
+      v4.x = element(4 * q);
+      v4.y = element(4 * q + 1);
+      v4.z = element(4 * q + 2);
+      v4.w = element(4 * q + 3);
+      __builtin_nontemporal_store(v4, reinterpret_cast<ud_vf4*>(vrow) + q);
     }
+    for (int e = 4 * total4 + lane; e < total; e += 64) __builtin_nontemporal_store(element(e), &vrow[e]);
   }
   if (mean) {
     float* mrow = mean + (size_t)row0 * F;
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, V
       for (int j = 0; j < P; ++j) {
         float v = 0.0f;
         if (j < n) {
-          const unsigned pid = staged ? s_id[wv][r * P + j] : trow[r * P + j];
+          const unsigned pid = staged ? s_id[wv][r * TS + j] : trow[r * TS + j];
           v = pts[(size_t)pid * F + f];
         }
         acc = __fadd_rn(acc, v);
@@ -459,10 +468,10 @@ constexpr int kLgTab = 12, kTab = 1 << kLgTab;      // hash slots: load factor <
 static_assert(kCap * 4 == kTab * 3, "kCap = 3/4 kTab");
 
 __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __restrict__ pairs,
-                                                    const unsigned* __restrict__ tab, int nchunks, int P,
+                                                    const unsigned* __restrict__ tab, int nchunks, int P, int TS,
                                                     unsigned* __restrict__ vtop, VoxRec* __restrict__ rec,
                                                     unsigned* __restrict__ nrec, unsigned char* __restrict__ flags,
-                                                    int32_t* __restrict__ ovf, int dbg) {
+                                                    int32_t* __restrict__ ovf) {
   __shared__ unsigned s_key[kCap];        // keys of the gathered pairs; later the ids grouped by voxel
   __shared__ unsigned s_pid[kCap];
   __shared__ unsigned short s_slot[kCap];
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
   __shared__ int s_ws[16];
   __shared__ unsigned s_cpos[1024], s_csrc[1024];
   __shared__ unsigned s_nv, s_ctr, s_base, s_nheavy;
-  __shared__ unsigned s_heavy[kCap / 9 + 1];
+  __shared__ unsigned s_heavy[kCap / 5 + 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int i = tid; i < kTab; i += 1024) {
     s_tkey[i] = kEmpty;
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
     if (tid == 0) *ovf = 1;
     return;
   }
-  if (n == 0 || dbg == 1) return;
+  if (n == 0) return;
   // 2. hash the keys: slot per pair, rank of the pair inside its voxel (arrival order: any will do)
   unsigned rk[kCap / 1024];
 #pragma unroll
@@ -544,7 +553,6 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
     }
   }
   __syncthreads();
-  if (dbg == 2) return;
   // 3. exclusive scan of the slot counts (thread t owns slots [8 t, 8 t + 8)); occupied slots = voxels
   {
     unsigned v[kTab / 1024], sum = 0u, occ = 0u;
@@ -582,7 +590,6 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
     if (i < n) s_key[s_tcnt[s_slot[i]] + rk[u]] = s_pid[i];
   }
   __syncthreads();
-  if (dbg == 4) return;
   // 5. a thread per occupied slot: the P smallest ids in ascending order (ids are unique), record, first-point flag
   const unsigned rbase = s_base;
 #pragma unroll 1
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
     if (key == kEmpty) continue;
     const unsigned o0 = s_tcnt[h], cnt = s_tcnt[h + 1] - o0;
     const unsigned j_rec = rbase + atomicAdd(&s_ctr, 1u);
-    unsigned* top = vtop + (size_t)j_rec * P;
+    unsigned* top = vtop + (size_t)j_rec * TS;       // id lists: TS = P rounded up to 4 words, written 16 bytes at a time
     unsigned first;
     if (cnt <= 8u) {
       // the common case (2-3 ids per voxel): all reads independent, position of an id = number of smaller ids
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
   for (unsigned e = wv; e < nheavy; e += 16) {
     const unsigned h = s_heavy[e] & 0xFFFFu, j_rec = rbase + (s_heavy[e] >> 16);
     const unsigned o0 = s_tcnt[h], cnt = s_tcnt[h + 1] - o0, keep = min(cnt, (unsigned)P);
-    unsigned* top = vtop + (size_t)j_rec * P;
+    unsigned* top = vtop + (size_t)j_rec * TS;
     unsigned last = 0u, first = 0u;
     for (unsigned j = 0; j < keep; ++j) {
       unsigned m = kEmpty;
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(256) void k_vp_rows(VoxParams p, const VoxRec* __re
                                                  const unsigned* __restrict__ nrec, const unsigned* __restrict__ vtop,
                                                  const unsigned long long* __restrict__ bitmap,
                                                  const int* __restrict__ bprefix, const unsigned short* __restrict__ wlocal,
-                                                 const int* __restrict__ samp_rank, unsigned* __restrict__ top,
+                                                 const int* __restrict__ samp_rank, int TS, unsigned* __restrict__ top,
                                                  unsigned* __restrict__ cnt, int32_t* __restrict__ coords) {
   const unsigned j = blockIdx.x * 256u + threadIdx.x;
   if (j >= *nrec) return;
@@ -712,9 +719,15 @@ __global__ __launch_bounds__(256) void k_vp_rows(VoxParams p, const VoxRec* __re
   *reinterpret_cast<int4*>(coords + row * 4) = make_int4(b, z, y, x);
   cnt[row] = q.z - 1u;
   const int keep = min((int)q.z, p.P);
-  const unsigned* src = vtop + (size_t)j * p.P;
-  unsigned* dst = top + row * p.P;
-  for (int k = 0; k < keep; ++k) dst[k] = src[k];
+  if ((TS & 3) == 0) {
+    const uint4* src = reinterpret_cast<const uint4*>(vtop + (size_t)j * TS);
+    uint4* dst = reinterpret_cast<uint4*>(top + row * TS);
+    for (int k = 0; 4 * k < keep; ++k) dst[k] = src[k];
+  } else {
+    const unsigned* src = vtop + (size_t)j * TS;
+    unsigned* dst = top + row * TS;
+    for (int k = 0; k < keep; ++k) dst[k] = src[k];
+  }
 }
 
 struct VoxWs {
@@ -784,7 +797,7 @@ struct VpWs {
   int* bprefix;
   int* samp_rank;
   size_t total_bytes;
-  int nchunks, NB, lgNB, nwords, ntile;
+  int nchunks, NB, lgNB, nwords, ntile, TS;
 };
 
 VpWs carve_vp(void* ws, int B, int N, int P, int maxM) {
@@ -805,9 +818,10 @@ VpWs carve_vp(void* ws, int B, int N, int P, int maxM) {
   w.pairs = a.take<unsigned long long>((size_t)w.nchunks * kCH);
   w.tab = a.take<unsigned>((size_t)w.NB * w.nchunks);
   w.flags = a.take<unsigned char>((size_t)w.nchunks * kCH);
-  w.vtop = a.take<unsigned>(total * P);
+  w.TS = (P + 3) / 4 * 4;
+  w.vtop = a.take<unsigned>(total * w.TS);
   const size_t cap = (size_t)B * maxM < total ? (size_t)B * maxM : total;
-  w.top = a.take<unsigned>(cap * P);
+  w.top = a.take<unsigned>(cap * w.TS);
   w.cnt = a.take<unsigned>(cap);
   w.rec = a.take<VoxRec>(total);
   w.nrec = a.take<unsigned>(4);
@@ -882,8 +896,7 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
     }
     {
       UdProfScope prof("voxelize.k_bucket", stream);
-      static const int dbg = getenv("UD_VOX_DBG") ? atoi(getenv("UD_VOX_DBG")) : 0;
-      k_vp_bucket<<<v.NB, 1024, 0, stream>>>(v.pairs, v.tab, v.nchunks, P, v.vtop, v.rec, v.nrec, v.flags, m_out + B + 1, dbg);
+      k_vp_bucket<<<v.NB, 1024, 0, stream>>>(v.pairs, v.tab, v.nchunks, P, v.TS, v.vtop, v.rec, v.nrec, v.flags, m_out + B + 1);
       UD_LAUNCH_CHECK();
     }
     {
@@ -896,12 +909,12 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
     {
       UdProfScope prof("voxelize.k_emit", stream);
       k_vp_rows<<<ud_div_up(total, 256), 256, 0, stream>>>(p, v.rec, v.nrec, v.vtop, v.bitmap, v.bprefix, v.wlocal,
-                                                           v.samp_rank, v.top, v.cnt, coords);
+                                                           v.samp_rank, v.TS, v.top, v.cnt, coords);
       UD_LAUNCH_CHECK();
     }
     {
       UdProfScope prof("voxelize.k_gather", stream);
-      k_gather<<<ud_div_up(cap, 256), 256, 0, stream>>>(points, p, v.top, v.cnt, m_out, voxels, num_points, mean_feats);
+      k_gather<<<ud_div_up(cap, 256), 256, 0, stream>>>(points, p, v.top, v.TS, v.cnt, m_out, voxels, num_points, mean_feats);
       UD_LAUNCH_CHECK();
     }
     return UD_OK;
@@ -931,7 +944,7 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
   }
   {
     UdProfScope prof("voxelize.k_gather", stream);
-    k_gather<<<ud_div_up(w.cap, 256), 256, 0, stream>>>(points, p, w.top, w.cnt, m_out, voxels,
+    k_gather<<<ud_div_up(w.cap, 256), 256, 0, stream>>>(points, p, w.top, P, w.cnt, m_out, voxels,
                                                         num_points, mean_feats);
     UD_LAUNCH_CHECK();
   }

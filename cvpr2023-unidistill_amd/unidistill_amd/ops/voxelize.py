@@ -17,7 +17,8 @@ def _f3(v):
     return (ctypes.c_float * len(v))(*[float(x) for x in v])
 
 
-ALGO = None      # None: partition + LDS sort, hash fallback on overflow; 0 / 1: force one algorithm (tests, timing)
+ALGO = None      # None: by size (below), hash fallback on overflow; 0 / 1: force one algorithm (tests, timing)
+SMALL_CLOUD = 160000   # points: below this the atomic hash (5 launches, ~15 us of atomics) beats the 6-launch partition path
 
 
 def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_voxels=True,
@@ -46,7 +47,7 @@ def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_vo
     mean = torch.empty((cap, F), dtype=torch.float32, device=dev) if want_mean else None
     m_out = torch.empty((B + 2,), dtype=torch.int32, device=dev)
     algo = ALGO if algo is None else algo
-    for a in ((0, 1) if algo is None else (algo,)):
+    for a in (((1,) if B * N < SMALL_CLOUD else (0, 1)) if algo is None else (algo,)):
         _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range),
                                    int(max_points), int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords),
                                    _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m_out), _lib.ptr(ws),
