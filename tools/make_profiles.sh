@@ -1,9 +1,10 @@
 #!/bin/bash
 # Regenerate the rocprofv3 evidence on the GPU box (run through gpurun); summaries land in
-# gpurun_out/profiles_rNN/ and are then copied to profiles/ (tracked).
-#   gpurun --timeout 2400 -- 'bash tools/make_profiles.sh r02'
+# gpurun_out/profiles_rNN/ and are then copied to profiles/ (tracked), together with profiles/traffic.json, which
+# bench.py reads for its `traffic` figures.
+#   gpurun --timeout 2400 -- 'bash tools/make_profiles.sh r03'
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -12,9 +13,9 @@ T=$GRAFT_REPO_ROOT/tools
 rm -rf /tmp/p_bench; rocprofv3 --kernel-trace --stats -d /tmp/p_bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_stdout.txt 2>&1
 DB=$(ls /tmp/p_bench/*/*.db | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo;
-  echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt; echo '```'; echo;
+  echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt | cut -c1-3000; echo '```'; echo;
   echo "## Roofline kernels of the bench legs (rocprofv3 durations; bench.py's own HIP-event figures are in the JSON above)"; echo;
-  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_insert|k_first|k_scan|k_assign|k_gather|k_bin|k_cell|k_fill|k_conv3x3_taps|k_conv1x1_line|k_conv1x1_mapped";
+  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_vp_|k_scan|k_gather|k_bin|k_cell|k_fill|k_conv_f32_taps|k_conv3x3_taps|k_conv_mfma_v2|k_conv3x3_wgrad_f32|k_conv1x1_wgrad_f32";
   echo; echo "## Kernels by total time, naive_conv / find-mode kernels excluded"; echo;
   python $T/rocpd_summary.py $DB | grep -v "naive_conv\|MIOpenConvUni\|Im2d2Col\|Col2Im" | head -45; } > $OUT/${R}_bench_kernel_stats.md
 # 2. steady-state training step by category (marker-delimited window): fp32 (headline) and bf16
@@ -24,10 +25,10 @@ for AC in "" bf16; do
   { echo "# Steady-state distillation step, B=4, $TAG, channels-last (6 steps between marker kernels) ($R)"; echo; echo '```'; grep "samples/s" $OUT/step_stdout_$TAG.txt; echo '```'; echo;
     TOP=30 python $T/rocpd_categories.py $(ls /tmp/p_step/*/*.db | head -1) 6 --top | cut -c1-180; } > $OUT/${R}_step_categories_$TAG.md
 done
-# 3. bev_pool / voxelize / dense() op level
-{ echo "# bev_pool + voxelize + dense() op-level timings ($R)"; echo; echo '```'; python $T/time_bev_pool.py 2>&1 | tail -4; python $T/exp_pool.py 2>&1 | tail -4; python $T/time_voxelize.py 2>&1 | tail -12; python $T/time_dense.py 2>&1 | tail -2; python $T/exp_stream.py 2>&1 | tail -5; echo '```'; } > $OUT/${R}_bevpool_voxelize_ops.md
+# 3. bev_pool / voxelize / dense() op level + the streaming reference points
+{ echo "# bev_pool + voxelize + dense() op-level timings ($R)"; echo; echo '```'; python $T/time_bev_pool.py 2>&1 | tail -4; echo "-- voxelize, algo 0 (hash partition + LDS):"; python $T/time_voxelize.py 2>&1 | tail -12; echo "-- voxelize, algo 1 (atomic hash):"; ALGO=1 python $T/time_voxelize.py 2>&1 | tail -12; python $T/time_dense.py 2>&1 | tail -2; python $T/time_stream.py 2>&1 | tail -5; echo "-- device-scope atomics vs plain accesses (tools/atomic_rate.hip):"; hipcc --offload-arch=gfx950 -O3 $T/atomic_rate.hip -o /tmp/atomic_rate 2>/dev/null && /tmp/atomic_rate; echo '```'; } > $OUT/${R}_bevpool_voxelize_ops.md
 rm -rf /tmp/p_vox; rocprofv3 --kernel-trace --stats -d /tmp/p_vox -- python $T/time_voxelize.py > /dev/null 2>&1
-{ echo; echo "## voxelize kernels (all six configurations of tools/time_voxelize.py pooled; rocprofv3 kernel durations)"; echo; python $T/rocpd_summary.py $(ls /tmp/p_vox/*/*.db | head -1) namespace; } >> $OUT/${R}_bevpool_voxelize_ops.md
+{ echo; echo "## voxelize kernels (algo 0; all six configurations of tools/time_voxelize.py pooled; rocprofv3 kernel durations)"; echo; python $T/rocpd_summary.py $(ls /tmp/p_vox/*/*.db | head -1) namespace; } >> $OUT/${R}_bevpool_voxelize_ops.md
 # 4. HBM traffic of the dominant kernels (separate --pmc passes, as MI355X_MICROARCH.md prescribes)
 rm -rf /tmp/pmc1 /tmp/pmc2
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc1 -- python $T/pmc_pool.py > /dev/null 2>&1
@@ -38,11 +39,19 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc2 -- python $T/pmc_pool.py 
 rm -rf /tmp/pmc3 /tmp/pmc4
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc3 -- python $T/time_voxelize.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc4 -- python $T/time_voxelize.py > /dev/null 2>&1
-{ echo "# HBM traffic of the voxelize kernels from PMC counters ($R; all six configurations of tools/time_voxelize.py pooled)"; echo; echo '```';
-  for k in k_insert k_first k_assign k_gather; do python $T/rocpd_pmc.py $(ls /tmp/pmc3/*/*.db | head -1) $k | tail -1; python $T/rocpd_pmc.py $(ls /tmp/pmc4/*/*.db | head -1) $k | tail -1; done; echo '```'; } > $OUT/${R}_pmc_voxelize.md
-# 5. sparse encoder
+{ echo "# HBM traffic of the voxelize kernels (algo 0) from PMC counters ($R; all six configurations of tools/time_voxelize.py pooled; KB)"; echo; echo '```';
+  for k in k_vp_partition k_vp_bucket k_vp_flags k_scan k_vp_rows k_gather; do python $T/rocpd_pmc.py $(ls /tmp/pmc3/*/*.db | head -1) $k | tail -1; python $T/rocpd_pmc.py $(ls /tmp/pmc4/*/*.db | head -1) $k | tail -1; done; echo '```'; } > $OUT/${R}_pmc_voxelize.md
+rm -rf /tmp/pmc5 /tmp/pmc6
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc5 -- python $T/pmc_conv3x3.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc6 -- python $T/pmc_conv3x3.py > /dev/null 2>&1
+{ echo "# HBM traffic of conv2d.k_conv3x3_taps (trunk 256 -> 128 @180 x 180 x 4, bf16) from PMC counters ($R; KB)"; echo; echo '```';
+  python $T/rocpd_pmc.py $(ls /tmp/pmc5/*/*.db | head -1) k_conv3x3_taps | tail -1; python $T/rocpd_pmc.py $(ls /tmp/pmc6/*/*.db | head -1) k_conv3x3_taps | tail -1; echo '```'; } > $OUT/${R}_pmc_conv3x3.md
+# 5. MFMA-only loop (the machine's sustained matrix rates)
+{ echo "# MFMA-only loop on the MI355X box (tools/mfma_peak.hip, $R)"; echo; echo '```'; hipcc --offload-arch=gfx950 -O3 $T/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && /tmp/mfma_peak | tee /tmp/mfma_peak.txt; echo '```'; } > $OUT/${R}_mfma_peak.md
+python $T/traffic_json.py $R $(ls /tmp/pmc1/*/*.db | head -1) $(ls /tmp/pmc2/*/*.db | head -1) $(ls /tmp/pmc3/*/*.db | head -1) $(ls /tmp/pmc4/*/*.db | head -1) $(ls /tmp/pmc5/*/*.db | head -1) $(ls /tmp/pmc6/*/*.db | head -1) /tmp/mfma_peak.txt > $OUT/traffic.json 2> $OUT/traffic_json.err
+# 6. sparse encoder
 rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T/time_spconv.py > $OUT/spconv_stdout.txt 2>&1
 { echo "# LiDAR sparse encoder forward, B=4 x 30k points ($R)"; echo; echo '```'; grep "encoder fwd" $OUT/spconv_stdout.txt; echo '```'; echo; python $T/rocpd_summary.py $(ls /tmp/p_sp/*/*.db | head -1) namespace | head -30; } > $OUT/${R}_spconv_encoder.md
-# 6. fp32 convolutions: ours vs library
-{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo '```'; } > $OUT/${R}_conv_f32.md
+# 7. fp32 convolutions: ours vs library (forward / data gradient, and the weight gradients of one step)
+{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py):"; python $T/time_f32_wgrad.py 2>&1 | tail -21; echo '```'; } > $OUT/${R}_conv_f32.md
 ls -la $OUT

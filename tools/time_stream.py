@@ -1,3 +1,4 @@
+"""Streaming reference points on this GPU (ud_bench_stream: read, copy, block-contiguous nontemporal read of a 484 MB tensor, cache scrubbed): what a pure streaming kernel reaches, next to which the gather kernels are judged."""
 import os as _os; _os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic weights (tools never train for real)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
