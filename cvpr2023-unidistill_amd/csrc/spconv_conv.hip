@@ -12,6 +12,7 @@
 // strides swapped; wgrad reduces over row chunks into ordered partials.
 #include "ud_common.h"
 #include "ud_prof.h"
+#include <cstdlib>
 
 namespace {
 
@@ -1475,6 +1476,168 @@ __global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__
   gW[t] = acc;
 }
 
+
+// ---- v3 (fp32, 64 / 128 channels, channel-contiguous weights): LDS-DMA, double-buffered 64-channel stages ---------------------
+// k_conv_mfma_v2 above commits the gathered rows and the offset's weights through registers into ONE 153 KB tile: its waves
+// spend 41-45 % of their time in the commit -> barrier -> MFMA -> barrier hand-over (81 TFLOP/s on the 128-channel layers).
+// Here a stage = (active offset, 64-channel half of Cin): 128 gathered row pieces (256 B each) + Cout weight row pieces,
+// moved L2 -> LDS by global_load_lds (per-lane source addresses: the gather costs no VGPR round trip, no ds_write), into one of
+// TWO stage buffers: stage s + 1 flies while stage s is multiplied, one barrier per stage.  Rows are unpadded 256 B = 16
+// 16-byte slots, XOR-swizzled with (row & 15) on the SOURCE address, so the b128 fragment reads (16 lanes = 16 rows, same
+// logical slot) touch 16 distinct slots.  Waves: 4 (32 rows) x 2 (Cout / 2 columns); per 16-channel group a wave reads 2 A + NT B
+// fragments for 8 NT MFMAs (a lane's 16-byte piece feeds four MFMAs, see conv2d_f32.hip).
+__device__ __attribute__((aligned(16))) unsigned int g_zero16s[4];
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ in, const int32_t* __restrict__ nbr, int K,
+                                                      int mirror, const float* __restrict__ W, WStrides ws,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int Mout,
+                                                      const int32_t* __restrict__ order, ConvEpilogue ep) {
+  constexpr int NT = COUT / 32;                      // 16-column tiles per wave (2 column halves)
+  constexpr int kAB = kTM2 * 256, kWB = COUT * 256, kStage = kAB + kWB;
+  constexpr int kHalves = CIN / 64;
+  constexpr int kAPieces = kTM2 / 4, kWPieces = COUT / 4;      // 1-KiB DMA pieces: 4 rows x 256 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_nbr = reinterpret_cast<int*>(smem + 2 * kStage);      // [K][kTM2]
+  unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
+  int* s_row = s_nbr + K * kTM2 + 4;                            // [kTM2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int row0 = blockIdx.x * kTM2;
+  const float* zero = reinterpret_cast<const float*>(g_zero16s);
+  if (tid == 0) s_active = 0u;
+  if (tid < kTM2) {
+    const int p = row0 + tid;
+    s_row[tid] = (p < Mout) ? (order ? order[p] : p) : -1;
+  }
+  __syncthreads();
+  unsigned mine = 0u;
+  for (int idx = tid; idx < kTM2 * K; idx += 512) {
+    const int r = idx / K, k = idx - r * K;
+    int v = -1;
+    const int orow = s_row[r];
+    if (orow >= 0) v = nbr[(size_t)orow * K + (mirror ? K - 1 - k : k)];
+    s_nbr[k * kTM2 + r] = v;
+    if (v >= 0) mine |= 1u << k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor((int)mine, o);
+  if (lane == 0 && mine) atomicOr(&s_active, mine);
+  __syncthreads();
+  const unsigned active = s_active;
+  unsigned wmask = 0u;                                 // offsets any of this wave's 32 rows uses
+  for (int k = 0; k < K; ++k) {                        // (skipping per 16-row tile instead measured no faster)
+    const int v = (lane < 32) ? s_nbr[k * kTM2 + wm * 32 + lane] : -1;
+    if (__any(v >= 0)) wmask |= 1u << k;
+  }
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // DMA of one stage: pieces are dealt to the 8 waves round-robin; lane -> (row 4 p + g, LDS slot li <- source slot li ^ (row & 15))
+  auto stage = [&](int k, int half, int buf) {
+    char* sb = smem + buf * kStage;
+    for (int p = wave; p < kAPieces; p += 8) {
+      const int r = 4 * p + g;
+      const int rr = s_nbr[k * kTM2 + r];
+      const float* src = rr >= 0 ? in + (size_t)rr * CIN + half * 64 + ((li ^ (r & 15)) << 2) : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sb + p * 1024), 16, 0, 0);
+    }
+    for (int p = wave; p < kWPieces; p += 8) {
+      const int n = 4 * p + g;
+      const float* src = W + (size_t)n * ws.sn + (size_t)k * ws.sk + half * 64 + ((li ^ (n & 15)) << 2);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sb + kAB + p * 1024), 16, 0, 0);
+    }
+  };
+  // fragment byte offsets inside a stage buffer, per 16-channel group cb: slot (4 cb + g) ^ li of row (tile * 16 + li)
+  int fo[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) fo[cb] = li * 256 + (((4 * cb + g) ^ li) << 4);
+
+  // stage list: (active offset, half) in order; `todo` walks the offsets
+  unsigned todo = active;
+  int k = todo ? (__ffs((int)todo) - 1) : -1, half = 0, buf = 0;
+  if (k >= 0) stage(k, 0, 0);
+  while (k >= 0) {
+    // the stage after this one
+    int kn = k, hn = half + 1;
+    if (hn == kHalves) {
+      hn = 0;
+      const unsigned rest = todo & (todo - 1);
+      kn = rest ? (__ffs((int)rest) - 1) : -1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // this stage has landed for everybody; everybody is done with the other buffer
+    if (kn >= 0) stage(kn, hn, buf ^ 1);
+    if ((wmask >> k) & 1u) {
+      const char* ab = smem + buf * kStage + (wm * 32) * 256;
+      const char* wb = smem + buf * kStage + kAB + (wn * (COUT / 2)) * 256;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        f32x4 a[2], b[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(ab + i * 4096 + fo[cb]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wb + t * 4096 + fo[cb]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[t][e], acc[i][t], 0, 0, 0);
+      }
+    }
+    if (hn == 0) todo &= todo - 1;
+    k = kn;
+    half = hn;
+    buf ^= 1;
+  }
+  // epilogue: acc[i][t][r] = out[row(wm * 32 + 16 i + 4 g + r)][wn * COUT / 2 + 16 t + li]
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = wn * (COUT / 2) + t * 16 + li;
+    const float bv = bias ? bias[col] : 0.f;
+    const float sc = ep.scale ? ep.scale[col] : 1.f;
+    const float sh = ep.shift ? ep.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = s_row[wm * 32 + 16 * i + 4 * g + r];
+        if (row >= 0) {
+          float v = acc[i][t][r] + bv;
+          if (ep.scale) v = v * sc + sh;
+          if (ep.residual) v += ep.residual[(size_t)row * COUT + col];
+          if (ep.relu) v = fmaxf(v, 0.f);
+          out[(size_t)row * COUT + col] = v;
+        }
+      }
+  }
+}
+
+template <int CIN, int COUT>
+int launch_conv_dma_f32(const float* in, const int32_t* nbr, int K, int mirror, const float* W, WStrides ws,
+                        const float* bias, float* out, int Mout, const int32_t* order, ConvEpilogue ep,
+                        hipStream_t stream) {
+  const size_t lds = 2 * (size_t)(kTM2 * 256 + COUT * 256) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_dma_f32<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    attr_set = true;
+  }
+  k_conv_dma_f32<CIN, COUT><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
 inline int pad16(int c) { return (c + 15) / 16 * 16; }
 
 template <int CIN_P, int COUT_P>
@@ -1567,6 +1730,13 @@ int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror,
                 const int32_t* order, ConvEpilogue ep, int algo, hipStream_t stream) {
   if (K <= 32 && algo == 3)
     return launch_conv_bf16<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, 0, stream);
+  // fp32, 64 / 128 channels exactly, channel-contiguous 16-byte-aligned weights: the LDS-DMA kernel
+  // (64 -> 64 stays on k_conv_mfma_v2: its stages are too short to cover the next stage's DMA: 650 vs 700 us)
+  if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128) && !(CIN_P == 64 && COUT_P == 64)) {
+    static const bool no_dma = getenv("UD_SPCONV_NO_DMA") != nullptr;       // A/B timing
+    if (!no_dma && K <= 32 && algo == 0 && cin == CIN_P && cout == COUT_P && ws.sc == 1 && (ws.sn & 3) == 0 && (ws.sk & 3) == 0)
+      return launch_conv_dma_f32<CIN_P, COUT_P>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep, stream);
+  }
   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles
   if (K <= 32 && algo != 2)
     return launch_conv_v2<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, stream);
