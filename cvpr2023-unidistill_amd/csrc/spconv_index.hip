@@ -68,10 +68,13 @@ __device__ __forceinline__ int index_lookup(const unsigned long long* __restrict
   return perm ? perm[rank] : rank;
 }
 
+// m_dev (all three per-row kernels): the row count lives in device memory (the launch covers an upper bound M) -- the
+// voxel count and the level sizes of a LiDAR encoder pass then need ONE host read instead of five.
 __global__ __launch_bounds__(256) void k_set_bits(const int32_t* __restrict__ coords, int M,
-                                                  GridShape g,
+                                                  const int32_t* __restrict__ m_dev, GridShape g,
                                                   unsigned long long* __restrict__ words) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (m_dev) M = min(M, *m_dev);
   if (i >= M) return;
   const int b = coords[i * 4 + 0], z = coords[i * 4 + 1], y = coords[i * 4 + 2],
             x = coords[i * 4 + 3];
@@ -131,11 +134,12 @@ __global__ __launch_bounds__(256) void k_word_prefix(const unsigned long long* _
 }
 
 __global__ __launch_bounds__(256) void k_fill_perm(const int32_t* __restrict__ coords, int M,
-                                                   GridShape g,
+                                                   const int32_t* __restrict__ m_dev, GridShape g,
                                                    const unsigned long long* __restrict__ words,
                                                    const unsigned* __restrict__ prefix,
                                                    int* __restrict__ perm) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (m_dev) M = min(M, *m_dev);
   if (i >= M) return;
   const int b = coords[i * 4 + 0], z = coords[i * 4 + 1], y = coords[i * 4 + 2],
             x = coords[i * 4 + 3];
@@ -171,9 +175,11 @@ struct ConvGeom {
 
 // Mark every output cell reachable from an active input under (kernel, stride, padding).
 __global__ __launch_bounds__(256) void k_mark_outputs(const int32_t* __restrict__ coords, int M,
-                                                      GridShape gin, GridShape gout, ConvGeom c,
+                                                      const int32_t* __restrict__ m_dev, GridShape gin,
+                                                      GridShape gout, ConvGeom c,
                                                       unsigned long long* __restrict__ words) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (m_dev) M = min(M, *m_dev);
   if (i >= M) return;
   const int b = coords[i * 4 + 0];
   const int in[3] = {coords[i * 4 + 1], coords[i * 4 + 2], coords[i * 4 + 3]};
@@ -351,9 +357,25 @@ extern "C" size_t ud_spconv_index_bytes(int B, int Dz, int Hy, int Wx, int M) {
 
 // Build the rank index of the site set coords i32[M,4] (b,z,y,x) on grid (B,Dz,Hy,Wx).
 // rows_sorted != 0: row i already IS rank i (outputs of ud_spconv_down_outputs) -> no perm.
+static int build_index_impl(const int32_t* coords, int M, const int32_t* m_dev, int B, int Dz, int Hy, int Wx,
+                            int rows_sorted, void* index, size_t index_bytes, ud_stream_t stream_);
+
 extern "C" int ud_spconv_build_index(const int32_t* coords, int M, int B, int Dz, int Hy, int Wx,
                                      int rows_sorted, void* index, size_t index_bytes,
                                      ud_stream_t stream_) {
+  return build_index_impl(coords, M, nullptr, B, Dz, Hy, Wx, rows_sorted, index, index_bytes, stream_);
+}
+
+// Same, with the row count in device memory: rows [0, min(*m_dev, M_cap)) of coords are indexed (index sized for M_cap).
+extern "C" int ud_spconv_build_index_dev(const int32_t* coords, const int32_t* m_dev, int M_cap, int B, int Dz, int Hy,
+                                         int Wx, int rows_sorted, void* index, size_t index_bytes,
+                                         ud_stream_t stream_) {
+  if (!m_dev) return UD_ERR_INVALID_ARG;
+  return build_index_impl(coords, M_cap, m_dev, B, Dz, Hy, Wx, rows_sorted, index, index_bytes, stream_);
+}
+
+static int build_index_impl(const int32_t* coords, int M, const int32_t* m_dev, int B, int Dz, int Hy, int Wx,
+                            int rows_sorted, void* index, size_t index_bytes, ud_stream_t stream_) {
   GridShape g{B, Dz, Hy, Wx};
   if (!shape_ok(g) || M < 0 || (M > 0 && !coords) || !index) return UD_ERR_INVALID_ARG;
   if (index_bytes < ud_spconv_index_bytes(B, Dz, Hy, Wx, M)) return UD_ERR_WORKSPACE;
@@ -363,13 +385,13 @@ extern "C" int ud_spconv_build_index(const int32_t* coords, int M, int B, int Dz
   int* part = (int*)((char*)index + used);
   UD_HIP_TRY(hipMemsetAsync(v.words, 0, v.nwords_padded * sizeof(unsigned long long), stream));
   if (M > 0) {
-    k_set_bits<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, v.words);
+    k_set_bits<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, m_dev, g, v.words);
     UD_LAUNCH_CHECK();
   }
   int rc = scan_words(v, g, part, nullptr, stream);
   if (rc != UD_OK) return rc;
   if (!rows_sorted && M > 0) {
-    k_fill_perm<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, v.words, v.prefix, v.perm);
+    k_fill_perm<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, m_dev, g, v.words, v.prefix, v.perm);
     UD_LAUNCH_CHECK();
   }
   return UD_OK;
@@ -394,10 +416,34 @@ extern "C" int ud_spconv_subm_rulebook(const void* index, int rows_sorted, const
 // Output sites of SparseConv3d(kernel, stride, padding) on the input site set: builds the OUTPUT
 // level's rank index (rows sorted), writes out_coords (up to out_cap rows) and the count m_out
 // (device int).  Output grid = floor((in + 2p - k) / s) + 1 per axis.
+static int down_outputs_impl(const int32_t* in_coords, int Min, const int32_t* min_dev, int B, int Dz, int Hy,
+                             int Wx, const int* ksize, const int* stride, const int* pad, void* out_index,
+                             size_t out_index_bytes, int32_t* out_coords, int out_cap, int32_t* m_out,
+                             ud_stream_t stream_);
+
 extern "C" int ud_spconv_down_outputs(const int32_t* in_coords, int Min, int B, int Dz, int Hy,
                                       int Wx, const int* ksize, const int* stride, const int* pad,
                                       void* out_index, size_t out_index_bytes, int32_t* out_coords,
                                       int out_cap, int32_t* m_out, ud_stream_t stream_) {
+  return down_outputs_impl(in_coords, Min, nullptr, B, Dz, Hy, Wx, ksize, stride, pad, out_index, out_index_bytes,
+                           out_coords, out_cap, m_out, stream_);
+}
+
+// Same, with the input row count in device memory (min(*min_dev, Min_cap) rows of in_coords are used): levels chain on the
+// device, m_out of one call is min_dev of the next.
+extern "C" int ud_spconv_down_outputs_dev(const int32_t* in_coords, const int32_t* min_dev, int Min_cap, int B, int Dz,
+                                          int Hy, int Wx, const int* ksize, const int* stride, const int* pad,
+                                          void* out_index, size_t out_index_bytes, int32_t* out_coords,
+                                          int out_cap, int32_t* m_out, ud_stream_t stream_) {
+  if (!min_dev) return UD_ERR_INVALID_ARG;
+  return down_outputs_impl(in_coords, Min_cap, min_dev, B, Dz, Hy, Wx, ksize, stride, pad, out_index, out_index_bytes,
+                           out_coords, out_cap, m_out, stream_);
+}
+
+static int down_outputs_impl(const int32_t* in_coords, int Min, const int32_t* min_dev, int B, int Dz, int Hy,
+                             int Wx, const int* ksize, const int* stride, const int* pad, void* out_index,
+                             size_t out_index_bytes, int32_t* out_coords, int out_cap, int32_t* m_out,
+                             ud_stream_t stream_) {
   if (!ksize || !stride || !pad || !out_index || !m_out || Min < 0) return UD_ERR_INVALID_ARG;
   GridShape gin{B, Dz, Hy, Wx};
   ConvGeom c;
@@ -420,7 +466,7 @@ extern "C" int ud_spconv_down_outputs(const int32_t* in_coords, int Min, int B, 
   int* part = (int*)((char*)out_index + used);
   UD_HIP_TRY(hipMemsetAsync(v.words, 0, v.nwords_padded * sizeof(unsigned long long), stream));
   if (Min > 0) {
-    k_mark_outputs<<<ud_div_up(Min, 256), 256, 0, stream>>>(in_coords, Min, gin, gout, c, v.words);
+    k_mark_outputs<<<ud_div_up(Min, 256), 256, 0, stream>>>(in_coords, Min, min_dev, gin, gout, c, v.words);
     UD_LAUNCH_CHECK();
   }
   int rc = scan_words(v, gout, part, m_out, stream);

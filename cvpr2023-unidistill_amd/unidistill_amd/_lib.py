@@ -39,6 +39,9 @@ _SIGS = {
                         + [c_void_p, c_size_t, c_void_p]),
     "ud_spconv_index_bytes": (c_size_t, [c_int] * 5),
     "ud_spconv_build_index": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "ud_spconv_build_index_dev": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "ud_spconv_down_outputs_dev": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 3
+                                   + [c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),
     "ud_spconv_subm_rulebook": (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
     "ud_spconv_down_outputs": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3
                                + [c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from ..ops import spconv as sp
-from ..ops.voxelize import MeanVFE, Voxelization
+from ..ops.voxelize import MeanVFE, Voxelization, voxelize_deferred
 
 
 def _conv_bn_relu(cin, cout, kernel, norm_fn, *, stride=1, padding=0, key=None, kind="subm"):
@@ -149,16 +149,32 @@ class LidarEncoder(nn.Module):
         self.map_to_bev = HeightCompression(num_bev_features=g("map_to_bev_num_features"))
 
     def prepare(self, lidar_points):
-        """Everything of a pass that sizes tensors from device-side counts (the voxel count and the site counts of the four
-        down-sampling levels: five host reads): voxelize + MeanVFE + the site pyramid.  Callers that overlap this encoder
-        with other work (train.DistillStep: the frozen teacher on a second stream) run it BEFORE they enqueue that work,
-        so each read waits for microseconds of index kernels instead of for whatever the GPU is busy with."""
+        """Everything of a pass that sizes tensors from device-side counts: voxelize + MeanVFE + the site sets of the four
+        down-sampling levels.  With equal-length clouds (the collate_fn case) all of it runs on device-side counts and the
+        voxel count, the voxelizer's overflow word and the four level sizes come back in ONE host read (spconv's API, and
+        rounds 1-2 here, read five times per pass); ragged inputs and the overflow fallback take the read-per-level path."""
+        pts = lidar_points if isinstance(lidar_points, (list, tuple)) else [lidar_points]
+        bb, vz = self.backbone_3d, self.voxelizer
+        if self.one_read and vz.fused_mean and all(p.shape == pts[0].shape for p in pts):
+            batch = torch.stack(list(pts), 0) if len(pts) > 1 else pts[0].unsqueeze(0)
+            B = batch.shape[0]
+            _, coords_cap, _, mean_cap, m_out, _ = voxelize_deferred(batch, vz.voxel_size, vz.point_cloud_range,
+                                                                     vz.max_num_points, vz.max_voxels)
+            geoms = [(m.kernel_size, m.stride, m.padding) for m in bb.modules()
+                     if isinstance(m, sp.SparseConv3d) and not m.subm and not m.inverse]
+            pyr = sp.DeferredPyramid(coords_cap, m_out[B:B + 1], bb.sparse_shape, B, geoms)
+            host = torch.cat([m_out[B:B + 2]] + pyr.counts()).cpu()         # THE host read of this encoder pass
+            if int(host[1]) == 0:                                           # no partition overflow in the voxelizer
+                M = int(host[0])
+                sites = pyr.finalize(M, host[2:].tolist())
+                return sp.SparseConvTensor(mean_cap[:M], None, None, None, _sites=sites)
         voxels, coords, num = self.voxelizer(lidar_points)
         feats = self.vfe(voxels, num)
-        bb = self.backbone_3d
         x = sp.SparseConvTensor(feats, coords.int(), bb.sparse_shape, len(lidar_points))
         bb.site_pyramid(x)
         return x
+
+    one_read = True        # False: the read-per-level path (A/B timing, tests)
 
     def forward(self, lidar_points, prepared=None):
         x = prepared if prepared is not None else self.prepare(lidar_points)

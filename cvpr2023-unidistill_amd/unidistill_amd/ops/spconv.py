@@ -120,6 +120,73 @@ class _SiteSet:
         return hit
 
 
+class DeferredPyramid:
+    """Site sets of a strided-conv chain built WITHOUT host reads in between: every level's output-site kernels take their
+    input row count from the device word the previous level (or the voxelizer) wrote, on launches that cover an upper
+    bound.  ``counts()`` is the tensor to read (once, together with anything else); ``finalize(host_counts)`` slices the
+    cap-sized buffers, wires the _SiteSet chain and builds the rulebooks with the exact sizes.
+    (spconv's API -- and round 1-2 here -- reads one size per level: five blocking reads per encoder pass.)"""
+
+    def __init__(self, coords_cap, m_dev, spatial_shape, batch_size, geoms):
+        """coords_cap i32[cap,4]; m_dev: 1-element int32 device tensor (rows in use); geoms: [(ksize, stride, pad)]."""
+        lib = _lib.load()
+        dev = coords_cap.device
+        st = _lib.stream_of(coords_cap)
+        self.coords_cap, self.shape0, self.B, self.geoms = coords_cap, tuple(int(v) for v in spatial_shape), int(batch_size), geoms
+        cap = coords_cap.shape[0]
+        B = self.B
+        nbytes = lib.ud_spconv_index_bytes(B, *self.shape0, cap)
+        self.index0 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.ud_spconv_build_index_dev(_lib.ptr(coords_cap), _lib.ptr(m_dev), cap, B, *self.shape0, 0,
+                                                 _lib.ptr(self.index0), nbytes, st), "ud_spconv_build_index_dev")
+        self.levels = []
+        in_coords, in_cnt, in_cap, in_shape = coords_cap, m_dev, cap, self.shape0
+        for ksize, stride, pad in geoms:
+            out_shape = tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip(in_shape, ksize, stride, pad))
+            reach = 1
+            for k, s_ in zip(ksize, stride):
+                reach *= (k + s_ - 1) // s_
+            cells = B * out_shape[0] * out_shape[1] * out_shape[2]
+            ocap = max(min(in_cap * reach, cells), 1)
+            ob = lib.ud_spconv_index_bytes(B, *out_shape, ocap)
+            out_index = torch.empty(ob, dtype=torch.uint8, device=dev)
+            out_coords = torch.empty((ocap, 4), dtype=torch.int32, device=dev)
+            m_out = torch.empty(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.ud_spconv_down_outputs_dev(_lib.ptr(in_coords), _lib.ptr(in_cnt), in_cap, B, *in_shape,
+                                                      _i3(ksize), _i3(stride), _i3(pad), _lib.ptr(out_index), ob,
+                                                      _lib.ptr(out_coords), ocap, _lib.ptr(m_out), st),
+                       "ud_spconv_down_outputs_dev")
+            self.levels.append((out_shape, out_index, out_coords, m_out))
+            in_coords, in_cnt, in_cap, in_shape = out_coords, m_out, ocap, out_shape
+
+    def counts(self):
+        return [lv[3] for lv in self.levels]
+
+    def finalize(self, M, level_counts):
+        """M rows at level 0, level_counts[i] rows at strided level i (host ints) -> the level-0 _SiteSet, chain wired."""
+        lib = _lib.load()
+        root = _SiteSet(self.coords_cap[:M], self.shape0, self.B, rows_sorted=False)
+        root._index = self.index0
+        cur = root
+        for (ksize, stride, pad), (out_shape, out_index, out_coords, _), Mout in zip(self.geoms, self.levels, level_counts):
+            Mout = int(Mout)
+            K = ksize[0] * ksize[1] * ksize[2]
+            dev = out_coords.device
+            oc = out_coords[:Mout]
+            out_set = _SiteSet(oc, out_shape, self.B, rows_sorted=True)
+            out_set._index = out_index
+            out_nbr = torch.empty((Mout, K), dtype=torch.int32, device=dev)
+            in_nbr = torch.empty((cur.M, K), dtype=torch.int32, device=dev)
+            B, Dz, Hy, Wx = cur._grid()
+            _lib.check(lib.ud_spconv_down_rulebook(_lib.ptr(cur.index()), 1 if cur.rows_sorted else 0, cur.M, B, Dz, Hy, Wx,
+                                                   _i3(ksize), _i3(stride), _i3(pad), _lib.ptr(oc), Mout,
+                                                   _lib.ptr(out_nbr), _lib.ptr(in_nbr), _lib.stream_of(oc)),
+                       "ud_spconv_down_rulebook")
+            cur._down[(ksize, stride, pad)] = (out_set, out_nbr, in_nbr)
+            cur = out_set
+        return root
+
+
 _ORDER_CACHE_ATTR = "_ud_mask_order"
 
 

@@ -62,6 +62,38 @@ def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_vo
             mean[:M] if want_mean else None, m_host[:B])
 
 
+def voxelize_deferred(points, voxel_size, pc_range, max_points, max_voxels, want_voxels=False, want_mean=True, algo=None):
+    """voxelize_batch without its host read: -> (voxels_cap | None, coords_cap i32[cap,4], num_cap, mean_cap | None,
+    m_out i32[B+2] ON THE DEVICE (per-sample counts, total, overflow word), algo used).  The caller reads m_out together
+    with whatever other sizes it needs (LidarEncoder.prepare: one read per encoder pass) and slices the cap-sized tensors."""
+    _lib.require_gpu(points)
+    if points.dtype != torch.float32:
+        raise TypeError("points must be float32")
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    points = points.contiguous()
+    B, N, F = points.shape
+    lib = _lib.load()
+    cap = lib.ud_voxelize_capacity(B, N, int(max_voxels))
+    need = lib.ud_voxelize_workspace_bytes(B, N, int(max_points), int(max_voxels))
+    if cap <= 0 or need == 0:
+        raise ValueError("invalid voxelization sizes")
+    dev = points.device
+    ws = _lib.workspace(dev, need, "voxelize")
+    voxels = torch.empty((cap, max_points, F), dtype=torch.float32, device=dev) if want_voxels else None
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, F), dtype=torch.float32, device=dev) if want_mean else None
+    m_out = torch.empty((B + 2,), dtype=torch.int32, device=dev)
+    algo = ALGO if algo is None else algo
+    if algo is None:
+        algo = 1 if B * N < SMALL_CLOUD else 0
+    _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range), int(max_points),
+                               int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(num), _lib.ptr(mean),
+                               _lib.ptr(m_out), _lib.ptr(ws), ws.numel(), algo, _lib.stream_of(points)), "ud_voxelize")
+    return voxels, coords, num, mean, m_out, algo
+
+
 class PointToVoxel:
     """Interface of ``spconv.pytorch.utils.PointToVoxel`` as the reference uses it
     (voxelization.py:31-38 ctor kwargs, :54 call): one sample per call, returns

@@ -221,6 +221,15 @@ int ud_spconv_down_outputs(const int32_t* in_coords, int Min, int B, int Dz, int
                            const int* ksize, const int* stride, const int* pad, void* out_index,
                            size_t out_index_bytes, int32_t* out_coords, int out_cap,
                            int32_t* m_out, ud_stream_t stream);
+/* Device-count variants: the row count of the input site set is read from device memory (the launches cover the upper
+ * bound M_cap / Min_cap), so ud_voxelize -> level index -> the four down-sampling levels of VoxelResBackBone8x
+ * (spconv_backbone.py:279-340) chain without a host read in between; ONE read of all counts sizes the tensors afterwards. */
+int ud_spconv_build_index_dev(const int32_t* coords, const int32_t* m_dev, int M_cap, int B, int Dz, int Hy, int Wx,
+                              int rows_sorted, void* index, size_t index_bytes, ud_stream_t stream);
+int ud_spconv_down_outputs_dev(const int32_t* in_coords, const int32_t* min_dev, int Min_cap, int B, int Dz, int Hy,
+                               int Wx, const int* ksize, const int* stride, const int* pad, void* out_index,
+                               size_t out_index_bytes, int32_t* out_coords, int out_cap, int32_t* m_out,
+                               ud_stream_t stream);
 
 /* out_nbr i32[Mout,K]: input row at o*s - p + k or -1; in_nbr i32[Min,K] (optional, for dgrad):
  * output row that input i feeds through offset k, or -1. */

@@ -113,3 +113,57 @@ def test_lidar_encoder_backward_runs_full_size():
     bev.square().mean().backward()
     for n, p in enc.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def _sync_count(fn):
+    """Number of blocking host<->device synchronisations fn() triggers (torch's sync debug mode, warn level)."""
+    import warnings
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode(1)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = fn()
+    finally:
+        torch.cuda.set_sync_debug_mode(0)
+    return out, sum("synchroniz" in str(x.message).lower() for x in w)
+
+
+@pytest.mark.parametrize("B,N", [(1, 30000), (4, 30000), (2, 250000)])
+def test_prepare_reads_the_host_once_and_matches_the_per_level_path(B, N):
+    """voxel count + overflow word + the four level sizes in ONE device->host read; sites, rulebooks and
+    the BEV map identical (bit for bit) to the read-per-level path."""
+    from unidistill_amd.layers.lidar import LidarEncoder
+    from unidistill_amd.ops import spconv as sp
+    from unidistill_amd import synthetic as syn
+    cfg = dict(voxel_size=list(syn.VOXEL_SIZE), point_cloud_range=list(syn.POINT_CLOUD_RANGE),
+               grid_size=list(syn.GRID_SIZE), max_num_points=10, max_voxels=(120000, 160000),
+               src_num_point_features=5, use_num_point_features=5, map_to_bev_num_features=256)
+    torch.manual_seed(0)
+    enc = LidarEncoder(cfg).cuda().eval()
+    g = syn.rng()
+    pts = [torch.from_numpy(syn.lidar_cloud(g, N, 1)).cuda() for _ in range(B)]
+    n = min(p.shape[0] for p in pts)
+    pts = [p[:n].contiguous() for p in pts]            # equal lengths: the collate_fn case
+    probe, n_probe = _sync_count(lambda: torch.ones(4, device="cuda").cpu())
+    enc.one_read = True
+    xa, n_one = _sync_count(lambda: enc.prepare(pts))
+    enc.one_read = False
+    xb, n_lvl = _sync_count(lambda: enc.prepare(pts))
+    if n_probe:                                        # sync debug mode reports on this build
+        assert n_one == 1, n_one
+        assert n_lvl >= 5, n_lvl
+    assert torch.equal(xa.indices, xb.indices) and torch.equal(xa.features, xb.features)
+    sa, sb = xa._sites, xb._sites
+    for m in enc.backbone_3d.modules():
+        if isinstance(m, sp.SparseConv3d) and not m.subm and not m.inverse:
+            (oa, na, ia), (ob, nb, ib) = (s.down(m.kernel_size, m.stride, m.padding) for s in (sa, sb))
+            assert torch.equal(oa.indices, ob.indices) and torch.equal(na, nb) and torch.equal(ia, ib)
+            assert torch.equal(oa.subm_rulebook((3, 3, 3)), ob.subm_rulebook((3, 3, 3)))
+            sa, sb = oa, ob
+    with torch.no_grad():
+        ya, n_fwd = _sync_count(lambda: enc(pts, prepared=xa))
+        yb = enc(pts, prepared=xb)
+    if n_probe:
+        assert n_fwd == 0, n_fwd
+    assert torch.equal(ya, yb)
