@@ -180,13 +180,17 @@ def mfma_leg(trainer, batch, fp32, steps=3):
         if key not in cache:
             x = torch.randn(B, cin, H, W, device=dev, generator=g).to(dt).contiguous(memory_format=torch.channels_last)
             w = (torch.randn(cout, 3, 3, cin, device=dev, generator=g) * 0.02).to(dt)
-            cache[key] = (x, w)
+            # fp32: parameter-shaped filters [Cout, Cin, 3, 3] of the layer (the launcher picks the transform / tap order)
+            wp = {r: (torch.randn((cin, cout, 3, 3) if r else (cout, cin, 3, 3), device=dev, generator=g) * 0.02) for r in (False, True)} if fp32 else None
+            cache[key] = (x, w, wp)
         ops.append((cache[key], cout, rev))
-    launch = c32._launch3 if fp32 else c16._launch
 
     def replay():
-        for (x, w), cout, rev in ops:
-            launch(x, w, cout, reverse_taps=rev)
+        for (x, w, wp), cout, rev in ops:
+            if fp32:
+                c32._launch3(x, wp[rev], transposed=rev)
+            else:
+                c16._launch(x, w, cout, reverse_taps=rev)
     replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 3 if fp32 else 5

@@ -5,6 +5,7 @@ BEVFusion_nuscenes_base_exp.py:107-135, lss_fpn.py:143-149).  Forward, data grad
 hand-written (csrc/conv2d_f32.hip, csrc/conv2d_f32_wgrad.hip).
 """
 import ctypes
+import os
 
 import torch
 
@@ -30,24 +31,73 @@ FLOP_COUNTER = None      # set to [0] to accumulate the multiply-add count of ev
 SHAPE_LOG = None         # set to [] to record (B, Cin, H, W, Cout, reverse_taps) of every 3x3 launch (bench.py replays them)
 
 
-def _launch3(x, w_tap, cout, bias=None, relu=False, reverse_taps=False, bn_stats=False):
+USE_WINOGRAD = os.environ.get("UD_F32_WINOGRAD", "1") != "0"   # 3x3: Winograd F(2x2,3x3) kernels where the map fills the blocks
+WINO_MIN_FILL = 0.7
+
+
+def wino_pays(H, W, cin, cout):
+    if not USE_WINOGRAD or cin % 8 or cout % 4:
+        return False
+    blocks = _lib.load().ud_conv3x3_wino_f32_blocks(H, W)
+    return ((H + 1) // 2) * ((W + 1) // 2) >= WINO_MIN_FILL * 64 * blocks
+
+
+def _wino_weights(weight, transposed):
+    """U = G g G^T in the kernel's stage order.  transposed: the data gradient's filter (Cin <-> Cout, taps reversed).  Cached on
+    the tensor object per version (frozen teacher weights: transformed once; trained ones: once per optimizer step)."""
+    cache = getattr(weight, "_ud_wino", None)
+    key = (bool(transposed), weight._version, weight.data_ptr())
+    if cache is not None and key in cache:
+        return cache[key]
+    lib = _lib.load()
+    w = weight.detach()
+    n, c = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    sn, sc = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
+    U = torch.empty(lib.ud_conv3x3_wino_f32_weight_bytes(c, n) // 4, dtype=torch.float32, device=w.device)
+    _lib.check(lib.ud_conv3x3_wino_f32_weights(_lib.ptr(w), sn, sc, w.stride(2), w.stride(3), n, c, 1 if transposed else 0,
+                                               _lib.ptr(U), _lib.stream_of(w)), "ud_conv3x3_wino_f32_weights")
+    try:
+        if cache is None or next(iter(cache))[1] != weight._version:
+            cache = {}
+        cache[key] = U
+        weight._ud_wino = cache
+    except (AttributeError, RuntimeError):
+        pass
+    return U
+
+
+def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False):
+    """3x3 / stride 1 / pad 1 of channels-last x with the parameter ``weight`` [Cout, Cin, 3, 3] (transposed: its data-gradient
+    filter, Cin <-> Cout with the taps reversed).  Winograd kernel where the map fills its tile blocks, else the direct one."""
     B, cin, H, W = x.shape
+    cout = weight.shape[1] if transposed else weight.shape[0]
     if FLOP_COUNTER is not None:
         FLOP_COUNTER[0] += 2 * B * H * W * cout * 9 * cin
     if SHAPE_LOG is not None:
-        SHAPE_LOG.append((B, cin, H, W, cout, bool(reverse_taps)))
+        SHAPE_LOG.append((B, cin, H, W, cout, bool(transposed)))
+    lib = _lib.load()
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if wino_pays(H, W, cin, cout):
+        U = _wino_weights(weight, transposed)
+        part, ns = (None, ctypes.c_int(0))
+        if bn_stats:
+            part, ns = _bn_partial(lib.ud_conv3x3_wino_bnstats_bytes(B, H, W, cout), x.device)
+        _lib.check(lib.ud_conv3x3_wino_nhwc_f32(_lib.ptr(x), _lib.ptr(U), _lib.ptr(y), B, H, W, cin, cout, _lib.ptr(bias), None,
+                                                1 if relu else 0, _lib.ptr(part), part.numel() * 4 if bn_stats else 0,
+                                                ctypes.addressof(ns), _lib.stream_of(x)), "ud_conv3x3_wino_nhwc_f32")
+        return (y, (part, ns.value, B * H * W)) if bn_stats else y
+    w = weight.detach()
+    w_tap = (w.permute(1, 2, 3, 0) if transposed else w.permute(0, 2, 3, 1)).contiguous()   # [n, 3, 3, c]; transposed: taps walked in reverse
     if bn_stats:      # + per-tile (sum, sum of squares) for the BatchNorm that follows: (y, (partial, slices, rows))
-        lib = _lib.load()
         part, ns = _bn_partial(lib.ud_conv3x3_bnstats_bytes(B, H, W, cout), x.device)
         _lib.check(lib.ud_conv3x3_bnstats_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
                                                    _lib.ptr(bias), _lib.ptr(part), part.numel() * 4,
                                                    ctypes.addressof(ns), _lib.stream_of(x)),
                    "ud_conv3x3_bnstats_nhwc_f32")
         return y, (part, ns.value, B * H * W)
-    _lib.check(_lib.load().ud_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
-                                               _lib.ptr(bias), None, None, None,
-                                               (1 if relu else 0) | (2 if reverse_taps else 0), _lib.stream_of(x)),
+    _lib.check(lib.ud_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
+                                       _lib.ptr(bias), None, None, None,
+                                       (1 if relu else 0) | (2 if transposed else 0), _lib.stream_of(x)),
                "ud_conv3x3_nhwc_f32")
     return y
 
@@ -122,7 +172,7 @@ class _ConvF32(torch.autograd.Function):
         w = weight.detach()
         st = holder is not None
         if ks == 3:
-            y = _launch3(x, w.permute(0, 2, 3, 1).contiguous(), weight.shape[0], b, bn_stats=st)   # [Cout, 3, 3, Cin]
+            y = _launch3(x, weight, b, bn_stats=st)
         else:
             y = _launch1(x, w.reshape(weight.shape[0], weight.shape[1]).contiguous(), weight.shape[0], b, bn_stats=st)
         if st:
@@ -151,9 +201,9 @@ class _ConvF32(torch.autograd.Function):
             gyp[:, :cout] = gy
             gyp[:, cout:] = 0
             if ks == 3:
-                wt = torch.zeros((weight.shape[1], 3, 3, cout + pad), dtype=w.dtype, device=w.device)
-                wt[..., :cout] = w.permute(1, 2, 3, 0)
-                gx = _launch3(gyp, wt, weight.shape[1], reverse_taps=True)
+                wp = torch.zeros((cout + pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+                wp[:cout] = w
+                gx = _launch3(gyp, wp, transposed=True)
                 if gskip is not None:
                     gx = gx + gskip
             else:
@@ -162,7 +212,7 @@ class _ConvF32(torch.autograd.Function):
                 gx = _launch1(gyp, wt, weight.shape[1], residual=gskip)
         elif ctx.needs_input_grad[0]:
             if ks == 3:      # un-flipped transposed weights [Cin, 3, 3, Cout], taps walked in reverse
-                gx = _launch3(gy, w.permute(1, 2, 3, 0).contiguous(), weight.shape[1], reverse_taps=True)
+                gx = _launch3(gy, weight, transposed=True)
             else:
                 gx = _launch1(gy, w.reshape(weight.shape[0], weight.shape[1]).t().contiguous(), weight.shape[1],
                               residual=gskip)

@@ -515,6 +515,23 @@ int ud_conv1x1_wgrad_mapped_nhwc_f32(const float* x, const float* dy, float* dw,
                                      const int* x_map, const int* dy_map, void* workspace, size_t workspace_bytes,
                                      ud_stream_t stream);
 
+/* fp32 3x3 / stride 1 / pad 1 as Winograd F(2x2, 3x3) on the fp32 MFMA pipe (2.25x fewer matrix flops than the direct form;
+ * same layers as ud_conv3x3_nhwc_f32: base_bev_backbone.py:30-110, center_head.py:311-420, lss_fpn.py:143-149; the framework the
+ * reference runs on picks the same algorithm family for fp32 3x3 layers).  Weights are transformed once per weight version:
+ *   ud_conv3x3_wino_f32_weights(w, strides of (n, c, ky, kx) in elements, N, C, flip, U): U = G g G^T of g[n][ky][kx][c]; the forward
+ *   pass uses (n, c) = (Cout, Cin), the data gradient (n, c) = (Cin, Cout) with flip = 1 (taps reversed);
+ *   U holds ud_conv3x3_wino_f32_weight_bytes(C, N) bytes.
+ * ud_conv3x3_wino_nhwc_f32: y = conv(x) (+ bias) (+ residual) (ReLU if flags & 1); partial != NULL also returns the per-workgroup
+ * BatchNorm partial sums [*slices][Cout][2] (ud_conv3x3_wino_bnstats_bytes).  Cin % 8 == 0, Cout % 4 == 0. */
+size_t ud_conv3x3_wino_f32_weight_bytes(int Cin, int Cout);
+size_t ud_conv3x3_wino_bnstats_bytes(int B, int H, int W, int Cout);
+int ud_conv3x3_wino_f32_blocks(int H, int W);   /* 64-tile blocks per image of the launch plan (fill = ceil(H/2) ceil(W/2) / (64 blocks)) */
+int ud_conv3x3_wino_f32_weights(const float* w, int64_t s_n, int64_t s_c, int64_t s_y, int64_t s_x, int N, int C, int flip,
+                                float* U, ud_stream_t stream);
+int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y, int B, int H, int W, int Cin, int Cout,
+                             const float* bias, const float* residual, int flags, float* partial, size_t partial_bytes,
+                             int* slices, ud_stream_t stream);
+
 /* ---- LiDAR input side ------------------------------------------------------------------
  * Replaces the numpy point transforms of the reference's data pipeline:
  * CollectLidarSweeps.forward (unidistill/data/multisensorfusion/transforms3d.py:379-414) and the point part

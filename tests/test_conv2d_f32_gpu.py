@@ -69,13 +69,15 @@ def test_conv_f32_dgrad_pads_cout_off_the_slice_width(hip_lib):
         w = (torch.randn(cout, cin, ks, ks, device="cuda") * 0.05).requires_grad_(True)
         name = "conv2d.k_conv3x3_f32" if ks == 3 else "conv2d.k_conv1x1_f32"
         _lib.prof_read(name, reset=True)
+        _lib.prof_read("conv2d.k_conv3x3_wino_f32", reset=True)
         _lib.prof_enable(True)
         y = c.conv3x3(x, w) if ks == 3 else c.conv1x1(x, w)
         gy = _cl(torch.randn_like(y))
         gx, = torch.autograd.grad(y, x, gy)
         torch.cuda.synchronize()
         _lib.prof_enable(False)
-        assert _lib.prof_read(name)[1] == 2          # forward + data gradient
+        # forward + data gradient, on the direct or (3x3) the Winograd kernel
+        assert _lib.prof_read(name)[1] + (_lib.prof_read("conv2d.k_conv3x3_wino_f32")[1] if ks == 3 else 0) == 2
         gx_ref, = torch.autograd.grad(F.conv2d(x, w, None, 1, ks // 2), x, gy)
         assert (gx - gx_ref).abs().max() <= 2e-5 * gx_ref.abs().max()
 
@@ -90,12 +92,13 @@ def test_fp32_trunk_routes_to_the_fp32_kernels_and_matches_library(hip_lib):
     m = BaseBEVBackbone([2, 2], [1, 2], [64, 128], [1, 2], [64, 64], 64).cuda().train()
     x = _cl(torch.randn(2, 64, 40, 40, device="cuda"))
     _lib.prof_read("conv2d.k_conv3x3_f32", reset=True)
+    _lib.prof_read("conv2d.k_conv3x3_wino_f32", reset=True)
     _lib.prof_enable(True)
     y, _ = m(x)
     torch.cuda.synchronize()
     _lib.prof_enable(False)
-    _, calls = _lib.prof_read("conv2d.k_conv3x3_f32")
-    assert calls == 5, calls           # 3 stride-1 convs of level 0 (incl. the ZeroPad one) + 2 of level 1
+    calls = _lib.prof_read("conv2d.k_conv3x3_f32")[1] + _lib.prof_read("conv2d.k_conv3x3_wino_f32")[1]
+    assert calls == 5, calls           # 3 stride-1 convs of level 0 (incl. the ZeroPad one) + 2 of level 1 (direct or Winograd kernel)
     dense.Conv2d.hip_enabled = False
     try:
         for mod in m.modules():        # same batch statistics on the second pass: reset what BN accumulated
@@ -259,3 +262,45 @@ def test_fp32_training_step_has_no_library_weight_gradient(hip_lib):
     for n, g in grads[0].items():
         r = grads[1][n]
         assert (g - r).abs().max() <= 2e-4 * r.abs().max(), n
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64, 16, 16), (2, 128, 128, 180, 180), (1, 256, 256, 90, 90), (3, 64, 192, 64, 176),
+                                   (2, 128, 64, 32, 88), (5, 256, 256, 16, 44), (1, 512, 64, 8, 22), (2, 72, 100, 27, 35),
+                                   (1, 64, 2688, 36, 28), (1, 64, 64, 1, 1), (1, 8, 4, 5, 3), (2, 2688, 64, 20, 12)])
+def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
+    """ud_conv3x3_wino_nhwc_f32 (forward, data gradient, BatchNorm partial sums) on every tile-block shape, ragged / odd maps and
+    channel counts off the 64-wide blocks: against an fp64 convolution, next to the direct fp32 MFMA kernel's own error.
+    Tolerance 2e-5 of the output's max (the direct kernels' bound); measured 1-3e-6 for both."""
+    from unidistill_amd.ops import conv2d_f32 as c
+    B, cin, cout, H, W = shape
+    torch.manual_seed(sum(shape))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda"))
+    w = torch.randn(cout, cin, 3, 3, device="cuda") * (9 * cin) ** -0.5
+    b = torch.randn(cout, device="cuda")
+    gy = _cl(torch.randn(B, cout, H, W, device="cuda"))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    gref = F.conv_transpose2d(gy.double(), w.double(), padding=1)
+    old = (c.USE_WINOGRAD, c.WINO_MIN_FILL)
+    try:
+        c.USE_WINOGRAD, c.WINO_MIN_FILL = True, 0.0
+        assert c.wino_pays(H, W, cin, cout)
+        y, (part, slices, rows) = c._launch3(x, w, b, bn_stats=True)
+        y2 = c._launch3(x, w, b, relu=True)
+        gx = c._launch3(gy, w, transposed=True) if cout % 8 == 0 else None
+        c.USE_WINOGRAD = False
+        yd = c._launch3(x, w, b) if cin % 32 == 0 else None
+    finally:
+        c.USE_WINOGRAD, c.WINO_MIN_FILL = old
+    tol = 2e-5 * float(ref.abs().max())
+    err = float((y.double() - ref).abs().max())
+    assert err <= tol, (err, tol)
+    if yd is not None:
+        assert err <= 4 * float((yd.double() - ref).abs().max()) + 1e-6 * float(ref.abs().max())
+    assert torch.equal(y2, torch.relu(y))
+    if gx is not None:
+        assert float((gx.double() - gref).abs().max()) <= 2e-5 * float(gref.abs().max())
+    st = part[:slices * cout * 2].view(slices, cout, 2).double().sum(0)
+    assert rows == B * H * W
+    ys = y.double()
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), ys.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st[:, 1].cpu().numpy(), (ys * ys).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)

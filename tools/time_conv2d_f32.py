@@ -3,6 +3,7 @@ forward and data gradient, at the shapes of the distillation step (B=4)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]
+os.environ.setdefault('UD_RANDOM_INIT', '1')
 import torch, torch.nn.functional as F
 from unidistill_amd.ops import conv2d_f32 as c
 d = torch.device("cuda:0")
@@ -23,9 +24,12 @@ for name, B, ci, co, H, W in shapes3:
     wt = w.permute(0, 2, 3, 1).contiguous()
     wl = w.contiguous(memory_format=torch.channels_last)
     fl = 2 * B * H * W * co * 9 * ci
-    a = t(lambda: c._launch3(x, wt, co))
+    c.USE_WINOGRAD = False
+    a = t(lambda: c._launch3(x, wl))
+    c.USE_WINOGRAD = True
+    a2 = t(lambda: c._launch3(x, wl)) if c.wino_pays(H, W, ci, co) else float("nan")
     b = t(lambda: F.conv2d(x, wl, None, 1, 1))
-    print(f"3x3 {name:32s} ours {a:8.1f} us ({fl/a/1e6:6.1f} TF)   library {b:8.1f} us ({fl/b/1e6:6.1f} TF)   x{b/a:.2f}")
+    print(f"3x3 {name:32s} direct {a:8.1f} us ({fl/a/1e6:6.1f} TF)   winograd {a2:8.1f} us ({fl/a2/1e6:6.1f} TF eff.)   library {b:8.1f} us ({fl/b/1e6:6.1f} TF)")
 shapes1 = [("64->256 @64x176 x24", 24, 64, 256, 64, 176), ("256->64 @64x176 x24", 24, 256, 64, 64, 176),
            ("512->128 @32x88 x24", 24, 512, 128, 32, 88), ("1024->256 @16x44 x24", 24, 1024, 256, 16, 44),
            ("depth 512->368 @16x44 x24", 24, 512, 368, 16, 44)]
