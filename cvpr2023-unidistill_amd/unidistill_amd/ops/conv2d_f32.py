@@ -33,6 +33,7 @@ SHAPE_LOG = None         # set to [] to record (B, Cin, H, W, Cout, reverse_taps
 
 USE_WINOGRAD = os.environ.get("UD_F32_WINOGRAD", "1") != "0"   # 3x3: Winograd F(2x2,3x3) kernels where the map fills the blocks
 WINO_MIN_FILL = 0.7
+USE_WINOGRAD_WGRAD = os.environ.get("UD_F32_WINOGRAD_WGRAD", "1") != "0"
 
 
 def wino_pays(H, W, cin, cout):
@@ -139,11 +140,13 @@ def weight_grad(x, gy, w, ks):
     lib = _lib.load()
     B, _, H, W = x.shape
     if ks == 3:
-        ws = _lib.workspace(x.device, lib.ud_conv3x3_wgrad_f32_workspace_bytes(B, H, W, cin, cout), "conv_wgrad")
+        wino = USE_WINOGRAD and USE_WINOGRAD_WGRAD
+        nbytes, fn = ((lib.ud_conv3x3_wino_wgrad_f32_workspace_bytes, lib.ud_conv3x3_wino_wgrad_nhwc_f32) if wino else
+                      (lib.ud_conv3x3_wgrad_f32_workspace_bytes, lib.ud_conv3x3_wgrad_nhwc_f32))
+        ws = _lib.workspace(x.device, nbytes(B, H, W, cin, cout), "conv_wgrad")
         dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device)
-        _lib.check(lib.ud_conv3x3_wgrad_nhwc_f32(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), B, H, W, cin, cout,
-                                                 _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
-                   "ud_conv3x3_wgrad_nhwc_f32")
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), B, H, W, cin, cout, _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
+                   "ud_conv3x3_wino_wgrad_nhwc_f32" if wino else "ud_conv3x3_wgrad_nhwc_f32")
         return dw.permute(0, 3, 1, 2)
     return wgrad_mapped(x, gy, B * H * W, cin, cout, None, None).view(cout, cin, 1, 1)
 

@@ -532,6 +532,12 @@ int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y, int B, in
                              const float* bias, const float* residual, int flags, float* partial, size_t partial_bytes,
                              int* slices, ud_stream_t stream);
 
+/* Weight gradient of the same layers through the Winograd form (gradient of ud_conv3x3_wino_nhwc_f32: 16 instead of 36 multiplications
+ * per 2 x 2 tile and (n, c)); same contract as ud_conv3x3_wgrad_nhwc_f32: dw [Cout][3][3][Cin], tile slices reduced in a fixed order. */
+size_t ud_conv3x3_wino_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ud_conv3x3_wino_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                   void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
 /* ---- LiDAR input side ------------------------------------------------------------------
  * Replaces the numpy point transforms of the reference's data pipeline:
  * CollectLidarSweeps.forward (unidistill/data/multisensorfusion/transforms3d.py:379-414) and the point part

@@ -245,7 +245,7 @@ def test_fp32_training_step_has_no_library_weight_gradient(hip_lib):
                 if isinstance(mod, torch.nn.BatchNorm2d):
                     mod.reset_running_stats()
             m.zero_grad(set_to_none=True)
-            for nm in ("conv2d.k_wgrad_f32", "conv2d.k_wgrad_1x1_f32"):
+            for nm in ("conv2d.k_wgrad_f32", "conv2d.k_wgrad_wino_f32", "conv2d.k_wgrad_1x1_f32"):
                 _lib.prof_read(nm, reset=True)
             _lib.prof_enable(hip)
             y, _ = m(x)
@@ -255,7 +255,7 @@ def test_fp32_training_step_has_no_library_weight_gradient(hip_lib):
         finally:
             dense.Conv2d.hip_enabled = True
         if hip:
-            n3 = _lib.prof_read("conv2d.k_wgrad_f32")[1]
+            n3 = _lib.prof_read("conv2d.k_wgrad_f32")[1] + _lib.prof_read("conv2d.k_wgrad_wino_f32")[1]   # direct or Winograd
             n1 = _lib.prof_read("conv2d.k_wgrad_1x1_f32")[1]
             assert n3 == 5 and n1 == 3, (n3, n1)       # 5 stride-1 3x3 convs; strided 3x3 + the two deblocks
         grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.dim() == 4})
@@ -268,7 +268,7 @@ def test_fp32_training_step_has_no_library_weight_gradient(hip_lib):
                                    (2, 128, 64, 32, 88), (5, 256, 256, 16, 44), (1, 512, 64, 8, 22), (2, 72, 100, 27, 35),
                                    (1, 64, 2688, 36, 28), (1, 64, 64, 1, 1), (1, 8, 4, 5, 3), (2, 2688, 64, 20, 12)])
 def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
-    """ud_conv3x3_wino_nhwc_f32 (forward, data gradient, BatchNorm partial sums) on every tile-block shape, ragged / odd maps and
+    """ud_conv3x3_wino_nhwc_f32 / ud_conv3x3_wino_wgrad_nhwc_f32 (forward, data gradient, weight gradient, BatchNorm partial sums) on every tile-block shape, ragged / odd maps and
     channel counts off the 64-wide blocks: against an fp64 convolution, next to the direct fp32 MFMA kernel's own error.
     Tolerance 2e-5 of the output's max (the direct kernels' bound); measured 1-3e-6 for both."""
     from unidistill_amd.ops import conv2d_f32 as c
@@ -287,6 +287,7 @@ def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
         y, (part, slices, rows) = c._launch3(x, w, b, bn_stats=True)
         y2 = c._launch3(x, w, b, relu=True)
         gx = c._launch3(gy, w, transposed=True) if cout % 8 == 0 else None
+        gw = c.weight_grad(x, gy, w, 3)
         c.USE_WINOGRAD = False
         yd = c._launch3(x, w, b) if cin % 32 == 0 else None
     finally:
@@ -299,6 +300,8 @@ def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
     assert torch.equal(y2, torch.relu(y))
     if gx is not None:
         assert float((gx.double() - gref).abs().max()) <= 2e-5 * float(gref.abs().max())
+    gwref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)
+    assert float((gw.double() - gwref).abs().max()) <= 1e-4 * float(gwref.abs().max())      # the direct weight-gradient kernels' bound
     st = part[:slices * cout * 2].view(slices, cout, 2).double().sum(0)
     assert rows == B * H * W
     ys = y.double()

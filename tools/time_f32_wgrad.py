@@ -40,7 +40,7 @@ def timeit(f):
         f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 10
-print(f"{'B':>3} {'Cin':>5} {'H':>4} {'W':>4} {'Cout':>5} ks  calls  ours ms TFLOP/s  ms/step | MIOpen ms TFLOP/s")
+print(f"{'B':>3} {'Cin':>5} {'H':>4} {'W':>4} {'Cout':>5} ks  calls  ours ms TFLOP/s  ms/step | MIOpen ms TFLOP/s | direct (non-Winograd) 3x3 ms")
 for (b, cin, h, w_, cout, ks), n in sorted(cnt.items(), key=lambda kv: -kv[1]):
     x = torch.randn(b, cin, h, w_, device=dev).contiguous(memory_format=torch.channels_last)
     gy = torch.randn(b, cout, h, w_, device=dev).contiguous(memory_format=torch.channels_last)
@@ -49,8 +49,13 @@ for (b, cin, h, w_, cout, ks), n in sorted(cnt.items(), key=lambda kv: -kv[1]):
     cf.USE_HIP_WGRAD = False
     ms_lib = timeit(lambda: fn(x, gy, w, ks))
     cf.USE_HIP_WGRAD = True
+    ms_dir = float("nan")
+    if ks == 3:
+        cf.USE_WINOGRAD_WGRAD = False
+        ms_dir = timeit(lambda: fn(x, gy, w, ks))
+        cf.USE_WINOGRAD_WGRAD = True
     fl = 2.0 * b * h * w_ * cin * cout * ks * ks
     tot += ms * n
     tot_lib += ms_lib * n
-    print(f"{b:3d} {cin:5d} {h:4d} {w_:4d} {cout:5d} {ks:2d} {n:6d} {ms:7.3f} {fl / ms / 1e9:8.1f} {ms * n:8.3f} | {ms_lib:7.3f} {fl / ms_lib / 1e9:8.1f}")
+    print(f"{b:3d} {cin:5d} {h:4d} {w_:4d} {cout:5d} {ks:2d} {n:6d} {ms:7.3f} {fl / ms / 1e9:8.1f} {ms * n:8.3f} | {ms_lib:7.3f} {fl / ms_lib / 1e9:8.1f} | {ms_dir:7.3f}")
 print(f"total ours {tot:.2f} ms/step, MIOpen {tot_lib:.2f} ms/step over {sum(cnt.values())} calls")
