@@ -154,16 +154,17 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     from unidistill_amd import _lib
     from unidistill_amd.ops import conv2d as c16, conv2d_f32 as c32
     c2 = c32 if fp32 else c16
-    prof_name = "conv2d.k_conv3x3_f32" if fp32 else "conv2d.k_conv3x3"
+    prof_names = ("conv2d.k_conv3x3_f32", "conv2d.k_conv3x3_wino_f32") if fp32 else ("conv2d.k_conv3x3",)
     peak = MFMA_PEAK_TFLOPS_F32 if fp32 else MFMA_PEAK_TFLOPS
     c2.FLOP_COUNTER = [0]
-    _lib.prof_read(prof_name, reset=True)
+    for nm in prof_names + ("conv2d.k_wgrad_f32", "conv2d.k_wgrad_wino_f32", "conv2d.k_wgrad_1x1_f32"):
+        _lib.prof_read(nm, reset=True)
     _lib.prof_enable(True)
     for _ in range(steps):
         trainer.step(batch)
     torch.cuda.synchronize()
     _lib.prof_enable(False)
-    ms, calls = _lib.prof_read(prof_name)
+    ms, calls = (sum(v) for v in zip(*[_lib.prof_read(nm) for nm in prof_names]))
     flops, c2.FLOP_COUNTER = c2.FLOP_COUNTER[0], None
     if not calls or ms <= 0:
         return None
@@ -202,16 +203,27 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     rp_ms = e0.elapsed_time(e1) / reps
     rp_flops = sum(2 * B * H * W * cout * 9 * cin for (B, cin, H, W, cout, _) in log)
     achieved = rp_flops / (rp_ms * 1e-3) / 1e12
+    # fp32: launches whose map fills the tile blocks run as Winograd F(2x2,3x3) -- 16 instead of 36 multiplications per 2 x 2
+    # outputs: `achieved` stays ALGORITHMIC (direct-form) flops / time as the contract defines it, `executed` is what the MFMA
+    # pipe actually ran
+    ex_flops = sum(2 * B * H * W * cout * 9 * cin * ((16.0 / 36.0) if fp32 and c32.wino_pays(H, W, cin, cout) else 1.0)
+                   for (B, cin, H, W, cout, _) in log)
+    n_wino = sum(1 for (B, cin, H, W, cout, _) in log if fp32 and c32.wino_pays(H, W, cin, cout))
     in_step = flops / (ms * 1e-3) / 1e12
     pf = profile_figures()
     loop = pf.get("mfma_only_loop_tflops", {})
     instr = "v_mfma_f32_16x16x4_f32" if fp32 else "v_mfma_f32_16x16x32_bf16"
     out = {"bound": "mfma",
-           "kernel": ("conv2d_f32.k_conv_f32_taps (ud_conv3x3_nhwc_f32" if fp32 else "conv2d.k_conv3x3_taps (ud_conv3x3_nhwc_bf16")
-                     + ": BEV trunk, head, ResNet 3x3 convs; fwd + dgrad)",
+           "kernel": ("conv2d_f32_wino.k_conv3x3_wino_f32 / conv2d_f32.k_conv_f32_taps (ud_conv3x3_wino_nhwc_f32, ud_conv3x3_nhwc_f32"
+                      if fp32 else "conv2d.k_conv3x3_taps (ud_conv3x3_nhwc_bf16") + ": BEV trunk, head, ResNet 3x3 convs; fwd + dgrad)",
            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "dtype": "f32" if fp32 else "bf16",
            "launches": len(log), "avg_kernel_us": rp_ms / len(log) * 1e3, "algorithmic_flops_per_step": rp_flops,
            "kernel_ms_per_step": rp_ms, "traffic": None,
+           "executed": ({"winograd_launches": n_wino, "flops_per_step": ex_flops, "TFLOP/s": ex_flops / (rp_ms * 1e-3) / 1e12,
+                         "frac_of_peak": ex_flops / (rp_ms * 1e-3) / 1e12 / peak,
+                         "note": "Winograd F(2x2,3x3) launches execute 16/36 of their algorithmic multiplications: achieved / frac "
+                                 "(algorithmic flops / time) can exceed the matrix peak; this object is the MFMA pipe's own load"}
+                        if fp32 else None),
            # what an MFMA-only loop sustains on the same machine with the instruction this kernel uses (tools/mfma_peak.hip;
            # profiles/traffic.json): informational, `frac` stays priced against the guide's nominal peak
            "mfma_only_loop": ({"instruction": instr, "TFLOP/s": loop[instr], "frac_of_loop": achieved / loop[instr],
@@ -228,8 +240,10 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     else:
         # the fp32 weight gradients of the same step (ud_conv3x3_wgrad_nhwc_f32 + ud_conv1x1_wgrad_mapped_nhwc_f32): in-step HIP events
         w3, n3 = _lib.prof_read("conv2d.k_wgrad_f32")
+        ww, nw = _lib.prof_read("conv2d.k_wgrad_wino_f32")
         w1, n1 = _lib.prof_read("conv2d.k_wgrad_1x1_f32")
         out["weight_gradients_in_step_events"] = {"k_wgrad_f32": {"ms_per_step": w3 / steps, "launches_per_step": n3 / steps},
+                                                  "k_wgrad_wino_f32": {"ms_per_step": ww / steps, "launches_per_step": nw / steps},
                                                   "k_wgrad_1x1_f32": {"ms_per_step": w1 / steps, "launches_per_step": n1 / steps}}
     return out
 

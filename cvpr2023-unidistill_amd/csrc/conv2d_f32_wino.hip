@@ -14,7 +14,8 @@
 // lane.  Per 8-input-channel stage: the raw (2 THB + 2) x (2 TWB + 2) x 8-channel patch and the 32 KB U stage arrive by
 // LDS-DMA (U is stored in exactly the LDS order: [cout block][stage][f][64][8]), every thread transforms one (tile, channel)
 // patch into V, and the MFMA loop reads 8-byte fragments (2 reduction steps per read).  Patch, V and U are double-buffered:
-// 150 KB of LDS, one workgroup per CU, two waves per SIMD.
+// 150 KB of LDS, one workgroup per CU, two waves per SIMD.  The whole stage is hand-scheduled: fragment reads one step ahead of
+// their MFMAs, the next stage's input transform spread over the steps, the stage barrier one step before the stage's end.
 #include "ud_common.h"
 #include "ud_prof.h"
 #include <cstdlib>
@@ -30,6 +31,7 @@ constexpr int kUOff = 0, kVOff = 2 * kUBytes, kPOff = kVOff + 2 * kVBytes, kWino
 
 struct WinoGeom {
   int B, H, W, Cin, Cout, bx, by;   // bx x by tile blocks per image
+  int n_full;                       // workgroups [0, n_full) own whole units (tile block, cout block); the rest own quarter units
 };
 struct WinoEp {
   const float* bias;
@@ -92,14 +94,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   const int g = lane >> 4, li = lane & 15;
   const int wq = wave & 3, wh = wave >> 2;
   const int nblocks = gm.B * gm.bx * gm.by;
-  const int per = (nblocks + 7) / 8;
-  int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);     // consecutive blocks of an XCD are spatial neighbours
-  if (blk >= nblocks) return;
+  // Unit = (tile block, 64-channel cout block), cout block major.  When the unit count leaves a short last round on the 256 CUs
+  // (e.g. 1040 units: 4 rounds + 16 units alone on the chip for a fifth), the launcher turns that remainder into QUARTER units:
+  // four workgroups per unit, each multiplying one 16-tile M block (q >= 0) -- a quarter unit costs ~0.4 of a whole one.
+  const int bid = blockIdx.x;
+  const int unit = bid < gm.n_full ? bid : gm.n_full + ((bid - gm.n_full) >> 2);
+  const int q = bid < gm.n_full ? -1 : (bid - gm.n_full) & 3;
+  const int cbi = unit / nblocks, ru = unit - cbi * nblocks;
+  int blk;
+  {   // consecutive workgroups go round the 8 XCDs: XCD k walks its own contiguous range of tile blocks (shared halos stay in its L2)
+    const int base = nblocks >> 3, extra = nblocks & 7, k = ru & 7;
+    blk = k * base + min(k, extra) + (ru >> 3);
+  }
   const int blk_lin = blk;
   const int b = blk / (gm.bx * gm.by);
   blk -= b * gm.bx * gm.by;
   const int ty0 = (blk / gm.bx) * THB, tx0 = (blk % gm.bx) * TWB;      // in tiles
-  const int n0 = blockIdx.y * kTN;
+  const int n0 = cbi * kTN;
   const int nchunks = gm.Cin / kKC;
   const float* zero = reinterpret_cast<const float*>(g_zero16w);
 
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
       pp[i] += pinc[i];
     }
   };
-  const float* up = U + (size_t)blockIdx.y * nchunks * (16 * 512) + wave * 1024 + lane * 4;
+  const float* up = U + (size_t)cbi * nchunks * (16 * 512) + wave * 1024 + lane * 4;
   auto stage_u = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma16w(up + i * 256, smem + kUOff + buf * kUBytes + (wave * 4 + i) * 1024);
@@ -199,44 +210,50 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   if (nchunks > 1) stage_p(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed
   __syncthreads();
-  transform(0);
-  auto stage_mma = [&](auto more_c, int chunk) {
-    constexpr bool more = decltype(more_c)::value;
+  // One barrier per stage, placed BEFORE the stage's last MFMA step: by then every wave holds its step-7 fragments in registers
+  // and has written its share of V(chunk + 1), so right after the barrier the next stage's DMA, first fragment reads and patch
+  // reads go out and complete under the 8 MFMAs of step 7 -- no bubble at the stage boundary.
+  auto step_mma = [&](int cur, int st) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = 2 * st + h;
+      acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[cur][h][0], qb[cur][h][0], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1[cur][h][0], qb[cur][h][0], acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[cur][h][1], qb[cur][h][1], acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1[cur][h][1], qb[cur][h][1], acc[f][1], 0, 0, 0);
+    }
+  };
+  auto stage_mma = [&](auto more_c, auto first_c, int chunk) {
+    constexpr bool more = decltype(more_c)::value, first = decltype(first_c)::value;
     const int cb = chunk & 1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();                      // V(chunk) written, U(chunk) and patch(chunk + 1) landed, buffers of chunk - 1 free
+    __syncthreads();      // V(chunk) written, U(chunk) and patch(chunk + 1) landed; everybody holds the last fragments of chunk - 1
     if (more) stage_u(cb ^ 1);
     if (chunk + 2 < nchunks) stage_p(cb);
     const unsigned pa = fa + cb * kVBytes, pb = fb + cb * kUBytes;
     const unsigned tvw = tv + (cb ^ 1) * kVBytes;
     float tw[16];
     UD_WN_LOADS(0, 0);
+    if constexpr (more) { UD_WN_TREADS((cb ^ 1) * kPBytes); }
+    if constexpr (!first) step_mma(1, 7);                 // last step of the previous stage: fragments already in registers
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
+    for (int st = 0; st < 7; ++st) {
       const int cur = st & 1;
-      if constexpr (more) if (st == 0) { UD_WN_TREADS((cb ^ 1) * kPBytes); }
-      if (more && st >= 4) {              // two V rows (four frequencies) per step
-        const int f0 = 4 * (st - 4);
+      if (more && st >= 3) {              // two V rows (four frequencies) per step
+        const int f0 = 4 * (st - 3);
         asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(tvw), "v"(tw[f0]), "v"(tw[f0 + 1]), "n"(8 * f0), "n"(8 * f0 + 8));
         asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(tvw), "v"(tw[f0 + 2]), "v"(tw[f0 + 3]), "n"(8 * f0 + 16), "n"(8 * f0 + 24));
       }
-      if (st + 1 < 8) {
-        if (cur == 0) UD_WN_LOADS(1, 2 * (st + 1)); else UD_WN_LOADS(0, 2 * (st + 1));
-      }
-      // operations issued after this step's fragments: the next step's 6 reads, plus the transform's reads (step 0) / writes (4-7)
+      if (cur == 0) UD_WN_LOADS(1, 2 * (st + 1)); else UD_WN_LOADS(0, 2 * (st + 1));
+      // operations issued after this step's fragments: the next step's 6 reads, plus the transform's reads (step 0) / writes (3-6)
       if (more) {
         if (st == 0) UD_WN_WAIT(0, 14);
         else if (st == 1) UD_WN_WAIT(1, 6);
         else if (st == 2) UD_WN_TWAIT(0, 6);
-        else if (st == 3) UD_WN_WAIT(1, 6);
-        else if (st == 4) UD_WN_WAIT(0, 8);
-        else if (st == 5) UD_WN_WAIT(1, 8);
-        else if (st == 6) UD_WN_WAIT(0, 8);
-        else UD_WN_WAIT(1, 2);
+        else if (cur == 0) UD_WN_WAIT(0, 8);
+        else UD_WN_WAIT(1, 8);
       } else {
-        if (st == 7) UD_WN_WAIT(1, 0);
-        else if (cur == 0) UD_WN_WAIT(0, 6);
-        else UD_WN_WAIT(1, 6);
+        if (cur == 0) UD_WN_WAIT(0, 6); else UD_WN_WAIT(1, 6);
       }
       if (st == 2 && more) {
         float d[4][4];
@@ -257,19 +274,93 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
           tw[4 * i + 3] = d[i][1] - d[i][3];
         }
       }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int f = 2 * st + h;
-        acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[cur][h][0], qb[cur][h][0], acc[f][0], 0, 0, 0);
-        acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1[cur][h][0], qb[cur][h][0], acc[f][1], 0, 0, 0);
-        acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[cur][h][1], qb[cur][h][1], acc[f][0], 0, 0, 0);
-        acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1[cur][h][1], qb[cur][h][1], acc[f][1], 0, 0, 0);
-      }
+      step_mma(cur, st);
     }
   };
+  if (q < 0) {
+    transform(0);
+    if (nchunks == 1) {
+      stage_mma(std::false_type{}, std::true_type{}, 0);
+    } else {
+      stage_mma(std::true_type{}, std::true_type{}, 0);
 #pragma unroll 1
-  for (int chunk = 0; chunk + 1 < nchunks; ++chunk) stage_mma(std::true_type{}, chunk);
-  stage_mma(std::false_type{}, nchunks - 1);
+      for (int chunk = 1; chunk + 1 < nchunks; ++chunk) stage_mma(std::true_type{}, std::false_type{}, chunk);
+      stage_mma(std::false_type{}, std::false_type{}, nchunks - 1);
+    }
+    UD_WN_WAIT(1, 0);
+    step_mma(1, 7);
+  } else {
+    // quarter unit: tile slots [16 q, 16 q + 16).  Waves 2q, 2q + 1 own those slots' input transform, the four waves of half
+    // q >> 1 multiply M block q & 1 into acc[.][0]; everybody stages U / the patch and meets at the stage barrier.  Plain
+    // sequence per stage (transform, then the MFMA steps with their fragments one step ahead).
+    const bool do_tr = (wave >> 1) == q, do_mma = wh == (q >> 1);
+    if (do_tr) transform(0);
+    const unsigned faq = fa + (q & 1) * 512;
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const int cb = chunk & 1;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool more = chunk + 1 < nchunks;
+      if (more) stage_u(cb ^ 1);
+      if (chunk + 2 < nchunks) stage_p(cb);
+      if (do_tr && more) {
+        const unsigned tvw = tv + (cb ^ 1) * kVBytes;
+        UD_WN_TREADS((cb ^ 1) * kPBytes);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(td[0][0]), "+v"(td[0][1]), "+v"(td[1][0]), "+v"(td[1][1]), "+v"(td[2][0]), "+v"(td[2][1]),
+                       "+v"(td[3][0]), "+v"(td[3][1]));
+        float d[4][4], tw[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[i][0] = td[i][0][0]; d[i][1] = td[i][0][1]; d[i][2] = td[i][1][0]; d[i][3] = td[i][1][1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float r0 = d[0][j] - d[2][j], r1 = d[1][j] + d[2][j], r2 = d[2][j] - d[1][j], r3 = d[1][j] - d[3][j];
+          d[0][j] = r0; d[1][j] = r1; d[2][j] = r2; d[3][j] = r3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          tw[4 * i + 0] = d[i][0] - d[i][2];
+          tw[4 * i + 1] = d[i][1] + d[i][2];
+          tw[4 * i + 2] = d[i][2] - d[i][1];
+          tw[4 * i + 3] = d[i][1] - d[i][3];
+        }
+#pragma unroll
+        for (int f0 = 0; f0 < 16; f0 += 2)
+          asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(tvw), "v"(tw[f0]), "v"(tw[f0 + 1]), "n"(8 * f0), "n"(8 * f0 + 8));
+      }
+      if (do_mma) {
+        const unsigned pa = faq + cb * kVBytes, pb = fb + cb * kUBytes;
+#define UD_WQ_LOADS(BUF, F)                                                                                             \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                       \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qa0[BUF][h]) : "v"(pa), "n"(((F) + h) * 2048));                 \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb[BUF][h]) : "v"(pb), "n"(((F) + h) * 2048));                  \
+  }
+#define UD_WQ_WAIT(BUF, N) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(qa0[BUF][0]), "+v"(qa0[BUF][1]), "+v"(qb[BUF][0]), "+v"(qb[BUF][1]))
+        UD_WQ_LOADS(0, 0);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const int cur = st & 1;
+          if (st + 1 < 8) {
+            if (cur == 0) { UD_WQ_LOADS(1, 2 * (st + 1)); UD_WQ_WAIT(0, 4); } else { UD_WQ_LOADS(0, 2 * (st + 1)); UD_WQ_WAIT(1, 4); }
+          } else {
+            UD_WQ_WAIT(1, 0);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int f = 2 * st + h;
+            acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[cur][h][0], qb[cur][h][0], acc[f][0], 0, 0, 0);
+            acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[cur][h][1], qb[cur][h][1], acc[f][0], 0, 0, 0);
+          }
+        }
+#undef UD_WQ_LOADS
+#undef UD_WQ_WAIT
+      }
+    }
+  }
 #undef UD_WN_TREADS
 #undef UD_WN_TWAIT
 #undef UD_WN_LOADS
@@ -282,13 +373,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (q >= 0 && (mb == 1 || wh != (q >> 1))) continue;      // quarter unit: one M block, held in acc[.][0]
       float s[2][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s[0][j] = acc[0 + j][mb][r] + acc[4 + j][mb][r] + acc[8 + j][mb][r];
         s[1][j] = acc[4 + j][mb][r] - acc[8 + j][mb][r] - acc[12 + j][mb][r];
       }
-      const int slot = 32 * wh + 16 * mb + 4 * g + r;
+      const int slot = 32 * wh + 16 * (q >= 0 ? (q & 1) : mb) + 4 * g + r;
       float* o = Os + (slot * 4) * 64 + (16 * (wq ^ g) + li);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -307,7 +399,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
     const int slot = row >> 2;
     const int sy = slot / TWB, sx = slot - sy * TWB;
     const int gy = 2 * (ty0 + sy) + ((row >> 1) & 1), gx = 2 * (tx0 + sx) + (row & 1);
-    if (slot >= TWB * THB || gy >= gm.H || gx >= gm.W || n >= gm.Cout) continue;
+    if (slot >= TWB * THB || gy >= gm.H || gx >= gm.W || n >= gm.Cout || (q >= 0 && (slot >> 4) != q)) continue;
     float4 v = *reinterpret_cast<const float4*>(Os + row * 64 + (c4 ^ (16 * ((row >> 4) & 3))));
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
@@ -333,13 +425,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
     }
     __syncthreads();
     if (tid < 64 && n0 + tid < gm.Cout) {
-      float a = 0.f, q = 0.f;
+      float a = 0.f, qq = 0.f;
       for (int k = 0; k < 32; ++k) {
         a += Os[(k * 64 + tid) * 2];
-        q += Os[(k * 64 + tid) * 2 + 1];
+        qq += Os[(k * 64 + tid) * 2 + 1];
       }
-      ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2] = a;
-      ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2 + 1] = q;
+      // whole units fill row `tile block`; quarter units rows past the tile blocks (zeroed by the launcher for the other cout
+      // blocks), and quarter 0 clears the unit's own row
+      const size_t row = q < 0 ? (size_t)blk_lin : (size_t)nblocks + 4 * (size_t)(unit - gm.n_full) + q;
+      ep.stats[(row * gm.Cout + n0 + tid) * 2] = a;
+      ep.stats[(row * gm.Cout + n0 + tid) * 2 + 1] = qq;
+      if (q == 0) ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2] = ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2 + 1] = 0.f;
     }
   }
 }
@@ -347,6 +443,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
 struct WinoPlan {
   int twb, thb, bx, by;
 };
+// units of the short last round that are issued as quarter units (0: none)
+int wino_split(long long units) {
+  static const int off = getenv("UD_WINO_NO_SPLIT") ? 1 : 0;
+  const int rem = (int)(units % 256);
+  return (!off && units > 256 && rem > 0 && rem <= 64) ? rem : 0;
+}
 // tile-block shape with the fewest padded slots for this map
 WinoPlan wino_plan(int H, int W) {
   static const int shapes[][2] = {{8, 8}, {9, 7}, {10, 6}, {4, 16}, {16, 4}, {11, 4}};
@@ -381,7 +483,7 @@ extern "C" int ud_conv3x3_wino_f32_blocks(int H, int W) {
 extern "C" size_t ud_conv3x3_wino_bnstats_bytes(int B, int H, int W, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   const WinoPlan p = wino_plan(H, W);
-  return (size_t)B * p.bx * p.by * Cout * 2 * sizeof(float);
+  return ((size_t)B * p.bx * p.by + 4 * 64) * Cout * 2 * sizeof(float);     // + the rows of up to 64 quarter-split units
 }
 
 extern "C" int ud_conv3x3_wino_f32_weights(const float* w, int64_t s_n, int64_t s_c, int64_t s_y, int64_t s_x, int N, int C,
@@ -404,12 +506,17 @@ extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y
   if (Cin % kKC != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   const WinoPlan p = wino_plan(H, W);
-  WinoGeom gm{B, H, W, Cin, Cout, p.bx, p.by};
-  WinoEp ep{bias, residual, flags & 1, partial};
   const int nblocks = B * p.bx * p.by;
+  const long long units = (long long)nblocks * ud_div_up(Cout, kTN);
+  if (units + 3 * 64 > 0x7fffffffll) return UD_ERR_UNSUPPORTED;
+  const int split = wino_split(units);
+  WinoGeom gm{B, H, W, Cin, Cout, p.bx, p.by, (int)units - split};
+  WinoEp ep{bias, residual, flags & 1, partial};
   if (partial) {
-    if (!slices || partial_bytes < (size_t)nblocks * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;
-    *slices = nblocks;
+    const size_t rows = (size_t)nblocks + 4 * (size_t)split;
+    if (!slices || partial_bytes < rows * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;
+    *slices = (int)rows;
+    if (split) UD_HIP_TRY(hipMemsetAsync(partial + (size_t)nblocks * Cout * 2, 0, 4 * (size_t)split * Cout * 2 * sizeof(float), stream));
   }
   static bool attr_set = false;
   if (!attr_set) {
@@ -420,7 +527,7 @@ extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y
     attr_set = true;
   }
   UdProfScope prof("conv2d.k_conv3x3_wino_f32", stream);
-  const dim3 grid((nblocks + 7) / 8 * 8, ud_div_up(Cout, kTN));
+  const dim3 grid((unsigned)(units + 3 * split));
 #define UD_WINO_LAUNCH(A, Bq) k_conv3x3_wino_f32<A, Bq><<<grid, 512, kWinoSmem, stream>>>(x, U, y, gm, ep)
   if (p.twb == 8) UD_WINO_LAUNCH(8, 8);
   else if (p.twb == 9) UD_WINO_LAUNCH(9, 7);

@@ -266,7 +266,8 @@ def test_fp32_training_step_has_no_library_weight_gradient(hip_lib):
 
 @pytest.mark.parametrize("shape", [(1, 64, 64, 16, 16), (2, 128, 128, 180, 180), (1, 256, 256, 90, 90), (3, 64, 192, 64, 176),
                                    (2, 128, 64, 32, 88), (5, 256, 256, 16, 44), (1, 512, 64, 8, 22), (2, 72, 100, 27, 35),
-                                   (1, 64, 2688, 36, 28), (1, 64, 64, 1, 1), (1, 8, 4, 5, 3), (2, 2688, 64, 20, 12)])
+                                   (1, 64, 2688, 36, 28), (1, 64, 64, 1, 1), (1, 8, 4, 5, 3), (2, 2688, 64, 20, 12),
+                                   (9, 64, 128, 64, 64), (5, 128, 64, 126, 90)])   # the last two (and the second): quarter-split last round
 def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
     """ud_conv3x3_wino_nhwc_f32 / ud_conv3x3_wino_wgrad_nhwc_f32 (forward, data gradient, weight gradient, BatchNorm partial sums) on every tile-block shape, ragged / odd maps and
     channel counts off the 64-wide blocks: against an fp64 convolution, next to the direct fp32 MFMA kernel's own error.
