@@ -51,10 +51,11 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b, float ac
 // thread per pixel; lane = channel with nine row reads per pixel and shuffle reductions; lane = channel with a register
 // halo and 64-lane DPP reductions -- instruction-bound: 140 instructions per pixel.)
 __device__ __attribute__((aligned(16))) unsigned int g_zero_f4[4];
-template <int KM>
+template <int KM, bool BN>
 __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ z, GTail t,
-                                                   int strip_rows, int strips) {
+                                                   int strip_rows, int strips, const float* __restrict__ bn_scale,
+                                                   const float* __restrict__ bn_shift) {
   // groups vary fastest over the grid: the workgroups running together consume whole pixel rows
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // A workgroup walks a 16-pixel-wide strip of `strip_rows` rows (a multiple of kTH): the window keeps sliding across the
@@ -95,6 +96,13 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
   }
   const size_t rstride = (size_t)t.W * Ct;
   int yy_next = ty0 - 1;
+  // bn_scale != nullptr: the input is the first convolution's raw output; BatchNorm (folded scale / shift) + ReLU are applied to
+  // every piece as it is loaded (padding stays zero) -- the hidden tensor is neither written normalised nor read back
+  float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (BN) {
+    bsc = *reinterpret_cast<const float4*>(bn_scale + g * kHC + 4 * cq);
+    bsh = *reinterpret_cast<const float4*>(bn_shift + g * kHC + 4 * cq);
+  }
   auto load_next = [&](float4* r) {
     const bool yok = yy_next >= 0 && yy_next < t.H;
 #pragma unroll
@@ -104,10 +112,27 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
     }
     ++yy_next;
   };
+  // BN: applied when a row ENTERS the 3-row window (it was fetched PD steps earlier and stays in flight until then), once per
+  // row; `yy` = the row's image row
+  auto bn_row = [&](float4* r, int yy) {
+    const bool yok = yy >= 0 && yy < t.H;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool ok = yok && xok[d];
+      r[d].x = ok ? fmaxf(fmaf(r[d].x, bsc.x, bsh.x), 0.f) : 0.f;
+      r[d].y = ok ? fmaxf(fmaf(r[d].y, bsc.y, bsh.y), 0.f) : 0.f;
+      r[d].z = ok ? fmaxf(fmaf(r[d].z, bsc.z, bsh.z), 0.f) : 0.f;
+      r[d].w = ok ? fmaxf(fmaf(r[d].w, bsc.w, bsh.w), 0.f) : 0.f;
+    }
+  };
   constexpr int PD = KM >= 4 ? 2 : 3;              // rows fetched ahead of their first use
   float4 rows[kTH + 2 + PD][3];                    // rows[r] = input row (block's first row) - 1 + r
 #pragma unroll
   for (int r = 0; r < 2 + PD; ++r) load_next(rows[r]);
+  if constexpr (BN) {
+    bn_row(rows[0], ty0 - 1);
+    bn_row(rows[1], ty0);
+  }
   float bv[KM];
 #pragma unroll
   for (int k = 0; k < KM; ++k) bv[k] = bias ? bias[g * KM + k] : 0.f;
@@ -118,6 +143,7 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
     for (int y = 0; y < kTH; ++y) {
       const int gy = y0 + y;
       load_next(rows[y + 2 + PD]);
+      if constexpr (BN) bn_row(rows[y + 2], gy + 1);
       float acc[KM];
 #pragma unroll
       for (int k = 0; k < KM; ++k) {
@@ -217,10 +243,11 @@ __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ d
 }
 
 // partial[slice][g][k][tap][c] = sum over the slice's tiles of a[q, c] * dz[q - (tap - 1), k]
-template <int KM>
+template <int KM, bool BN>
 __global__ __launch_bounds__(256) void k_gtail_wgrad(const float* __restrict__ a, const float* __restrict__ dz,
                                                      float* __restrict__ partial, GTail t, int strip_rows, int strips,
-                                                     int nstrips, int S) {
+                                                     int nstrips, int S, const float* __restrict__ bn_scale,
+                                                     const float* __restrict__ bn_shift) {
   // Same lane map and strip walk as k_gtail_fwd: lane = (pixel column ps of a 4-wide strip, channel quad cq), the wave walks
   // down its strip with the 3 x 3 window of dz values (KM <= 4 floats per pixel, staged once per strip in LDS) in
   // registers; per row one 16-byte load of the hidden tensor and 9 * KM packed FMAs on 4-channel accumulators.  The first
@@ -237,6 +264,11 @@ __global__ __launch_bounds__(256) void k_gtail_wgrad(const float* __restrict__ a
   for (int k = 0; k < KM; ++k)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) acc[k][tap] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);   // see k_gtail_fwd
+  if constexpr (BN) {
+    bsc = *reinterpret_cast<const float4*>(bn_scale + g * kHC + 4 * cq);
+    bsh = *reinterpret_cast<const float4*>(bn_shift + g * kHC + 4 * cq);
+  }
   for (int st = blockIdx.y; st < nstrips; st += S) {
     int r = st;
     const int tx = r % t.tiles_x;
@@ -287,7 +319,14 @@ __global__ __launch_bounds__(256) void k_gtail_wgrad(const float* __restrict__ a
 #pragma unroll
         for (int d = 0; d < 3; ++d) zw[y + 2][d] = zp[d];
         zp += kHW;
-        const float4 x4 = av[y];                         // 0 outside the image / strip: contributes nothing
+        float4 x4 = av[y];                               // 0 outside the image / strip: contributes nothing
+        if constexpr (BN) {                              // BatchNorm + ReLU at the row's (single) use: the fetch stays PD rows ahead
+          const bool ok = xok && y0 + y < y_end;
+          x4.x = ok ? fmaxf(fmaf(x4.x, bsc.x, bsh.x), 0.f) : 0.f;
+          x4.y = ok ? fmaxf(fmaf(x4.y, bsc.y, bsh.y), 0.f) : 0.f;
+          x4.z = ok ? fmaxf(fmaf(x4.z, bsc.z, bsh.z), 0.f) : 0.f;
+          x4.w = ok ? fmaxf(fmaf(x4.w, bsc.w, bsh.w), 0.f) : 0.f;
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           // the output pixel that read this input through tap (ty, tx) is (row - (ty - 1), column - (tx - 1))
@@ -350,9 +389,9 @@ int gtail_slices(int ntiles) { return ntiles < 32 ? ntiles : 32; }
 
 }  // namespace
 
-extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float* bias, float* z, int B, int H,
-                                    int W, int G, int KM, ud_stream_t stream_) {
-  if (!a || !w || !z || !gtail_ok(B, H, W, G, KM)) return UD_ERR_INVALID_ARG;
+static int gtail_fwd_impl(const float* a, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                          float* z, int B, int H, int W, int G, int KM, ud_stream_t stream_) {
+  if (!a || !w || !z || !gtail_ok(B, H, W, G, KM) || (bn_scale == nullptr) != (bn_shift == nullptr)) return UD_ERR_INVALID_ARG;
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
   UdProfScope prof("head_tail.k_gtail_fwd", stream);
@@ -362,13 +401,26 @@ extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float*
   const int strips = ud_div_up(H, strip_rows);
   const dim3 grid(G, B * t.tiles_x * strips);
   switch (KM) {
-    case 1: k_gtail_fwd<1><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
-    case 2: k_gtail_fwd<2><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
-    case 3: k_gtail_fwd<3><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
-    default: k_gtail_fwd<4><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips); break;
+    case 1: if (bn_scale) k_gtail_fwd<1, true><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); else k_gtail_fwd<1, false><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); break;
+    case 2: if (bn_scale) k_gtail_fwd<2, true><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); else k_gtail_fwd<2, false><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); break;
+    case 3: if (bn_scale) k_gtail_fwd<3, true><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); else k_gtail_fwd<3, false><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); break;
+    default: if (bn_scale) k_gtail_fwd<4, true><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); else k_gtail_fwd<4, false><<<grid, 256, 0, stream>>>(a, w, bias, z, t, strip_rows, strips, bn_scale, bn_shift); break;
   }
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+extern "C" int ud_head_tail_f32_fwd(const float* a, const float* w, const float* bias, float* z, int B, int H,
+                                    int W, int G, int KM, ud_stream_t stream_) {
+  return gtail_fwd_impl(a, nullptr, nullptr, w, bias, z, B, H, W, G, KM, stream_);
+}
+
+// a = the first convolution's raw output; relu(a * scale + shift) (training- or eval-mode BatchNorm folded per channel) is applied
+// as the pieces are loaded
+extern "C" int ud_head_tail_f32_bn_fwd(const float* a, const float* bn_scale, const float* bn_shift, const float* w,
+                                       const float* bias, float* z, int B, int H, int W, int G, int KM, ud_stream_t stream_) {
+  if (!bn_scale || !bn_shift) return UD_ERR_INVALID_ARG;
+  return gtail_fwd_impl(a, bn_scale, bn_shift, w, bias, z, B, H, W, G, KM, stream_);
 }
 
 extern "C" int ud_head_tail_f32_dgrad(const float* dz, const float* w, float* da, int B, int H, int W, int G,
@@ -397,9 +449,9 @@ extern "C" size_t ud_head_tail_f32_wgrad_workspace_bytes(int B, int H, int W, in
   return ud_align_up((size_t)gtail_slices(ntiles) * G * KM * 9 * kHC * sizeof(float));
 }
 
-extern "C" int ud_head_tail_f32_wgrad(const float* a, const float* dz, float* dw, int B, int H, int W, int G,
-                                      int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
-  if (!a || !dz || !dw || !gtail_ok(B, H, W, G, KM)) return UD_ERR_INVALID_ARG;
+static int gtail_wgrad_impl(const float* a, const float* bn_scale, const float* bn_shift, const float* dz, float* dw, int B,
+                            int H, int W, int G, int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  if (!a || !dz || !dw || !gtail_ok(B, H, W, G, KM) || (bn_scale == nullptr) != (bn_shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (!workspace || workspace_bytes < ud_head_tail_f32_wgrad_workspace_bytes(B, H, W, G, KM)) return UD_ERR_WORKSPACE;
   GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
   hipStream_t stream = (hipStream_t)stream_;
@@ -411,14 +463,26 @@ extern "C" int ud_head_tail_f32_wgrad(const float* a, const float* dz, float* dw
   UdProfScope prof("head_tail.k_gtail_wgrad", stream);
   const dim3 grid(G, S);
   switch (KM) {
-    case 1: k_gtail_wgrad<1><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
-    case 2: k_gtail_wgrad<2><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
-    case 3: k_gtail_wgrad<3><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
-    default: k_gtail_wgrad<4><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S); break;
+    case 1: if (bn_scale) k_gtail_wgrad<1, true><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); else k_gtail_wgrad<1, false><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); break;
+    case 2: if (bn_scale) k_gtail_wgrad<2, true><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); else k_gtail_wgrad<2, false><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); break;
+    case 3: if (bn_scale) k_gtail_wgrad<3, true><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); else k_gtail_wgrad<3, false><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); break;
+    default: if (bn_scale) k_gtail_wgrad<4, true><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); else k_gtail_wgrad<4, false><<<grid, 256, 0, stream>>>(a, dz, partial, t, strip_rows, strips, nstrips, S, bn_scale, bn_shift); break;
   }
   UD_LAUNCH_CHECK();
   const long long n = (long long)G * KM * 9 * kHC;
   k_gtail_wsum<<<ud_div_up(n, 256), 256, 0, stream>>>(partial, S, n, dw);
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+extern "C" int ud_head_tail_f32_wgrad(const float* a, const float* dz, float* dw, int B, int H, int W, int G,
+                                      int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  return gtail_wgrad_impl(a, nullptr, nullptr, dz, dw, B, H, W, G, KM, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int ud_head_tail_f32_bn_wgrad(const float* a, const float* bn_scale, const float* bn_shift, const float* dz,
+                                         float* dw, int B, int H, int W, int G, int KM, void* workspace,
+                                         size_t workspace_bytes, ud_stream_t stream_) {
+  if (!bn_scale || !bn_shift) return UD_ERR_INVALID_ARG;
+  return gtail_wgrad_impl(a, bn_scale, bn_shift, dz, dw, B, H, W, G, KM, workspace, workspace_bytes, stream_);
 }

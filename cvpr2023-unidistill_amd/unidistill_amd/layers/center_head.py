@@ -432,6 +432,7 @@ class PackedSepHeads(nn.Module):
         self.c2_bias = nn.Parameter(torch.zeros(G * self.kmax))
         self.bn_eps, self.bn_momentum = 1e-5, 0.1
         self.fused_tail = True      # HIP tail kernel when the hidden tensor is CUDA bf16
+        self.fused_bn_tail_f32 = True   # fp32: BatchNorm + ReLU inside the grouped tail kernels (False: separate streaming pass)
         self.register_buffer("_c2_rows", torch.arange(G * self.kmax), persistent=False)
         self.register_buffer("_c2_grp", torch.arange(G * self.kmax) // self.kmax, persistent=False)
         # initialise exactly like the reference's per-head modules (center_head.py:323-362)
@@ -484,6 +485,11 @@ class PackedSepHeads(nn.Module):
             # fp32 mode on the GPU: BN + ReLU as one streaming pass, then the 42 second convs as ONE grouped fp32
             # kernel (the block-diagonal dense conv below costs 42x the FLOPs: 19 ms per fwd+bwd at B = 4)
             partial = getattr(y, "_ud_bn_partial", None) if self.training else None
+            if self.fused_bn_tail_f32:
+                # ... with BatchNorm + ReLU applied inside the tail kernels as they load y: the normalised hidden tensor never exists
+                return self._split(head_tail_f32.bn_relu_group_tail(
+                    y, self.bn_weight, self.bn_bias, self.bn_running_mean, self.bn_running_var, self.training,
+                    self.bn_momentum, self.bn_eps, None, partial, self.c2_weight, self.c2_bias, G, self.kmax))
             a = hipbn._BnActFn.apply(y if y.is_contiguous(memory_format=torch.channels_last)
                                      else y.contiguous(memory_format=torch.channels_last),
                                      self.bn_weight, self.bn_bias, None, self.bn_running_mean, self.bn_running_var,

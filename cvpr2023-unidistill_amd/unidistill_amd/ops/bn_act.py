@@ -34,49 +34,60 @@ def _workspace(dev, C):
     return _lib.workspace(dev, n, "bn_act")
 
 
+def batch_stats(x, gamma, beta, running_mean, running_var, training, momentum, eps, tracked=None, partial=None):
+    """-> f32 [5, C]: mean, var, invstd, scale, shift of BatchNorm over x ([B, C, H, W] channels-last or [M, C]); training: batch
+    statistics (from the producing convolution's per-tile partials when given) and the running buffers updated; eval: running."""
+    lib = _lib.load()
+    _lib.require_gpu(x, gamma, beta)
+    f32 = x.dtype == torch.float32
+    k_stats = lib.ud_bn_stats_f32 if f32 else lib.ud_bn_stats
+    C = x.shape[1]
+    P = x.numel() // C
+    dev = x.device
+    g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
+    b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
+    stream = _lib.stream_of(x)
+    if training:
+        # one [5, C] block: mean, var, invstd, scale, shift (addressed by offset: no per-row views)
+        vec = torch.empty((5, C), dtype=torch.float32, device=dev)
+        v0, row = vec.data_ptr(), 4 * C
+        ws = _workspace(dev, C)
+        fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
+        rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
+        if partial is not None and partial[2] == P:
+            # the producing convolution already reduced every tile (ud_conv*_bnstats_nhwc_*): second pass only
+            _lib.check(lib.ud_bn_stats_from_partials(partial[0].data_ptr(), int(partial[1]), P, C, g32.data_ptr(),
+                                                     b32.data_ptr(), float(eps), v0, v0 + row, v0 + 2 * row,
+                                                     v0 + 3 * row, v0 + 4 * row, _lib.ptr(rm), _lib.ptr(rv),
+                                                     float(momentum or 0.0), _lib.ptr(tracked), stream),
+                       "ud_bn_stats_from_partials")
+        else:
+            _lib.check(k_stats(x.data_ptr(), P, C, g32.data_ptr(), b32.data_ptr(), float(eps),
+                               v0, v0 + row, v0 + 2 * row, v0 + 3 * row, v0 + 4 * row,
+                               _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
+                               _lib.ptr(tracked), ws.data_ptr(), ws.numel(), stream), "ud_bn_stats")
+        if running_mean is not None and not fp32_buffers:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(vec[0], alpha=momentum)
+                running_var.mul_(1 - momentum).add_(vec[1], alpha=momentum * P / max(P - 1, 1))
+        return vec
+    invstd = torch.rsqrt(running_var.float() + eps)
+    mean = running_mean.float()
+    scale = g32 * invstd
+    return torch.stack((mean, invstd * invstd, invstd, scale, b32 - mean * scale))
+
+
 class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu,
                 tracked=None, partial=None):
         lib = _lib.load()
-        _lib.require_gpu(x, gamma, beta)
-        f32 = x.dtype == torch.float32
-        k_stats, k_fwd = (lib.ud_bn_stats_f32, lib.ud_bn_act_fwd_f32) if f32 else (lib.ud_bn_stats, lib.ud_bn_act_fwd)
+        k_fwd = lib.ud_bn_act_fwd_f32 if x.dtype == torch.float32 else lib.ud_bn_act_fwd
         C = x.shape[1]
         P = x.numel() // C
-        dev = x.device
-        g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
-        b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
         stream = _lib.stream_of(x)
-        if training:
-            # one [5, C] block: mean, var, invstd, scale, shift (addressed by offset: no per-row views)
-            vec = torch.empty((5, C), dtype=torch.float32, device=dev)
-            v0, row = vec.data_ptr(), 4 * C
-            ws = _workspace(dev, C)
-            fp32_buffers = running_mean is not None and running_mean.dtype == torch.float32
-            rm, rv = (running_mean, running_var) if fp32_buffers else (None, None)   # updated in-kernel
-            if partial is not None and partial[2] == P:
-                # the producing convolution already reduced every tile (ud_conv*_bnstats_nhwc_*): second pass only
-                _lib.check(lib.ud_bn_stats_from_partials(partial[0].data_ptr(), int(partial[1]), P, C, g32.data_ptr(),
-                                                         b32.data_ptr(), float(eps), v0, v0 + row, v0 + 2 * row,
-                                                         v0 + 3 * row, v0 + 4 * row, _lib.ptr(rm), _lib.ptr(rv),
-                                                         float(momentum or 0.0), _lib.ptr(tracked), stream),
-                           "ud_bn_stats_from_partials")
-            else:
-                _lib.check(k_stats(x.data_ptr(), P, C, g32.data_ptr(), b32.data_ptr(), float(eps),
-                                   v0, v0 + row, v0 + 2 * row, v0 + 3 * row, v0 + 4 * row,
-                                   _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
-                                   _lib.ptr(tracked), ws.data_ptr(), ws.numel(), stream), "ud_bn_stats")
-            if running_mean is not None and not fp32_buffers:
-                with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(vec[0], alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(vec[1], alpha=momentum * P / max(P - 1, 1))
-        else:
-            invstd = torch.rsqrt(running_var.float() + eps)
-            mean = running_mean.float()
-            scale = g32 * invstd
-            vec = torch.stack((mean, invstd * invstd, invstd, scale, b32 - mean * scale))
-            v0, row = vec.data_ptr(), 4 * C
+        vec = batch_stats(x, gamma, beta, running_mean, running_var, training, momentum, eps, tracked, partial)
+        v0, row = vec.data_ptr(), 4 * C
         if residual is not None:
             residual = _like(residual, x)
         y = torch.empty_like(x)

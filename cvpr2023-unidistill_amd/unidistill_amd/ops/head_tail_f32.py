@@ -56,3 +56,72 @@ class _GroupTail(torch.autograd.Function):
 
 def group_tail(a, weight, bias, G, KM):
     return _GroupTail.apply(a, weight, bias, G, KM)
+
+
+class _BnReluGroupTail(torch.autograd.Function):
+    """relu(bn(y)) -> 42 grouped second convolutions with BatchNorm + ReLU applied as the tail kernels LOAD the first
+    convolution's raw output y (ud_head_tail_f32_bn_fwd / _bn_wgrad): the normalised hidden tensor (1.39 GB at B = 4) is
+    neither written nor read back -- forward: 2 passes over it instead of 4; backward: the tail's weight gradient reads y, its
+    data gradient feeds the BatchNorm backward (ud_bn_act_bwd_f32, ReLU mask recomputed from y) directly."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, tracked, partial, weight, bias, G, KM):
+        from . import bn_act
+        _lib.require_gpu(y, weight)
+        y = y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
+        B, C, H, W = y.shape
+        assert C == G * 64 and weight.shape == (G * KM, 64, 3, 3)
+        vec = bn_act.batch_stats(y, gamma, beta, running_mean, running_var, training, momentum, eps, tracked, partial)
+        v0, row = vec.data_ptr(), 4 * C
+        wt = weight.detach().permute(0, 2, 3, 1).contiguous()          # [G*KM, 3, 3, 64] = [G][KM][9][64]
+        z = torch.empty((B, G * KM, H, W), dtype=torch.float32, device=y.device, memory_format=torch.channels_last)
+        b = None if bias is None else bias.detach().contiguous()
+        _lib.check(_lib.load().ud_head_tail_f32_bn_fwd(_lib.ptr(y), v0 + 3 * row, v0 + 4 * row, _lib.ptr(wt), _lib.ptr(b),
+                                                       _lib.ptr(z), B, H, W, G, KM, _lib.stream_of(y)),
+                   "ud_head_tail_f32_bn_fwd")
+        ctx.save_for_backward(y, vec, wt)
+        ctx.cfg = (G, KM, bias is not None, bool(training))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        from . import bn_act
+        y, vec, wt = ctx.saved_tensors
+        G, KM, has_bias, training = ctx.cfg
+        if not training:
+            raise NotImplementedError("fused BatchNorm backward covers training-mode statistics only")
+        lib = _lib.load()
+        B, C, H, W = y.shape
+        P = B * H * W
+        dz = dz.float()
+        dz = dz if dz.is_contiguous(memory_format=torch.channels_last) else dz.contiguous(memory_format=torch.channels_last)
+        st = _lib.stream_of(y)
+        v0, row = vec.data_ptr(), 4 * C
+        dy = dgamma = dbeta = dw = db = None
+        if ctx.needs_input_grad[10]:
+            need = lib.ud_head_tail_f32_wgrad_workspace_bytes(B, H, W, G, KM)
+            ws = _lib.workspace(y.device, need, "head_tail_f32")
+            dwt = torch.empty((G * KM, 3, 3, 64), dtype=torch.float32, device=y.device)
+            _lib.check(lib.ud_head_tail_f32_bn_wgrad(_lib.ptr(y), v0 + 3 * row, v0 + 4 * row, _lib.ptr(dz), _lib.ptr(dwt), B, H, W,
+                                                     G, KM, _lib.ptr(ws), ws.numel(), st), "ud_head_tail_f32_bn_wgrad")
+            dw = dwt.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            da = torch.empty_like(y)                     # gradient at relu(bn(y))
+            _lib.check(lib.ud_head_tail_f32_dgrad(_lib.ptr(dz), _lib.ptr(wt), _lib.ptr(da), B, H, W, G, KM, st),
+                       "ud_head_tail_f32_dgrad")
+            dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
+            bws = bn_act._workspace(y.device, C)
+            g0 = dgb.data_ptr()
+            dy = torch.empty_like(y)
+            _lib.check(lib.ud_bn_act_bwd_f32(y.data_ptr(), None, da.data_ptr(), v0 + 3 * row, v0 + 4 * row, v0, v0 + 2 * row,
+                                             dy.data_ptr(), None, g0, g0 + row, P, C, 1, bws.data_ptr(), bws.numel(), st),
+                       "ud_bn_act_bwd")
+            dgamma, dbeta = dgb[0], dgb[1]
+        if has_bias and ctx.needs_input_grad[11]:
+            db = dz.sum((0, 2, 3))
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None, dw, db, None, None
+
+
+def bn_relu_group_tail(y, gamma, beta, running_mean, running_var, training, momentum, eps, tracked, partial, weight, bias, G, KM):
+    return _BnReluGroupTail.apply(y, gamma, beta, running_mean, running_var, training, momentum, eps, tracked, partial,
+                                  weight, bias, G, KM)

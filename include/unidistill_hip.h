@@ -410,6 +410,13 @@ int ud_head_tail_f32_dgrad(const float* dz, const float* w, float* da, int B, in
 size_t ud_head_tail_f32_wgrad_workspace_bytes(int B, int H, int W, int G, int KM);
 int ud_head_tail_f32_wgrad(const float* a, const float* dz, float* dw, int B, int H, int W, int G, int KM,
                            void* workspace, size_t workspace_bytes, ud_stream_t stream);
+/* The same second convolutions reading the first convolution's RAW output: relu(a * scale + shift) -- the BatchNorm of the SepHead
+ * (center_head.py:341-350) folded per channel [G*64] -- is applied to every piece as it is loaded, in the forward and in the weight
+ * gradient; the normalised 1.39 GB hidden tensor is never written or read back. */
+int ud_head_tail_f32_bn_fwd(const float* a, const float* bn_scale, const float* bn_shift, const float* w, const float* bias,
+                            float* z, int B, int H, int W, int G, int KM, ud_stream_t stream);
+int ud_head_tail_f32_bn_wgrad(const float* a, const float* bn_scale, const float* bn_shift, const float* dz, float* dw, int B,
+                              int H, int W, int G, int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* ---- Dense 3x3 / stride 1 / pad 1 convolution, channels-last bf16 (BEV trunk + head convs) ----------
  * Replaces nn.Conv2d(k=3, s=1, p=1) of BaseBEVBackbone (reference unidistill/layers/blocks_2d/det3d/

@@ -135,7 +135,45 @@ def test_fp32_group_tail_vs_grouped_conv(hip_lib, shape):
         assert (x - y).abs().max() <= 2e-5 * y.abs().max() + 1e-6, name
 
 
-def test_fp32_packed_heads_use_the_group_kernel_and_match_the_library_path(hip_lib):
+@pytest.mark.parametrize("shape", [(2, 20, 36, 5, 3), (1, 17, 9, 42, 3), (2, 8, 16, 3, 4), (2, 100, 140, 42, 3)])
+@pytest.mark.parametrize("training", [True, False])
+def test_fp32_bn_relu_group_tail_vs_torch(hip_lib, shape, training):
+    """ud_head_tail_f32_bn_fwd / _bn_wgrad (BatchNorm + ReLU applied as the tail kernels load the raw hidden tensor) + the
+    BatchNorm backward fed by the tail's data gradient == F.batch_norm -> relu -> grouped conv3x3 in torch: output, running
+    buffers, and the gradients of the hidden tensor, gamma, beta, tail weights and bias."""
+    import torch
+    import torch.nn.functional as F
+    from unidistill_amd.ops import head_tail_f32 as h
+    B, H, W, G, KM = shape
+    C = G * 64
+    torch.manual_seed(sum(shape))
+    y = (torch.randn(B, C, H, W, device="cuda") * 1.5 + 0.3).contiguous(memory_format=torch.channels_last)
+    gamma = (torch.rand(C, device="cuda") + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, device="cuda") * 0.2).requires_grad_(True)
+    # the ReLU is not differentiable at 0 and the two sides round bn(y) differently: move the few elements that normalise to
+    # within 1e-3 of 0 away from it (an element on the other branch shifts dy, dgamma and dbeta by its whole gradient)
+    zn = F.batch_norm(y, None, None, gamma.detach(), beta.detach(), True, 0.0, 1e-5)
+    y = (y + (zn.abs() < 1e-3).float() * 0.05 * torch.sign(gamma.detach()).view(1, -1, 1, 1)).requires_grad_(True)
+    w = (torch.randn(G * KM, 64, 3, 3, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.randn(G * KM, device="cuda").requires_grad_(True)
+    rm0, rv0 = torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5
+    rm, rv = rm0.clone(), rv0.clone()
+    z = h.bn_relu_group_tail(y, gamma, beta, rm, rv, training, 0.1, 1e-5, None, None, w, b, G, KM)
+    rm_r, rv_r = rm0.clone(), rv0.clone()
+    zr = F.conv2d(torch.relu(F.batch_norm(y, rm_r, rv_r, gamma, beta, training, 0.1, 1e-5)), w, b, padding=1, groups=G)
+    assert (z - zr).abs().max() <= 2e-5 * zr.abs().max() + 1e-6
+    assert torch.allclose(rm, rm_r, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv_r, rtol=1e-5, atol=1e-6)
+    if not training:
+        return
+    gz = torch.randn_like(z)
+    got = torch.autograd.grad(z, (y, gamma, beta, w, b), gz)
+    ref = torch.autograd.grad(zr, (y, gamma, beta, w, b), gz)
+    for a, r, name in zip(got, ref, ("dy", "dgamma", "dbeta", "dw", "db")):
+        assert (a - r).abs().max() <= 1e-4 * r.abs().max() + 1e-6, name
+
+
+@pytest.mark.parametrize("fused_bn", [True, False])
+def test_fp32_packed_heads_use_the_group_kernel_and_match_the_library_path(hip_lib, fused_bn):
     import torch
     from unidistill_amd import _lib
     from unidistill_amd.layers import center_head as ch
@@ -143,6 +181,7 @@ def test_fp32_packed_heads_use_the_group_kernel_and_match_the_library_path(hip_l
     torch.manual_seed(3)
     heads = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "hm": (2, 2)}
     m = ch.PackedSepHeads(64, [heads, heads], head_conv=64, final_kernel=3).cuda().train()
+    m.fused_bn_tail_f32 = fused_bn
     with torch.no_grad():
         m.c2_weight.normal_(0, 0.05)
     x = torch.randn(2, 64, 24, 20, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
