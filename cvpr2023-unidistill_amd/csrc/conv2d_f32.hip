@@ -480,7 +480,9 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
                const char* name, hipStream_t stream, size_t stats_bytes = 0, int* slices_out = nullptr) {
   UdProfScope prof(name, stream);
   static const int force64 = getenv("UD_F32_TN64") ? atoi(getenv("UD_F32_TN64")) : 0;
-  const bool narrow = force64 || gm.Cout <= 64 || ntiles * ud_div_up(gm.Cout, 128) <= 256;
+  // 1x1: 64-wide output-channel tiles (49 KB of LDS: three workgroups per CU) measured faster than or equal to the 128-wide ones on
+  // 19 of the 21 plain 1x1 shapes of the distillation step (tools/time_f32_1x1.py: 8.65 -> 8.17 ms per step); UD_F32_TN64=-1: wide
+  const bool narrow = force64 > 0 || gm.Cout <= 64 || (KS == 1 && force64 == 0) || ntiles * ud_div_up(gm.Cout, 128) <= 256;
   const int ntn = ud_div_up(gm.Cout, narrow ? 64 : 128);
   if constexpr (KS == 1) {
     static bool line_set = false;
@@ -625,7 +627,8 @@ extern "C" int ud_conv1x1_mapped_nhwc_f32(const float* x, const float* w, float*
   }
   const int ntiles = gm.tiles_y;
   UdProfScope prof("conv2d.k_conv1x1_f32", stream);
-  const bool narrow = Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256;
+  static const int force64 = getenv("UD_F32_TN64") ? atoi(getenv("UD_F32_TN64")) : 0;
+  const bool narrow = force64 > 0 || Cout <= 64 || ntiles * ud_div_up(Cout, 128) <= 256;
   const dim3 grid((ntiles + 7) / 8 * 8, ud_div_up(Cout, narrow ? 64 : 128));
   if (narrow) k_conv1x1_mapped_f32<64><<<grid, 256, conv_smem_bytes_f(64), stream>>>(x, w, y, gm, ep);
   else k_conv1x1_mapped_f32<128><<<grid, 256, conv_smem_bytes_f(128), stream>>>(x, w, y, gm, ep);

@@ -331,6 +331,10 @@ def _pmap(mode, s, Ho, Wo, H, W, C, a=0, b=0):
 def _mapped(x, w2d, y, P, K, N, imap, omap):
     """1x1 kernel over pixel maps; bf16 or (the reference's arithmetic) fp32 by the dtype of x."""
     if x.dtype == torch.float32:
+        from . import conv2d_f32 as _c32
+        if _c32.LOG_1X1 is not None:
+            _c32.LOG_1X1.append(("mapped", P, K, N, None if imap is None else tuple(imap), None if omap is None else tuple(omap),
+                                 tuple(x.shape), tuple(y.shape)))
         _lib.check(_lib.load().ud_conv1x1_mapped_nhwc_f32(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), P, K, N, imap, omap,
                                                           _lib.stream_of(x)), "ud_conv1x1_mapped_nhwc_f32")
         return

@@ -103,8 +103,13 @@ def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False)
     return y
 
 
+LOG_1X1 = None           # set to [] to record ("line", P, Cin, Cout) of every plain 1x1 launch (tools/time_f32_1x1.py)
+
+
 def _launch1(x, w, cout, bias=None, residual=None, bn_stats=False):
     B, cin, H, W = x.shape
+    if LOG_1X1 is not None:
+        LOG_1X1.append(("line", B * H * W, cin, cout, None, None))
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if bn_stats:
         lib = _lib.load()
