@@ -302,7 +302,7 @@ def spconv_leg(device, batch):
     by_n, us_n = sum(l["bytes"] for l in narrow), sum(l["us"] for l in narrow)
     fl_all, us_all = sum(l["flops"] for l in layers), sum(l["us"] for l in layers)
     ach = fl_w / us_w / 1e6 if us_w else 0.0
-    return {"bound": "mfma", "kernel": "spconv_conv.k_conv_mfma_v2<128,128> (ud_spconv_conv, fp32: the 128-channel layers of "
+    return {"bound": "mfma", "kernel": "spconv_conv.k_conv_dma_f32<128,128> (ud_spconv_conv, fp32: the 128-channel layers of "
                                        "VoxelResBackBone8x; narrower layers are gather/scatter-bound, see hbm_layers)",
             "achieved": ach, "peak": MFMA_PEAK_TFLOPS_F32, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_F32,
             "launches": len(wide), "avg_kernel_us": us_w / max(len(wide), 1), "traffic": None,

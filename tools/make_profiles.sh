@@ -12,10 +12,10 @@ T=$GRAFT_REPO_ROOT/tools
 # 1. the bench command itself: kernel trace; summary restricted to the steady state (no warm-up / MIOpen find kernels)
 rm -rf /tmp/p_bench; rocprofv3 --kernel-trace --stats -d /tmp/p_bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_stdout.txt 2>&1
 DB=$(ls /tmp/p_bench/*/*.db | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo;
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo; echo "The JSON line below was measured UNDER the tracer (about 8 us added per launch, ~2 000 launches per step: ms_per_step is ~15 ms above the un-instrumented run that bench.py / the driver reports); it is kept for the kernel table's context, not as the result."; echo;
   echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt | cut -c1-3000; echo '```'; echo;
   echo "## Roofline kernels of the bench legs (rocprofv3 durations; bench.py's own HIP-event figures are in the JSON above)"; echo;
-  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_vp_|k_scan|k_gather|k_bin|k_cell|k_fill|k_conv_f32_taps|k_conv3x3_taps|k_conv_mfma_v2|k_conv3x3_wgrad_f32|k_conv1x1_wgrad_f32";
+  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_vp_|k_scan|k_gather|k_bin|k_cell|k_fill|k_conv_f32_taps|k_conv3x3_wino_f32|k_wino_wgrad|k_conv3x3_taps|k_conv_mfma_v2|k_conv_dma_f32|k_conv3x3_wgrad_f32|k_conv1x1_wgrad_f32";
   echo; echo "## Kernels by total time, naive_conv / find-mode kernels excluded"; echo;
   python $T/rocpd_summary.py $DB | grep -v "naive_conv\|MIOpenConvUni\|Im2d2Col\|Col2Im" | head -45; } > $OUT/${R}_bench_kernel_stats.md
 # 2. steady-state training step by category (marker-delimited window): fp32 (headline) and bf16
@@ -53,5 +53,5 @@ python $T/traffic_json.py $R $(ls /tmp/pmc1/*/*.db | head -1) $(ls /tmp/pmc2/*/*
 rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T/time_spconv.py > $OUT/spconv_stdout.txt 2>&1
 { echo "# LiDAR sparse encoder forward, B=4 x 30k points ($R)"; echo; echo '```'; grep "encoder fwd" $OUT/spconv_stdout.txt; echo '```'; echo; python $T/rocpd_summary.py $(ls /tmp/p_sp/*/*.db | head -1) namespace | head -30; } > $OUT/${R}_spconv_encoder.md
 # 7. fp32 convolutions: ours vs library (forward / data gradient, and the weight gradients of one step)
-{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py):"; python $T/time_f32_wgrad.py 2>&1 | tail -21; echo '```'; } > $OUT/${R}_conv_f32.md
+{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels (direct and Winograd F(2x2,3x3)) vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py; 3x3: Winograd form, last column = the direct kernel):"; python $T/time_f32_wgrad.py 2>&1 | tail -22; echo; echo "-- plain 1x1 launches of one step (tools/time_f32_1x1.py):"; python $T/time_f32_1x1.py 2>&1 | grep -E "kind|line|total"; echo '```'; } > $OUT/${R}_conv_f32.md
 ls -la $OUT
