@@ -283,6 +283,9 @@ __global__ __launch_bounds__(256) void k_dense(float* __restrict__ feat,
   __syncthreads();
   const size_t plane = (size_t)g.Dz * g.Hy * g.Wx;
   const size_t base = (size_t)b * C * plane + ((size_t)z * g.Hy + y) * g.Wx + x0;
+  // every channel run starts on a 16-byte boundary and is a whole number of 16-byte pieces (<= 64 of them)
+  const bool vec4 = !BWD && (g.Wx & 3) == 0 && (nx & 3) == 0 && (x0 & 3) == 0 && nx <= 256 &&
+                    (reinterpret_cast<size_t>(dense) & 15) == 0;
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int nc = min(64, C - c0);
     if (!BWD) {
@@ -297,12 +300,24 @@ __global__ __launch_bounds__(256) void k_dense(float* __restrict__ feat,
       for (int j = 0; j < kDenseX / 4; ++j)
         if (wv + 4 * j < nx) s_t[wv + 4 * j][lane] = v[j];
       __syncthreads();
+      if (vec4) {                                  // 16-byte stores: a 720-byte run is 45 of them (one per lane)
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+          const int c = wv * 16 + i, x = 4 * lane;
+          if (c < nc && x < nx) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 q = {s_t[x][c], s_t[x + 1][c], s_t[x + 2][c], s_t[x + 3][c]};
+            __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(&dense[base + (size_t)(c0 + c) * plane + x]));
+          }
+        }
+      } else {
 #pragma unroll 2
-      for (int i = 0; i < 16; ++i) {              // wave wv stores channels wv*16 .. +15: one 4*nx-byte run each
-        const int c = wv * 16 + i;
-        if (c < nc)
-          for (int x = lane; x < nx; x += 64)
-            __builtin_nontemporal_store(s_t[x][c], &dense[base + (size_t)(c0 + c) * plane + x]);
+        for (int i = 0; i < 16; ++i) {            // wave wv stores channels wv*16 .. +15: one 4*nx-byte run each
+          const int c = wv * 16 + i;
+          if (c < nc)
+            for (int x = lane; x < nx; x += 64)
+              __builtin_nontemporal_store(s_t[x][c], &dense[base + (size_t)(c0 + c) * plane + x]);
+        }
       }
       __syncthreads();
     } else {
