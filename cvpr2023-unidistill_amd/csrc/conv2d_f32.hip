@@ -114,11 +114,12 @@ __device__ __forceinline__ void store_tile_f32(const f32x4 (&acc)[RW][4], float*
     }
     __syncthreads();
     if (tid < kTN && n0 + tid < gm.Cout) {
-      float a = 0.f, q = 0.f;
+      double ad = 0.0, qd = 0.0;          // row-group sums combine in double
       for (int k = 0; k < kGroups; ++k) {
-        a += Os[(k * kTN + tid) * 2];
-        q += Os[(k * kTN + tid) * 2 + 1];
+        ad += (double)Os[(k * kTN + tid) * 2];
+        qd += (double)Os[(k * kTN + tid) * 2 + 1];
       }
+      const float a = (float)ad, q = (float)qd;
       ep.stats[((size_t)tile_lin * gm.Cout + n0 + tid) * 2] = a;
       ep.stats[((size_t)tile_lin * gm.Cout + n0 + tid) * 2 + 1] = q;
     }

@@ -425,11 +425,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
     }
     __syncthreads();
     if (tid < 64 && n0 + tid < gm.Cout) {
-      float a = 0.f, qq = 0.f;
+      double ad = 0.0, qd = 0.0;          // the 32 row-group sums combine in double (sum of squares minus mean^2 comes next)
       for (int k = 0; k < 32; ++k) {
-        a += Os[(k * 64 + tid) * 2];
-        qq += Os[(k * 64 + tid) * 2 + 1];
+        ad += (double)Os[(k * 64 + tid) * 2];
+        qd += (double)Os[(k * 64 + tid) * 2 + 1];
       }
+      const float a = (float)ad, qq = (float)qd;
       // whole units fill row `tile block`; quarter units rows past the tile blocks (zeroed by the launcher for the other cout
       // blocks), and quarter 0 clears the unit's own row
       const size_t row = q < 0 ? (size_t)blk_lin : (size_t)nblocks + 4 * (size_t)(unit - gm.n_full) + q;

@@ -115,7 +115,7 @@ class Conv2d(nn.Conv2d):
         s_ = st[0]
         if k[0] == s_ and hipconv.supported_patch(x, self.weight, s_):
             y = hipconv.conv_patch(x, self.weight, s_)
-        elif k[0] == 1 and hipconv.supported_1x1(x, self.weight):
+        elif k[0] == 1 and hipconv.supported_1x1(x, self.weight, strided=True):
             y = hipconv.conv1x1_strided(x, self.weight, s_)
         else:
             return None

@@ -184,9 +184,10 @@ def conv3x3_inference(x, weight, bias=None, scale=None, shift=None, residual=Non
 GEMM_1X1_MAX_PIXELS = 1024     # per image; above this MIOpen's 1x1 conv beats the GEMM (tools/exp_conv1x1.py)
 
 
-def supported_1x1(x, weight):
+def supported_1x1(x, weight, strided=False):
+    """strided: the 1x1 / stride s path, whose data gradient reduces over Cout in 64- (bf16) / 32-channel (fp32) slices."""
     return (x.is_cuda and x.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1)
-            and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0)
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % (64 if strided else 8) == 0)
 
 
 def weight_grad_1x1(x, gy, weight):
@@ -372,8 +373,9 @@ def supported_patch(x, weight, s, transposed=False):
     if not (x.is_cuda and x.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (s, s) and s >= 2):
         return False
     cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    # the transposed form's data gradient gathers through the mode-1 map: a 64-channel slice must stay inside one block row
     return cin % 64 == 0 and cout % 8 == 0 and x.shape[1] == cin and (transposed or (s * cin) % 64 == 0) \
-        and (not transposed or (s * s * cout) % 64 == 0)
+        and (not transposed or ((s * s * cout) % 64 == 0 and (s * cout) % 64 == 0))
 
 
 class _ConvPatchFn(torch.autograd.Function):
