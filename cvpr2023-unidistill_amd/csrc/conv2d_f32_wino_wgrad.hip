@@ -13,6 +13,10 @@
 // them and writes V / DY [f][tile][64] to LDS (double-buffered, 2 x 64 KB); the MFMA loop reads 16-byte fragments
 // (lane group g = tile 4k + g, lane li = rows / columns 4 li .. 4 li + 3): 2 reads feed 16 MFMAs.  Slices are reduced in a
 // fixed order (deterministic; no atomics).
+// SQ counters (tools/pmc_wino.py): MFMA pipe 50 % busy, no LDS bank conflicts.  Tried and measured slower or equal: raw rows staged once
+// per 8-tile stage by LDS-DMA with every wave building its two frequencies' fragments on the fly (26 KB per stage instead of 40 KB of
+// L2 -> L1 traffic, no V / DY tensors: 0.234 ms vs 0.224 at 128 -> 128 @180^2 x 4; software-pipelined under the previous group's
+// MFMAs with sched_group_barrier: 0.269 ms, register-bound at 256); prefetch one vs two stages ahead (equal).
 #include "ud_common.h"
 #include "ud_prof.h"
 #include <cstdlib>
@@ -56,40 +60,60 @@ __global__ __launch_bounds__(512) void k_wino_wgrad_f32(const float* __restrict_
     const int rem = (int)(t - (long long)tb * per);
     tty = rem / gm.TX, ttx = rem - tty * gm.TX;
   }
-  unsigned rowoff[4], coloff[4];
+  // Addressing state of the wave's current tile (wave-uniform): element offsets of its 4 patch rows / 4 patch columns in x and of the
+  // 2 x 2 block in dy, and the validity masks.  Interior tiles of a row (9 stages in 11 on the 180-wide maps) only step the column
+  // offsets by 8 tiles; the full recomputation (clamps, masks: ~200 scalar instructions) runs at row ends and image borders.
+  unsigned rowx[4], colx[4], rowd[2], cold[2], xm_cur = 0, dm_cur = 0;
+  bool st_interior = false, wrapped = true;
+  const bool xfull = c0 + 64 <= gm.Cin, dfull = n0 + 64 <= gm.Cout;
   auto load_part = [&](auto set_c, int part) {   // four parts: the stage loop spreads them between its first MFMAs
     constexpr int S = decltype(set_c)::value;
     if (part == 0) {
-      const int tv = tb < gm.B ? 1 : 0;
-      const unsigned img = (unsigned)(tv ? tb : 0) * gm.H * gm.W;
-      unsigned rmask = 0, cmask = 0;
+      const bool inter = tb < gm.B && ttx >= 1 && 2 * ttx + 2 < gm.W;
+      if (st_interior && inter && !wrapped) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gy = 2 * tty - 1 + i, gx = 2 * ttx - 1 + i;
-        rmask |= (unsigned)((gy >= 0) & (gy < gm.H) & tv) << i;
-        cmask |= (unsigned)((gx >= 0) & (gx < gm.W)) << i;
-        rowoff[i] = img + (unsigned)min(max(gy, 0), gm.H - 1) * gm.W;
-        coloff[i] = (unsigned)min(max(gx, 0), gm.W - 1);
+        for (int j = 0; j < 4; ++j) colx[j] += 2 * kST * (unsigned)gm.Cin;
+        cold[0] += 2 * kST * (unsigned)gm.Cout;
+        cold[1] += 2 * kST * (unsigned)gm.Cout;
+      } else {
+        const int tv = tb < gm.B ? 1 : 0;
+        const unsigned img = (unsigned)(tv ? tb : 0) * gm.H * gm.W;
+        unsigned rmask = 0, cmask = 0, rowoff[4], coloff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int gy = 2 * tty - 1 + i, gx = 2 * ttx - 1 + i;
+          rmask |= (unsigned)((gy >= 0) & (gy < gm.H) & tv) << i;
+          cmask |= (unsigned)((gx >= 0) & (gx < gm.W)) << i;
+          rowoff[i] = img + (unsigned)min(max(gy, 0), gm.H - 1) * gm.W;
+          coloff[i] = (unsigned)min(max(gx, 0), gm.W - 1);
+          rowx[i] = rowoff[i] * (unsigned)gm.Cin;
+          colx[i] = coloff[i] * (unsigned)gm.Cin;
+        }
+        rowd[0] = rowoff[1] * (unsigned)gm.Cout, rowd[1] = rowoff[2] * (unsigned)gm.Cout;
+        cold[0] = coloff[1] * (unsigned)gm.Cout, cold[1] = coloff[2] * (unsigned)gm.Cout;
+        xm_cur = dm_cur = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xm_cur |= ((rmask >> i) & 1) ? cmask << (4 * i) : 0u;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) dm_cur |= ((rmask >> (a + 1)) & 1) ? ((cmask >> 1) & 3u) << (2 * a) : 0u;
       }
-      xmask[S] = dmask[S] = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xmask[S] |= ((rmask >> i) & 1) ? cmask << (4 * i) : 0u;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) dmask[S] |= ((rmask >> (a + 1)) & 1) ? ((cmask >> 1) & 3u) << (2 * a) : 0u;
+      st_interior = inter;
+      xmask[S] = xm_cur, dmask[S] = dm_cur;
     } else if (part < 3) {
 #pragma unroll
       for (int i = 2 * (part - 1); i < 2 * (part - 1) + 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rx[S][4 * i + j] = x[(rowoff[i] + coloff[j]) * (unsigned)gm.Cin + xlane];
+        for (int j = 0; j < 4; ++j) rx[S][4 * i + j] = x[rowx[i] + colx[j] + xlane];
     } else {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          rd[S][2 * a + q] = dy[(rowoff[a + 1] + coloff[q + 1]) * (unsigned)gm.Cout + dlane];
+        for (int q = 0; q < 2; ++q) rd[S][2 * a + q] = dy[rowd[a] + cold[q] + dlane];
       ttx += kST;                          // next stage
+      wrapped = false;
       while (ttx >= gm.TX) {
         ttx -= gm.TX;
+        wrapped = true;
         if (++tty == gm.TY) tty = 0, ++tb;
       }
     }
@@ -105,8 +129,10 @@ __global__ __launch_bounds__(512) void k_wino_wgrad_f32(const float* __restrict_
     float* D = reinterpret_cast<float*>(smem + buf * kBufBytes) + wave * 64 + lane;
     float* V = reinterpret_cast<float*>(smem + buf * kBufBytes + kVHalf) + wave * 64 + lane;
     if (part == 0) {          // DY = A dy A^T, A = [[1, 0], [1, 1], [1, -1], [0, -1]]
+      if (!(dfull && dmask[S] == 0xFu)) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) rd[S][k] = (nok && ((dmask[S] >> k) & 1)) ? rd[S][k] : 0.f;
+        for (int k = 0; k < 4; ++k) rd[S][k] = (nok && ((dmask[S] >> k) & 1)) ? rd[S][k] : 0.f;
+      }
       const float* r = rd[S];
       const float z[4][2] = {{r[0], r[1]}, {r[0] + r[2], r[1] + r[3]}, {r[0] - r[2], r[1] - r[3]}, {-r[2], -r[3]}};
 #pragma unroll
@@ -117,8 +143,10 @@ __global__ __launch_bounds__(512) void k_wino_wgrad_f32(const float* __restrict_
         D[(4 * i + 3) * 512] = -z[i][1];
       }
     } else if (part == 1) {   // V = B^T x B: column pass
+      if (!(xfull && xmask[S] == 0xFFFFu)) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) rx[S][k] = (cok && ((xmask[S] >> k) & 1)) ? rx[S][k] : 0.f;
+        for (int k = 0; k < 16; ++k) rx[S][k] = (cok && ((xmask[S] >> k) & 1)) ? rx[S][k] : 0.f;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         td[0][j] = rx[S][j] - rx[S][8 + j];
@@ -297,8 +325,8 @@ extern "C" int ud_conv3x3_wino_wgrad_nhwc_f32(const float* x, const float* dy, f
     attr_set = true;
   }
   UdProfScope prof("conv2d.k_wgrad_wino_f32", stream);
-  WwGeom gm{B, H, W, Cin, Cout, p.TX, p.TY, p.ntiles, p.nstages, p.sps};
   float* partial = static_cast<float*>(workspace);
+  WwGeom gm{B, H, W, Cin, Cout, p.TX, p.TY, p.ntiles, p.nstages, p.sps};
   k_wino_wgrad_f32<<<dim3(p.nslices, p.nb, p.cb), 512, 2 * kBufBytes, stream>>>(x, dy, partial, gm);
   UD_LAUNCH_CHECK();
   k_wino_wgrad_finish<<<dim3(Cout, ud_div_up(Cin, 64)), 256, 0, stream>>>(partial, p.nslices, Cout, Cin, dw);
