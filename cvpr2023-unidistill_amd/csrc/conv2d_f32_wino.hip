@@ -118,8 +118,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   int pinc[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    // patch rows are stored even columns first, then odd ones: the transform's lanes (consecutive tiles, fixed patch column) then
+    // read consecutive 32-byte slots instead of every other one (4-way LDS bank conflicts: 18 M conflict cycles per launch)
     const int q = (wave + 8 * i) * 32 + (lane >> 1);
-    const int qy = q / PW, qx = q - qy * PW;
+    const int qy = q / PW, qs = q - qy * PW;
+    const int qx = qs < PW / 2 ? 2 * qs : 2 * (qs - PW / 2) + 1;
     const int gy = 2 * ty0 + qy - 1, gx = 2 * tx0 + qx - 1;
     const bool ok = q < PP && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
     pp[i] = ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + (lane & 1) * 4 : zero;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   // input transform: thread (tile slot t, channel c)
   const int t = tid >> 3, c = tid & 7;
   const int tyl = min(t / TWB, THB - 1), txl = t % TWB;
-  const int pbase = ((2 * tyl) * PW + 2 * txl) * 8 + c;
+  const int pbase = ((2 * tyl) * PW + txl) * 8 + c;      // slot of patch column 2 txl (even columns first, see stage_p)
   auto transform = [&](int buf) {
     const float* P = reinterpret_cast<const float*>(smem + kPOff + buf * kPBytes) + pbase;
     float* V = reinterpret_cast<float*>(smem + kVOff + buf * kVBytes) + t * 8 + c;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = P[(i * PW + j) * 8];
+      for (int j = 0; j < 4; ++j) d[i][j] = P[(i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float r0 = d[0][j] - d[2][j], r1 = d[1][j] + d[2][j], r2 = d[2][j] - d[1][j], r3 = d[1][j] - d[3][j];
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   const unsigned tv = kVOff + (t * 8 + c) * 4;
 #define UD_WN_TREADS(POFF)                                                                                              \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
-    asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:8" : "=v"(td[i][0]) : "v"(tp[i] + (POFF)));                     \
-    asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:24" : "=v"(td[i][1]) : "v"(tp[i] + (POFF)));                   \
+    asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:8" : "=v"(td[i][0]) : "v"(tp[i] + (POFF)));   /* columns 0, 2 */ \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(td[i][1]) : "v"(tp[i] + (POFF)), "n"((PW / 2) * 8), "n"((PW / 2) * 8 + 8)); /* 1, 3 */ \
   }
 #define UD_WN_TWAIT(BUF, N)                                                                                             \
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                              \
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
         float d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          d[i][0] = td[i][0][0]; d[i][1] = td[i][0][1]; d[i][2] = td[i][1][0]; d[i][3] = td[i][1][1];
+          d[i][0] = td[i][0][0]; d[i][2] = td[i][0][1]; d[i][1] = td[i][1][0]; d[i][3] = td[i][1][1];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
         float d[4][4], tw[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          d[i][0] = td[i][0][0]; d[i][1] = td[i][0][1]; d[i][2] = td[i][1][0]; d[i][3] = td[i][1][1];
+          d[i][0] = td[i][0][0]; d[i][2] = td[i][0][1]; d[i][1] = td[i][1][0]; d[i][3] = td[i][1][1];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
