@@ -66,22 +66,32 @@ def batch_stats(x, gamma, beta, running_mean, running_var, training, momentum, e
                                v0, v0 + row, v0 + 2 * row, v0 + 3 * row, v0 + 4 * row,
                                _lib.ptr(rm), _lib.ptr(rv), float(momentum or 0.0),
                                _lib.ptr(tracked), ws.data_ptr(), ws.numel(), stream), "ud_bn_stats")
+        if rm is not None:       # written through raw pointers by the statistics kernel: tell autograd's version counters
+            torch.autograd.graph.increment_version(rm)
+            torch.autograd.graph.increment_version(rv)
         if running_mean is not None and not fp32_buffers:
             with torch.no_grad():
                 running_mean.mul_(1 - momentum).add_(vec[0], alpha=momentum)
                 running_var.mul_(1 - momentum).add_(vec[1], alpha=momentum * P / max(P - 1, 1))
         return vec
-    # eval mode: the folded vectors depend on parameters / buffers only -- computed once per version of the four tensors (a frozen
-    # teacher runs ~70 eval-mode BatchNorms per step: six tiny launches each otherwise)
+    # eval mode: the folded vectors depend on parameters / buffers only -- for FROZEN affine parameters (the distillation teacher:
+    # ~70 eval-mode BatchNorms per step, six tiny launches each) they are computed once per version of the four tensors.  Trainable
+    # gamma / beta are folded on every call (fused optimizers do not move the version counter); the kernels that update the running
+    # buffers in place bump their versions (see above).
+    def fold():
+        invstd = torch.rsqrt(running_var.float() + eps)
+        mean = running_mean.float()
+        scale = g32 * invstd
+        return torch.stack((mean, invstd * invstd, invstd, scale, b32 - mean * scale))
+
+    if gamma.requires_grad or beta.requires_grad or torch.cuda.is_current_stream_capturing():
+        return fold()
     key = (running_mean._version, running_var._version, gamma._version, beta._version, float(eps),
-           running_mean.data_ptr(), gamma.data_ptr(), beta.data_ptr())
+           running_mean.data_ptr(), running_var.data_ptr(), gamma.data_ptr(), beta.data_ptr())
     hit = getattr(running_var, "_ud_bn_eval", None)
     if hit is not None and hit[0] == key:
         return hit[1]
-    invstd = torch.rsqrt(running_var.float() + eps)
-    mean = running_mean.float()
-    scale = g32 * invstd
-    vec = torch.stack((mean, invstd * invstd, invstd, scale, b32 - mean * scale))
+    vec = fold()
     try:
         running_var._ud_bn_eval = (key, vec)
     except (AttributeError, RuntimeError):

@@ -45,23 +45,29 @@ def wino_pays(H, W, cin, cout):
 
 def _wino_weights(weight, transposed):
     """U = G g G^T in the kernel's stage order.  transposed: the data gradient's filter (Cin <-> Cout, taps reversed).  Cached on
-    the tensor object per version (frozen teacher weights: transformed once; trained ones: once per optimizer step)."""
-    cache = getattr(weight, "_ud_wino", None)
-    key = (bool(transposed), weight._version, weight.data_ptr())
-    if cache is not None and key in cache:
-        return cache[key]
+    the tensor object for FROZEN weights only (requires_grad False: the distillation teacher), keyed by version + storage;
+    trainable weights are transformed on every call -- fused optimizers update parameters without moving the version counter
+    (measured: torch._fused_adamw_ leaves ``_version`` unchanged), so a version-keyed cache would serve stale filters."""
     lib = _lib.load()
     w = weight.detach()
-    n, c = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
-    sn, sc = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
-    U = torch.empty(lib.ud_conv3x3_wino_f32_weight_bytes(c, n) // 4, dtype=torch.float32, device=w.device)
-    _lib.check(lib.ud_conv3x3_wino_f32_weights(_lib.ptr(w), sn, sc, w.stride(2), w.stride(3), n, c, 1 if transposed else 0,
-                                               _lib.ptr(U), _lib.stream_of(w)), "ud_conv3x3_wino_f32_weights")
+
+    def make():
+        n, c = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+        sn, sc = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
+        U = torch.empty(lib.ud_conv3x3_wino_f32_weight_bytes(c, n) // 4, dtype=torch.float32, device=w.device)
+        _lib.check(lib.ud_conv3x3_wino_f32_weights(_lib.ptr(w), sn, sc, w.stride(2), w.stride(3), n, c, 1 if transposed else 0,
+                                                   _lib.ptr(U), _lib.stream_of(w)), "ud_conv3x3_wino_f32_weights")
+        return U
+
+    if weight.requires_grad or torch.cuda.is_current_stream_capturing():
+        return make()
+    key = (bool(transposed), weight._version, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+    cache = getattr(weight, "_ud_wino", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    U = make()
     try:
-        if cache is None or next(iter(cache))[1] != weight._version:
-            cache = {}
-        cache[key] = U
-        weight._ud_wino = cache
+        weight._ud_wino = (key, U)
     except (AttributeError, RuntimeError):
         pass
     return U

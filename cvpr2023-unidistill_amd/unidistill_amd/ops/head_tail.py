@@ -51,6 +51,9 @@ class _HeadTailFn(torch.autograd.Function):
                                               float(eps), _lib.ptr(mean), _lib.ptr(var),
                                               _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rm), _lib.ptr(rv),
                                               float(momentum or 0.0), None, _lib.ptr(ws), ws.numel(), stream), "ud_head_tail_stats")
+            if rm is not None:            # written through raw pointers by the kernel: move the version counters
+                torch.autograd.graph.increment_version(rm)
+                torch.autograd.graph.increment_version(rv)
             if running_mean is not None and not fp32_buffers:
                 n = B * H * W
                 with torch.no_grad():     # nn.BatchNorm2d bookkeeping: unbiased variance in the buffers

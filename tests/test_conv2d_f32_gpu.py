@@ -308,3 +308,26 @@ def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
     ys = y.double()
     np.testing.assert_allclose(st[:, 0].cpu().numpy(), ys.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(st[:, 1].cpu().numpy(), (ys * ys).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
+def test_winograd_filters_follow_parameter_updates_that_skip_the_version_counter(hip_lib):
+    """torch's fused optimizers step parameters without moving ``_version`` (measured on torch._fused_adamw_): the transformed
+    Winograd filters of a TRAINABLE weight must therefore never come from a version-keyed cache; a frozen weight's may, and
+    must follow a regular in-place update."""
+    from unidistill_amd.ops import conv2d_f32 as c
+    torch.manual_seed(5)
+    x = _cl(torch.randn(2, 64, 36, 28, device="cuda"))
+    gy = _cl(torch.randn(2, 64, 36, 28, device="cuda"))
+    for trainable in (True, False):
+        w = (torch.randn(64, 64, 3, 3, device="cuda") * 0.05).requires_grad_(trainable)
+        assert c.wino_pays(36, 28, 64, 64)
+        y1, g1 = c._launch3(x, w), c._launch3(gy, w, transposed=True)
+        v = w._version
+        if trainable:
+            w.data.mul_(2.0)                       # an update the version counter does not see (what a fused optimizer does)
+            assert w._version == v
+        else:
+            with torch.no_grad():
+                w.mul_(2.0)
+        y2, g2 = c._launch3(x, w), c._launch3(gy, w, transposed=True)
+        assert torch.allclose(y2, 2 * y1, rtol=1e-5, atol=1e-6) and torch.allclose(g2, 2 * g1, rtol=1e-5, atol=1e-6), trainable
