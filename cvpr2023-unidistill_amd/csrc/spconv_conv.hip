@@ -1576,23 +1576,42 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
     __syncthreads();                       // this stage has landed for everybody; everybody is done with the other buffer
     if (kn >= 0) stage(kn, hn, buf ^ 1);
     if ((wmask >> k) & 1u) {
-      const char* ab = smem + buf * kStage + (wm * 32) * 256;
-      const char* wb = smem + buf * kStage + kAB + (wn * (COUT / 2)) * 256;
+      // fragment reads by hand, one 16-channel group ahead of its MFMAs: hipcc puts `s_waitcnt vmcnt(0)` in front of a compiled LDS
+      // read that follows an LDS-DMA issue -- i.e. it waited here for the NEXT stage's DMA issued four lines up, and the double
+      // buffer bought nothing
+      const unsigned ab = buf * kStage + (wm * 32) * 256, wb = buf * kStage + kAB + (wn * (COUT / 2)) * 256;
+      f32x4 fa[2][2], fbv[2][NT];
+#define UD_SD_LOADS(BUF, CB)                                                                                            \
+  do {                                                                                                                  \
+    const unsigned va_ = ab + fo[CB], vb_ = wb + fo[CB];                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                       \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[BUF][i]) : "v"(va_), "n"(i * 4096));                       \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                      \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbv[BUF][t]) : "v"(vb_), "n"(t * 4096));                      \
+  } while (0)
+      UD_SD_LOADS(0, 0);
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
-        f32x4 a[2], b[NT];
+        const int cur = cb & 1;
+        if (cb + 1 < 4) {
+          if (cur == 0) UD_SD_LOADS(1, cb + 1); else UD_SD_LOADS(0, cb + 1);
+          if (NT == 4) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(ab + i * 4096 + fo[cb]);
+        for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(fa[cur][i]));       // the values are valid from here on
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4*>(wb + t * 4096 + fo[cb]);
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(fbv[cur][t]));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[t][e], acc[i][t], 0, 0, 0);
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][e], fbv[cur][t][e], acc[i][t], 0, 0, 0);
       }
+#undef UD_SD_LOADS
     }
     if (hn == 0) todo &= todo - 1;
     k = kn;
