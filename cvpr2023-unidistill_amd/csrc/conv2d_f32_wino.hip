@@ -20,6 +20,7 @@
 #include "ud_prof.h"
 #include <cstdlib>
 #include <type_traits>
+#include <algorithm>
 
 namespace {
 
@@ -31,7 +32,8 @@ constexpr int kUOff = 0, kVOff = 2 * kUBytes, kPOff = kVOff + 2 * kVBytes, kWino
 
 struct WinoGeom {
   int B, H, W, Cin, Cout, bx, by;   // bx x by tile blocks per image
-  int n_full;                       // workgroups [0, n_full) own whole units (tile block, cout block); the rest own quarter units
+  int n_full;                       // work items [0, n_full) are whole units (tile block, cout block); the rest quarter units
+  int n_items;                      // n_full + 4 x (quarter-split units): a workgroup walks items blockIdx.x, + gridDim.x, ...
 };
 struct WinoEp {
   const float* bias;
@@ -97,37 +99,43 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   // Unit = (tile block, 64-channel cout block), cout block major.  When the unit count leaves a short last round on the 256 CUs
   // (e.g. 1040 units: 4 rounds + 16 units alone on the chip for a fifth), the launcher turns that remainder into QUARTER units:
   // four workgroups per unit, each multiplying one 16-tile M block (q >= 0) -- a quarter unit costs ~0.4 of a whole one.
-  const int bid = blockIdx.x;
-  const int unit = bid < gm.n_full ? bid : gm.n_full + ((bid - gm.n_full) >> 2);
-  const int q = bid < gm.n_full ? -1 : (bid - gm.n_full) & 3;
-  const int cbi = unit / nblocks, ru = unit - cbi * nblocks;
-  int blk;
-  {   // consecutive workgroups go round the 8 XCDs: XCD k walks its own contiguous range of tile blocks (shared halos stay in its L2)
-    const int base = nblocks >> 3, extra = nblocks & 7, k = ru & 7;
-    blk = k * base + min(k, extra) + (ru >> 3);
-  }
-  const int blk_lin = blk;
-  const int b = blk / (gm.bx * gm.by);
-  blk -= b * gm.bx * gm.by;
-  const int ty0 = (blk / gm.bx) * THB, tx0 = (blk % gm.bx) * TWB;      // in tiles
-  const int n0 = cbi * kTN;
+  // PERSISTENT workgroups (one per CU): item = blockIdx.x, + gridDim.x, ...; the next item's first stages are DMA-ed while the
+  // current one runs its epilogue (a unit of a Cin = 64 layer is 8 stages: launch + first-stage latency + epilogue were 26 % of it).
+  int unit, q, cbi, blk_lin, b, ty0, tx0, n0;
   const int nchunks = gm.Cin / kKC;
   const float* zero = reinterpret_cast<const float*>(g_zero16w);
-
   const float* pp[2];
   int pinc[2];
+  const float* up;
+  auto setup = [&](int item) {
+    unit = item < gm.n_full ? item : gm.n_full + ((item - gm.n_full) >> 2);
+    q = item < gm.n_full ? -1 : (item - gm.n_full) & 3;
+    cbi = unit / nblocks;
+    const int ru = unit - cbi * nblocks;
+    int blk;
+    {   // consecutive items go round the 8 XCDs: XCD k walks its own contiguous range of tile blocks (shared halos stay in its L2)
+      const int base = nblocks >> 3, extra = nblocks & 7, k = ru & 7;
+      blk = k * base + min(k, extra) + (ru >> 3);
+    }
+    blk_lin = blk;
+    b = blk / (gm.bx * gm.by);
+    blk -= b * gm.bx * gm.by;
+    ty0 = (blk / gm.bx) * THB, tx0 = (blk % gm.bx) * TWB;      // in tiles
+    n0 = cbi * kTN;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    // patch rows are stored even columns first, then odd ones: the transform's lanes (consecutive tiles, fixed patch column) then
-    // read consecutive 32-byte slots instead of every other one (4-way LDS bank conflicts: 18 M conflict cycles per launch)
-    const int q = (wave + 8 * i) * 32 + (lane >> 1);
-    const int qy = q / PW, qs = q - qy * PW;
-    const int qx = qs < PW / 2 ? 2 * qs : 2 * (qs - PW / 2) + 1;
-    const int gy = 2 * ty0 + qy - 1, gx = 2 * tx0 + qx - 1;
-    const bool ok = q < PP && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
-    pp[i] = ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + (lane & 1) * 4 : zero;
-    pinc[i] = ok ? kKC : 0;
-  }
+    for (int i = 0; i < 2; ++i) {
+      // patch rows are stored even columns first, then odd ones: the transform's lanes (consecutive tiles, fixed patch column)
+      // then read consecutive 32-byte slots instead of every other one (4-way LDS bank conflicts: 18 M conflict cycles per launch)
+      const int qq = (wave + 8 * i) * 32 + (lane >> 1);
+      const int qy = qq / PW, qs = qq - qy * PW;
+      const int qx = qs < PW / 2 ? 2 * qs : 2 * (qs - PW / 2) + 1;
+      const int gy = 2 * ty0 + qy - 1, gx = 2 * tx0 + qx - 1;
+      const bool ok = qq < PP && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
+      pp[i] = ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + (lane & 1) * 4 : zero;
+      pinc[i] = ok ? kKC : 0;
+    }
+    up = U + (size_t)cbi * nchunks * (16 * 512) + wave * 1024 + lane * 4;
+  };
   auto stage_p = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -135,7 +143,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
       pp[i] += pinc[i];
     }
   };
-  const float* up = U + (size_t)cbi * nchunks * (16 * 512) + wave * 1024 + lane * 4;
   auto stage_u = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma16w(up + i * 256, smem + kUOff + buf * kUBytes + (wave * 4 + i) * 1024);
@@ -168,8 +175,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   };
 
   f32x4 acc[16][2];
-#pragma unroll
-  for (int f = 0; f < 16; ++f) acc[f][0] = acc[f][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned fa = kVOff + ((32 * wh + li) * 8 + 2 * g) * 4, fb = kUOff + ((16 * wq + li) * 8 + 2 * g) * 4;
 
   // MFMA loop fragments: hand-placed ds_read_b64 (two frequencies = 6 reads per step, one step ahead of the 8 MFMAs that consume
@@ -208,11 +213,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
                  "+v"(td[0][0]), "+v"(td[0][1]), "+v"(td[1][0]), "+v"(td[1][1]), "+v"(td[2][0]), "+v"(td[2][1]),         \
                  "+v"(td[3][0]), "+v"(td[3][1]))
 
-  stage_p(0);
-  stage_u(0);
-  if (nchunks > 1) stage_p(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed
-  __syncthreads();
+  auto first_stages = [&]() {      // the DMA an item needs before its first stage (pointers advance as in the stage loop)
+    stage_p(0);
+    stage_u(0);
+    if (nchunks > 1) stage_p(1);
+  };
   // One barrier per stage, placed BEFORE the stage's last MFMA step: by then every wave holds its step-7 fragments in registers
   // and has written its share of V(chunk + 1), so right after the barrier the next stage's DMA, first fragment reads and patch
   // reads go out and complete under the 8 MFMAs of step 7 -- no bubble at the stage boundary.
@@ -280,6 +285,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
       step_mma(cur, st);
     }
   };
+  int item = blockIdx.x;
+  setup(item);
+  first_stages();
+#pragma unroll 1
+  for (;;) {
+#pragma unroll
+  for (int f = 0; f < 16; ++f) acc[f][0] = acc[f][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA (and the previous item's stores) are done
+  __syncthreads();                                       // first stages in LDS; everybody has left the previous item's epilogue
   if (q < 0) {
     transform(0);
     if (nchunks == 1) {
@@ -364,26 +378,30 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
       }
     }
   }
-#undef UD_WN_TREADS
-#undef UD_WN_TWAIT
-#undef UD_WN_LOADS
-#undef UD_WN_WAIT
-  __syncthreads();
+  __syncthreads();                  // everybody is done with U / V / the patches of this item
+  // this item's epilogue identity, then the NEXT item's first stages go out (patch buffers and U0 are free; the output tile
+  // below lives in the V region) and land during the epilogue
+  const int e_q = q, e_b = b, e_ty0 = ty0, e_tx0 = tx0, e_n0 = n0, e_unit = unit, e_blk = blk_lin;
+  const int next = item + gridDim.x;
+  if (next < gm.n_items) {
+    setup(next);
+    first_stages();
+  }
   // output transform in registers -> fp32 tile in LDS: row = slot * 4 + a * 2 + b, 64 channels per row, the 16-channel group
   // XOR-ed with the row's lane group (four lane groups write rows 16 apart = the same banks otherwise)
-  float* Os = reinterpret_cast<float*>(smem);
+  float* Os = reinterpret_cast<float*>(smem + kVOff);
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (q >= 0 && (mb == 1 || wh != (q >> 1))) continue;      // quarter unit: one M block, held in acc[.][0]
+      if (e_q >= 0 && (mb == 1 || wh != (e_q >> 1))) continue;      // quarter unit: one M block, held in acc[.][0]
       float s[2][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s[0][j] = acc[0 + j][mb][r] + acc[4 + j][mb][r] + acc[8 + j][mb][r];
         s[1][j] = acc[4 + j][mb][r] - acc[8 + j][mb][r] - acc[12 + j][mb][r];
       }
-      const int slot = 32 * wh + 16 * (q >= 0 ? (q & 1) : mb) + 4 * g + r;
+      const int slot = 32 * wh + 16 * (e_q >= 0 ? (e_q & 1) : mb) + 4 * g + r;
       float* o = Os + (slot * 4) * 64 + (16 * (wq ^ g) + li);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
       }
     }
   __syncthreads();
-  const int c4 = (tid & 15) * 4, n = n0 + c4;
+  const int c4 = (tid & 15) * 4, n = e_n0 + c4;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ep.bias && n < gm.Cout) bv = *reinterpret_cast<const float4*>(ep.bias + n);
@@ -401,11 +419,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
     const int row = (tid >> 4) + 32 * k;
     const int slot = row >> 2;
     const int sy = slot / TWB, sx = slot - sy * TWB;
-    const int gy = 2 * (ty0 + sy) + ((row >> 1) & 1), gx = 2 * (tx0 + sx) + (row & 1);
-    if (slot >= TWB * THB || gy >= gm.H || gx >= gm.W || n >= gm.Cout || (q >= 0 && (slot >> 4) != q)) continue;
+    const int gy = 2 * (e_ty0 + sy) + ((row >> 1) & 1), gx = 2 * (e_tx0 + sx) + (row & 1);
+    if (slot >= TWB * THB || gy >= gm.H || gx >= gm.W || n >= gm.Cout || (e_q >= 0 && (slot >> 4) != e_q)) continue;
     float4 v = *reinterpret_cast<const float4*>(Os + row * 64 + (c4 ^ (16 * ((row >> 4) & 3))));
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+    const size_t off = ((size_t)(e_b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
     if (ep.residual) {
       const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
       v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
@@ -427,7 +445,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
       Os[(grp * 64 + c4 + e) * 2 + 1] = q4[e];
     }
     __syncthreads();
-    if (tid < 64 && n0 + tid < gm.Cout) {
+    if (tid < 64 && e_n0 + tid < gm.Cout) {
       double ad = 0.0, qd = 0.0;          // the 32 row-group sums combine in double (sum of squares minus mean^2 comes next)
       for (int k = 0; k < 32; ++k) {
         ad += (double)Os[(k * 64 + tid) * 2];
@@ -436,13 +454,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
       const float a = (float)ad, qq = (float)qd;
       // whole units fill row `tile block`; quarter units rows past the tile blocks (zeroed by the launcher for the other cout
       // blocks), and quarter 0 clears the unit's own row
-      const size_t row = q < 0 ? (size_t)blk_lin : (size_t)nblocks + 4 * (size_t)(unit - gm.n_full) + q;
-      ep.stats[(row * gm.Cout + n0 + tid) * 2] = a;
-      ep.stats[(row * gm.Cout + n0 + tid) * 2 + 1] = qq;
-      if (q == 0) ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2] = ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2 + 1] = 0.f;
+      const size_t row = e_q < 0 ? (size_t)e_blk : (size_t)nblocks + 4 * (size_t)(e_unit - gm.n_full) + e_q;
+      ep.stats[(row * gm.Cout + e_n0 + tid) * 2] = a;
+      ep.stats[(row * gm.Cout + e_n0 + tid) * 2 + 1] = qq;
+      if (e_q == 0) ep.stats[((size_t)e_blk * gm.Cout + e_n0 + tid) * 2] = ep.stats[((size_t)e_blk * gm.Cout + e_n0 + tid) * 2 + 1] = 0.f;
     }
   }
+  if (next >= gm.n_items) break;
+  item = next;
+  }
 }
+
+#undef UD_WN_TREADS
+#undef UD_WN_TWAIT
+#undef UD_WN_LOADS
+#undef UD_WN_WAIT
 
 struct WinoPlan {
   int twb, thb, bx, by;
@@ -514,7 +540,7 @@ extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y
   const long long units = (long long)nblocks * ud_div_up(Cout, kTN);
   if (units + 3 * 64 > 0x7fffffffll) return UD_ERR_UNSUPPORTED;
   const int split = wino_split(units);
-  WinoGeom gm{B, H, W, Cin, Cout, p.bx, p.by, (int)units - split};
+  WinoGeom gm{B, H, W, Cin, Cout, p.bx, p.by, (int)units - split, (int)units + 3 * split};
   WinoEp ep{bias, residual, flags & 1, partial};
   if (partial) {
     const size_t rows = (size_t)nblocks + 4 * (size_t)split;
@@ -531,7 +557,8 @@ extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y
     attr_set = true;
   }
   UdProfScope prof("conv2d.k_conv3x3_wino_f32", stream);
-  const dim3 grid((unsigned)(units + 3 * split));
+  static const int persist = getenv("UD_WINO_GRID") ? atoi(getenv("UD_WINO_GRID")) : 256;      // one workgroup per CU
+  const dim3 grid((unsigned)std::min<long long>(units + 3 * split, persist > 0 ? persist : units + 3 * split));
 #define UD_WINO_LAUNCH(A, Bq) k_conv3x3_wino_f32<A, Bq><<<grid, 512, kWinoSmem, stream>>>(x, U, y, gm, ep)
   if (p.twb == 8) UD_WINO_LAUNCH(8, 8);
   else if (p.twb == 9) UD_WINO_LAUNCH(9, 7);
