@@ -48,21 +48,33 @@ __global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
     pos[gid * 3 + 1] = kept ? y : -1;
     pos[gid * 3 + 2] = kept ? x : -1;
   }
-  // Consecutive frustum points mostly fall into the same cell: one atomic per run of equal cells.
-  const int lane = ud_lane();
-  const int prev = __shfl_up(cell, 1);
-  const bool start = (lane == 0) || (prev != cell);
-  const unsigned long long starts = __ballot(start);
-  const unsigned long long upto = starts & ((2ull << lane) - 1ull);  // run starts at or below me
-  const int lead = 63 - __clzll(upto);
-  const unsigned long long after = starts & ~((2ull << lead) - 1ull);
-  const int end = after ? (__ffsll((long long)after) - 1) : 64;
-  int base = 0;
-  if (cell >= 0 && lane == lead) base = atomicAdd(&count[cell], end - lead);
-  base = __shfl(base, lead);
+  // One global atomic per DISTINCT cell of the workgroup's 256 points: frustum points are ordered (camera, depth, image row, image
+  // column), so a workgroup holds ~6 image rows of one depth plane -- the rows of a column fall into the same BEV cell (only z
+  // differs).  Device-scope atomics run at 24.7 G/s on this chip whatever their flavour (tools/atomic_rate.hip); one per run of equal
+  // consecutive cells (~280 k at 473 k points) was 11 of this kernel's 17 us.  The cells are counted in an LDS hash (LDS atomics), a
+  // thread per occupied slot reserves the cell's range, and every point takes base + its LDS ticket.
+  constexpr int kSlots = 512;
+  __shared__ int s_key[kSlots], s_cnt[kSlots], s_base[kSlots];
+  for (int i = threadIdx.x; i < kSlots; i += 256) s_key[i] = -1, s_cnt[i] = 0;
+  __syncthreads();
+  int slot = -1, ticket = 0;
+  if (cell >= 0) {
+    unsigned h = ((unsigned)cell * 2654435761u) >> 23;            // 9 bits
+    for (;;) {
+      const int prev = atomicCAS(&s_key[h], -1, cell);
+      if (prev == -1 || prev == cell) break;
+      h = (h + 1) & (kSlots - 1);
+    }
+    slot = (int)h;
+    ticket = atomicAdd(&s_cnt[slot], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSlots; i += 256)
+    if (s_cnt[i] > 0) s_base[i] = atomicAdd(&count[s_key[i]], s_cnt[i]);
+  __syncthreads();
   if (gid < total) {
     cellid[gid] = cell;
-    rank[gid] = base + (lane - lead);
+    rank[gid] = cell >= 0 ? s_base[slot] + ticket : 0;
   }
 }
 
