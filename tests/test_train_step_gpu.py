@@ -106,3 +106,32 @@ def test_cfg1_camera_only_student_one_camera():
     assert torch.isfinite(out["loss"])
     assert sum(int(not torch.equal(a, b)) for a, b in zip(before, tr.params)) >= 0.95 * len(before)
     assert _finite_grads(step.model.parameters()) == len(tr.params)
+
+
+@pytest.mark.parametrize("autocast", [None, torch.bfloat16])
+def test_the_forward_pass_sees_the_optimizer_updates(autocast):
+    """Every cached re-layout of a weight (Winograd filters, tap-major / transposed copies, bf16 casts, folded BatchNorm) must
+    follow the parameter: fused optimizers step parameters WITHOUT moving their version counters, so a version-keyed cache of a
+    trainable weight silently trains against stale filters.  Check end to end: on a fixed batch the loss of the LiDAR detector
+    falls over a few steps, and the student's BEV features for the same input change after every step."""
+    from unidistill_amd import train
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tr = train.Trainer(train.DetectStep("lidar"), device=dev, autocast_dtype=autocast, channels_last=True)
+    batch = train.synthetic_batch(dev, batch_size=2, with_imgs=False)
+    losses = [float(tr.step(batch)["loss"].detach()) for _ in range(8)]
+    assert all(l == l for l in losses)
+    assert min(losses[-3:]) < 0.9 * losses[0], losses
+    model = tr.module.model if hasattr(tr.module, "model") else tr.module
+    pts = [p for p in batch["points"]]
+
+    def bev():
+        model.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=autocast or torch.float32, enabled=autocast is not None):
+            out = model.extract_bev(pts, None, None)
+        model.train()
+        return (out[0] if isinstance(out, (tuple, list)) else out).float().clone()
+    f0 = bev()
+    tr.step(batch)
+    f1 = bev()
+    assert not torch.equal(f0, f1)
