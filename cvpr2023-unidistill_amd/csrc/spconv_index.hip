@@ -566,6 +566,39 @@ __global__ __launch_bounds__(256) void k_bev_nhwc(unsigned short* __restrict__ f
   if (!BWD) *reinterpret_cast<uint2*>(dst) = make_uint2(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16));
 }
 
+// fp32 twin (the reference's arithmetic): the channels-last fp32 BEV map the trunk's kernels read, written once -- instead of the
+// NCDHW dense() tensor plus an NCHW -> NHWC copy of it (47 + 86 us at B = 4).
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bev_nhwc_f32(float* __restrict__ feat, const int32_t* __restrict__ rowmap, int C,
+                                                      GridShape g, float* __restrict__ bev) {
+  const int CO = C * g.Dz, pieces = CO / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)g.B * g.Hy * g.Wx * pieces;
+  if (t >= total) return;
+  const int piece = (int)(t % pieces);
+  const long long pix = t / pieces;
+  const int x = (int)(pix % g.Wx), y = (int)((pix / g.Wx) % g.Hy), b = (int)(pix / ((long long)g.Wx * g.Hy));
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  float* dst = bev + pix * CO + piece * 4;
+  if (BWD) {
+    const float4 gq = *reinterpret_cast<const float4*>(dst);
+    v[0] = gq.x; v[1] = gq.y; v[2] = gq.z; v[3] = gq.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int o = piece * 4 + e, c = o / g.Dz, z = o - c * g.Dz;
+    const int row = rowmap[g.lin(b, z, y, x)];
+    if (row >= 0) {
+      if (BWD) feat[(size_t)row * C + c] = v[e];
+      else v[e] = feat[(size_t)row * C + c];
+    }
+  }
+  if (!BWD) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((f32x4v){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(dst));
+  }
+}
+
 extern "C" size_t ud_sparse_bev_workspace_bytes(int B, int Dz, int Hy, int Wx) {
   GridShape g{B, Dz, Hy, Wx};
   if (!shape_ok(g)) return 0;
@@ -615,6 +648,41 @@ extern "C" int ud_bev_to_sparse_bf16(const void* gbev, const int32_t* coords, in
                                                               (unsigned short*)gbev);
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+
+// fp32: feat f32[M,C] -> bev f32[B,Hy,Wx,C*Dz], and its backward (gfeat rows of active voxels are written; the caller zeroes gfeat).
+static int bev_f32_impl(float* feat, const int32_t* coords, int M, int C, int B, int Dz, int Hy, int Wx, float* bev,
+                        void* workspace, size_t workspace_bytes, bool bwd, hipStream_t stream) {
+  GridShape g{B, Dz, Hy, Wx};
+  if (!shape_ok(g) || C <= 0 || M < 0 || !bev) return UD_ERR_INVALID_ARG;
+  if ((C * Dz) % 4) return UD_ERR_UNSUPPORTED;
+  if (bwd && M == 0) return UD_OK;
+  if (M > 0 && (!feat || !coords)) return UD_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx)) return UD_ERR_WORKSPACE;
+  int32_t* rowmap = reinterpret_cast<int32_t*>(workspace);
+  UD_HIP_TRY(hipMemsetAsync(rowmap, 0xFF, (size_t)g.cells() * sizeof(int32_t), stream));
+  if (M > 0) {
+    k_fill_rowmap<<<ud_div_up(M, 256), 256, 0, stream>>>(coords, M, g, rowmap);
+    UD_LAUNCH_CHECK();
+  }
+  const long long total = (long long)B * Hy * Wx * (C * Dz / 4);
+  UdProfScope prof("spconv.k_bev_f32", stream);
+  if (bwd) k_bev_nhwc_f32<true><<<ud_div_up(total, 256), 256, 0, stream>>>(feat, rowmap, C, g, bev);
+  else k_bev_nhwc_f32<false><<<ud_div_up(total, 256), 256, 0, stream>>>(feat, rowmap, C, g, bev);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+extern "C" int ud_sparse_to_bev_f32(const float* feat, const int32_t* coords, int M, int C, int B, int Dz, int Hy, int Wx,
+                                    float* bev, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  return bev_f32_impl(const_cast<float*>(feat), coords, M, C, B, Dz, Hy, Wx, bev, workspace, workspace_bytes, false,
+                      (hipStream_t)stream_);
+}
+
+extern "C" int ud_bev_to_sparse_f32(const float* gbev, const int32_t* coords, int M, int C, int B, int Dz, int Hy, int Wx,
+                                    float* gfeat, void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  return bev_f32_impl(gfeat, coords, M, C, B, Dz, Hy, Wx, const_cast<float*>(gbev), workspace, workspace_bytes, true,
+                      (hipStream_t)stream_);
 }
 
 // SparseConvTensor.dense(): dense f32[B, C, Dz, Hy, Wx] = 0 everywhere, feat[row, :] at coords.

@@ -59,6 +59,8 @@ _SIGS = {
     "ud_spconv_tile_masks": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ud_sparse_bev_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_sparse_to_bev_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_sparse_to_bev_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_bev_to_sparse_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_bev_to_sparse_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_sparse_to_dense": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_dense_to_sparse": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -463,8 +463,12 @@ class _DenseFn(torch.autograd.Function):
         return g, None, None
 
 
+FUSED_BEV = True         # False: bev() = dense().view(...) (tests, A/B timing)
+
+
 class _BevFn(torch.autograd.Function):
-    """bf16 features [M, C] -> channels-last bf16 BEV map [B, C*Dz, Hy, Wx] (ud_sparse_to_bev_bf16)."""
+    """features [M, C] (bf16 or fp32) -> channels-last BEV map [B, C*Dz, Hy, Wx] of the same dtype in one pass
+    (ud_sparse_to_bev_bf16 / ud_sparse_to_bev_f32) -- HeightCompression without the NCDHW tensor and its layout copy."""
 
     @staticmethod
     def forward(ctx, features, indices, grid):
@@ -472,26 +476,27 @@ class _BevFn(torch.autograd.Function):
         features = features.contiguous()
         B, Dz, Hy, Wx = grid
         M, C = features.shape
-        bev = torch.empty((B, Hy, Wx, C * Dz), dtype=torch.bfloat16, device=features.device)
+        f32 = features.dtype == torch.float32
+        bev = torch.empty((B, Hy, Wx, C * Dz), dtype=features.dtype, device=features.device)
         ws = _lib.workspace(features.device, lib.ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx), "sparse_bev")
-        _lib.check(lib.ud_sparse_to_bev_bf16(_lib.ptr(features), _lib.ptr(indices), M, C, B, Dz, Hy, Wx,
-                                             _lib.ptr(bev), _lib.ptr(ws), ws.numel(), _lib.stream_of(bev)),
-                   "ud_sparse_to_bev_bf16")
+        fn = lib.ud_sparse_to_bev_f32 if f32 else lib.ud_sparse_to_bev_bf16
+        _lib.check(fn(_lib.ptr(features), _lib.ptr(indices), M, C, B, Dz, Hy, Wx, _lib.ptr(bev), _lib.ptr(ws), ws.numel(),
+                      _lib.stream_of(bev)), "ud_sparse_to_bev")
         ctx.save_for_backward(indices)
-        ctx.cfg = (grid, M, C)
+        ctx.cfg = (grid, M, C, features.dtype)
         return bev.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gbev):
         (indices,) = ctx.saved_tensors
-        (B, Dz, Hy, Wx), M, C = ctx.cfg
+        (B, Dz, Hy, Wx), M, C, dt = ctx.cfg
         lib = _lib.load()
-        g = gbev.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
-        gfeat = torch.zeros((M, C), dtype=torch.bfloat16, device=g.device)
+        g = gbev.to(dt).permute(0, 2, 3, 1).contiguous()
+        gfeat = torch.zeros((M, C), dtype=dt, device=g.device)
         ws = _lib.workspace(g.device, lib.ud_sparse_bev_workspace_bytes(B, Dz, Hy, Wx), "sparse_bev")
-        _lib.check(lib.ud_bev_to_sparse_bf16(_lib.ptr(g), _lib.ptr(indices), M, C, B, Dz, Hy, Wx,
-                                             _lib.ptr(gfeat), _lib.ptr(ws), ws.numel(), _lib.stream_of(g)),
-                   "ud_bev_to_sparse_bf16")
+        fn = lib.ud_bev_to_sparse_f32 if dt == torch.float32 else lib.ud_bev_to_sparse_bf16
+        _lib.check(fn(_lib.ptr(g), _lib.ptr(indices), M, C, B, Dz, Hy, Wx, _lib.ptr(gfeat), _lib.ptr(ws), ws.numel(),
+                      _lib.stream_of(g)), "ud_bev_to_sparse")
         return gfeat, None, None
 
 
@@ -528,7 +533,8 @@ class SparseConvTensor:
         features give a channels-last bf16 map in one kernel; otherwise dense().view(...)."""
         grid = (self.batch_size,) + tuple(self._sites.spatial_shape)
         C = self.features.shape[1]
-        if self.features.dtype == torch.bfloat16 and (C * grid[1]) % 4 == 0 and self.indices.shape[0] > 0:
+        if self.features.dtype in (torch.bfloat16, torch.float32) and (C * grid[1]) % 4 == 0 and self.indices.shape[0] > 0 \
+                and FUSED_BEV:
             return _BevFn.apply(self.features, self.indices, grid)
         d = self.dense()
         n, c, dz, h, w = d.shape

@@ -306,6 +306,11 @@ int ud_sparse_to_bev_bf16(const void* feat, const int32_t* coords, int M, int C,
                           int Wx, void* bev, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 int ud_bev_to_sparse_bf16(const void* gbev, const int32_t* coords, int M, int C, int B, int Dz, int Hy,
                           int Wx, void* gfeat, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+/* fp32 twin (the reference's arithmetic): the channels-last fp32 BEV map in one pass instead of dense() + an NCHW -> NHWC copy. */
+int ud_sparse_to_bev_f32(const float* feat, const int32_t* coords, int M, int C, int B, int Dz, int Hy, int Wx, float* bev,
+                         void* workspace, size_t workspace_bytes, ud_stream_t stream);
+int ud_bev_to_sparse_f32(const float* gbev, const int32_t* coords, int M, int C, int B, int Dz, int Hy, int Wx, float* gfeat,
+                         void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Distillation losses (feature / relation / response) + gaussian box mask   */

@@ -256,6 +256,31 @@ def test_bev_nhwc_bf16_equals_dense_view():
     assert torch.equal(fb.grad.float(), ff.grad)
 
 
+def test_bev_nhwc_f32_equals_dense_view():
+    """fp32 features: SparseConvTensor.bev() (ud_sparse_to_bev_f32: channels-last map in one pass) == dense().view(N, C*D, H, W),
+    forward and backward, bit for bit (pure data movement)."""
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(9)
+    shape = (3, 2, 21, 19)
+    coords = _sites(rng, *shape, 0.3)
+    feat = rng.standard_normal((len(coords), 20)).astype(np.float32)
+    x = _tensor(coords, feat, shape)
+    f1 = x.features.detach().clone().requires_grad_(True)
+    bev = x.replace_feature(f1).bev()
+    assert bev.dtype == torch.float32 and bev.shape == (3, 40, 21, 19) and bev.is_contiguous(memory_format=torch.channels_last)
+    f2 = x.features.detach().clone().requires_grad_(True)
+    sp.FUSED_BEV = False
+    try:
+        ref = x.replace_feature(f2).bev()
+    finally:
+        sp.FUSED_BEV = True
+    assert torch.equal(bev, ref)
+    g = torch.randn(3, 40, 21, 19, device="cuda")
+    bev.backward(g)
+    ref.backward(g)
+    assert torch.equal(f1.grad, f2.grad)
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (32, 32), (32, 64)])
 def test_bf16_weight_gradient_many_tiles_per_chunk(cin, cout):
     """The LDS-DMA weight-gradient kernel on a rulebook long enough that every workgroup walks many 64-row
