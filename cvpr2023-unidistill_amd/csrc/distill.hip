@@ -507,16 +507,21 @@ __global__ __launch_bounds__(256) void k_mask_pixels(const BoxG* __restrict__ bo
 // ---- response distillation -------------------------------------------------------------------------
 constexpr int kMaxHm = 8;
 constexpr int kMaxReg = 48;
+struct RespStride {
+  int sb, sc, sp;       // element strides of batch, channel and (linearised) pixel: NCHW = (ch HW, HW, 1), a channels-last map = (HW ch, 1, ch)
+};
 struct RespArgs {
   const float* s_hm[kMaxHm];
   const float* t_hm[kMaxHm];
   float* g_hm[kMaxHm];
   int hm_ch[kMaxHm];
+  RespStride s_hm_st[kMaxHm], t_hm_st[kMaxHm], g_hm_st[kMaxHm];
   int n_hm;
   const float* s_reg[kMaxReg];
   const float* t_reg[kMaxReg];
   float* g_reg[kMaxReg];
   int reg_ch[kMaxReg];
+  RespStride s_reg_st[kMaxReg], t_reg_st[kMaxReg], g_reg_st[kMaxReg];
   int n_reg;
   int reg_total;
   float lo, hi;  // teacher sigmoid clamp
@@ -527,7 +532,8 @@ __device__ __forceinline__ float teacher_prob(float logit, float lo, float hi) {
   return fminf(fmaxf(y, lo), hi);
 }
 
-// one thread per BEV pixel; tensors are dense NCHW [B, ch, H, W]
+// one thread per BEV pixel; every tensor [B, ch, H, W] comes with its (batch, channel, pixel) strides -- dense NCHW, channels-last
+// maps and channel slices of a packed channels-last head output are all read in place
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_resp(RespArgs a, const float* __restrict__ mask, int HW,
                                               float* __restrict__ partial,
@@ -545,14 +551,14 @@ __global__ __launch_bounds__(256) void k_resp(RespArgs a, const float* __restric
     int arg_t = 0, arg_c = 0;
     for (int i = 0; i < a.n_hm; ++i)
       for (int c = 0; c < a.hm_ch[i]; ++c) {
-        const size_t o = ((size_t)b * a.hm_ch[i] + c) * HW + pix;
-        const float sv = a.s_hm[i][o];
+        const float sv = a.s_hm[i][(size_t)b * a.s_hm_st[i].sb + (size_t)c * a.s_hm_st[i].sc + (size_t)pix * a.s_hm_st[i].sp];
         if (sv > smax) {
           smax = sv;
           arg_t = i;
           arg_c = c;
         }
-        tmax = fmaxf(tmax, teacher_prob(a.t_hm[i][o], a.lo, a.hi));
+        tmax = fmaxf(tmax, teacher_prob(a.t_hm[i][(size_t)b * a.t_hm_st[i].sb + (size_t)c * a.t_hm_st[i].sc +
+                                                  (size_t)pix * a.t_hm_st[i].sp], a.lo, a.hi));
       }
     const float d = smax - tmax;
     if (!BWD) {
@@ -561,19 +567,21 @@ __global__ __launch_bounds__(256) void k_resp(RespArgs a, const float* __restric
       const float gc = (*gscale_cls) * mk * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
       for (int i = 0; i < a.n_hm; ++i)
         for (int c = 0; c < a.hm_ch[i]; ++c)
-          a.g_hm[i][((size_t)b * a.hm_ch[i] + c) * HW + pix] = (i == arg_t && c == arg_c) ? gc : 0.f;
+          a.g_hm[i][(size_t)b * a.g_hm_st[i].sb + (size_t)c * a.g_hm_st[i].sc + (size_t)pix * a.g_hm_st[i].sp] =
+              (i == arg_t && c == arg_c) ? gc : 0.f;
     }
     // box-regression response: mean over all regression channels of |s - t|
     float acc = 0.f;
     const float gr = BWD ? (*gscale_reg) * mk / (float)a.reg_total : 0.f;
     for (int i = 0; i < a.n_reg; ++i)
       for (int c = 0; c < a.reg_ch[i]; ++c) {
-        const size_t o = ((size_t)b * a.reg_ch[i] + c) * HW + pix;
-        const float e = a.s_reg[i][o] - a.t_reg[i][o];
+        const float e = a.s_reg[i][(size_t)b * a.s_reg_st[i].sb + (size_t)c * a.s_reg_st[i].sc + (size_t)pix * a.s_reg_st[i].sp] -
+                        a.t_reg[i][(size_t)b * a.t_reg_st[i].sb + (size_t)c * a.t_reg_st[i].sc + (size_t)pix * a.t_reg_st[i].sp];
         if (!BWD)
           acc += fabsf(e);
         else
-          a.g_reg[i][o] = gr * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
+          a.g_reg[i][(size_t)b * a.g_reg_st[i].sb + (size_t)c * a.g_reg_st[i].sc + (size_t)pix * a.g_reg_st[i].sp] =
+              gr * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
       }
     dr = (acc / (float)a.reg_total) * mk;
   }
@@ -737,10 +745,25 @@ extern "C" int ud_distill_gaussian_mask(const float* gt, int B, int M, int S, do
   return UD_OK;
 }
 
+// strides: per tensor (sb, sc, sp) triples, or nullptr = dense NCHW
+static bool resp_stride(RespStride& d, const int64_t* st, int i, int ch, int HW) {
+  if (!st) {
+    d = RespStride{ch * HW, HW, 1};
+    return true;
+  }
+  const int64_t lim = 1ll << 31;
+  if (st[3 * i] < 0 || st[3 * i] >= lim || st[3 * i + 1] < 0 || st[3 * i + 1] >= lim || st[3 * i + 2] < 0 || st[3 * i + 2] >= lim)
+    return false;
+  d = RespStride{(int)st[3 * i], (int)st[3 * i + 1], (int)st[3 * i + 2]};
+  return true;
+}
+
 static int fill_resp(RespArgs& a, const float* const* s_hm, const float* const* t_hm,
                      float* const* g_hm, const int* hm_ch, int n_hm, const float* const* s_reg,
                      const float* const* t_reg, float* const* g_reg, const int* reg_ch, int n_reg,
-                     float lo, float hi) {
+                     float lo, float hi, int HW, const int64_t* s_hm_st = nullptr, const int64_t* t_hm_st = nullptr,
+                     const int64_t* g_hm_st = nullptr, const int64_t* s_reg_st = nullptr, const int64_t* t_reg_st = nullptr,
+                     const int64_t* g_reg_st = nullptr) {
   if (n_hm <= 0 || n_hm > kMaxHm || n_reg <= 0 || n_reg > kMaxReg) return UD_ERR_UNSUPPORTED;
   a.n_hm = n_hm;
   a.n_reg = n_reg;
@@ -753,6 +776,9 @@ static int fill_resp(RespArgs& a, const float* const* s_hm, const float* const* 
     a.t_hm[i] = t_hm[i];
     a.g_hm[i] = g_hm ? g_hm[i] : nullptr;
     a.hm_ch[i] = hm_ch[i];
+    if (!resp_stride(a.s_hm_st[i], s_hm_st, i, hm_ch[i], HW) || !resp_stride(a.t_hm_st[i], t_hm_st, i, hm_ch[i], HW) ||
+        !resp_stride(a.g_hm_st[i], g_hm_st, i, hm_ch[i], HW))
+      return UD_ERR_UNSUPPORTED;
   }
   for (int i = 0; i < n_reg; ++i) {
     if (!s_reg[i] || !t_reg[i] || reg_ch[i] <= 0) return UD_ERR_INVALID_ARG;
@@ -761,6 +787,9 @@ static int fill_resp(RespArgs& a, const float* const* s_hm, const float* const* 
     a.g_reg[i] = g_reg ? g_reg[i] : nullptr;
     a.reg_ch[i] = reg_ch[i];
     a.reg_total += reg_ch[i];
+    if (!resp_stride(a.s_reg_st[i], s_reg_st, i, reg_ch[i], HW) || !resp_stride(a.t_reg_st[i], t_reg_st, i, reg_ch[i], HW) ||
+        !resp_stride(a.g_reg_st[i], g_reg_st, i, reg_ch[i], HW))
+      return UD_ERR_UNSUPPORTED;
   }
   return UD_OK;
 }
@@ -778,7 +807,7 @@ extern "C" int ud_distill_resp_fwd(const float* const* s_hm, const float* const*
     return UD_ERR_INVALID_ARG;
   RespArgs a;
   int rc = fill_resp(a, s_hm, t_hm, nullptr, hm_ch, n_hm, s_reg, t_reg, nullptr, reg_ch, n_reg,
-                     clamp_lo, clamp_hi);
+                     clamp_lo, clamp_hi, H * W);
   if (rc != UD_OK) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid(ud_div_up((long long)H * W, 256), B);
@@ -802,7 +831,50 @@ extern "C" int ud_distill_resp_bwd(const float* const* s_hm, const float* const*
     return UD_ERR_INVALID_ARG;
   RespArgs a;
   int rc = fill_resp(a, s_hm, t_hm, g_hm, hm_ch, n_hm, s_reg, t_reg, g_reg, reg_ch, n_reg, clamp_lo,
-                     clamp_hi);
+                     clamp_hi, H * W);
+  if (rc != UD_OK) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid(ud_div_up((long long)H * W, 256), B);
+  k_resp<true><<<grid, 256, 0, stream>>>(a, mask, H * W, nullptr, gscale_cls, gscale_reg);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+// The same two passes on tensors read IN PLACE: every tensor [B, ch, H, W] comes with an (sb, sc, sp) element-stride triple (batch,
+// channel, linearised pixel; the map must be pixel-linear: stride(H) == W * stride(W)) -- channels-last maps and channel slices of the
+// packed head output need no dense NCHW copies (84 small copies per distillation step).  *_st: int64[n][3], host arrays.
+extern "C" int ud_distill_resp_fwd_strided(const float* const* s_hm, const int64_t* s_hm_st, const float* const* t_hm,
+                                           const int64_t* t_hm_st, const int* hm_ch, int n_hm, const float* const* s_reg,
+                                           const int64_t* s_reg_st, const float* const* t_reg, const int64_t* t_reg_st,
+                                           const int* reg_ch, int n_reg, const float* mask, int B, int H, int W,
+                                           float clamp_lo, float clamp_hi, float* partial, ud_stream_t stream_) {
+  if (!s_hm || !t_hm || !hm_ch || !s_reg || !t_reg || !reg_ch || !mask || !partial || !s_hm_st || !t_hm_st || !s_reg_st || !t_reg_st)
+    return UD_ERR_INVALID_ARG;
+  RespArgs a;
+  int rc = fill_resp(a, s_hm, t_hm, nullptr, hm_ch, n_hm, s_reg, t_reg, nullptr, reg_ch, n_reg, clamp_lo, clamp_hi, H * W,
+                     s_hm_st, t_hm_st, nullptr, s_reg_st, t_reg_st, nullptr);
+  if (rc != UD_OK) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid(ud_div_up((long long)H * W, 256), B);
+  UdProfScope prof("distill.k_resp", stream);
+  k_resp<false><<<grid, 256, 0, stream>>>(a, mask, H * W, partial, nullptr, nullptr);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+extern "C" int ud_distill_resp_bwd_strided(const float* const* s_hm, const int64_t* s_hm_st, const float* const* t_hm,
+                                           const int64_t* t_hm_st, float* const* g_hm, const int64_t* g_hm_st, const int* hm_ch,
+                                           int n_hm, const float* const* s_reg, const int64_t* s_reg_st,
+                                           const float* const* t_reg, const int64_t* t_reg_st, float* const* g_reg,
+                                           const int64_t* g_reg_st, const int* reg_ch, int n_reg, const float* mask, int B, int H,
+                                           int W, float clamp_lo, float clamp_hi, const float* gscale_cls,
+                                           const float* gscale_reg, ud_stream_t stream_) {
+  if (!s_hm || !t_hm || !g_hm || !hm_ch || !s_reg || !t_reg || !g_reg || !reg_ch || !mask || !gscale_cls || !gscale_reg ||
+      !s_hm_st || !t_hm_st || !g_hm_st || !s_reg_st || !t_reg_st || !g_reg_st)
+    return UD_ERR_INVALID_ARG;
+  RespArgs a;
+  int rc = fill_resp(a, s_hm, t_hm, g_hm, hm_ch, n_hm, s_reg, t_reg, g_reg, reg_ch, n_reg, clamp_lo, clamp_hi, H * W, s_hm_st,
+                     t_hm_st, g_hm_st, s_reg_st, t_reg_st, g_reg_st);
   if (rc != UD_OK) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid(ud_div_up((long long)H * W, 256), B);

@@ -80,6 +80,10 @@ _SIGS = {
     "ud_distill_resp_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                     c_float, c_void_p, c_void_p, c_void_p]),
+    "ud_distill_resp_fwd_strided": (c_int, [c_void_p] * 4 + [c_void_p, c_int] + [c_void_p] * 4 + [c_void_p, c_int, c_void_p,
+                                            c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "ud_distill_resp_bwd_strided": (c_int, [c_void_p] * 6 + [c_void_p, c_int] + [c_void_p] * 6 + [c_void_p, c_int, c_void_p,
+                                            c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "ud_voxelize_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_voxelize_capacity": (c_int, [c_int] * 3),
     "ud_voxelize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int]

@@ -110,24 +110,41 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _in_place(t):
+    """fp32 CUDA map [B, ch, H, W] whose pixels are linear in memory (stride(H) == W * stride(W)): dense NCHW, channels-last, or a
+    channel slice of a channels-last tensor -- read by the kernels through (sb, sc, sp) strides; anything else gets a dense copy."""
+    if t.dtype != torch.float32 or not (t.stride(2) == t.shape[3] * t.stride(3) or t.shape[2] == 1):
+        t = t.contiguous().float()
+    return t
+
+
+def _stride_array(tensors):
+    flat = []
+    for t in tensors:
+        flat += [t.stride(0), t.stride(1), t.stride(3)]
+    return (ctypes.c_int64 * len(flat))(*flat)
+
+
 class _RespDistill(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mask, weight, clamp, n_hm, *tensors):
-        # tensors = student hm[n_hm], student reg[n_reg], teacher hm[n_hm], teacher reg[n_reg]
+        # tensors = student hm[n_hm], student reg[n_reg], teacher hm[n_hm], teacher reg[n_reg]; all read in place (the head outputs
+        # are channel slices of one packed channels-last tensor: 84 dense copies per step otherwise)
         n_reg = len(tensors) // 2 - n_hm
-        s_hm = [t.contiguous().float() for t in tensors[:n_hm]]
-        s_reg = [t.contiguous().float() for t in tensors[n_hm:n_hm + n_reg]]
-        t_hm = [t.detach().contiguous().float() for t in tensors[n_hm + n_reg:2 * n_hm + n_reg]]
-        t_reg = [t.detach().contiguous().float() for t in tensors[2 * n_hm + n_reg:]]
+        s_hm = [_in_place(t) for t in tensors[:n_hm]]
+        s_reg = [_in_place(t) for t in tensors[n_hm:n_hm + n_reg]]
+        t_hm = [_in_place(t.detach()) for t in tensors[n_hm + n_reg:2 * n_hm + n_reg]]
+        t_reg = [_in_place(t.detach()) for t in tensors[2 * n_hm + n_reg:]]
         B, _, H, W = s_hm[0].shape
         hm_ch = (ctypes.c_int * n_hm)(*[t.shape[1] for t in s_hm])
         reg_ch = (ctypes.c_int * n_reg)(*[t.shape[1] for t in s_reg])
         nblk = B * ((H * W + 255) // 256)
         partial = torch.empty((nblk, 2), dtype=torch.float32, device=mask.device)
-        _lib.check(_lib.load().ud_distill_resp_fwd(
-            _ptr_array(s_hm), _ptr_array(t_hm), hm_ch, n_hm, _ptr_array(s_reg), _ptr_array(t_reg),
-            reg_ch, n_reg, _lib.ptr(mask), B, H, W, float(clamp), float(1.0 - clamp),
-            _lib.ptr(partial), _lib.stream_of(mask)), "ud_distill_resp_fwd")
+        _lib.check(_lib.load().ud_distill_resp_fwd_strided(
+            _ptr_array(s_hm), _stride_array(s_hm), _ptr_array(t_hm), _stride_array(t_hm), hm_ch, n_hm,
+            _ptr_array(s_reg), _stride_array(s_reg), _ptr_array(t_reg), _stride_array(t_reg), reg_ch, n_reg,
+            _lib.ptr(mask), B, H, W, float(clamp), float(1.0 - clamp), _lib.ptr(partial), _lib.stream_of(mask)),
+            "ud_distill_resp_fwd_strided")
         den = weight + 1e-4
         sums = partial.sum(0)
         ctx.save_for_backward(mask, den, *s_hm, *s_reg, *t_hm, *t_reg)
@@ -142,17 +159,21 @@ class _RespDistill(torch.autograd.Function):
         s_hm, s_reg = rest[:n_hm], rest[n_hm:n_hm + n_reg]
         t_hm, t_reg = rest[n_hm + n_reg:2 * n_hm + n_reg], rest[2 * n_hm + n_reg:]
         B, _, H, W = s_hm[0].shape
-        gh = [torch.empty_like(t) for t in s_hm]
-        gr = [torch.empty_like(t) for t in s_reg]
+        # all student-side gradients live in ONE channels-last buffer [B, H, W, sum ch] (one allocation; the split node that produced
+        # the head outputs concatenates channel slices of it)
+        chs = [t.shape[1] for t in s_hm] + [t.shape[1] for t in s_reg]
+        pack = torch.empty((B, H, W, sum(chs)), dtype=torch.float32, device=mask.device).permute(0, 3, 1, 2)
+        views = list(pack.split_with_sizes(chs, dim=1))
+        gh, gr = views[:n_hm], views[n_hm:]
         sc = (g_cls / den).reshape(1).float().contiguous()
         sr = (g_reg / den).reshape(1).float().contiguous()
         hm_ch = (ctypes.c_int * n_hm)(*[t.shape[1] for t in s_hm])
         reg_ch = (ctypes.c_int * n_reg)(*[t.shape[1] for t in s_reg])
-        _lib.check(_lib.load().ud_distill_resp_bwd(
-            _ptr_array(s_hm), _ptr_array(t_hm), _ptr_array(gh), hm_ch, n_hm, _ptr_array(s_reg),
-            _ptr_array(t_reg), _ptr_array(gr), reg_ch, n_reg, _lib.ptr(mask), B, H, W, float(clamp),
-            float(1.0 - clamp), _lib.ptr(sc), _lib.ptr(sr), _lib.stream_of(mask)),
-            "ud_distill_resp_bwd")
+        _lib.check(_lib.load().ud_distill_resp_bwd_strided(
+            _ptr_array(s_hm), _stride_array(s_hm), _ptr_array(t_hm), _stride_array(t_hm), _ptr_array(gh), _stride_array(gh),
+            hm_ch, n_hm, _ptr_array(s_reg), _stride_array(s_reg), _ptr_array(t_reg), _stride_array(t_reg), _ptr_array(gr),
+            _stride_array(gr), reg_ch, n_reg, _lib.ptr(mask), B, H, W, float(clamp), float(1.0 - clamp), _lib.ptr(sc),
+            _lib.ptr(sr), _lib.stream_of(mask)), "ud_distill_resp_bwd_strided")
         return (None, None, None, None, *gh, *gr, *([None] * (n_hm + n_reg)))
 
 

@@ -370,6 +370,20 @@ int ud_distill_resp_bwd(const float* const* s_hm, const float* const* t_hm, floa
                         int n_reg, const float* mask, int B, int H, int W, float clamp_lo,
                         float clamp_hi, const float* gscale_cls, const float* gscale_reg,
                         ud_stream_t stream);
+/* The same two passes with every tensor read / written in place through an (sb, sc, sp) element-stride triple (batch, channel,
+ * linearised pixel; stride(H) == W * stride(W)): channels-last maps and channel slices of the packed CenterHead output need no dense
+ * NCHW copies.  *_st: host int64[n][3]. */
+int ud_distill_resp_fwd_strided(const float* const* s_hm, const int64_t* s_hm_st, const float* const* t_hm,
+                                const int64_t* t_hm_st, const int* hm_ch, int n_hm, const float* const* s_reg,
+                                const int64_t* s_reg_st, const float* const* t_reg, const int64_t* t_reg_st, const int* reg_ch,
+                                int n_reg, const float* mask, int B, int H, int W, float clamp_lo, float clamp_hi, float* partial,
+                                ud_stream_t stream);
+int ud_distill_resp_bwd_strided(const float* const* s_hm, const int64_t* s_hm_st, const float* const* t_hm,
+                                const int64_t* t_hm_st, float* const* g_hm, const int64_t* g_hm_st, const int* hm_ch, int n_hm,
+                                const float* const* s_reg, const int64_t* s_reg_st, const float* const* t_reg,
+                                const int64_t* t_reg_st, float* const* g_reg, const int64_t* g_reg_st, const int* reg_ch,
+                                int n_reg, const float* mask, int B, int H, int W, float clamp_lo, float clamp_hi,
+                                const float* gscale_cls, const float* gscale_reg, ud_stream_t stream);
 
 /* ---- Detection-head tail: BatchNorm -> ReLU -> per-head 3x3 conv (64 -> k) --------------------------
  * Replaces modules 1..3 of every SepHead stack (reference unidistill/layers/head/det3d/

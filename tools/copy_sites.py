@@ -1,0 +1,47 @@
+"""Where do the layout / dtype copies of one fp32 distillation step come from?  Wraps Tensor.contiguous / Tensor.to / Tensor.float /
+Tensor.copy_ for one step and counts, per calling source line inside the package, the calls that really copied (new storage)."""
+import collections, os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]
+os.environ.setdefault("UD_RANDOM_INIT", "1")
+import torch
+from unidistill_amd import train as T
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+tr = T.Trainer(T.DistillStep("camera_exp_distill_lidar"), device=dev, autocast_dtype=None, channels_last=True)
+batch = T.synthetic_batch(dev, 4)
+for _ in range(3):
+    tr.step(batch)
+torch.cuda.synchronize()
+cnt, byt = collections.Counter(), collections.Counter()
+
+
+def site():
+    for fr in reversed(traceback.extract_stack()[:-2]):
+        if "unidistill_amd/" in fr.filename:
+            return f"{fr.filename.split('unidistill_amd/')[-1]}:{fr.lineno} {fr.line[:70]}"
+    return "?"
+
+
+def wrap(name):
+    orig = getattr(torch.Tensor, name)
+
+    def f(self, *a, **k):
+        out = orig(self, *a, **k)
+        if torch.is_tensor(out) and out.is_cuda and (name == "copy_" or out.data_ptr() != self.data_ptr()):
+            s = site()
+            cnt[(name, s)] += 1
+            byt[(name, s)] += out.numel() * out.element_size()
+        return out
+    setattr(torch.Tensor, name, f)
+    return orig
+
+
+origs = {n: wrap(n) for n in ("contiguous", "to", "float", "copy_", "clone")}
+tr.step(batch)
+torch.cuda.synchronize()
+for n, o in origs.items():
+    setattr(torch.Tensor, n, o)
+print("copies in one step (python-visible):", sum(cnt.values()))
+for (name, s), n in cnt.most_common(45):
+    print(f"{n:4d} {byt[(name, s)] / 1e6:9.1f} MB  {name:10s} {s}")
