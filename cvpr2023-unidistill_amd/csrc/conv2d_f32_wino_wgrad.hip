@@ -217,16 +217,33 @@ __global__ __launch_bounds__(512) void k_wino_wgrad_f32(const float* __restrict_
         UD_WW_WAIT(1, 0);
       }
       const int fi = st >> 1;
+      // the raw loads of stage k + 2 are woven between the 16 MFMAs of step 0, the transform of stage k + 1 between those of step 3:
+      // one MFMA, then a few of the other instructions (sched_group_barrier) -- chunks of them between groups of four MFMAs left the
+      // pipe idle while both waves of the SIMD, in lockstep behind the stage barrier, worked through the same chunk (10.8 -> 10.4 ms
+      // per step; spreading each over two steps was slower again)
+      const bool ride = (st == 0 && more2) || (st == 3 && more);
+      if (ride) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (st == 0) load_raw(SetP{}); else transform(SetQ{}, P ^ 1);
+      }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        if ((st == 0 && more2) || (st == 3 && more)) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (st == 0) load_part(SetP{}, a); else transform_part(SetQ{}, P ^ 1, a);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           acc[fi][a][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[cur][a], qb[cur][q], acc[fi][a][q], 0, 0, 0);
+      if (ride) {
+#pragma unroll
+        for (int i_ = 0; i_ < 16; ++i_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (st == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
