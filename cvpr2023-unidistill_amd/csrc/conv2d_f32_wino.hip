@@ -283,6 +283,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
         }
       }
       step_mma(cur, st);
+      if (st == 2 && more) {              // weave the transform's 32 additions between this step's 8 MFMAs
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+      }
     }
   };
   int item = blockIdx.x;
