@@ -236,14 +236,25 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
     const int cb = chunk & 1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();      // V(chunk) written, U(chunk) and patch(chunk + 1) landed; everybody holds the last fragments of chunk - 1
-    if (more) stage_u(cb ^ 1);
-    if (chunk + 2 < nchunks) stage_p(cb);
     const unsigned pa = fa + cb * kVBytes, pb = fb + cb * kUBytes;
     const unsigned tvw = tv + (cb ^ 1) * kVBytes;
     float tw[16];
     UD_WN_LOADS(0, 0);
     if constexpr (more) { UD_WN_TREADS((cb ^ 1) * kPBytes); }
-    if constexpr (!first) step_mma(1, 7);                 // last step of the previous stage: fragments already in registers
+    // the next stage's DMA issue is woven between the 8 MFMAs of the previous stage's last step (fragments already in registers)
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stage_u(cb ^ 1);
+    if (chunk + 2 < nchunks) stage_p(cb);
+    if constexpr (!first) {
+      step_mma(1, 7);
+#pragma unroll
+      for (int i_ = 0; i_ < 8; ++i_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < 7; ++st) {
       const int cur = st & 1;
