@@ -37,6 +37,8 @@ struct WinoGeom {
 };
 struct WinoEp {
   const float* bias;
+  const float* scale;               // folded eval-mode BatchNorm: v * scale + shift after the bias (both or neither)
+  const float* shift;
   const float* residual;
   int relu;
   float* stats;                     // [blocks][Cout][2] per-workgroup (sum, sum of squares) of the stored outputs, or nullptr
@@ -430,8 +432,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
   __syncthreads();
   const int c4 = (tid & 15) * 4, n = e_n0 + c4;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), scv = make_float4(1.f, 1.f, 1.f, 1.f), shv = bv;
   if (ep.bias && n < gm.Cout) bv = *reinterpret_cast<const float4*>(ep.bias + n);
+  if (ep.scale && n < gm.Cout) {
+    scv = *reinterpret_cast<const float4*>(ep.scale + n);
+    shv = *reinterpret_cast<const float4*>(ep.shift + n);
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int row = (tid >> 4) + 32 * k;
@@ -441,6 +447,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino_f32(const float* __restric
     if (slot >= TWB * THB || gy >= gm.H || gx >= gm.W || n >= gm.Cout || (e_q >= 0 && (slot >> 4) != e_q)) continue;
     float4 v = *reinterpret_cast<const float4*>(Os + row * 64 + (c4 ^ (16 * ((row >> 4) & 3))));
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    if (ep.scale) {
+      v.x = v.x * scv.x + shv.x; v.y = v.y * scv.y + shv.y; v.z = v.z * scv.z + shv.z; v.w = v.w * scv.w + shv.w;
+    }
     const size_t off = ((size_t)(e_b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
     if (ep.residual) {
       const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
@@ -545,12 +554,13 @@ extern "C" int ud_conv3x3_wino_f32_weights(const float* w, int64_t s_n, int64_t 
   return UD_OK;
 }
 
-// y = conv3x3(x) (+ bias) (+ residual) (ReLU if flags & 1) with U from ud_conv3x3_wino_f32_weights(N = Cout, C = Cin); partial != nullptr:
+// y = conv3x3(x) (+ bias) (* scale + shift: a folded eval-mode BatchNorm) (+ residual) (ReLU if flags & 1) with U from ud_conv3x3_wino_f32_weights(N = Cout, C = Cin); partial != nullptr:
 // also the per-workgroup BatchNorm partial sums ([*slices][Cout][2], same contract as ud_conv3x3_bnstats_nhwc_f32).
 extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y, int B, int H, int W, int Cin, int Cout,
-                                        const float* bias, const float* residual, int flags, float* partial,
-                                        size_t partial_bytes, int* slices, ud_stream_t stream_) {
+                                        const float* bias, const float* scale, const float* shift, const float* residual,
+                                        int flags, float* partial, size_t partial_bytes, int* slices, ud_stream_t stream_) {
   if (!x || !U || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (Cin % kKC != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   const WinoPlan p = wino_plan(H, W);
@@ -559,7 +569,7 @@ extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y
   if (units + 3 * 64 > 0x7fffffffll) return UD_ERR_UNSUPPORTED;
   const int split = wino_split(units);
   WinoGeom gm{B, H, W, Cin, Cout, p.bx, p.by, (int)units - split, (int)units + 3 * split};
-  WinoEp ep{bias, residual, flags & 1, partial};
+  WinoEp ep{bias, scale, shift, residual, flags & 1, partial};
   if (partial) {
     const size_t rows = (size_t)nblocks + 4 * (size_t)split;
     if (!slices || partial_bytes < rows * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;

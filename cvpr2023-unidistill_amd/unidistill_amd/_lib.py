@@ -119,8 +119,8 @@ _SIGS = {
     "ud_conv3x3_wino_wgrad_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_conv3x3_wino_f32_blocks": (c_int, [c_int, c_int]),
     "ud_conv3x3_wino_f32_weights": (c_int, [c_void_p] + [c_i64] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),
-    "ud_conv3x3_wino_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_size_t,
-                                                                      c_void_p, c_void_p]),
+    "ud_conv3x3_wino_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p, c_size_t,
+                                                                                        c_void_p, c_void_p]),
     "ud_conv1x1_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p, c_size_t, c_void_p]),
     "ud_assign_targets": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p, c_void_p] + [c_int] * 8 + [c_float] * 5
                           + [c_void_p] * 6),

@@ -220,6 +220,13 @@ class FusedSequential(nn.Sequential):
                     and _is3x3_any(mods[i + 1], 0) and hipconv32.supported(x, mods[i + 1].weight, 3) \
                     and _fp32_kernel_pays(mods[i + 1], x):
                 # fp32 mode: ZeroPad2d(1) + unpadded 3x3 conv == the kernel's implicit padding
+                j = i + 2
+                if j < n and _can_fuse_inference(x, mods[j], mods[i + 1]):      # frozen network: conv + BN (+ ReLU) in one kernel
+                    relu = j + 1 < n and isinstance(mods[j + 1], nn.ReLU)
+                    scale, shift = folded_batchnorm(mods[j])
+                    x = hipconv32.conv3x3_inference(x, mods[i + 1].weight, mods[i + 1].bias, scale, shift, relu)
+                    i = j + (2 if relu else 1)
+                    continue
                 x = hipconv32.conv3x3(x, mods[i + 1].weight, mods[i + 1].bias, _feeds_training_bn(mods, i + 2))
                 i += 2
                 continue
@@ -228,6 +235,14 @@ class FusedSequential(nn.Sequential):
                     relu = i + 1 < n and isinstance(mods[i + 1], nn.ReLU)
                     x = batchnorm_act(m, x, None, relu)
                     i += 2 if relu else 1
+                    continue
+                if (isinstance(m, Conv2d) and Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x)
+                        and _is3x3_any(m, 1) and hipconv32.supported(x, m.weight, 3) and _fp32_kernel_pays(m, x)
+                        and i + 1 < n and _can_fuse_inference(x, mods[i + 1], m)):
+                    relu = i + 2 < n and isinstance(mods[i + 2], nn.ReLU)       # frozen network, fp32: conv + BN (+ ReLU) fused
+                    scale, shift = folded_batchnorm(mods[i + 1])
+                    x = hipconv32.conv3x3_inference(x, m.weight, m.bias, scale, shift, relu)
+                    i += 3 if relu else 2
                     continue
                 x = m(x, _feeds_training_bn(mods, i + 1)) if isinstance(m, Conv2d) else m(x)
                 i += 1

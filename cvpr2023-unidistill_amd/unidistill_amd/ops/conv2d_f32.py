@@ -73,7 +73,7 @@ def _wino_weights(weight, transposed):
     return U
 
 
-def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False):
+def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False, scale=None, shift=None):
     """3x3 / stride 1 / pad 1 of channels-last x with the parameter ``weight`` [Cout, Cin, 3, 3] (transposed: its data-gradient
     filter, Cin <-> Cout with the taps reversed).  Winograd kernel where the map fills its tile blocks, else the direct one."""
     B, cin, H, W = x.shape
@@ -89,8 +89,8 @@ def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False)
         part, ns = (None, ctypes.c_int(0))
         if bn_stats:
             part, ns = _bn_partial(lib.ud_conv3x3_wino_bnstats_bytes(B, H, W, cout), x.device)
-        _lib.check(lib.ud_conv3x3_wino_nhwc_f32(_lib.ptr(x), _lib.ptr(U), _lib.ptr(y), B, H, W, cin, cout, _lib.ptr(bias), None,
-                                                1 if relu else 0, _lib.ptr(part), part.numel() * 4 if bn_stats else 0,
+        _lib.check(lib.ud_conv3x3_wino_nhwc_f32(_lib.ptr(x), _lib.ptr(U), _lib.ptr(y), B, H, W, cin, cout, _lib.ptr(bias),
+                                                _lib.ptr(scale), _lib.ptr(shift), None, 1 if relu else 0, _lib.ptr(part), part.numel() * 4 if bn_stats else 0,
                                                 ctypes.addressof(ns), _lib.stream_of(x)), "ud_conv3x3_wino_nhwc_f32")
         return (y, (part, ns.value, B * H * W)) if bn_stats else y
     w = weight.detach()
@@ -103,7 +103,7 @@ def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False)
                    "ud_conv3x3_bnstats_nhwc_f32")
         return y, (part, ns.value, B * H * W)
     _lib.check(lib.ud_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(w_tap), _lib.ptr(y), B, H, W, cin, cout,
-                                       _lib.ptr(bias), None, None, None,
+                                       _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), None,
                                        (1 if relu else 0) | (2 if transposed else 0), _lib.stream_of(x)),
                "ud_conv3x3_nhwc_f32")
     return y
@@ -251,6 +251,15 @@ def _apply(x, weight, bias, ks, with_skip, bn_stats):
 
 def conv3x3(x, weight, bias=None, bn_stats=False):
     return _apply(x, weight, bias, 3, False, bn_stats)
+
+
+def conv3x3_inference(x, weight, bias=None, scale=None, shift=None, relu=False):
+    """Inference 3x3 convolution with the fused epilogue (+ bias) (* scale + shift: a folded eval-mode BatchNorm) (ReLU): the frozen
+    teacher's conv -> BN -> ReLU links in one kernel (no autograd graph)."""
+    with torch.no_grad():
+        _lib.require_gpu(x, weight)
+        b = None if bias is None else bias.detach().float().contiguous()
+        return _launch3(_nhwc(x), weight, b, relu=relu, scale=scale, shift=shift)
 
 
 def conv1x1(x, weight, bias=None, bn_stats=False):

@@ -547,7 +547,7 @@ int ud_conv1x1_wgrad_mapped_nhwc_f32(const float* x, const float* dy, float* dw,
  *   ud_conv3x3_wino_f32_weights(w, strides of (n, c, ky, kx) in elements, N, C, flip, U): U = G g G^T of g[n][ky][kx][c]; the forward
  *   pass uses (n, c) = (Cout, Cin), the data gradient (n, c) = (Cin, Cout) with flip = 1 (taps reversed);
  *   U holds ud_conv3x3_wino_f32_weight_bytes(C, N) bytes.
- * ud_conv3x3_wino_nhwc_f32: y = conv(x) (+ bias) (+ residual) (ReLU if flags & 1); partial != NULL also returns the per-workgroup
+ * ud_conv3x3_wino_nhwc_f32: y = conv(x) (+ bias) (* scale + shift: folded eval-mode BatchNorm, both or NULL) (+ residual) (ReLU if flags & 1); partial != NULL also returns the per-workgroup
  * BatchNorm partial sums [*slices][Cout][2] (ud_conv3x3_wino_bnstats_bytes).  Cin % 8 == 0, Cout % 4 == 0. */
 size_t ud_conv3x3_wino_f32_weight_bytes(int Cin, int Cout);
 size_t ud_conv3x3_wino_bnstats_bytes(int B, int H, int W, int Cout);
@@ -555,8 +555,8 @@ int ud_conv3x3_wino_f32_blocks(int H, int W);   /* 64-tile blocks per image of t
 int ud_conv3x3_wino_f32_weights(const float* w, int64_t s_n, int64_t s_c, int64_t s_y, int64_t s_x, int N, int C, int flip,
                                 float* U, ud_stream_t stream);
 int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y, int B, int H, int W, int Cin, int Cout,
-                             const float* bias, const float* residual, int flags, float* partial, size_t partial_bytes,
-                             int* slices, ud_stream_t stream);
+                             const float* bias, const float* scale, const float* shift, const float* residual, int flags,
+                             float* partial, size_t partial_bytes, int* slices, ud_stream_t stream);
 
 /* Weight gradient of the same layers through the Winograd form (gradient of ud_conv3x3_wino_nhwc_f32: 16 instead of 36 multiplications
  * per 2 x 2 tile and (n, c)); same contract as ud_conv3x3_wgrad_nhwc_f32: dw [Cout][3][3][Cin], tile slices reduced in a fixed order. */

@@ -331,3 +331,38 @@ def test_winograd_filters_follow_parameter_updates_that_skip_the_version_counter
                 w.mul_(2.0)
         y2, g2 = c._launch3(x, w), c._launch3(gy, w, transposed=True)
         assert torch.allclose(y2, 2 * y1, rtol=1e-5, atol=1e-6) and torch.allclose(g2, 2 * g1, rtol=1e-5, atol=1e-6), trainable
+
+
+def test_fp32_frozen_trunk_fuses_conv_bn_relu_and_matches_the_unfused_path(hip_lib):
+    """Eval-mode (frozen teacher) BaseBEVBackbone in fp32: conv + folded BatchNorm + ReLU run as ONE kernel per link (scale / shift in
+    the Winograd or direct epilogue) -- same output as the conv followed by the streaming BatchNorm kernel, and no BatchNorm launch."""
+    from unidistill_amd import _lib
+    from unidistill_amd.layers import dense
+    from unidistill_amd.layers.bev import BaseBEVBackbone
+    torch.manual_seed(1)
+    m = BaseBEVBackbone([2, 2], [1, 2], [64, 128], [1, 2], [64, 64], 64).cuda()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    m.eval().requires_grad_(False)
+    x = _cl(torch.randn(2, 64, 44, 36, device="cuda"))
+    _lib.prof_read("bn_act.k_fwd", reset=True)
+    _lib.prof_enable(True)
+    with torch.no_grad():
+        y, _ = m(x)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    fused_bn_launches = _lib.prof_read("bn_act.k_fwd")[1]
+    old = dense._can_fuse_inference
+    dense._can_fuse_inference = lambda *a: False
+    try:
+        with torch.no_grad():
+            yr, _ = m(x)
+    finally:
+        dense._can_fuse_inference = old
+    assert (y - yr).abs().max() <= 2e-5 * yr.abs().max()
+    assert fused_bn_launches <= 3, fused_bn_launches        # only the strided conv / deblock links keep a separate BatchNorm pass
