@@ -166,9 +166,19 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
 }
 
 // da[q, g*64 + c] = sum_{tap, k} dz[q - (tap - 1), g*KM + k] * w[g][k][tap][c]
-template <int KM>
+// MODE 0 stores da.  MODE 1 / 2 are the BatchNorm backward of the fused (relu(bn(y)) -> tail) block computed ON the data
+// gradient instead of after it: da is recomputed in both passes and never stored (1.39 GB at B = 4, written once and read
+// twice by the separate kernels).  MODE 1: partial[slice][c] = (sum dr, sum dr * (y - mean)) with dr = da where
+// y * scale + shift > 0; MODE 2: dy = scale * dr + k2 * y + k0 (k0 / k2 from k_gtail_bn_final).
+struct GTailBn {
+  const float *y, *scale, *shift, *mean, *k0, *k2;
+  float* partial;
+};
+
+template <int KM, int MODE>
 __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ dz, const float* __restrict__ w,
-                                                     float* __restrict__ da, GTail t, int strip_rows, int strips) {
+                                                     float* __restrict__ da, GTail t, int strip_rows, int strips,
+                                                     GTailBn bn) {
   // Lane map and strip walk of k_gtail_fwd / k_gtail_wgrad: lane = (pixel column of a 4-wide strip, channel quad); the
   // lane's 9 * KM weight quads stay in registers, the 3 x 3 window of dz values slides down the strip (dz halo of the strip
   // staged once in LDS), one 16-byte store per pixel and lane.  (First version: lane = channel, a pixel per wave step, nine
@@ -201,10 +211,31 @@ __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ d
     for (int tap = 0; tap < 9; ++tap)
       wr[k][tap] = *reinterpret_cast<const float4*>(w + ((size_t)(g * KM + k) * 9 + tap) * kHC + 4 * cq);
   __syncthreads();
-  if (tx0 + 4 * wave >= t.W) return;
   const int px = 4 * wave + ps, gx = tx0 + px;
-  float* po = da + ((size_t)(b * t.H + ty0) * t.W + gx) * Ct + g * kHC + 4 * cq;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, bs, bt, bm, b0, b2;
+  if (MODE != 0) {
+    const int c0 = g * kHC + 4 * cq;
+    bs = *reinterpret_cast<const float4*>(bn.scale + c0);
+    bt = *reinterpret_cast<const float4*>(bn.shift + c0);
+    if (MODE == 1) bm = *reinterpret_cast<const float4*>(bn.mean + c0);
+    if (MODE == 2) {
+      b0 = *reinterpret_cast<const float4*>(bn.k0 + c0);
+      b2 = *reinterpret_cast<const float4*>(bn.k2 + c0);
+    }
+  }
+  if (tx0 + 4 * wave < t.W) {
+  const size_t o0 = ((size_t)(b * t.H + ty0) * t.W + gx) * Ct + g * kHC + 4 * cq;
+  float* po = da + o0;
   const size_t rstride = (size_t)t.W * Ct;
+  // y rows are fetched kYD rows ahead of their use through a register ring (a load issued where its row is used exposes the
+  // full HBM latency per row at two waves per SIMD: 2.7 TB/s); rows past the image are clamped, never used
+  constexpr int kYD = 4;
+  const float* ybase = MODE != 0 ? bn.y + ((size_t)b * t.H * t.W + min(gx, t.W - 1)) * Ct + g * kHC + 4 * cq : nullptr;
+  float4 yq[kYD];
+  if (MODE != 0) {
+#pragma unroll
+    for (int i = 0; i < kYD; ++i) yq[i] = *reinterpret_cast<const float4*>(ybase + (size_t)min(ty0 + i, t.H - 1) * rstride);
+  }
   float4 zw[kTH + 2][3];                              // zw[r][d]: dz of output pixel (block row - 1 + r, px - 1 + d)
   const float4* zp = s_z + px;
 #pragma unroll
@@ -232,14 +263,81 @@ __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ d
           o.w = fmaf(zk[k], wr[k][tap].w, o.w);
         }
       }
-      if (y0 + y < y_end && gx < t.W) *reinterpret_cast<float4*>(po) = o;
+      if (y0 + y < y_end && gx < t.W) {
+        if (MODE == 0) {
+          *reinterpret_cast<float4*>(po) = o;
+        } else {
+          const float4 yv = yq[y % kYD];
+          o.x = fmaf(yv.x, bs.x, bt.x) > 0.f ? o.x : 0.f;
+          o.y = fmaf(yv.y, bs.y, bt.y) > 0.f ? o.y : 0.f;
+          o.z = fmaf(yv.z, bs.z, bt.z) > 0.f ? o.z : 0.f;
+          o.w = fmaf(yv.w, bs.w, bt.w) > 0.f ? o.w : 0.f;
+          if (MODE == 1) {
+            s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
+            s2.x = fmaf(o.x, yv.x - bm.x, s2.x);
+            s2.y = fmaf(o.y, yv.y - bm.y, s2.y);
+            s2.z = fmaf(o.z, yv.z - bm.z, s2.z);
+            s2.w = fmaf(o.w, yv.w - bm.w, s2.w);
+          } else {
+            float4 r;
+            r.x = fmaf(bs.x, o.x, fmaf(b2.x, yv.x, b0.x));
+            r.y = fmaf(bs.y, o.y, fmaf(b2.y, yv.y, b0.y));
+            r.z = fmaf(bs.z, o.z, fmaf(b2.z, yv.z, b0.z));
+            r.w = fmaf(bs.w, o.w, fmaf(b2.w, yv.w, b0.w));
+            *reinterpret_cast<float4*>(po) = r;
+          }
+        }
+      }
       po += rstride;
+      if (MODE != 0)
+        yq[y % kYD] = *reinterpret_cast<const float4*>(ybase + (size_t)min(y0 + y + kYD, t.H - 1) * rstride);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int d = 0; d < 3; ++d) zw[i][d] = zw[i + kTH][d];
   }
+  }
+  if (MODE == 1) {
+    // fixed-order sum over the workgroup's 16 pixel columns (4 per wave x 4 waves), one (sum, sum * centred) pair per channel
+    __shared__ float4 red[2][16][16];
+    red[0][4 * wave + ps][cq] = s1;
+    red[1][4 * wave + ps][cq] = s2;
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      const float* rp = reinterpret_cast<const float*>(&red[which][0][0]) + c;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += rp[i * 64];
+      bn.partial[((size_t)blockIdx.y * Ct + g * kHC + c) * 2 + which] = a;
+    }
+  }
+}
+
+// dgamma / dbeta and the two per-channel constants of the dy pass (the k_bn_bwd_final of bn_act.hip on this layout)
+__global__ void k_gtail_bn_final(const float* __restrict__ partial, int slices, int C, long long P,
+                                 const float* __restrict__ scale, const float* __restrict__ mean,
+                                 const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                 float* __restrict__ k0, float* __restrict__ k2) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float a = 0.f, q = 0.f;
+  for (int s = lane; s < slices; s += 64) {
+    a += partial[((size_t)s * C + c) * 2];
+    q += partial[((size_t)s * C + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane != 0) return;
+  const float is = invstd[c], dg = q * is, inv_p = 1.0f / (float)P;
+  dbeta[c] = a;
+  dgamma[c] = dg;
+  const float kk2 = -scale[c] * (dg * inv_p) * is;
+  k2[c] = kk2;
+  k0[c] = -scale[c] * (a * inv_p) - kk2 * mean[c];
 }
 
 // partial[slice][g][k][tap][c] = sum over the slice's tiles of a[q, c] * dz[q - (tap - 1), k]
@@ -433,11 +531,69 @@ extern "C" int ud_head_tail_f32_dgrad(const float* dz, const float* w, float* da
   while (strip_rows > kTH && (long long)G * B * t.tiles_x * ud_div_up(H, strip_rows) < 2048) strip_rows -= kTH;
   const int strips = ud_div_up(H, strip_rows);
   const dim3 grid(G, B * t.tiles_x * strips);
+  const GTailBn none{};
   switch (KM) {
-    case 1: k_gtail_dgrad<1><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
-    case 2: k_gtail_dgrad<2><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
-    case 3: k_gtail_dgrad<3><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
-    default: k_gtail_dgrad<4><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips); break;
+    case 1: k_gtail_dgrad<1, 0><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips, none); break;
+    case 2: k_gtail_dgrad<2, 0><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips, none); break;
+    case 3: k_gtail_dgrad<3, 0><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips, none); break;
+    default: k_gtail_dgrad<4, 0><<<grid, 256, 0, stream>>>(dz, w, da, t, strip_rows, strips, none); break;
+  }
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+static void gtail_bn_grid(const GTail& t, int* strip_rows, int* strips) {
+  int sr = kStripMax;
+  while (sr > kTH && (long long)t.G * t.B * t.tiles_x * ud_div_up(t.H, sr) < 2048) sr -= kTH;
+  *strip_rows = sr;
+  *strips = ud_div_up(t.H, sr);
+}
+
+extern "C" size_t ud_head_tail_f32_bn_bwd_workspace_bytes(int B, int H, int W, int G, int KM) {
+  if (!gtail_ok(B, H, W, G, KM)) return 0;
+  GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
+  int strip_rows, strips;
+  gtail_bn_grid(t, &strip_rows, &strips);
+  const size_t C = (size_t)G * kHC;
+  return ud_align_up(((size_t)B * t.tiles_x * strips * C * 2 + 2 * C) * sizeof(float));
+}
+
+extern "C" int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const float* y, const float* bn_scale,
+                                       const float* bn_shift, const float* mean, const float* invstd, float* dy,
+                                       float* dgamma, float* dbeta, int B, int H, int W, int G, int KM, void* workspace,
+                                       size_t workspace_bytes, ud_stream_t stream_) {
+  if (!dz || !w || !y || !bn_scale || !bn_shift || !mean || !invstd || !dy || !dgamma || !dbeta || !gtail_ok(B, H, W, G, KM))
+    return UD_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < ud_head_tail_f32_bn_bwd_workspace_bytes(B, H, W, G, KM)) return UD_ERR_WORKSPACE;
+  GTail t{B, H, W, G, KM, ud_div_up(W, kTW), ud_div_up(H, kTH)};
+  hipStream_t stream = (hipStream_t)stream_;
+  int strip_rows, strips;
+  gtail_bn_grid(t, &strip_rows, &strips);
+  const int slices = B * t.tiles_x * strips, C = G * kHC;
+  const dim3 grid(G, slices);
+  float* partial = (float*)workspace;
+  float* k0 = partial + (size_t)slices * C * 2;
+  float* k2 = k0 + C;
+  GTailBn bn{y, bn_scale, bn_shift, mean, k0, k2, partial};
+  {
+    UdProfScope prof("head_tail.k_gtail_bn_bwd_reduce", stream);
+    switch (KM) {
+      case 1: k_gtail_dgrad<1, 1><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+      case 2: k_gtail_dgrad<2, 1><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+      case 3: k_gtail_dgrad<3, 1><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+      default: k_gtail_dgrad<4, 1><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+    }
+    UD_LAUNCH_CHECK();
+    k_gtail_bn_final<<<C, 64, 0, stream>>>(partial, slices, C, (long long)B * H * W, bn_scale, mean, invstd, dgamma, dbeta,
+                                           k0, k2);
+    UD_LAUNCH_CHECK();
+  }
+  UdProfScope prof("head_tail.k_gtail_bn_bwd_dx", stream);
+  switch (KM) {
+    case 1: k_gtail_dgrad<1, 2><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+    case 2: k_gtail_dgrad<2, 2><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+    case 3: k_gtail_dgrad<3, 2><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+    default: k_gtail_dgrad<4, 2><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
   }
   UD_LAUNCH_CHECK();
   return UD_OK;

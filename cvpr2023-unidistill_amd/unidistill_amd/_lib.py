@@ -147,6 +147,8 @@ _SIGS = {
     "ud_head_tail_f32_bn_fwd": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "ud_head_tail_f32_bn_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_f32_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "ud_head_tail_f32_bn_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
+    "ud_head_tail_f32_bn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_f32_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_head_tail_f32_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_bn_stats_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7

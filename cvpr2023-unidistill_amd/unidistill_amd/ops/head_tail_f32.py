@@ -58,11 +58,14 @@ def group_tail(a, weight, bias, G, KM):
     return _GroupTail.apply(a, weight, bias, G, KM)
 
 
+FUSED_BN_BWD = True     # False: tail dgrad -> stored gradient -> ud_bn_act_bwd_f32 (the measured alternative)
+
+
 class _BnReluGroupTail(torch.autograd.Function):
     """relu(bn(y)) -> 42 grouped second convolutions with BatchNorm + ReLU applied as the tail kernels LOAD the first
     convolution's raw output y (ud_head_tail_f32_bn_fwd / _bn_wgrad): the normalised hidden tensor (1.39 GB at B = 4) is
     neither written nor read back -- forward: 2 passes over it instead of 4; backward: the tail's weight gradient reads y, its
-    data gradient feeds the BatchNorm backward (ud_bn_act_bwd_f32, ReLU mask recomputed from y) directly."""
+    data gradient is recomputed inside the two BatchNorm-backward passes (ud_head_tail_f32_bn_bwd), never stored."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, tracked, partial, weight, bias, G, KM):
@@ -106,16 +109,22 @@ class _BnReluGroupTail(torch.autograd.Function):
                                                      G, KM, _lib.ptr(ws), ws.numel(), st), "ud_head_tail_f32_bn_wgrad")
             dw = dwt.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            da = torch.empty_like(y)                     # gradient at relu(bn(y))
-            _lib.check(lib.ud_head_tail_f32_dgrad(_lib.ptr(dz), _lib.ptr(wt), _lib.ptr(da), B, H, W, G, KM, st),
-                       "ud_head_tail_f32_dgrad")
             dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
-            bws = bn_act._workspace(y.device, C)
             g0 = dgb.data_ptr()
             dy = torch.empty_like(y)
-            _lib.check(lib.ud_bn_act_bwd_f32(y.data_ptr(), None, da.data_ptr(), v0 + 3 * row, v0 + 4 * row, v0, v0 + 2 * row,
-                                             dy.data_ptr(), None, g0, g0 + row, P, C, 1, bws.data_ptr(), bws.numel(), st),
-                       "ud_bn_act_bwd")
+            if FUSED_BN_BWD:     # the tail's data gradient is recomputed inside both BatchNorm-backward passes, never stored
+                bws = _lib.workspace(y.device, lib.ud_head_tail_f32_bn_bwd_workspace_bytes(B, H, W, G, KM), "head_tail_f32_bn")
+                _lib.check(lib.ud_head_tail_f32_bn_bwd(_lib.ptr(dz), _lib.ptr(wt), y.data_ptr(), v0 + 3 * row, v0 + 4 * row, v0,
+                                                       v0 + 2 * row, dy.data_ptr(), g0, g0 + row, B, H, W, G, KM,
+                                                       _lib.ptr(bws), bws.numel(), st), "ud_head_tail_f32_bn_bwd")
+            else:
+                da = torch.empty_like(y)                     # gradient at relu(bn(y))
+                _lib.check(lib.ud_head_tail_f32_dgrad(_lib.ptr(dz), _lib.ptr(wt), _lib.ptr(da), B, H, W, G, KM, st),
+                           "ud_head_tail_f32_dgrad")
+                bws = bn_act._workspace(y.device, C)
+                _lib.check(lib.ud_bn_act_bwd_f32(y.data_ptr(), None, da.data_ptr(), v0 + 3 * row, v0 + 4 * row, v0,
+                                                 v0 + 2 * row, dy.data_ptr(), None, g0, g0 + row, P, C, 1, bws.data_ptr(),
+                                                 bws.numel(), st), "ud_bn_act_bwd")
             dgamma, dbeta = dgb[0], dgb[1]
         if has_bias and ctx.needs_input_grad[11]:
             db = dz.sum((0, 2, 3))

@@ -436,6 +436,12 @@ int ud_head_tail_f32_bn_fwd(const float* a, const float* bn_scale, const float* 
                             float* z, int B, int H, int W, int G, int KM, ud_stream_t stream);
 int ud_head_tail_f32_bn_wgrad(const float* a, const float* bn_scale, const float* bn_shift, const float* dz, float* dw, int B,
                               int H, int W, int G, int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+/* Backward of relu(bn(y)) -> second convolutions down to y in two passes that RECOMPUTE the tail's data gradient instead of
+ * storing it: dgamma / dbeta [G*64] (training-mode statistics: mean / invstd of y, folded scale / shift) and dy [B, H, W, G*64]. */
+size_t ud_head_tail_f32_bn_bwd_workspace_bytes(int B, int H, int W, int G, int KM);
+int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const float* y, const float* bn_scale, const float* bn_shift,
+                            const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W,
+                            int G, int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* ---- Dense 3x3 / stride 1 / pad 1 convolution, channels-last bf16 (BEV trunk + head convs) ----------
  * Replaces nn.Conv2d(k=3, s=1, p=1) of BaseBEVBackbone (reference unidistill/layers/blocks_2d/det3d/

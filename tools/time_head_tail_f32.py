@@ -24,3 +24,21 @@ for k in ("k_gtail_fwd", "k_gtail_dgrad", "k_gtail_wgrad"):
     ms, n = _lib.prof_read("head_tail." + k)
     t = ms / max(n, 1)
     print(f"{k:16s} {t*1e3:8.1f} us   ({gb/t:6.2f} TB/s over the 1.39 GB hidden tensor)")
+
+# the BatchNorm-fused block: relu(bn(y)) -> tail, backward down to y
+gamma = torch.rand(G * 64, device=d).add_(0.5).requires_grad_(True)
+beta = (torch.randn(G * 64, device=d) * 0.1).requires_grad_(True)
+rm, rv = torch.zeros(G * 64, device=d), torch.ones(G * 64, device=d)
+for fused in (True, False):
+  h.FUSED_BN_BWD = fused; print('fused BN backward' if fused else 'separate dgrad + BN backward')
+  for i in range(7):
+      if i == 2:
+          torch.cuda.synchronize(); _lib.prof_enable(True)
+      z = h.bn_relu_group_tail(a, gamma, beta, rm, rv, True, 0.1, 1e-5, None, None, w, b, G, KM); z.backward(gz)
+  torch.cuda.synchronize(); _lib.prof_enable(False)
+  for k in ("head_tail.k_gtail_fwd", "head_tail.k_gtail_wgrad", "head_tail.k_gtail_bn_bwd_reduce",
+            "head_tail.k_gtail_bn_bwd_dx", "head_tail.k_gtail_dgrad", "bn_act.k_bwd_reduce", "bn_act.k_bwd_dx"):
+      ms, n = _lib.prof_read(k)
+      if n:
+          t = ms / n
+          print(f"{k:34s} {t*1e3:8.1f} us   ({gb/t:6.2f} TB/s over 1.39 GB)")
