@@ -15,7 +15,7 @@ from torch import nn
 
 from . import config as C
 from . import _lib
-from .dist import get_world_size, reduce_mean_many
+from .dist import get_world_size, is_distributed, reduce_mean_many
 from .models import BEVFusionCenterHead
 from .ops import distill as D
 
@@ -206,7 +206,8 @@ class Trainer:
         self.module.train()
         trainable = [p for p in self.module.parameters() if p.requires_grad]
         self.ddp = None
-        if get_world_size() > 1:
+        # UD_FORCE_DDP=1: wrap even a one-rank process group (the RCCL path exercised on a one-GPU box)
+        if get_world_size() > 1 or (is_distributed() and os.environ.get("UD_FORCE_DDP") == "1"):
             # DDP compares gradient strides with its bucket views literally; a 1x1 (transposed) convolution's weight
             # gradient comes back from the channels-last kernels with different strides on its size-1 axes (same
             # memory), which would cost a warning and a copy per step: re-label the strides, no data movement.

@@ -68,3 +68,40 @@ def test_two_rank_rccl_ddp_step(hip_lib, tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", "29534", str(path)]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and res.stdout.count("NCCL_OK") == 2, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path[:0] = [{root!r}, {pkg!r}]
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))         # RCCL communicator of one rank
+from unidistill_amd import train, dist as ud
+t = torch.arange(8, device="cuda", dtype=torch.float32)
+dist.all_reduce(t)
+assert torch.equal(t, torch.arange(8, device="cuda", dtype=torch.float32))
+assert float(ud.reduce_mean(torch.tensor(3.0, device="cuda"))) == 3.0
+torch.manual_seed(0)
+tr = train.Trainer(train.DistillStep("camera_exp_distill_lidar"), device=torch.device("cuda", 0), channels_last=True)
+assert tr.ddp is not None, "UD_FORCE_DDP did not wrap the step"
+batch = train.synthetic_batch(torch.device("cuda", 0), 1, rank=0)
+for _ in range(2):                              # the second step is the one that trips over unused parameters
+    out = tr.step(batch)
+assert torch.isfinite(out["loss"])
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+'''
+
+
+def test_one_rank_rccl_ddp_distill_step(hip_lib, tmp_path):
+    """The RCCL code path on a one-GPU box: backend "nccl" with ONE rank (communicator creation, bucketed gradient
+    all-reduce through DistributedDataParallel with bucket views, barrier, teardown) around two distillation steps
+    of the benchmark workload.  What it cannot show is a second peer; `test_two_rank_rccl_ddp_step` does, on two GPUs."""
+    from conftest import PKG
+    script = _RCCL_ONE_RANK.format(root=ROOT, pkg=PKG)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UD_FORCE_DDP="1", UD_RANDOM_INIT="1")
+    path = tmp_path / "rccl_one_rank.py"
+    path.write_text(script)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29536", str(path)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "RCCL_ONE_RANK_OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
