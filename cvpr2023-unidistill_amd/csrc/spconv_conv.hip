@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_v2(const float* __restrict__ 
   int* s_row = s_nbr + K * kTM2 + 4;                    // [kTM2] output row of each tile row (-1: none)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int row0 = blockIdx.x * kTM2;
+  const int row0 = (int)(gridDim.x - 1u - blockIdx.x) * kTM2;   // mask-sorted rows: the tiles with the most active offsets sit at the end -> dispatch them first (longest first)
   if (tid == 0) s_active = 0u;
   __syncthreads();
   // tile row -> output row: identity, or the caller's mask-sorted order (rows with similar
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16(const float* __restrict_
   int* s_row = s_nbr + K * kTM2 + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int row0 = blockIdx.x * kTM2;
+  const int row0 = (int)(gridDim.x - 1u - blockIdx.x) * kTM2;   // mask-sorted rows: the tiles with the most active offsets sit at the end -> dispatch them first (longest first)
   if (tid == 0) s_active = 0u;
   if (tid < kTM2) {
     const int p = row0 + tid;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16_fast(
   float* Os = reinterpret_cast<float*>(smem);       // [kTM2][LDO], aliases As/Bs after the K loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int row0 = blockIdx.x * kTM2;
+  const int row0 = (int)(gridDim.x - 1u - blockIdx.x) * kTM2;   // mask-sorted rows: the tiles with the most active offsets sit at the end -> dispatch them first (longest first)
   if (tid == 0) s_active = 0u;
   if (tid < kTM2) {
     const int p = row0 + tid;
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(512) void k_conv_mfma_bf16_dma(
   float* Os = reinterpret_cast<float*>(smem);       // [kTM2][LDO], aliases As/Bs after the K loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int row0 = blockIdx.x * kTM2;
+  const int row0 = (int)(gridDim.x - 1u - blockIdx.x) * kTM2;   // mask-sorted rows: the tiles with the most active offsets sit at the end -> dispatch them first (longest first)
   if (tid == 0) s_active = 0u;
   if (tid < kTM2) {
     const int p = row0 + tid;
@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
-  const int row0 = blockIdx.x * kTM2;
+  const int row0 = (int)(gridDim.x - 1u - blockIdx.x) * kTM2;   // mask-sorted rows: the tiles with the most active offsets sit at the end -> dispatch them first (longest first)
   const float* zero = reinterpret_cast<const float*>(g_zero16s);
   if (tid == 0) s_active = 0u;
   if (tid < kTM2) {

@@ -203,9 +203,17 @@ def mask_order(nbr, mirror=False):
         if K > 31 or nbr.shape[0] == 0:
             order = False
         else:
-            bits = (1 << torch.arange(K, device=nbr.device, dtype=torch.int32))
-            mask = ((nbr >= 0).int() * bits[None, :]).sum(1, dtype=torch.int32)
-            order = torch.argsort(mask).int().contiguous()
+            # bit weights by rarity (no host read): the most frequent offset (the centre, the in-plane faces) gets
+            # bit 0, the rarest (the corners) the top bits -- rows then group by their RARE neighbours first, which
+            # leaves a tile fewer active offsets than the plain offset-index weights (20.2 vs 20.6 of 27 at the
+            # 128-channel level, 0.915 vs 0.902 useful MFMA rows per wave).  Ascending sort = tiles with the most
+            # active offsets last; the kernels dispatch the LAST tile first (longest first).
+            act = nbr >= 0
+            by_freq = torch.argsort(act.sum(0), descending=True, stable=True)
+            bits = torch.zeros(K, device=nbr.device, dtype=torch.int32)
+            bits[by_freq] = 1 << torch.arange(K, device=nbr.device, dtype=torch.int32)
+            mask = (act.int() * bits[None, :]).sum(1, dtype=torch.int32)
+            order = torch.argsort(mask, stable=True).int().contiguous()
         setattr(nbr, key, order)
     return None if order is False else order
 
