@@ -1541,15 +1541,19 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
   // DMA of one stage: pieces are dealt to the 8 waves round-robin; lane -> (row 4 p + g, LDS slot li <- source slot li ^ (row & 15))
   auto stage = [&](int k, int half, int buf) {
     char* sb = smem + buf * kStage;
-    for (int p = wave; p < kAPieces; p += 8) {
-      const int r = 4 * p + g;
-      const int rr = s_nbr[k * kTM2 + r];
-      const float* src = rr >= 0 ? in + (size_t)rr * CIN + half * 64 + ((li ^ (r & 15)) << 2) : zero;
+    int rr[kAPieces / 8];
+#pragma unroll
+    for (int i = 0; i < kAPieces / 8; ++i) rr[i] = s_nbr[k * kTM2 + 4 * (wave + 8 * i) + g];     // one LDS round trip, not four
+#pragma unroll
+    for (int i = 0; i < kAPieces / 8; ++i) {
+      const int p = wave + 8 * i, r = 4 * p + g;
+      const float* src = rr[i] >= 0 ? in + (size_t)rr[i] * CIN + half * 64 + ((li ^ (r & 15)) << 2) : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sb + p * 1024), 16, 0, 0);
     }
-    for (int p = wave; p < kWPieces; p += 8) {
-      const int n = 4 * p + g;
+#pragma unroll
+    for (int i = 0; i < kWPieces / 8; ++i) {
+      const int p = wave + 8 * i, n = 4 * p + g;
       const float* src = W + (size_t)n * ws.sn + (size_t)k * ws.sk + half * 64 + ((li ^ (n & 15)) << 2);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sb + kAB + p * 1024), 16, 0, 0);
