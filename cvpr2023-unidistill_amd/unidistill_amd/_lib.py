@@ -107,6 +107,9 @@ _SIGS = {
                                           + [c_void_p, c_size_t, c_void_p]),
     "ud_image_normalize": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "ud_collate_pad": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p]),
+    "ud_stem_pack_weights": (c_int, [c_void_p] + [c_i64] * 4 + [c_void_p]),
+    "ud_stem_conv7x7_bn_relu": (c_int, [c_void_p] + [c_i64] * 4 + [c_int] * 3 + [c_void_p] * 4 + [c_int, c_void_p]),
+    "ud_maxpool3x3s2_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "ud_conv1x1_wgrad_workspace_bytes": (c_size_t, [c_i64, c_int, c_int]),
     "ud_conv3x3_wgrad_f32_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_conv3x3_wgrad_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),

@@ -1,4 +1,5 @@
-"""Image branch: ResNet-50 backbone + SECONDFPN neck in plain PyTorch-ROCm (MIOpen convs).
+"""Image branch: ResNet-50 backbone + SECONDFPN neck on the HIP convolution / BatchNorm kernels (layers/dense.py); the frozen
+7x7 stem + max-pool run on csrc/stem.hip.
 
 The reference builds these through mmdet / mmdet3d (lss_fpn.py:143-149, configs
 BEVFusion_nuscenes_centerhead_fusion_exp.py:24-39); neither package nor its source is part of the
@@ -13,6 +14,7 @@ import torch
 from torch import nn
 
 from .dense import Conv2d, ConvTranspose2d, FusedSequential, batchnorm_act
+from ..ops import stem as hipstem
 
 
 def _resolve_checkpoint(spec):
@@ -61,6 +63,7 @@ class Bottleneck(nn.Module):
 class ResNet(nn.Module):
     """ResNet-50/101 trunk returning the feature maps listed in ``out_indices``."""
     arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+    hip_stem = True            # class-wide switch (tests / A-B timing)
 
     def __init__(self, depth=50, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_eval=False,
                  init_cfg=None, **_):
@@ -133,8 +136,26 @@ class ResNet(nn.Module):
             else:
                 warnings.warn(f"ResNet init_cfg checkpoint {spec!r} not found: Kaiming initialisation kept")
 
+    def stem_takes_any_layout(self, x):
+        """True when the stem runs on the HIP kernel, which reads x through its strides (no layout copy needed in front)."""
+        w, mp = self.conv1.weight, self.maxpool
+        if not ResNet.hip_stem:
+            return False
+        return bool(Conv2d.hip_enabled and x.is_cuda and w.is_contiguous(memory_format=torch.channels_last)
+                    and not w.is_contiguous() and hipstem.supported(x, self.conv1, self.bn1)
+                    and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False))
+
+    def _hip_stem(self, x):
+        """The frozen stem on csrc/stem.hip (conv1 + eval bn1 + ReLU in one fp32-MFMA kernel, then the max-pool): NHWC models
+        only (the stem filter in channels-last memory is the model's layout flag, see train.to_channels_last)."""
+        if not self.stem_takes_any_layout(x):
+            return None
+        ac = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        return hipstem.stem(x, self.conv1, self.bn1, torch.bfloat16 if ac else torch.float32)
+
     def forward(self, x):
-        x = self.maxpool(batchnorm_act(self.bn1, self.conv1(x)))
+        y = self._hip_stem(x)
+        x = self.maxpool(batchnorm_act(self.bn1, self.conv1(x))) if y is None else y
         outs = []
         for i in range(4):
             x = getattr(self, f"layer{i + 1}")(x)

@@ -93,7 +93,10 @@ class LSSFPN(nn.Module):
         B, S, N, C, H, W = imgs.shape
         x = imgs.reshape(B * S * N, C, H, W)
         w = next((p for p in self.img_backbone.parameters() if p.dim() == 4), None)   # the stem convolution
-        if w is not None and w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous():
+        any_layout = getattr(self.img_backbone, "stem_takes_any_layout", None)
+        if any_layout is not None and any_layout(x):
+            pass                                                       # the HIP stem reads the images through their strides
+        elif w is not None and w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous():
             x = x.contiguous(memory_format=torch.channels_last)        # NHWC model -> NHWC input
         f = self.img_neck(self.img_backbone(x))[0]
         return f.reshape(B, S, N, f.shape[1], f.shape[2], f.shape[3])

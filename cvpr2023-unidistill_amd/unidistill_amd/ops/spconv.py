@@ -209,11 +209,12 @@ def mask_order(nbr, mirror=False):
             # 128-channel level, 0.915 vs 0.902 useful MFMA rows per wave).  Ascending sort = tiles with the most
             # active offsets last; the kernels dispatch the LAST tile first (longest first).
             act = nbr >= 0
-            by_freq = torch.argsort(act.sum(0), descending=True, stable=True)
+            # offset frequencies from every (M / 4096)-th row: a column sum over all rows costs 1.1 ms per rulebook
+            by_freq = torch.argsort(act[::max(1, nbr.shape[0] // 4096)].sum(0), descending=True, stable=True)
             bits = torch.zeros(K, device=nbr.device, dtype=torch.int32)
             bits[by_freq] = 1 << torch.arange(K, device=nbr.device, dtype=torch.int32)
             mask = (act.int() * bits[None, :]).sum(1, dtype=torch.int32)
-            order = torch.argsort(mask, stable=True).int().contiguous()
+            order = torch.argsort(mask).int().contiguous()
         setattr(nbr, key, order)
     return None if order is False else order
 

@@ -594,6 +594,22 @@ int ud_image_normalize(const unsigned char* img, float* out, const float* mean, 
 int ud_collate_pad(const float* const* samples, const int64_t* rows, int B, int64_t L, int W, float* out,
                    ud_stream_t stream);
 
+/* ---- frozen ResNet stem (image branch) ----------------------------------------------------------------
+ * conv1 (7x7 / stride 2 / pad 3, 3 -> 64, no bias) + bn1 (eval mode, folded to scale / shift) + ReLU, then max-pool 3x3 /
+ * stride 2 / pad 1, of the mmdet ResNet-50 the reference builds in unidistill/layers/blocks_3d/mmdet3d/lss_fpn.py:143-149 with
+ * frozen_stages = 0 (exps/.../BEVFusion_nuscenes_centerhead_fusion_exp.py:24-31).  Forward only (the stem takes no gradient).
+ *   ud_stem_pack_weights     : HOST helper: w = host pointer to the [64][3][7][7] filters (strides in floats) ->
+ *                              packed f32[7*6*4*16*4] in the kernel's MFMA operand order (once per frozen filter)
+ *   ud_stem_conv7x7_bn_relu  : x f32 [B][3][H][W] through its strides in floats (NCHW planes or channels-last memory),
+ *                              packed_w / scale[64] / shift[64] device f32 -> y [B][OH][OW][64] channels-last, f32 or bf16
+ *                              (OH = (H - 1) / 2 + 1, same for OW); fp32 MFMA, exact products
+ *   ud_maxpool3x3s2_nhwc     : x [B][H][W][C] -> y [B][(H - 1) / 2 + 1][(W - 1) / 2 + 1][C], f32 (C % 4 == 0) or bf16 (C % 8 == 0) */
+int ud_stem_pack_weights(const float* w, int64_t sn, int64_t sc, int64_t sky, int64_t skx, float* packed);
+int ud_stem_conv7x7_bn_relu(const float* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int H, int W,
+                            const float* packed_w, const float* scale, const float* shift, void* y, int out_bf16,
+                            ud_stream_t stream);
+int ud_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int is_bf16, ud_stream_t stream);
+
 /* ---- BatchNorm2d (+ residual) (+ ReLU), channels-last bf16 ------------------------------------------
  * The Conv2d -> BatchNorm2d -> ReLU links of the reference's dense layers (base_bev_backbone.py:48-66,
  * center_head.py:408-420, the mmdet ResNet bottlenecks) as HBM-bound streaming kernels over
