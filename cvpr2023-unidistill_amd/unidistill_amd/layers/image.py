@@ -150,7 +150,7 @@ class ResNet(nn.Module):
         only (the stem filter in channels-last memory is the model's layout flag, see train.to_channels_last)."""
         if not self.stem_takes_any_layout(x):
             return None
-        ac = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        ac = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
         return hipstem.stem(x, self.conv1, self.bn1, torch.bfloat16 if ac else torch.float32)
 
     def forward(self, x):

@@ -53,5 +53,5 @@ python $T/traffic_json.py $R $(ls /tmp/pmc1/*/*.db | head -1) $(ls /tmp/pmc2/*/*
 rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T/time_spconv.py > $OUT/spconv_stdout.txt 2>&1
 { echo "# LiDAR sparse encoder forward, B=4 x 30k points ($R)"; echo; echo '```'; grep "encoder fwd" $OUT/spconv_stdout.txt; echo '```'; echo; python $T/rocpd_summary.py $(ls /tmp/p_sp/*/*.db | head -1) namespace | head -30; } > $OUT/${R}_spconv_encoder.md
 # 7. fp32 convolutions: ours vs library (forward / data gradient, and the weight gradients of one step)
-{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels (direct and Winograd F(2x2,3x3)) vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py; 3x3: Winograd form, last column = the direct kernel):"; python $T/time_f32_wgrad.py 2>&1 | tail -22; echo; echo "-- plain 1x1 launches of one step (tools/time_f32_1x1.py):"; python $T/time_f32_1x1.py 2>&1 | grep -E "kind|line|total"; echo '```'; } > $OUT/${R}_conv_f32.md
+{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels (direct and Winograd F(2x2,3x3)) vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py; 3x3: Winograd form, last column = the direct kernel):"; python $T/time_f32_wgrad.py 2>&1 | tail -22; echo; echo "-- plain 1x1 launches of one step (tools/time_f32_1x1.py):"; python $T/time_f32_1x1.py 2>&1 | grep -E "kind|line|total"; echo; echo "-- frozen ResNet stem, 24 x 256 x 704 (tools/time_stem.py):"; python $T/time_stem.py 2>&1 | grep "us "; echo '```'; } > $OUT/${R}_conv_f32.md
 ls -la $OUT
