@@ -56,6 +56,8 @@ _SIGS = {
     "ud_spconv_wgrad_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_spconv_wgrad_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t,
                                                                    c_void_p]),
+    "ud_spconv_mask_order_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ud_spconv_mask_order": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_spconv_tile_masks": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ud_sparse_bev_workspace_bytes": (c_size_t, [c_int] * 4),
     "ud_sparse_to_bev_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -203,18 +203,17 @@ def mask_order(nbr, mirror=False):
         if K > 31 or nbr.shape[0] == 0:
             order = False
         else:
-            # bit weights by rarity (no host read): the most frequent offset (the centre, the in-plane faces) gets
-            # bit 0, the rarest (the corners) the top bits -- rows then group by their RARE neighbours first, which
-            # leaves a tile fewer active offsets than the plain offset-index weights (20.2 vs 20.6 of 27 at the
-            # 128-channel level, 0.915 vs 0.902 useful MFMA rows per wave).  Ascending sort = tiles with the most
-            # active offsets last; the kernels dispatch the LAST tile first (longest first).
-            act = nbr >= 0
-            # offset frequencies from every (M / 4096)-th row: a column sum over all rows costs 1.1 ms per rulebook
-            by_freq = torch.argsort(act[::max(1, nbr.shape[0] // 4096)].sum(0), descending=True, stable=True)
-            bits = torch.zeros(K, device=nbr.device, dtype=torch.int32)
-            bits[by_freq] = 1 << torch.arange(K, device=nbr.device, dtype=torch.int32)
-            mask = (act.int() * bits[None, :]).sum(1, dtype=torch.int32)
-            order = torch.argsort(mask).int().contiguous()
+            # one C-ABI call (ud_spconv_mask_order): offset frequencies from a row sample, bit weights by rarity -- the
+            # most frequent offset (the centre, the in-plane faces) gets bit 0, the rarest (the corners) the top bits, so
+            # rows group by their RARE neighbours first (20.2 vs 20.6 of 27 active offsets per tile at the 128-channel
+            # level, 0.915 vs 0.902 useful MFMA rows per wave) -- masks, and a stable radix sort over the K mask bits.
+            # Ascending = tiles with the most active offsets last; the kernels dispatch the LAST tile first.
+            lib = _lib.load()
+            M = nbr.shape[0]
+            ws = _lib.workspace(nbr.device, lib.ud_spconv_mask_order_workspace_bytes(M, K), "mask_order")
+            order = torch.empty(M, dtype=torch.int32, device=nbr.device)
+            _lib.check(lib.ud_spconv_mask_order(_lib.ptr(nbr), M, K, _lib.ptr(order), _lib.ptr(ws), ws.numel(),
+                                                _lib.stream_of(nbr)), "ud_spconv_mask_order")
         setattr(nbr, key, order)
     return None if order is False else order
 

@@ -275,6 +275,11 @@ int ud_spconv_wgrad_bf16(const void* in, const int32_t* nbr, const void* gout, f
  * a pair at offset k; computed internally when NULL.  It depends on the rulebook only. */
 int ud_spconv_tile_masks(const int32_t* nbr, int Mout, int K, const int32_t* row_order, unsigned* masks,
                          ud_stream_t stream);
+/* Row order of a rulebook for the kernels above (`row_order`): rows sorted (stable) by their neighbour bit mask, the bit of
+ * offset k weighted by its rarity among ~4 096 sampled rows (rarest on top).  order: i32[Mout].  K <= 31. */
+size_t ud_spconv_mask_order_workspace_bytes(int Mout, int K);
+int ud_spconv_mask_order(const int32_t* nbr, int Mout, int K, int32_t* order, void* workspace, size_t workspace_bytes,
+                         ud_stream_t stream);
 /* Mixed-precision inference variant: the bf16-operand MFMA kernel (algo 3 above) with bf16 tensors in
  * HBM so the gather moves half the bytes.  io_flags bit 0: `in` is bf16 [*, Cin] (Cin % 4 == 0);
  * bit 1: `out` and `ep_residual` are bf16 [Mout, Cout]; bit 2: `W` is bf16 (w_sc == 1).  K <= 32. */

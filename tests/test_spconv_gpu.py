@@ -317,3 +317,23 @@ def test_bf16_weight_gradient_many_tiles_per_chunk(cin, cout):
     np.testing.assert_allclose(a.cpu().numpy(), ref, **_tol(ref))
     c = run(nbr, g16, 1, None, None)                                                          # nothing permuted
     np.testing.assert_allclose(c.cpu().numpy(), ref, **_tol(ref))
+
+
+@pytest.mark.parametrize("M,K", [(1251, 27), (70000, 27), (5, 3), (4096 * 3 + 17, 8)])
+def test_mask_order_vs_numpy(M, K):
+    """ud_spconv_mask_order (offset ranks from sampled rows, rarity-weighted masks, stable radix sort) bit for bit against
+    its numpy restatement -- index work: exact."""
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(M + K)
+    p = rng.uniform(0.15, 0.95, K)
+    nbr_h = np.where(rng.uniform(size=(M, K)) < p[None, :], rng.integers(0, M, (M, K)), -1).astype(np.int32)
+    nbr = torch.from_numpy(nbr_h).cuda()
+    order = sp.mask_order(nbr, False).cpu().numpy()
+    act = nbr_h >= 0
+    step = max(1, M // 4096)
+    cnt = act[::step].sum(0)
+    rank = np.array([sum((cnt[j] > cnt[k]) or (cnt[j] == cnt[k] and j < k) for j in range(K)) for k in range(K)])
+    mask = (act.astype(np.int64) << rank[None, :]).sum(1)
+    ref = np.argsort(mask, kind="stable")
+    assert order.dtype == np.int32 and np.array_equal(order, ref)
+    assert sp.mask_order(nbr, True) is sp.mask_order(nbr, False)          # cached on the rulebook, shared with the mirrored pass
