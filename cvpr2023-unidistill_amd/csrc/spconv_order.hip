@@ -2,45 +2,52 @@
 // spconv's implicit GEMM behind SubMConv3d / SparseConv3d, unidistill/layers/blocks_3d/det3d/spconv_backbone.py:10-113):
 // rows sorted by their neighbour bit mask, so that a 128-row tile activates few of the K kernel offsets.
 //
-//   k_offset_ranks  one workgroup: offset frequencies from ~4 096 sampled rows (LDS histogram), bit position of offset k =
-//                   its rank by descending frequency (ties: lower k first) -- the rarest offsets (the corners of a 3x3x3
-//                   kernel) get the top bits, so rows group by their rare neighbours first (20.2 instead of 20.6 active
-//                   offsets per tile at the 128-channel level of the LiDAR encoder)
-//   k_row_masks     mask[r] = OR over k of (nbr[r][k] >= 0) << bitpos[k];  iota[r] = r
+//   k_offset_counts offset frequencies from ~4 096 sampled rows (LDS histograms, K integer atomics per workgroup)
+//   k_row_masks     bit position of offset k = its rank by descending frequency (ties: lower k first) -- the rarest offsets
+//                   (the corners of a 3x3x3 kernel) get the top bits, so rows group by their rare neighbours first (20.2
+//                   instead of 20.6 active offsets per tile at the 128-channel level of the LiDAR encoder);
+//                   mask[r] = OR over k of (nbr[r][k] >= 0) << bitpos[k];  iota[r] = r
 //   rocprim::radix_sort_pairs over the K mask bits (stable: equal masks keep their row order) -> order[]
 // One call from the host side instead of ~16 tensor-library launches per rulebook (nine rulebooks per encoder pass).
 #include "ud_common.h"
 #include "ud_prof.h"
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_offset_ranks(const int32_t* __restrict__ nbr, int M, int K, int step,
-                                                      int* __restrict__ bitpos) {
+// offset frequencies over every step-th row: LDS histogram per workgroup, K device-scope atomics per workgroup
+__global__ __launch_bounds__(256) void k_offset_counts(const int32_t* __restrict__ nbr, int M, int K, int step,
+                                                       unsigned* __restrict__ cnt) {
   __shared__ unsigned s_cnt[32];
   if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
   const long long total = (long long)((M + step - 1) / step) * K;
-  for (long long e = threadIdx.x; e < total; e += 256) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int r = (int)(e / K) * step, k = (int)(e % K);
     if (nbr[(size_t)r * K + k] >= 0) atomicAdd(&s_cnt[k], 1u);
   }
   __syncthreads();
-  if ((int)threadIdx.x < K) {
-    const int k = threadIdx.x;
-    const unsigned mine = s_cnt[k];
-    int rank = 0;
-    for (int j = 0; j < K; ++j) rank += (s_cnt[j] > mine) || (s_cnt[j] == mine && j < k);
-    bitpos[k] = rank;
-  }
+  if ((int)threadIdx.x < K && s_cnt[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
+// bit position of offset k = its rank by descending frequency (ties: lower k first), recomputed by every workgroup from the K
+// counters; mask[r] = OR over k of (nbr[r][k] >= 0) << bitpos[k];  iota[r] = r
 __global__ __launch_bounds__(256) void k_row_masks(const int32_t* __restrict__ nbr, int M, int K,
-                                                   const int* __restrict__ bitpos, unsigned* __restrict__ mask,
+                                                   const unsigned* __restrict__ cnt, unsigned* __restrict__ mask,
                                                    int32_t* __restrict__ iota) {
+  __shared__ unsigned s_c[32];
   __shared__ int s_pos[32];
-  if ((int)threadIdx.x < K) s_pos[threadIdx.x] = bitpos[threadIdx.x];
+  if ((int)threadIdx.x < K) s_c[threadIdx.x] = cnt[threadIdx.x];
+  __syncthreads();
+  if ((int)threadIdx.x < K) {
+    const int k = threadIdx.x;
+    const unsigned mine = s_c[k];
+    int rank = 0;
+    for (int j = 0; j < K; ++j) rank += (s_c[j] > mine) || (s_c[j] == mine && j < k);
+    s_pos[k] = rank;
+  }
   __syncthreads();
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= M) return;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void k_row_masks(const int32_t* __restrict__ n
 }
 
 struct OrderWs {
-  int* bitpos;
+  unsigned* cnt;
   unsigned* mask;
   unsigned* mask_sorted;
   int32_t* iota;
@@ -63,7 +70,7 @@ struct OrderWs {
 OrderWs carve_order(void* ws, int M, int K) {
   UdArena a(ws, (size_t)-1);
   OrderWs w;
-  w.bitpos = a.take<int>(32);
+  w.cnt = a.take<unsigned>(32);
   w.mask = a.take<unsigned>(M);
   w.mask_sorted = a.take<unsigned>(M);
   w.iota = a.take<int32_t>(M);
@@ -90,9 +97,11 @@ extern "C" int ud_spconv_mask_order(const int32_t* nbr, int M, int K, int32_t* o
   OrderWs w = carve_order(workspace, M, K);
   UdProfScope prof("spconv.mask_order", stream);
   const int step = M / 4096 > 1 ? M / 4096 : 1;
-  k_offset_ranks<<<1, 256, 0, stream>>>(nbr, M, K, step, w.bitpos);
+  UD_HIP_TRY(hipMemsetAsync(w.cnt, 0, 32 * sizeof(unsigned), stream));
+  const long long sampled = (long long)((M + step - 1) / step) * K;
+  k_offset_counts<<<(unsigned)std::min<long long>(64, (sampled + 2047) / 2048), 256, 0, stream>>>(nbr, M, K, step, w.cnt);
   UD_LAUNCH_CHECK();
-  k_row_masks<<<ud_div_up(M, 256), 256, 0, stream>>>(nbr, M, K, w.bitpos, w.mask, w.iota);
+  k_row_masks<<<ud_div_up(M, 256), 256, 0, stream>>>(nbr, M, K, w.cnt, w.mask, w.iota);
   UD_LAUNCH_CHECK();
   size_t bytes = w.sort_bytes;
   UD_HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp, bytes, (const unsigned*)w.mask, w.mask_sorted, (const int32_t*)w.iota,

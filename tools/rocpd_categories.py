@@ -15,7 +15,7 @@ if "--top" in sys.argv:
 cats = [("ours:conv2d (MFMA; 3x3 and 1x1: fwd, dgrad, wgrad; 7x7 stem + max-pool)", r"k_conv3x3|k_conv1x1|k_wgrad_sum|k_conv_f32|k_wino|k_stem_conv|k_maxpool3s2"),
         ("ours:head_tail", r"k_tail_|k_stats_|k_sum_slices|k_gtail"),
         ("ours:bn_act", r"k_bn_act|k_bn_bwd_reduce|k_bn_bwd_dx|k_bn_stats|k_bn_bwd_final"),
-        ("ours:spconv", r"k_conv_mfma|k_conv_dma|k_wgrad_mfma|k_wgrad_bf16|k_wgrad_reduce|k_wgrad_generic|k_tile_masks|k_conv_generic|k_subm|k_down|k_set_bits|k_word|k_fill_perm|k_mark|k_emit|k_dense"),
+        ("ours:spconv", r"k_conv_mfma|k_conv_dma|k_wgrad_mfma|k_wgrad_bf16|k_wgrad_reduce|k_wgrad_generic|k_tile_masks|k_conv_generic|k_subm|k_down|k_set_bits|k_word|k_fill_perm|k_mark|k_emit|k_dense|k_offset_counts|k_row_masks"),
         ("ours:voxelize", r"k_insert|k_first|k_scan|k_assign|k_gather"),
         ("ours:lss/bev_pool", r"k_pool|k_bin|k_cell|k_fill\(|k_geometry|k_prepare|k_depth|k_transpose|k_lift|k_bwd|k_to_nhwc"),
         ("ours:distill", r"k_feat|k_rel|k_resp|k_mask|k_box"),
