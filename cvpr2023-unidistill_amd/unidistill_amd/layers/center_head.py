@@ -520,6 +520,13 @@ class PackedSepHeads(nn.Module):
         rest = z.shape[1] - sum(sizes)
         if rest:
             sizes.append(rest)
+        if self.training and z.is_cuda and z.dtype in (torch.float32, torch.bfloat16) \
+                and not (z.is_contiguous() and z.dtype == torch.float32):
+            # channels-last (and, under autocast, bf16) tail output of the training head: ONE copy to fp32 planes, so that
+            # the head slices are the contiguous [H, W] planes the fused detection-loss kernels read (ops/det_loss.py: 2
+            # launches) -- on strided slices get_loss falls back to its tensor-op formulation, ~330 small launches forward
+            # and as many backward
+            z = z.to(torch.float32, memory_format=torch.contiguous_format)
         parts = iter(z.split_with_sizes(sizes, dim=1))
         outs = [dict() for _ in range(self.num_tasks)]
         for t, name, kout in self.layout:
