@@ -21,6 +21,9 @@ SKIP = ("aten.view", "aten._unsafe_view", "aten.detach", "aten.alias", "aten.t."
         "aten.empty", "aten.unbind", "aten.split", "aten.narrow", "aten.stride", "aten.size", "aten.is_", "aten.lift_fresh",
         "aten.sym_", "prim.", "aten.new_empty", "aten.empty_like", "aten.empty_strided", "aten._local_scalar_dense", "aten.item")
 cnt = collections.Counter()
+special = collections.Counter()
+engine = collections.Counter()
+FILTER = [f for f in os.environ.get("OPS", "").split(",") if f]      # OPS=index_put,sort: list these ops with their sites
 
 
 class Count(TorchDispatchMode):
@@ -33,6 +36,10 @@ class Count(TorchDispatchMode):
                     site = f"{fr.filename.split('unidistill_amd/')[-1]}:{fr.lineno} {fr.name}"
                     break
             cnt[site] += 1
+            if site.startswith("(autograd"):
+                engine[name] += 1
+            if FILTER and any(f in name for f in FILTER):
+                special[(name, site)] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -46,3 +53,8 @@ for s, n in cnt.items():
     by_fn[s.split(" ")[0].split(":")[0] + " " + s.split(" ")[-1]] += n
 for s, n in by_fn.most_common(40):
     print(f"{n:5d}  {s}")
+for (name, site), n in special.most_common(40):
+    print(f"{n:5d}  {name:40s} {site}")
+print("ops issued outside a package frame (autograd engine, optimizer):")
+for name, n in engine.most_common(25):
+    print(f"{n:5d}  {name}")
