@@ -98,13 +98,18 @@ def test_model_return_feature_mode_vs_reference(golden, hip_lib):
     assert trunk.shape[1] == 24 and len(heads) == len(S.TASKS)
 
 
-def test_distill_training_step_vs_reference(golden, hip_lib):
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_distill_training_step_vs_reference(golden, hip_lib, channels_last):
+    """channels_last=True is the benchmark's layout: NHWC convolution weights, the head's packed tail output copied to planes for
+    the fused detection-loss kernels (layers/center_head.py:_split), strided response distillation."""
     from unidistill_amd import train
     g = golden("model_step")
     student, teacher = _model(g, "student"), _model(g, "teacher")
     step = train.DistillStep("camera_exp_distill_lidar", student=student, teacher=teacher, geometry=S.GEOMETRY)
     step.overlap_teacher = False
     step.cuda().train()
+    if channels_last:
+        train.to_channels_last(step)
     assert not step.teacher_model.training and step.model.training
     out = step(_batch(g))
     out["loss"].backward()
