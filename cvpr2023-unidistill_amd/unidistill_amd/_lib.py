@@ -141,6 +141,9 @@ _SIGS = {
     "ud_nms_bev_workspace_bytes": (c_size_t, [c_int]),
     "ud_nms_rotated_bev": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "ud_proposal_workspace_bytes": (c_size_t, [c_int] * 3),
+    "ud_proposal_layer": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_float] * 5 + [c_void_p, c_float, c_float]
+                          + [c_void_p] * 4 + [c_void_p, c_size_t, c_void_p]),
     "ud_bn_act_workspace_bytes": (c_size_t, [c_int]),
     "ud_bn_stats": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7
                     + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -3,25 +3,38 @@
 Mirrors of CenterPointGenProposals and IouAwareGenProposals (reference
 unidistill/layers/head/det3d/generate_proposals/centerpoint_gen_proposals.py:8-340,
 iou_aware_gen_proposals.py:6-247): same constructor arguments, same ``generate_predicted_boxes``
-contract and outputs.  The decode is batched tensor code; NMS runs on ops/nms.py (or any
-``nms_fn(boxes, scores, thresh, pre_maxsize, post_max_size)`` passed in -- the CPU tests use the oracle).
+contract and outputs.  The whole layer -- every task and every sample -- is three launches of
+libunidistill_hip (``ud_proposal_layer``, csrc/proposals.hip): the head tensors are read in place
+through their strides (NCHW planes or channel slices of the packed channels-last head output), and
+the only host read is the per-sample box count that sizes the ``pred_dicts`` slices.  GPU only.
 """
+import ctypes
+
 import torch
 from torch import nn
 
+from .. import _lib
 
-def _gather_map(feat, inds):
-    """feat [B, C, H, W], inds [B, K] (flat y*W+x) -> [B, K, C]."""
-    B, C = feat.shape[:2]
-    flat = feat.reshape(B, C, -1)
-    return flat.gather(2, inds[:, None, :].expand(B, C, inds.shape[1])).transpose(1, 2)
+_HEADS = ("hm", "reg", "height", "dim", "rot", "vel", "iou")
+
+
+def _desc(t, H, W):
+    """(device pointer, (batch, channel, pixel) strides in elements) of a logical [B, c, H, W] fp32 tensor
+    whose H, W dims collapse to one pixel stride (true for NCHW and channels-last alike)."""
+    sb, sc, sh, sw = t.stride()
+    if t.dtype != torch.float32 or (H > 1 and sh != W * sw):
+        t = t.float().contiguous()
+        sb, sc, sh, sw = t.stride()
+    return t, (sb, sc, sw)
 
 
 class CenterPointGenProposals(nn.Module):
+    iou_aware = False
+
     def __init__(self, dataset_name, class_names, post_center_limit_range, score_threshold, pc_range,
                  out_size_factor, voxel_size, no_log, nms_iou_threshold_train, nms_pre_max_size_train,
                  nms_post_max_size_train, nms_iou_threshold_test, nms_pre_max_size_test,
-                 nms_post_max_size_test, nms_fn=None):
+                 nms_post_max_size_test):
         super().__init__()
         self.dataset_name = dataset_name
         self.class_names = class_names
@@ -37,118 +50,98 @@ class CenterPointGenProposals(nn.Module):
         self.nms_iou_threshold_test = nms_iou_threshold_test
         self.nms_pre_max_size_test = nms_pre_max_size_test
         self.nms_post_max_size_test = nms_post_max_size_test
-        self.nms_fn = nms_fn
         self.training = True
 
-    # -- pieces ------------------------------------------------------------------------------------
-    @staticmethod
-    def _topk(scores, K):
-        """Per-class top-K then top-K over classes (centerpoint_gen_proposals.py:66-83)."""
-        B, C, H, W = scores.shape
-        s1, i1 = torch.topk(scores.reshape(B, C, -1), K)
-        i1 = i1 % (H * W)
-        s2, i2 = torch.topk(s1.reshape(B, -1), K)
-        cls = (i2 / K).int()
-        inds = i1.reshape(B, -1).gather(1, i2)
-        ys = (inds / W).int().float()
-        xs = (inds % W).int().float()
-        return s2, inds, cls, ys, xs
+    def _alphas(self, n_tasks):
+        return None
 
-    def _nms_scores(self, scores, inds, task_id, extra):
-        return scores
+    def _run(self, pred_dicts, class_offsets, alphas):
+        """All tasks of ``pred_dicts`` in one ud_proposal_layer call -> (rois, scores, labels, counts)."""
+        lib = _lib.load()
+        T = len(pred_dicts)
+        hm0 = pred_dicts[0]["hm"]
+        _lib.require_gpu(hm0)
+        B, _, H, W = hm0.shape
+        nbox = 9 if self.dataset_name == "nuscenes" else 7
+        ptrs, strides, keep_alive, ncs = [], [], [], []
+        for pred in pred_dicts:
+            ncs.append(int(pred["hm"].shape[1]))
+            for name in _HEADS:
+                t = pred.get(name)
+                if t is None or (name == "vel" and nbox == 7) or (name == "iou" and not self.iou_aware):
+                    ptrs.append(None)
+                    strides += [0, 0, 0]
+                    continue
+                _lib.require_gpu(t)
+                t, st = _desc(t, H, W)
+                keep_alive.append(t)
+                ptrs.append(t.data_ptr())
+                strides += list(st)
+        K, post = int(self.nms_pre_max_size_use), int(self.nms_post_max_size_use)
+        dev = hm0.device
+        rois = torch.empty((B, T * post, nbox), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, T * post), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, T * post), dtype=torch.int64, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        nbytes = lib.ud_proposal_workspace_bytes(B, T, K)
+        if nbytes == 0:
+            raise RuntimeError(f"ud_proposal_layer: unsupported sizes B={B} T={T} K={K}")
+        ws = _lib.workspace(dev, nbytes, "proposals")
+        c_ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        c_str = (ctypes.c_longlong * len(strides))(*strides)
+        c_nc = (ctypes.c_int * T)(*ncs)
+        c_off = (ctypes.c_int * T)(*class_offsets)
+        c_alpha = (ctypes.c_float * T)(*alphas) if alphas is not None else None
+        c_rng = (ctypes.c_float * 6)(*[float(v) for v in self.post_center_limit_range])
+        _lib.check(lib.ud_proposal_layer(
+            c_ptrs, c_str, c_nc, c_off, c_alpha, B, T, H, W, K, post, nbox, 1 if self.no_log else 0,
+            float(self.out_size_factor), float(self.voxel_size[0]), float(self.voxel_size[1]),
+            float(self.pc_range[0]), float(self.pc_range[1]), c_rng, float(self.score_threshold),
+            float(self.nms_iou_threshold_use), _lib.ptr(rois), _lib.ptr(scores), _lib.ptr(labels),
+            _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_of(hm0)), "ud_proposal_layer")
+        return rois, scores, labels, counts
 
-    def _select(self, boxes, scores, thresh, pre, post):
-        if self.nms_fn is not None:
-            return self.nms_fn(boxes, scores, thresh, pre, post)
-        from ..ops import nms
-        return nms.nms_rotated(boxes, scores, thresh, pre, post)
-
-    @torch.no_grad()
-    def proposal_layer(self, heat, rots, rotc, hei, dim, vel, reg=None, raw_rot=False, task_id=-1, **extra):
-        assert reg is not None and raw_rot is False
-        B = heat.shape[0]
-        K = self.nms_pre_max_size_use
-        scores, inds, clses, ys, xs = self._topk(heat, K)
-        nms_scores = self._nms_scores(scores, inds, task_id, extra)
-        reg = _gather_map(reg, inds)
-        xs = xs[:, :, None] + reg[:, :, 0:1]
-        ys = ys[:, :, None] + reg[:, :, 1:2]
-        rot = torch.atan2(_gather_map(rots, inds), _gather_map(rotc, inds))
-        hei = _gather_map(hei, inds)
-        dim = _gather_map(dim, inds)
-        xs = xs * self.out_size_factor * self.voxel_size[0] + self.pc_range[0]
-        ys = ys * self.out_size_factor * self.voxel_size[1] + self.pc_range[1]
-        parts = [xs, ys, hei, dim, rot]
-        if self.dataset_name == "nuscenes":
-            parts.append(_gather_map(vel, inds))
-        boxes = torch.cat(parts, dim=2)
-        rng = torch.tensor(self.post_center_limit_range, device=boxes.device, dtype=boxes.dtype)
-        mask = (boxes[..., :3] >= rng[:3]).all(2) & (boxes[..., :3] <= rng[3:]).all(2)
-        mask &= scores > self.score_threshold
-        out = []
-        for i in range(B):
-            m = mask[i]
-            b3, sc, lb, ns = boxes[i, m], scores[i, m], clses[i, m].float(), nms_scores[i, m]
-            if ns.shape[0] != 0:
-                sel = self._select(b3[:, :7], ns, self.nms_iou_threshold_use, self.nms_pre_max_size_use,
-                                   self.nms_post_max_size_use)
-            else:
-                sel = torch.zeros((0,), dtype=torch.long, device=b3.device)
-            out.append({"boxes": b3[sel], "scores": sc[sel], "labels": lb[sel].long()})
-        return out
-
-    def _task_inputs(self, pred_dict):
-        hm = pred_dict["hm"].float().sigmoid()
-        dim = pred_dict["dim"].float()
-        if not self.no_log:
-            dim = torch.clamp(torch.exp(dim), min=0.001, max=30)
-        rot = pred_dict["rot"].float()
-        vel = pred_dict["vel"].float() if self.dataset_name == "nuscenes" else None
-        return dict(heat=hm, rots=rot[:, 0:1], rotc=rot[:, 1:2], hei=pred_dict["height"].float(), dim=dim,
-                    vel=vel, reg=pred_dict["reg"].float())
-
-    @torch.no_grad()
-    def generate_predicted_boxes(self, forward_ret_dict, data_dict):
-        pred_dicts = forward_ret_dict["multi_head_features"]
+    def _phase(self):
         phase = "train" if self.training else "test"
         self.nms_iou_threshold_use = getattr(self, f"nms_iou_threshold_{phase}")
         self.nms_pre_max_size_use = getattr(self, f"nms_pre_max_size_{phase}")
         self.nms_post_max_size_use = getattr(self, f"nms_post_max_size_{phase}")
-        per_task = []
-        for task_id, pred in enumerate(pred_dicts):
-            per_task.append(self.proposal_layer(task_id=task_id, **self._task_inputs(pred),
-                                                **self._extra_inputs(pred)))
-        B = len(per_task[0])
-        num_rois = self.nms_post_max_size_use * len(self.class_names)
-        out, rois, roi_scores, roi_labels = [], [], [], []
-        for b in range(B):
-            boxes, scores, labels, offset = [], [], [], 1          # global labels start at 1
-            for task_id, names in enumerate(self.class_names):
-                boxes.append(per_task[task_id][b]["boxes"])
-                scores.append(per_task[task_id][b]["scores"])
-                labels.append(per_task[task_id][b]["labels"] + offset)
-                offset += len(names)
-            boxes, scores, labels = torch.cat(boxes), torch.cat(scores), torch.cat(labels)
-            n = boxes.shape[0]
-            roi = boxes.new_zeros(num_rois, boxes.shape[-1])
-            roi_score, roi_label = scores.new_zeros(num_rois), labels.new_zeros(num_rois)
-            roi[:n], roi_score[:n], roi_label[:n] = boxes, scores, labels
-            rois.append(roi); roi_scores.append(roi_score); roi_labels.append(roi_label)
-            out.append({"pred_boxes": boxes, "pred_scores": scores, "pred_labels": labels})
-        data_dict["pred_dicts"] = out
-        data_dict["rois"] = torch.stack(rois)
-        data_dict["roi_scores"] = torch.stack(roi_scores)
-        data_dict["roi_labels"] = torch.stack(roi_labels)
+
+    @torch.no_grad()
+    def proposal_layer(self, pred_dict, task_id=-1):
+        """One task (reference proposal_layer, iou_aware_gen_proposals.py:43-139): list over samples of
+        {"boxes", "scores", "labels"} with task-local labels."""
+        if not hasattr(self, "nms_pre_max_size_use"):
+            self._phase()
+        alphas = self._alphas(max(task_id + 1, 1))
+        rois, scores, labels, counts = self._run([pred_dict], [-1], alphas and [alphas[task_id]])
+        counts = counts.tolist()
+        return [{"boxes": rois[b, :n], "scores": scores[b, :n], "labels": labels[b, :n]}
+                for b, n in enumerate(counts)]
+
+    @torch.no_grad()
+    def generate_predicted_boxes(self, forward_ret_dict, data_dict):
+        pred_dicts = forward_ret_dict["multi_head_features"]
+        self._phase()
+        offsets, off = [], 0                                   # global labels start at 1 (added on the device)
+        for names in self.class_names:
+            offsets.append(off)
+            off += len(names)
+        rois, scores, labels, counts = self._run(pred_dicts, offsets, self._alphas(len(pred_dicts)))
+        counts = counts.tolist()                               # the one host read of the layer
+        data_dict["pred_dicts"] = [{"pred_boxes": rois[b, :n], "pred_scores": scores[b, :n],
+                                    "pred_labels": labels[b, :n]} for b, n in enumerate(counts)]
+        data_dict["rois"] = rois
+        data_dict["roi_scores"] = scores
+        data_dict["roi_labels"] = labels
         data_dict["has_class_labels"] = True
         data_dict.pop("batch_index", None)
         return data_dict
 
-    def _extra_inputs(self, pred_dict):
-        return {}
-
 
 class IouAwareGenProposals(CenterPointGenProposals):
     """NMS ranks by score^(1-a) * iou^a with the predicted IoU map (iou_aware_gen_proposals.py:43-66)."""
+    iou_aware = True
 
     def __init__(self, *args, iou_aware_list=None, **kw):
         if iou_aware_list is None and len(args) == 15:
@@ -156,11 +149,5 @@ class IouAwareGenProposals(CenterPointGenProposals):
         super().__init__(*args, **kw)
         self.iou_aware_list = iou_aware_list
 
-    def _extra_inputs(self, pred_dict):
-        return {"iouhm": pred_dict["iou"].float()}
-
-    def _nms_scores(self, scores, inds, task_id, extra):
-        B, K = scores.shape
-        iou = torch.clamp(_gather_map(extra["iouhm"], inds).reshape(B, K) / 2 + 0.5, 0, 1)
-        a = self.iou_aware_list[task_id]
-        return (scores ** (1 - a)).mul(iou ** a)
+    def _alphas(self, n_tasks):
+        return [float(self.iou_aware_list[t]) for t in range(n_tasks)]

@@ -672,6 +672,32 @@ int ud_nms_rotated_bev(const float* boxes, int N, float thresh, long long* keep,
                        void* workspace, size_t workspace_bytes, ud_stream_t stream);
 int ud_boxes_iou_bev(const float* a, int Na, const float* b, int Nb, float* iou, ud_stream_t stream);
 
+/* ---- Proposal layer on the device: top-K decode + IoU-aware score + filters + rotated NMS + roi packing ----
+ * Replaces IouAwareGenProposals / CenterPointGenProposals.generate_predicted_boxes (reference layers/head/
+ * det3d/generate_proposals/iou_aware_gen_proposals.py:43-139, centerpoint_gen_proposals.py:66-105,232-340)
+ * for all T <= 8 tasks and B samples in three launches; nothing synchronises with the host.
+ *   heads   HOST array [T*7] of device pointers: hm, reg, height, dim, rot, vel, iou of task t (raw head
+ *           outputs, fp32, logical shape [B, c, H, W]); vel may be NULL when box_dim == 7, iou when iou_alpha
+ *           is NULL (plain CenterPoint: NMS ranks by the heat-map score).
+ *   strides HOST array [T*7*3]: (batch, channel, pixel) strides in elements of each tensor (NCHW planes:
+ *           (c*H*W, H*W, 1); channel slices of a channels-last packed map: (H*W*Ctot, 1, Ctot)).
+ *   num_classes / class_offsets / iou_alpha  HOST arrays [T]: classes of the task's heat map, number of
+ *           classes of the tasks before it (labels are 1-based global ids), IoU-aware exponent a
+ *           (NMS score = score^(1-a) * clamp(iou/2+0.5, 0, 1)^a).
+ *   K = nms_pre_max_size (<= 2048), post_max = nms_post_max_size (<= 512); box = (x, y, z, dx, dy, dz, rot
+ *   [, vx, vy]); dx..dz = clamp(exp(dim), 0.001, 30) unless no_log; x = (col + reg.x) * out_size_factor *
+ *   voxel_x + pc_x (same fp32 operation order as the reference); kept iff center_range[0:3] <= (x,y,z) <=
+ *   center_range[3:6] (HOST array [6]) and score > score_threshold.
+ * Outputs: rois f32[B, T*post_max, box_dim], roi_scores f32[B, T*post_max], roi_labels i64[B, T*post_max]
+ * (tasks back to back, each in NMS order, zero padded), num_boxes i32[B] = rows in use per sample. */
+size_t ud_proposal_workspace_bytes(int B, int T, int K);
+int ud_proposal_layer(const float* const* heads, const long long* strides, const int* num_classes,
+                      const int* class_offsets, const float* iou_alpha, int B, int T, int H, int W, int K,
+                      int post_max, int box_dim, int no_log, float out_size_factor, float voxel_x,
+                      float voxel_y, float pc_x, float pc_y, const float* center_range, float score_threshold,
+                      float nms_threshold, float* rois, float* roi_scores, long long* roi_labels,
+                      int* num_boxes, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
 /* ---- Detection loss of the CenterPoint heads (focal + gathered regression / IoU terms) ------------------
  * CenterHeadIouAware.get_loss (reference layers/head/det3d/center_head_iou_aware.py:55-298, losses/det3d.py:
  * 287-421) for all T <= 8 tasks at once.  Head tensors are given as device-pointer tables (any

@@ -273,6 +273,77 @@ def nms_bev(boxes, thresh):
     return keep[:n].copy()
 
 
+def proposal_layer(heads, class_names, post_center_limit_range, score_threshold, pc_range, out_size_factor,
+                   voxel_size, no_log, nms_iou_threshold, nms_pre_max_size, nms_post_max_size,
+                   iou_aware_list=None, with_vel=True):
+    """numpy restatement of IouAwareGenProposals / CenterPointGenProposals.generate_predicted_boxes
+    (reference layers/head/det3d/generate_proposals/iou_aware_gen_proposals.py:43-139 proposal_layer,
+    centerpoint_gen_proposals.py:66-83 _topk, :85-105 _nms_gpu_3d, :232-340 generate_predicted_boxes), with
+    the missing `iou3d_nms_cuda.nms_gpu` = nms_bev above.  heads: list over tasks of dicts of f32[B,c,H,W]
+    (hm reg height dim rot [vel] [iou], raw head outputs).  fp32 operations in the reference's order.
+    -> rois f32[B,T*post,nb], roi_scores f32[B,T*post], roi_labels i64[B,T*post], counts[B]."""
+    f = np.float32
+    T = len(heads)
+    B, _, H, W = heads[0]["hm"].shape
+    K, post = nms_pre_max_size, nms_post_max_size
+    nb = 9 if with_vel else 7
+    rois = np.zeros((B, T * post, nb), f)
+    roi_scores = np.zeros((B, T * post), f)
+    roi_labels = np.zeros((B, T * post), np.int64)
+    counts = np.zeros((B,), np.int64)
+    lo, hi = np.asarray(post_center_limit_range[:3], f), np.asarray(post_center_limit_range[3:], f)
+    offset = 1                                                  # centerpoint_gen_proposals.py: labels start at 1
+    for t, pred in enumerate(heads):
+        hm = _f32(pred["hm"])
+        heat = (f(1) / (f(1) + np.exp(-hm))).astype(f)         # pred_dict["hm"].sigmoid()
+        nc = heat.shape[1]
+        flat = lambda a: _f32(a).reshape(B, -1, H * W)
+        dim = flat(pred["dim"])
+        if not no_log:
+            dim = np.clip(np.exp(dim), f(0.001), f(30)).astype(f)
+        for b in range(B):
+            sc = heat[b].reshape(-1)
+            # _topk: per-class top-K then top-K of the union == top-K of all (class, pixel) scores;
+            # equal scores: lower (class, pixel) first (stable)
+            order = np.argsort(-sc, kind="stable")[:min(K, sc.size)]
+            scores = sc[order]
+            cls = (order // (H * W)).astype(f)
+            pix = order % (H * W)
+            ys, xs = (pix // W).astype(f), (pix % W).astype(f)
+            reg = flat(pred["reg"])[b][:, pix]
+            xs = xs + reg[0]
+            ys = ys + reg[1]
+            rot = flat(pred["rot"])[b][:, pix]
+            rot = np.arctan2(rot[0], rot[1]).astype(f)
+            hei = flat(pred["height"])[b][0, pix]
+            xs = (xs * f(out_size_factor) * f(voxel_size[0]) + f(pc_range[0])).astype(f)
+            ys = (ys * f(out_size_factor) * f(voxel_size[1]) + f(pc_range[1])).astype(f)
+            cols = [xs, ys, hei, dim[b][0, pix], dim[b][1, pix], dim[b][2, pix], rot]
+            if with_vel:
+                vel = flat(pred["vel"])[b][:, pix]
+                cols += [vel[0], vel[1]]
+            boxes = np.stack(cols, 1).astype(f)
+            nms_scores = scores
+            if iou_aware_list is not None:
+                iou = np.clip(flat(pred["iou"])[b][0, pix] / f(2) + f(0.5), f(0), f(1)).astype(f)
+                a = iou_aware_list[t]
+                nms_scores = (np.power(scores, f(1 - a)) * np.power(iou, f(a))).astype(f)
+            mask = (boxes[:, :3] >= lo).all(1) & (boxes[:, :3] <= hi).all(1) & (scores > f(score_threshold))
+            boxes, scores, cls, nms_scores = boxes[mask], scores[mask], cls[mask], nms_scores[mask]
+            sel = np.zeros((0,), np.int64)
+            if len(nms_scores):
+                o = np.argsort(-nms_scores, kind="stable")[:K]
+                kept = nms_bev(boxes[o][:, :7], float(nms_iou_threshold))
+                sel = o[kept][:post]
+            n0, n = counts[b], len(sel)
+            rois[b, n0:n0 + n] = boxes[sel]
+            roi_scores[b, n0:n0 + n] = scores[sel]
+            roi_labels[b, n0:n0 + n] = cls[sel].astype(np.int64) + offset
+            counts[b] += n
+        offset += len(class_names[t])
+    return rois, roi_scores, roi_labels, counts
+
+
 def conv3x3_nhwc(x, w, bias=None):
     """y[b,h,w,n] = sum_{ty,tx,c} x[b,h+ty-1,w+tx-1,c] * w[n,ty,tx,c] (zero padding), float64 accumulate.
     Plain numpy restatement of nn.Conv2d(k=3, s=1, p=1) on channels-last data (reference
