@@ -122,8 +122,14 @@ def roofline_leg(device, batch):
     pf = profile_figures().get("bev_pool.k_pool", {})
     traffic = pf.get("hbm_bytes") if pf.get("shape") == {"C": C, "nx": nx, "ny": ny, "N": N, "B": B} else None
     achieved = alg / (k_us * 1e-6) / 1e9
+    in_grid = float((pos[..., 0] >= 0).float().mean())
     return {"bound": "hbm", "kernel": "bev_pool.k_pool (ud_bev_pool_fwd, reference op boundary)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # `frac` prices ALL B*N feature rows (SURVEY 8d's algorithmic bytes); the kernel only reads the in-grid ones,
+            # so its real HBM throughput is frac_counter_bytes (PMC bytes / time), NOT frac: do not read frac as bandwidth
+            "in_grid_fraction": in_grid,
+            "frac_meaning": "algorithmic bytes (all %d rows, %.0f %% of them in-grid and actually read) / kernel time / 8 TB/s; "
+                            "HBM throughput of the kernel itself = frac_counter_bytes" % (B * N, 100 * in_grid),
             "avg_kernel_us": k_us, "launches": k_calls, "algorithmic_bytes_per_launch": alg,
             "op_avg_us": op_ms / reps * 1e3, "op_GBps": alg / (op_ms / reps * 1e-3) / 1e9,
             # whole op (memset + k_bin + scan + k_fill + k_pool) against the same algorithmic bytes
@@ -209,24 +215,30 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     ex_flops = sum(2 * B * H * W * cout * 9 * cin * ((16.0 / 36.0) if fp32 and c32.wino_pays(H, W, cin, cout) else 1.0)
                    for (B, cin, H, W, cout, _) in log)
     n_wino = sum(1 for (B, cin, H, W, cout, _) in log if fp32 and c32.wino_pays(H, W, cin, cout))
+    executed = ex_flops / (rp_ms * 1e-3) / 1e12
     in_step = flops / (ms * 1e-3) / 1e12
+    if fp32:                                   # in-step events: priced by executed flops as well
+        in_step *= ex_flops / rp_flops
     pf = profile_figures()
     loop = pf.get("mfma_only_loop_tflops", {})
     instr = "v_mfma_f32_16x16x4_f32" if fp32 else "v_mfma_f32_16x16x32_bf16"
     out = {"bound": "mfma",
            "kernel": ("conv2d_f32_wino.k_conv3x3_wino_f32 / conv2d_f32.k_conv_f32_taps (ud_conv3x3_wino_nhwc_f32, ud_conv3x3_nhwc_f32"
                       if fp32 else "conv2d.k_conv3x3_taps (ud_conv3x3_nhwc_bf16") + ": BEV trunk, head, ResNet 3x3 convs; fwd + dgrad)",
-           "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "dtype": "f32" if fp32 else "bf16",
+           # fp32: achieved / frac = the flops the MFMA pipe EXECUTES (Winograd launches run 16/36 of the direct-form
+           # multiplications) / time: a roofline fraction, always <= 1; the direct-form rate is kept beside it
+           "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak, "dtype": "f32" if fp32 else "bf16",
            "launches": len(log), "avg_kernel_us": rp_ms / len(log) * 1e3, "algorithmic_flops_per_step": rp_flops,
            "kernel_ms_per_step": rp_ms, "traffic": None,
-           "executed": ({"winograd_launches": n_wino, "flops_per_step": ex_flops, "TFLOP/s": ex_flops / (rp_ms * 1e-3) / 1e12,
-                         "frac_of_peak": ex_flops / (rp_ms * 1e-3) / 1e12 / peak,
-                         "note": "Winograd F(2x2,3x3) launches execute 16/36 of their algorithmic multiplications: achieved / frac "
-                                 "(algorithmic flops / time) can exceed the matrix peak; this object is the MFMA pipe's own load"}
-                        if fp32 else None),
+           "executed": ({"winograd_launches": n_wino, "flops_per_step": ex_flops, "TFLOP/s": executed,
+                         "frac_of_peak": executed / peak} if fp32 else None),
+           "algorithmic_equivalent": ({"TFLOP/s": achieved, "x_matrix_peak": achieved / peak,
+                                       "note": "direct-form flops (2 B H W Cout 9 Cin) of the same launches / time: what a direct "
+                                               "convolution would have to sustain to match; NOT a roofline fraction (Winograd "
+                                               "F(2x2,3x3) executes 16/36 of these multiplications)"} if fp32 else None),
            # what an MFMA-only loop sustains on the same machine with the instruction this kernel uses (tools/mfma_peak.hip;
            # profiles/traffic.json): informational, `frac` stays priced against the guide's nominal peak
-           "mfma_only_loop": ({"instruction": instr, "TFLOP/s": loop[instr], "frac_of_loop": achieved / loop[instr],
+           "mfma_only_loop": ({"instruction": instr, "TFLOP/s": loop[instr], "frac_of_loop": executed / loop[instr],
                                "source": loop.get("source")} if instr in loop else None),
            "in_step_events": {"achieved": in_step, "frac": in_step / peak, "launches": calls,
                               "avg_kernel_us": ms / calls * 1e3, "kernel_ms_per_step": ms / steps,
@@ -363,6 +375,9 @@ def voxelize_leg(device):
             ms, n = _lib.prof_read("voxelize." + k)
             kern[k] = ms / max(n, 1) * 1e3
         M = int(m[B])
+        if int(m[B + 1]) != 0:                 # a partition overflowed: algo 0 left the voxelization incomplete
+            raise RuntimeError("voxelize_leg: algo 0 overflowed a partition on the synthetic cloud; the timed op is not a "
+                               "complete voxelization (the product wrapper would repeat with algo 1)")
         alg = B * N * F * 4 + M * (P * F * 4 + 12 + 4)          # N*20 + M*216 bytes
         dom = max(kern, key=kern.get)
         cases.append({"points": B * N, "voxels": M, "algorithmic_bytes": alg, "op_us": op_us,
@@ -479,6 +494,49 @@ def timed_steps(trainer, batch, args, world, device):
     return dt, loss
 
 
+def host_enqueue_leg(trainer, batch, steps=5):
+    """Host-side cost of one training step: CPU seconds the process spends enqueuing it (python wrappers, autograd engine
+    thread, HIP launches), with the runtime's synchronisation switched from spinning to blocking so that the waits for the
+    GPU do not count.  With 8 ranks on one host this -- not xGMI -- bounds the scaling: a step is host-bound when
+    host_enqueue_ms approaches ms_per_step."""
+    import ctypes
+    hip = None
+    try:                                       # the HIP runtime this process already runs on (torch's copy)
+        path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+        hip = ctypes.CDLL(path)
+    except (StopIteration, OSError):
+        pass
+    blocking = hip is not None and hip.hipSetDeviceFlags(ctypes.c_uint(4)) == 0      # hipDeviceScheduleBlockingSync
+    for _ in range(2):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    w0, c0 = time.perf_counter(), time.process_time()
+    for _ in range(steps):
+        trainer.step(batch)
+    c1 = time.process_time()
+    torch.cuda.synchronize()
+    w1 = time.perf_counter()
+    if hip is not None:
+        hip.hipSetDeviceFlags(ctypes.c_uint(0))                                      # hipDeviceScheduleAuto
+    return {"host_enqueue_ms": (c1 - c0) / steps * 1e3, "wall_ms": (w1 - w0) / steps * 1e3, "steps": steps,
+            "sync_mode": "blocking" if blocking else "spin (flag refused: waits are counted)",
+            "note": "process CPU time per step (main thread + autograd thread + runtime threads) while the step is "
+                    "enqueued; GPU waits block instead of spinning during this leg"}
+
+
+def assert_fracs(obj, path="line"):
+    """Every emitted `frac` is a roofline fraction: <= 1 by construction (a larger value means the timed kernel does not do
+    the counted work)."""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if k == "frac" and v is not None:
+                assert 0.0 <= v <= 1.0, f"{path}.frac = {v}: not a roofline fraction"
+            assert_fracs(v, f"{path}.{k}")
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            assert_fracs(v, f"{path}[{i}]")
+
+
 PRECISION_NOTE = {
     None: "fp32 everywhere (the reference's arithmetic): hand-written HIP for voxelize / sparse convs (fp32 MFMA) / "
           "lift-splat / target assignment / losses / BatchNorm+ReLU chains / head tail (grouped fp32 kernels), every "
@@ -526,6 +584,7 @@ def main():
     dt, loss = timed_steps(trainer, batch, args, world, device)
     # second precision + the MFMA legs take extra (collective) training steps: EVERY rank runs them
     bf16, mfma, mfma32 = None, None, None
+    host = host_enqueue_leg(trainer, batch)          # collective steps: every rank
     if ac is None and not args.no_roofline:
         mfma32 = mfma_leg(trainer, batch, fp32=True)
     if ac is None and not args.no_bf16_leg:
@@ -539,6 +598,7 @@ def main():
                 "final_loss": loss16, "precision": PRECISION_NOTE[torch.bfloat16],
                 "note": "same workload, batch and step as the headline under bf16 autocast + channels-last "
                         "(BASELINE.json configs[4]-style mixed precision; NOT the headline: the reference trains in fp32)"}
+        bf16["host_enqueue"] = host_enqueue_leg(trainer16, batch)
         if not args.no_roofline:
             mfma = mfma_leg(trainer16, batch, fp32=False)
         del trainer16
@@ -560,6 +620,7 @@ def main():
                        "precision": PRECISION_NOTE[ac],
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
                        "executor": "eager+DDP"},
+            "host_enqueue_ms": host["host_enqueue_ms"], "host_enqueue": host,
         }
         if bf16 is not None:
             line["bf16_mixed_precision"] = bf16
@@ -574,6 +635,7 @@ def main():
                 line["roofline_mfma"] = mfma
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(device)
+        assert_fracs(line)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -998,11 +998,11 @@ template <int NT, int CT>
 int launch_wgrad1x1(const void* x, const void* dy, float* partial, long long P, int Cin, int Cout,
                     const Wgrad1x1Plan& pl, const PixMap& xmap, const PixMap& ymap, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * 64 * (NT + CT) * 2;
-  static bool set = false;
-  if (!set) {
+  static UdDeviceOnce set;
+  if (const unsigned long long set_bit = set.pending()) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_wgrad_dma<NT, CT>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    set = true;
+    set.mark(set_bit);
   }
   k_conv1x1_wgrad_dma<NT, CT><<<dim3(pl.slices, pl.n_tiles * pl.c_tiles), 256, lds, stream>>>(
       (const unsigned short*)x, (const unsigned short*)dy, partial, P, Cin, Cout, pl.c_tiles, pl.steps_per_slice,
@@ -1036,9 +1036,9 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
   hipStream_t stream = (hipStream_t)stream_;
   ConvGeom gm{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W, PixMap{}, PixMap{}};
   ConvEp ep{bias, scale, shift, reinterpret_cast<const unsigned short*>(residual), relu & 1, (relu >> 1) & 1, stats};
-  static bool attr_set = false;
+  static UdDeviceOnce attr_set;
   static int force_rw = 0;         // UD_CONV_RW=n: pixel rows per wave (timing experiments only)
-  if (!attr_set) {
+  if (const unsigned long long attr_set_bit = attr_set.pending()) {
 #define UD_TAPS_ATTR(TN, RW)                                                                                          \
   UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps<TN, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                  (int)conv_taps_smem_bytes(TN, RW)))
@@ -1046,7 +1046,7 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
     UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
 #undef UD_TAPS_ATTR
     if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   UdProfScope prof("conv2d.k_conv3x3", stream);
   const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
@@ -1133,8 +1133,8 @@ static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Ci
     if (stats_bytes < (size_t)gm.tiles_y * Cout * 2 * sizeof(float) || !slices_out) return UD_ERR_WORKSPACE;
     *slices_out = gm.tiles_y;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = attr_set.pending()) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(128)));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1143,7 +1143,7 @@ static int conv1x1_impl(const void* x, const void* w, void* y, int64_t P, int Ci
                                    (int)conv_smem_bytes(128)));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes(64)));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   const int ntiles = gm.tiles_y;
   const int gx = (ntiles + 7) / 8 * 8;
@@ -1220,11 +1220,11 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
     ConvGeom gd{B, H, W, Cin, Cout, ud_div_up(W, kTW), ud_div_up(H, kTH), (long long)B * H * W};
     int per;
     const int S = wgrad_dma_slices(B, H, W, Cin, Cout, &per);
-    static bool set_dma = false;
-    if (!set_dma) {
+    static UdDeviceOnce set_dma;
+    if (const unsigned long long set_dma_bit = set_dma.pending()) {
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_taps, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kWgradDmaLds));
-      set_dma = true;
+      set_dma.mark(set_dma_bit);
     }
     UdProfScope prof("conv2d.k_wgrad_dma", stream);
     k_conv3x3_wgrad_taps<<<dim3(S, ud_div_up(Cout, 64) * (Cin / 64)), 256, kWgradDmaLds, stream>>>(
@@ -1242,10 +1242,10 @@ extern "C" int ud_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* 
   const dim3 grid(S, 9 * n_tiles * c_tiles);
   if (CT == 128) {
     const size_t lds = (size_t)2 * kWP * (144 + 144) * 2;
-    static bool set128 = false;
-    if (!set128) {
+    static UdDeviceOnce set128;
+    if (const unsigned long long set128_bit = set128.pending()) {
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      set128 = true;
+      set128.mark(set128_bit);
     }
     k_conv3x3_wgrad<128><<<grid, 256, lds, stream>>>((const unsigned short*)x, (const unsigned short*)dy, partial, gm, c_tiles, n_tiles);
   } else {

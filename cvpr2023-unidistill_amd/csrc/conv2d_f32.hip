@@ -486,13 +486,13 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
   const bool narrow = force64 > 0 || gm.Cout <= 64 || (KS == 1 && force64 == 0) || ntiles * ud_div_up(gm.Cout, 128) <= 256;
   const int ntn = ud_div_up(gm.Cout, narrow ? 64 : 128);
   if constexpr (KS == 1) {
-    static bool line_set = false;
-    if (!line_set) {
+    static UdDeviceOnce line_set;
+    if (const unsigned long long line_set_bit = line_set.pending()) {
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)conv_smem_bytes_f(128)));
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_f32_line<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)conv_smem_bytes_f(64)));
-      line_set = true;
+      line_set.mark(line_set_bit);
     }
     if (ep.stats) {
       if (stats_bytes < (size_t)ntiles * gm.Cout * 2 * sizeof(float) || !slices_out) return UD_ERR_WORKSPACE;
@@ -504,16 +504,16 @@ int launch_f32(const float* x, const float* w, float* y, const ConvGeomF& gm, co
     UD_LAUNCH_CHECK();
     return UD_OK;
   } else {
-    static bool taps_set = false;
+    static UdDeviceOnce taps_set;
     static int force_rw = 0;     // UD_CONV_RW=n: pixel rows per wave (timing experiments only)
-    if (!taps_set) {
+    if (const unsigned long long taps_set_bit = taps_set.pending()) {
 #define UD_TAPS_ATTR(TN, RW)                                                                                          \
   UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_f32_taps<TN, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                  (int)conv_taps_smem_bytes_f(TN, RW)))
       UD_TAPS_ATTR(128, 4); UD_TAPS_ATTR(128, 3); UD_TAPS_ATTR(128, 2); UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
 #undef UD_TAPS_ATTR
       if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
-      taps_set = true;
+      taps_set.mark(taps_set_bit);
     }
     // Tile height = waves x rows per wave.  A CU works through ceil(workgroups / 256) tiles (two at a time, sharing its
     // MFMA pipes: with a 32-cycle fp32 MFMA a tap is MFMA-bound whatever the height), so the launch takes about
@@ -618,13 +618,13 @@ extern "C" int ud_conv1x1_mapped_nhwc_f32(const float* x, const float* w, float*
   const int H = (int)((P + kTW - 1) / kTW);
   ConvGeomF gm{1, H, kTW, Cin, Cout, 1, ud_div_up(H, kTH), (long long)P, im, om};
   ConvEpF ep{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
-  static bool attr_set = false;
-  if (!attr_set) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = attr_set.pending()) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped_f32<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes_f(128)));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1_mapped_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)conv_smem_bytes_f(64)));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   const int ntiles = gm.tiles_y;
   UdProfScope prof("conv2d.k_conv1x1_f32", stream);

@@ -336,11 +336,11 @@ extern "C" int ud_conv3x3_wgrad_nhwc_f32(const float* x, const float* dy, float*
   int per;
   const int S = wg3_slices(B, H, W, Cin, Cout, &per);
   constexpr int lds16 = 2 * WgTile<16, 8>::kBufBytes, lds20 = 2 * WgTile<20, 6>::kBufBytes;
-  static bool set = false;
-  if (!set) {
+  static UdDeviceOnce set;
+  if (const unsigned long long set_bit = set.pending()) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_f32<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_f32<20, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds20));
-    set = true;
+    set.mark(set_bit);
   }
   const int c_tiles = ud_div_up(Cin, 64);
   {

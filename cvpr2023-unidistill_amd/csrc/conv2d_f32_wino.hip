@@ -576,13 +576,13 @@ extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y
     *slices = (int)rows;
     if (split) UD_HIP_TRY(hipMemsetAsync(partial + (size_t)nblocks * Cout * 2, 0, 4 * (size_t)split * Cout * 2 * sizeof(float), stream));
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = attr_set.pending()) {
 #define UD_WINO_ATTR(A, Bq) \
   UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wino_f32<A, Bq>, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoSmem))
     UD_WINO_ATTR(8, 8); UD_WINO_ATTR(9, 7); UD_WINO_ATTR(10, 6); UD_WINO_ATTR(4, 16); UD_WINO_ATTR(16, 4); UD_WINO_ATTR(11, 4);
 #undef UD_WINO_ATTR
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   UdProfScope prof("conv2d.k_conv3x3_wino_f32", stream);
   static const int persist = getenv("UD_WINO_GRID") ? atoi(getenv("UD_WINO_GRID")) : 256;      // one workgroup per CU

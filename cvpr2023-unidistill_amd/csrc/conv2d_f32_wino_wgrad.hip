@@ -336,10 +336,10 @@ extern "C" int ud_conv3x3_wino_wgrad_nhwc_f32(const float* x, const float* dy, f
   if (p.nb > 65535 || p.cb > 65535 || (long long)B * H * W * Cin >= (1ll << 31) || (long long)B * H * W * Cout >= (1ll << 31))
     return UD_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = attr_set.pending()) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wino_wgrad_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   UdProfScope prof("conv2d.k_wgrad_wino_f32", stream);
   float* partial = static_cast<float*>(workspace);

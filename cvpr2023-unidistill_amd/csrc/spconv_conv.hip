@@ -1650,11 +1650,11 @@ int launch_conv_dma_f32(const float* in, const int32_t* nbr, int K, int mirror, 
                         const float* bias, float* out, int Mout, const int32_t* order, ConvEpilogue ep,
                         hipStream_t stream) {
   const size_t lds = 2 * (size_t)(kTM2 * 256 + COUT * 256) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = attr_set.pending()) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_dma_f32<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   k_conv_dma_f32<CIN, COUT><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep);
   UD_LAUNCH_CHECK();
@@ -1668,15 +1668,15 @@ int launch_conv_v2(const float* in, int cin, const int32_t* nbr, int K, int mirr
                    WStrides ws, const float* bias, float* out, int cout, int Mout,
                    const int32_t* order, ConvEpilogue ep, hipStream_t stream) {
   const size_t lds = (size_t)(kTM2 + COUT_P) * (CIN_P + 8) * sizeof(float) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = (lds > 64 * 1024) ? attr_set.pending() : 0ull) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P, true, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P, true, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_v2<CIN_P, COUT_P, false, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   const bool va = (cin & 3) == 0, vb = va && ws.sc == 1;
   const dim3 grid(ud_div_up(Mout, kTM2));
@@ -1703,11 +1703,11 @@ int launch_conv_bf16(const float* in, int cin, const int32_t* nbr, int K, int mi
   if (io == 7 && cin == CP && (cout & 7) == 0 && (ws.sn & 7) == 0 && (ws.sk & 7) == 0) {
     const size_t lds_d = dma_front_bytes(CP, COUT_P) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
     if (lds_d <= 160 * 1024) {
-      static bool dma_attr_set = false;
-      if (!dma_attr_set && lds_d > 64 * 1024) {
+      static UdDeviceOnce dma_attr_set;
+      if (const unsigned long long dma_attr_set_bit = (lds_d > 64 * 1024) ? dma_attr_set.pending() : 0ull) {
         UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_bf16_dma<CP, COUT_P>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
-        dma_attr_set = true;
+        dma_attr_set.mark(dma_attr_set_bit);
       }
       k_conv_mfma_bf16_dma<CP, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds_d, stream>>>(
           reinterpret_cast<const unsigned short*>(in), cin, nbr, K, mirror,
@@ -1720,11 +1720,11 @@ int launch_conv_bf16(const float* in, int cin, const int32_t* nbr, int K, int mi
   if (io == 7 && (cin & 7) == 0 && (cout & 7) == 0 && (ws.sn & 7) == 0 && (ws.sk & 7) == 0) {
     const size_t lds_f = fast_front_bytes(CP, COUT_P) + (size_t)K * kTM2 * sizeof(int) + 16 +
                          kTM2 * sizeof(int);
-    static bool fast_attr_set = false;
-    if (!fast_attr_set && lds_f > 64 * 1024) {
+    static UdDeviceOnce fast_attr_set;
+    if (const unsigned long long fast_attr_set_bit = (lds_f > 64 * 1024) ? fast_attr_set.pending() : 0ull) {
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_bf16_fast<CP, COUT_P>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-      fast_attr_set = true;
+      fast_attr_set.mark(fast_attr_set_bit);
     }
     k_conv_mfma_bf16_fast<CP, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds_f, stream>>>(
         reinterpret_cast<const unsigned short*>(in), cin, nbr, K, mirror,
@@ -1735,11 +1735,11 @@ int launch_conv_bf16(const float* in, int cin, const int32_t* nbr, int K, int mi
   }
   const size_t lds = (size_t)(kTM2 + COUT_P) * (CP + 8) * sizeof(unsigned short) +
                      (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = (lds > 64 * 1024) ? attr_set.pending() : 0ull) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma_bf16<CP, COUT_P>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   k_conv_mfma_bf16<CP, COUT_P><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(
       in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, io);
@@ -1765,11 +1765,11 @@ int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror,
     return launch_conv_v2<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, stream);
   if (ep.scale || ep.residual || ep.relu) return UD_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(kTM + COUT_P) * (CIN_P + 4) * sizeof(float) + kTM * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = (lds > 64 * 1024) ? attr_set.pending() : 0ull) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_mfma<CIN_P, COUT_P>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   k_conv_mfma<CIN_P, COUT_P><<<ud_div_up(Mout, kTM), 256, lds, stream>>>(
       in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout);
@@ -1784,20 +1784,20 @@ int launch_wgrad(const float* in, int cin, const int32_t* nbr, int K, const floa
   dim3 grid(K, G);
   if (cin % 4 == 0 && cout % 4 == 0) {        // 16-byte row copies (every layer but the 5-channel input conv)
     const size_t lds = (size_t)kTM * (WgLd<CIN_P>::v + WgLd<COUT_P>::v) * sizeof(float) + kTM * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static UdDeviceOnce attr_set;
+    if (const unsigned long long attr_set_bit = (lds > 64 * 1024) ? attr_set.pending() : 0ull) {
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_rows<CIN_P, COUT_P>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      attr_set.mark(attr_set_bit);
     }
     k_wgrad_rows<CIN_P, COUT_P><<<grid, 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial, Mout, rows_per_chunk);
   } else {
     const size_t lds = (size_t)(CIN_P + COUT_P) * (kTM + 4) * sizeof(float) + kTM * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static UdDeviceOnce attr_set;
+    if (const unsigned long long attr_set_bit = (lds > 64 * 1024) ? attr_set.pending() : 0ull) {
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_mfma<CIN_P, COUT_P>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      attr_set.mark(attr_set_bit);
     }
     k_wgrad_mfma<CIN_P, COUT_P><<<grid, 256, lds, stream>>>(in, cin, nbr, K, gout, cout, partial,
                                                             Mout, rows_per_chunk);
@@ -1929,13 +1929,13 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
     UD_LAUNCH_CHECK();
   }
   const size_t lds = (size_t)2 * kWR * (CIN_P + COUT_P + 32) * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = (lds > 64 * 1024) ? attr_set.pending() : 0ull) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16<CIN_P, COUT_P, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16<CIN_P, COUT_P, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   if constexpr ((CIN_P == 32 || CIN_P == 64 || CIN_P == 128) && (COUT_P == 32 || COUT_P == 64 || COUT_P == 128)) {
     // the DMA kernel walks nbr in tile order: either nothing is permuted (order NULL) or the caller passes a
@@ -1943,13 +1943,13 @@ int launch_wgrad_bf16(const float* in, int cin, const int32_t* nbr, int K, const
     const bool presorted = (io_bf16 & 2) != 0;
     if ((io_bf16 & 1) && cin == CIN_P && cout == COUT_P && (order == nullptr || presorted)) {
       const size_t lds_d = (size_t)2 * kWR * (CIN_P + COUT_P) * sizeof(unsigned short);
-      static bool dma_set = false;
-      if (!dma_set && lds_d > 64 * 1024) {
+      static UdDeviceOnce dma_set;
+      if (const unsigned long long dma_set_bit = (lds_d > 64 * 1024) ? dma_set.pending() : 0ull) {
         UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16_dma<CIN_P, COUT_P, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
         UD_HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_bf16_dma<CIN_P, COUT_P, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
-        dma_set = true;
+        dma_set.mark(dma_set_bit);
       }
       const unsigned short* in16 = reinterpret_cast<const unsigned short*>(in);
       const unsigned short* g16 = reinterpret_cast<const unsigned short*>(gout);

@@ -206,11 +206,11 @@ extern "C" int ud_stem_conv7x7_bn_relu(const float* x, int64_t sb, int64_t sc, i
   gm.sx = sx;
   const long long ntiles = (long long)B * gm.tiles_y * gm.tiles_x;
   if (ntiles >= (1ll << 31)) return UD_ERR_INVALID_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static UdDeviceOnce attr_set;
+  if (const unsigned long long attr_set_bit = attr_set.pending()) {
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_stem_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_stem_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
-    attr_set = true;
+    attr_set.mark(attr_set_bit);
   }
   UdProfScope prof("stem.k_stem_conv", stream);
   const int grid = (int)(ntiles < 512 ? ntiles : 512);          // persistent: two workgroups per CU keep the filters in LDS

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "unidistill_hip.h"
 
 #define UD_WAVE 64
@@ -36,6 +37,21 @@ struct UdArena {
 };
 
 static inline int ud_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Guard for "set once" HIP state that is really PER DEVICE (hipFuncSetAttribute: a process that drives several GPUs,
+// or several host threads, must not skip it on a device that has not seen it): a bit per device ordinal; racing
+// threads may both run the guarded block (idempotent calls), none can skip it.
+//   static UdDeviceOnce once;  if (const unsigned long long bit = once.pending()) { ...; once.mark(bit); }
+struct UdDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  unsigned long long pending() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long b = 1ull << (d & 63);
+    return (done.load(std::memory_order_acquire) & b) ? 0ull : b;
+  }
+  void mark(unsigned long long b) { done.fetch_or(b, std::memory_order_release); }
+};
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int ud_lane() { return threadIdx.x & (UD_WAVE - 1); }

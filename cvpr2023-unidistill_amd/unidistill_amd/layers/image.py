@@ -128,11 +128,14 @@ class ResNet(nn.Module):
                 warnings.warn(f"ResNet init_cfg checkpoint {spec!r} not found: UD_RANDOM_INIT=1 keeps the Kaiming "
                               "initialisation (benchmark mode; the reference starts from ImageNet weights)")
             elif self.frozen_stages >= 0:
-                # a frozen, randomly initialised stem can never be trained: refuse instead of training on it silently
-                raise FileNotFoundError(
+                # a frozen, randomly initialised stem can never be trained: refuse to TRAIN on it -- at the first training
+                # forward, not here, so that building the model in order to load a full trained checkpoint (evaluation,
+                # resume) works without any environment variable
+                self._missing_pretrained = (
                     f"ResNet init_cfg checkpoint {spec!r} not found and frozen_stages={self.frozen_stages} freezes "
-                    "the stem: point UD_RESNET50_CKPT (or init_cfg['checkpoint']) at a local torchvision ResNet-50 "
-                    "state_dict, or set UD_RANDOM_INIT=1 for synthetic benchmarks / tests")
+                    "the stem: load a checkpoint (load_state_dict), point UD_RESNET50_CKPT (or init_cfg['checkpoint']) at a "
+                    "local torchvision ResNet-50 state_dict, or set UD_RANDOM_INIT=1 for synthetic benchmarks / tests")
+                self.register_load_state_dict_post_hook(lambda m, _keys: setattr(m, "_missing_pretrained", None))
             else:
                 warnings.warn(f"ResNet init_cfg checkpoint {spec!r} not found: Kaiming initialisation kept")
 
@@ -153,7 +156,11 @@ class ResNet(nn.Module):
         ac = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
         return hipstem.stem(x, self.conv1, self.bn1, torch.bfloat16 if ac else torch.float32)
 
+    _missing_pretrained = None
+
     def forward(self, x):
+        if self._missing_pretrained and self.training and torch.is_grad_enabled():
+            raise FileNotFoundError(self._missing_pretrained)
         y = self._hip_stem(x)
         x = self.maxpool(batchnorm_act(self.bn1, self.conv1(x))) if y is None else y
         outs = []

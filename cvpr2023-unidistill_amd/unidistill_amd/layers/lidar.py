@@ -155,6 +155,7 @@ class LidarEncoder(nn.Module):
         rounds 1-2 here, read five times per pass); ragged inputs and the overflow fallback take the read-per-level path."""
         pts = lidar_points if isinstance(lidar_points, (list, tuple)) else [lidar_points]
         bb, vz = self.backbone_3d, self.voxelizer
+        overflowed = False
         if self.one_read and vz.fused_mean and all(p.shape == pts[0].shape for p in pts):
             batch = torch.stack(list(pts), 0) if len(pts) > 1 else pts[0].unsqueeze(0)
             B = batch.shape[0]
@@ -168,7 +169,8 @@ class LidarEncoder(nn.Module):
                 M = int(host[0])
                 sites = pyr.finalize(M, host[2:].tolist())
                 return sp.SparseConvTensor(mean_cap[:M], None, None, None, _sites=sites)
-        voxels, coords, num = self.voxelizer(lidar_points)
+            overflowed = True                                               # seen the fast path overflow: straight to the hash path
+        voxels, coords, num = self.voxelizer(lidar_points, algo=1 if overflowed else None)
         feats = self.vfe(voxels, num)
         x = sp.SparseConvTensor(feats, coords.int(), bb.sparse_shape, len(lidar_points))
         bb.site_pyramid(x)

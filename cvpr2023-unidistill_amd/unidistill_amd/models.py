@@ -62,7 +62,8 @@ class DetHead(nn.Module):
 
     def forward(self, x, gt_boxes, targets=None):
         ret = self.dense_head(x, gt_boxes, targets=targets)
-        if self.training and "box_encoding" in ret and targets is None:      # (precomputed targets are already cleaned)
+        # precomputed targets are cleaned by whoever built them and say so (train.DistillStep.prep); anything else is cleaned here
+        if self.training and "box_encoding" in ret and not (targets is not None and targets.get("box_encoding_clean")):
             for enc in ret["box_encoding"].values():
                 enc[torch.isinf(enc)] = 0          # log(0) of zero-size boxes (fusion_exp.py:124-126)
         return ret

@@ -85,6 +85,8 @@ def batch_stats(x, gamma, beta, running_mean, running_var, training, momentum, e
         return torch.stack((mean, invstd * invstd, invstd, scale, b32 - mean * scale))
 
     if gamma.requires_grad or beta.requires_grad or torch.cuda.is_current_stream_capturing():
+        if getattr(running_var, "_ud_bn_eval", None) is not None and not torch.cuda.is_current_stream_capturing():
+            running_var._ud_bn_eval = None   # trained now, possibly frozen again later: never serve the old fold
         return fold()
     key = (running_mean._version, running_var._version, gamma._version, beta._version, float(eps),
            running_mean.data_ptr(), running_var.data_ptr(), gamma.data_ptr(), beta.data_ptr())

@@ -68,6 +68,8 @@ def _cached(weight, key, make):
     the tensor and rebuilt when its version counter moves.  Trainable weights are converted on every
     call: fused optimizers update parameters without touching the version counter."""
     if weight.requires_grad or torch.cuda.is_current_stream_capturing():
+        if weight.requires_grad and getattr(weight, key, None) is not None:
+            setattr(weight, key, None)      # trained now, possibly frozen again later: never serve the old copy
         return make(weight.detach())
     ver = (weight._version, weight.data_ptr())
     hit = getattr(weight, key, None)

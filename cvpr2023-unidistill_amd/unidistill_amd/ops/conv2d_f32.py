@@ -60,6 +60,8 @@ def _wino_weights(weight, transposed):
         return U
 
     if weight.requires_grad or torch.cuda.is_current_stream_capturing():
+        if weight.requires_grad and getattr(weight, "_ud_wino", None) is not None:
+            weight._ud_wino = None          # a weight that is trained now and frozen again later must not find its old filters
         return make()
     key = (bool(transposed), weight._version, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
     cache = getattr(weight, "_ud_wino", None)

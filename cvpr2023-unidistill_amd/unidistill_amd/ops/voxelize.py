@@ -147,7 +147,9 @@ class Voxelization(nn.Module):
             return mv[0]
         return mv
 
-    def forward(self, points):
+    def forward(self, points, algo=None):
+        """algo: None = the wrapper's choice (fast path, repeated on the hash path after an overflow); 1 = the hash path
+        directly (a caller that has already seen the fast path's overflow word)."""
         if not isinstance(points, (list, tuple)):
             points = [points]
         same = all(p.shape == points[0].shape for p in points)
@@ -155,7 +157,7 @@ class Voxelization(nn.Module):
             batch = torch.stack(list(points), 0) if len(points) > 1 else points[0].unsqueeze(0)
             vox, coords, num, mean, _ = voxelize_batch(
                 batch, self.voxel_size, self.point_cloud_range, self.max_num_points,
-                self.max_voxels, want_voxels=not self.fused_mean, want_mean=self.fused_mean)
+                self.max_voxels, want_voxels=not self.fused_mean, want_mean=self.fused_mean, algo=algo)
             return (mean if self.fused_mean else vox), coords, num
         outs = []
         for i, p in enumerate(points):

@@ -86,6 +86,7 @@ class DistillStep(nn.Module):
         targets = head.assign_targets(gt)
         for enc in targets["box_encoding"].values():
             enc[torch.isinf(enc)] = 0
+        targets["box_encoding_clean"] = True       # DetHead.forward skips its own clean-up only on this flag
         G = self.geo
         pcr, vs, osf = G["point_cloud_range"], G["voxel_size"], G["out_size_factor"]
         corners, valid = D.box_corners_bev(gt9, pcr, vs, osf)
@@ -195,10 +196,15 @@ def to_channels_last(module):
 
 
 class Trainer:
-    """AdamW + grad clip + (optional) DDP around a module whose forward(batch) returns {'loss'}."""
+    """AdamW + MultiStepLR + grad clip + (optional) DDP around a module whose forward(batch) returns {'loss'}.
+
+    configure_optimizers of the reference (BEVFusion_nuscenes_base_exp.py:436-441) returns
+    ``[AdamW(lr, weight_decay=1e-7)], [MultiStepLR(optimizer, [10, 15])]``; Lightning steps such a scheduler
+    once per EPOCH: ``epoch_end()`` here is that hook (``lr_milestones=None`` disables it)."""
 
     def __init__(self, step_module, lr=2e-4, weight_decay=1e-7, grad_clip=0.1, device=None,
-                 bucket_cap_mb=64, autocast_dtype=None, channels_last=False):
+                 bucket_cap_mb=64, autocast_dtype=None, channels_last=False, lr_milestones=(10, 15),
+                 lr_gamma=0.1):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.module = step_module.to(self.device)
         if channels_last:
@@ -221,6 +227,10 @@ class Trainer:
                 bucket_cap_mb=bucket_cap_mb,
                 gradient_as_bucket_view=True, broadcast_buffers=False, find_unused_parameters=False)
         self.opt = torch.optim.AdamW(trainable, lr=lr, weight_decay=weight_decay, fused=True)
+        self.scheduler = None
+        if lr_milestones:
+            self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.opt, list(lr_milestones), gamma=lr_gamma)
+        self.epoch = 0
         self.params = trainable
         self.grad_clip = grad_clip
         self.autocast_dtype = autocast_dtype
@@ -238,6 +248,25 @@ class Trainer:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip, foreach=True)
         self.opt.step()
         return out
+
+    def epoch_end(self):
+        """Lightning's per-epoch scheduler step: lr x 0.1 after epochs 10 and 15 (MultiStepLR [10, 15])."""
+        self.epoch += 1
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return self.opt.param_groups[0]["lr"]
+
+    def state_dict(self):
+        return {"optimizer": self.opt.state_dict(), "epoch": self.epoch,
+                "scheduler": None if self.scheduler is None else self.scheduler.state_dict()}
+
+    def load_state_dict(self, state):
+        from .ops import invalidate_caches
+        invalidate_caches(self.module)          # cached re-layouts of frozen weights never outlive a (re)load
+        self.opt.load_state_dict(state["optimizer"])
+        self.epoch = state.get("epoch", 0)
+        if self.scheduler is not None and state.get("scheduler") is not None:
+            self.scheduler.load_state_dict(state["scheduler"])
 
 
 class DetectStep(nn.Module):

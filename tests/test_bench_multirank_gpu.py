@@ -29,6 +29,50 @@ def test_two_rank_bench_completes(hip_lib):
     assert "Grad strides do not match bucket view strides" not in res.stderr, res.stderr[-1500:]
 
 
+_GLOO_DISTILL = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path[:0] = [{root!r}, {pkg!r}]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                                  # both ranks share the box's one GPU
+dist.init_process_group("gloo")
+from unidistill_amd import train
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)                                      # same initial weights on every rank
+tr = train.Trainer(train.DistillStep({workload!r}), device=dev, channels_last=True)
+assert tr.ddp is not None
+batch = train.synthetic_batch(dev, 1, rank=rank)          # rank-specific data: gradients differ before the all-reduce
+for _ in range(3):
+    out = tr.step(batch)
+    assert torch.isfinite(out["loss"])
+flat = torch.cat([p.detach().flatten() for p in tr.params])
+ref = flat.clone()
+dist.broadcast(ref, 0)
+assert torch.equal(flat, ref), "ranks diverged: max |d| = %g" % float((flat - ref).abs().max())
+losses = [None, None]
+dist.all_gather_object(losses, float(out["loss"]))
+assert losses[0] != losses[1], "ranks saw the same batch"
+dist.barrier(); dist.destroy_process_group()
+print("GLOO_DISTILL_OK", rank)
+'''
+
+
+@pytest.mark.parametrize("workload,port", [("camera_exp_distill_lidar", 29541), ("lidar_exp_distill_fusion", 29542)])
+def test_two_rank_distill_steps_keep_ranks_identical(hip_lib, tmp_path, workload, port):
+    """Two data-parallel ranks (gloo collectives, both on GPU 0: the one-GPU box cannot host two RCCL ranks) run three
+    distillation steps of the two multi-GPU BASELINE workloads on DIFFERENT batches: DDP buckets (bucket views,
+    find_unused_parameters=False, a LiDAR student with data-dependent rulebooks), the packed normaliser all-reduce and
+    the fused optimizer must leave every trainable parameter bit-identical on both ranks."""
+    from conftest import PKG
+    path = tmp_path / "gloo_distill.py"
+    path.write_text(_GLOO_DISTILL.format(root=ROOT, pkg=PKG, workload=workload))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UD_RANDOM_INIT="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(path)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and res.stdout.count("GLOO_DISTILL_OK") == 2, res.stdout[-1500:] + res.stderr[-3000:]
+    assert "Grad strides do not match bucket view strides" not in res.stderr, res.stderr[-1500:]
+
+
 _NCCL_SCRIPT = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path[:0] = [{root!r}, {pkg!r}]

@@ -185,6 +185,53 @@ def test_inverse_conv_shapes_and_empty_input():
     assert e.dense().abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("shape,p,pd", [((2, 8, 12, 12), 0.2, (1, 1, 1)), ((1, 11, 20, 18), 0.1, (0, 1, 1))])
+def test_inverse_conv_values_vs_oracle_and_dense_transposed_conv(shape, p, pd):
+    """SparseInverseConv3d (spconv: the transposed rulebook of the SparseConv3d sharing its indice_key, SAME kernel
+    offsets, outputs at the fine sites): values vs the oracle's conv over ``in_nbr`` and vs torch's dense
+    conv_transpose3d sampled at the fine sites; gradients vs autograd through that dense formulation."""
+    from unidistill_amd.ops import spconv as sp
+    rng = np.random.default_rng(61 + shape[1])
+    coords = _sites(rng, *shape, p)
+    feat = rng.standard_normal((len(coords), 16)).astype(np.float32)
+    x = _tensor(coords, feat, shape)
+    x.features.requires_grad_(True)
+    torch.manual_seed(2)
+    down = sp.SparseConv3d(16, 32, 3, stride=2, padding=pd, indice_key="k").cuda()
+    up = sp.SparseInverseConv3d(32, 16, 3, indice_key="k").cuda()
+    mid = down(x)
+    z = up(mid)
+    assert z.features.shape == (len(coords), 16) and z.indices is x.indices
+    oc, onbr, inbr, oshape = oracle.spconv_down(coords, shape, (3, 3, 3), (2, 2, 2), pd)
+    Wd = down.weight.detach().cpu().numpy().reshape(32, 27, 16)
+    Wu = up.weight.detach().cpu().numpy().reshape(16, 27, 32)
+    d_ref = oracle.spconv_conv(feat, onbr, Wd, down.bias.detach().cpu().numpy())
+    z_ref = oracle.spconv_conv(d_ref, inbr, Wu, up.bias.detach().cpu().numpy())
+    np.testing.assert_allclose(z.features.detach().cpu().numpy(), z_ref, **_tol(z_ref))
+    # independent formulation: dense coarse map -> conv_transpose3d -> sampled at the fine sites
+    B, Dz, Hy, Wx = shape
+    dm = torch.zeros((B, 32) + tuple(oshape[1:]), dtype=torch.float64, device="cuda")
+    ocl = torch.from_numpy(oc).long().cuda()
+    mid_leaf = mid.features.detach().double().requires_grad_(True)
+    dm = dm.index_put((ocl[:, 0], slice(None), ocl[:, 1], ocl[:, 2], ocl[:, 3]), mid_leaf)
+    wt = up.weight.detach().double().permute(4, 0, 1, 2, 3).contiguous().requires_grad_(True)   # [Cin, Cout, kz, ky, kx]
+    opad = [d - ((o - 1) * 2 - 2 * q + 3) for d, o, q in zip((Dz, Hy, Wx), oshape[1:], pd)]
+    dense = torch.nn.functional.conv_transpose3d(dm, wt, up.bias.detach().double(), stride=2, padding=pd,
+                                                 output_padding=opad)
+    cl = torch.from_numpy(coords).long().cuda()
+    z_dense = dense[cl[:, 0], :, cl[:, 1], cl[:, 2], cl[:, 3]]
+    np.testing.assert_allclose(z.features.detach().cpu().numpy(), z_dense.detach().float().cpu().numpy(), **_tol(z_ref))
+    g = torch.from_numpy(rng.standard_normal(z_ref.shape).astype(np.float32)).cuda()
+    mid.features.retain_grad()
+    z.features.backward(g)
+    z_dense.backward(g.double())
+    gw_ref = wt.grad.permute(1, 2, 3, 4, 0).float().cpu().numpy()
+    np.testing.assert_allclose(up.weight.grad.cpu().numpy(), gw_ref, rtol=1e-4, atol=2e-4 * max(1.0, np.abs(gw_ref).max()))
+    gm_ref = mid_leaf.grad.float().cpu().numpy()
+    np.testing.assert_allclose(mid.features.grad.cpu().numpy(), gm_ref, **_tol(gm_ref))
+    assert x.features.grad is not None and torch.isfinite(x.features.grad).all()
+
+
 def test_rulebook_shared_between_indice_keys():
     from unidistill_amd.ops import spconv as sp
     rng = np.random.default_rng(8)

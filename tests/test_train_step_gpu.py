@@ -85,6 +85,34 @@ def test_cfg4_lidar_student_fusion_teacher_three_loss_step():
     assert (e["feat"], e["rel"], e["resp"]) == (10.0, 1.0, 10.0)       # lidar_exp_distill_fusion.py loss weights
 
 
+def test_lidar_student_camera_teacher_step():
+    """The fourth distillation experiment (..._lidar_exp_distill_camera.py:404,504-509): LiDAR student, camera
+    teacher, loss weights 10 / 5 / 1."""
+    step, out = _distill_step_checks("lidar_exp_distill_camera", batch_size=2, sweeps=1, ac=None)
+    assert step.teacher_model.camera_encoder is not None and step.teacher_model.lidar_encoder is None
+    assert step.model.camera_encoder is None and step.model.lidar_encoder is not None
+    e = step.exp
+    assert (e["feat"], e["rel"], e["resp"], e["clamp"]) == (10.0, 5.0, 1.0, 1e-4)
+
+
+def test_trainer_lr_schedule_is_multistep_10_15():
+    """configure_optimizers (BEVFusion_nuscenes_base_exp.py:436-441): AdamW(lr, wd 1e-7) + MultiStepLR [10, 15],
+    stepped once per epoch."""
+    from unidistill_amd import train
+    dev = torch.device("cuda:0")
+    tr = train.Trainer(train.DetectStep("lidar"), device=dev, lr=2e-4)
+    assert tr.opt.defaults["weight_decay"] == 1e-7
+    lrs = [tr.opt.param_groups[0]["lr"]] + [tr.epoch_end() for _ in range(16)]
+    assert lrs[0] == lrs[9] == 2e-4
+    assert abs(lrs[10] - 2e-5) < 1e-12 and abs(lrs[14] - 2e-5) < 1e-12 and abs(lrs[15] - 2e-6) < 1e-13
+    state = tr.state_dict()
+    tr2 = train.Trainer(train.DetectStep("lidar", model=tr.module.model), device=dev, lr=2e-4)
+    tr2.load_state_dict(state)
+    assert tr2.epoch == 16 and abs(tr2.opt.param_groups[0]["lr"] - 2e-6) < 1e-13
+    batch = train.synthetic_batch(dev, batch_size=1, with_imgs=False)
+    assert torch.isfinite(tr2.step(batch)["loss"])               # fused AdamW takes the scheduled lr
+
+
 def test_cfg5_camera_student_fusion_teacher_bf16_10_sweeps():
     """BASELINE configs[4]: fusion teacher + camera student, bf16 mixed precision, 10-sweep LiDAR clouds."""
     step, out = _distill_step_checks("camera_exp_distill_fusion", batch_size=1, sweeps=10, ac=torch.bfloat16)
