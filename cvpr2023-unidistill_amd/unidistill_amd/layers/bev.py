@@ -102,7 +102,7 @@ class FusionEncoder(nn.Module):
         self.use_elementwise = use_elementwise
         if not use_elementwise:
             self.att = nn.Sequential(nn.AdaptiveAvgPool2d(1),
-                                     nn.Conv2d(input_channel, input_channel, 1), nn.Sigmoid())
+                                     Conv2d(input_channel, input_channel, 1), nn.Sigmoid())
             self.reduce_conv = FusedSequential(Conv2d(input_channel, output_channel, 3, padding=1, bias=False),
                                              nn.BatchNorm2d(output_channel), nn.ReLU(True))
 

@@ -213,7 +213,7 @@ def test_inverse_conv_values_vs_oracle_and_dense_transposed_conv(shape, p, pd):
     dm = torch.zeros((B, 32) + tuple(oshape[1:]), dtype=torch.float64, device="cuda")
     ocl = torch.from_numpy(oc).long().cuda()
     mid_leaf = mid.features.detach().double().requires_grad_(True)
-    dm = dm.index_put((ocl[:, 0], slice(None), ocl[:, 1], ocl[:, 2], ocl[:, 3]), mid_leaf)
+    dm[ocl[:, 0], :, ocl[:, 1], ocl[:, 2], ocl[:, 3]] = mid_leaf
     wt = up.weight.detach().double().permute(4, 0, 1, 2, 3).contiguous().requires_grad_(True)   # [Cin, Cout, kz, ky, kx]
     opad = [d - ((o - 1) * 2 - 2 * q + 3) for d, o, q in zip((Dz, Hy, Wx), oshape[1:], pd)]
     dense = torch.nn.functional.conv_transpose3d(dm, wt, up.bias.detach().double(), stride=2, padding=pd,
