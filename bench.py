@@ -494,12 +494,29 @@ def timed_steps(trainer, batch, args, world, device):
     return dt, loss
 
 
-def host_enqueue_leg(trainer, batch, steps=5):
-    """Host-side cost of one training step: CPU seconds the process spends enqueuing it (python wrappers, autograd engine
-    thread, HIP launches), with the runtime's synchronisation switched from spinning to blocking so that the waits for the
-    GPU do not count.  With 8 ranks on one host this -- not xGMI -- bounds the scaling: a step is host-bound when
-    host_enqueue_ms approaches ms_per_step."""
+def _thread_cpu_seconds():
+    """{tid: (name, user + system CPU seconds)} of every thread of this process (/proc, 10 ms ticks)."""
+    tick = os.sysconf("SC_CLK_TCK")
+    out = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{tid}/stat").read()
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(tid)] = (f[f.index("(") + 1:f.rindex(")")], (int(rest[11]) + int(rest[12])) / tick)
+        except Exception:
+            pass
+    return out
+
+
+def host_enqueue_leg(trainer, batch, steps=20):
+    """Host-side cost of one training step: CPU time of the threads that ENQUEUE it -- the main thread (forward, losses,
+    optimizer) and the autograd engine's thread (backward) -- with the runtime's synchronisation switched from spinning to
+    blocking so that waiting for the GPU does not count.  These two run one after the other, so their sum is the host's
+    critical path per step: a step is host-bound when it approaches ms_per_step (8 ranks on one host: this, not xGMI, bounds
+    the scaling).  The HIP runtime's own helper thread polls completion signals the whole time the GPU is busy; it is listed
+    separately and is not enqueue work."""
     import ctypes
+    import threading
     hip = None
     try:                                       # the HIP runtime this process already runs on (torch's copy)
         path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
@@ -510,18 +527,24 @@ def host_enqueue_leg(trainer, batch, steps=5):
     for _ in range(2):
         trainer.step(batch)
     torch.cuda.synchronize()
-    w0, c0 = time.perf_counter(), time.process_time()
+    c0, w0 = _thread_cpu_seconds(), time.perf_counter()
     for _ in range(steps):
         trainer.step(batch)
-    c1 = time.process_time()
     torch.cuda.synchronize()
-    w1 = time.perf_counter()
+    w1, c1 = time.perf_counter(), _thread_cpu_seconds()
     if hip is not None:
         hip.hipSetDeviceFlags(ctypes.c_uint(0))                                      # hipDeviceScheduleAuto
-    return {"host_enqueue_ms": (c1 - c0) / steps * 1e3, "wall_ms": (w1 - w0) / steps * 1e3, "steps": steps,
+    main_tid = threading.get_native_id()
+    ms = {"main": 0.0, "autograd": 0.0, "runtime_and_other": 0.0}
+    for tid, (name, t) in c1.items():
+        d = (t - c0.get(tid, (name, 0.0))[1]) / steps * 1e3
+        ms["main" if tid == main_tid else "autograd" if name.startswith("pt_autograd") else "runtime_and_other"] += d
+    return {"host_enqueue_ms": ms["main"] + ms["autograd"], "main_thread_ms": ms["main"],
+            "autograd_thread_ms": ms["autograd"], "runtime_and_other_threads_ms": ms["runtime_and_other"],
+            "wall_ms": (w1 - w0) / steps * 1e3, "steps": steps,
             "sync_mode": "blocking" if blocking else "spin (flag refused: waits are counted)",
-            "note": "process CPU time per step (main thread + autograd thread + runtime threads) while the step is "
-                    "enqueued; GPU waits block instead of spinning during this leg"}
+            "note": "per-thread CPU time from /proc/self/task (10 ms ticks over %d steps); host_enqueue_ms = main + autograd "
+                    "thread" % steps}
 
 
 def assert_fracs(obj, path="line"):
