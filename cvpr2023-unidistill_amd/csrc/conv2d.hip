@@ -24,6 +24,7 @@
 #include "ud_prof.h"
 #include "conv_pixmap.h"
 #include "wgrad_sum.h"
+#include "conv3x3_p.h"
 
 namespace {
 
@@ -1049,6 +1050,15 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
     attr_set.mark(attr_set_bit);
   }
   UdProfScope prof("conv2d.k_conv3x3", stream);
+  if (ud_conv3x3_p_supported(B, H, W, Cin, Cout)) {       // persistent 32x32x16 kernel (csrc/conv2d_p.hip)
+    if (stats) {
+      const int slices = ud_conv3x3_p_slices(B, H, W);
+      if (stats_bytes < (size_t)slices * Cout * 2 * sizeof(float) || !slices_out) return UD_ERR_WORKSPACE;
+      *slices_out = slices;
+    }
+    return ud_conv3x3_p_launch(x, w, y, B, H, W, Cin, Cout, bias, scale, shift, residual, relu & 1, (relu >> 1) & 1, stats,
+                               stream);
+  }
   const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
   const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
   unsigned short* ys = reinterpret_cast<unsigned short*>(y);
