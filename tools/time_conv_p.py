@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cvpr2023-unidistill_amd")]
 import torch
 from unidistill_amd.ops import conv2d as c2
+from unidistill_amd import _lib
+_lib.load().ud_conv3x3_persistent(int(os.environ.get('UD_CONV_P', '1')))
 dev = torch.device("cuda:0"); B = int(os.environ.get("B", 4))
 SHAPES = [("trunk b0 256->128", B, 256, 180, 180, 128), ("trunk b0 128->128", B, 128, 180, 180, 128),
           ("trunk b1 256->256", B, 256, 90, 90, 256), ("head shared 512->64", B, 512, 180, 180, 64),
