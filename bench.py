@@ -494,57 +494,25 @@ def timed_steps(trainer, batch, args, world, device):
     return dt, loss
 
 
-def _thread_cpu_seconds():
-    """{tid: (name, user + system CPU seconds)} of every thread of this process (/proc, 10 ms ticks)."""
-    tick = os.sysconf("SC_CLK_TCK")
-    out = {}
-    for tid in os.listdir("/proc/self/task"):
-        try:
-            f = open(f"/proc/self/task/{tid}/stat").read()
-            rest = f[f.rindex(")") + 2:].split()
-            out[int(tid)] = (f[f.index("(") + 1:f.rindex(")")], (int(rest[11]) + int(rest[12])) / tick)
-        except Exception:
-            pass
-    return out
-
-
-def host_enqueue_leg(trainer, batch, steps=20):
+def host_enqueue_leg(workload, batch, bf16):
     """Host-side cost of one training step: CPU time of the threads that ENQUEUE it -- the main thread (forward, losses,
-    optimizer) and the autograd engine's thread (backward) -- with the runtime's synchronisation switched from spinning to
-    blocking so that waiting for the GPU does not count.  These two run one after the other, so their sum is the host's
-    critical path per step: a step is host-bound when it approaches ms_per_step (8 ranks on one host: this, not xGMI, bounds
-    the scaling).  The HIP runtime's own helper thread polls completion signals the whole time the GPU is busy; it is listed
-    separately and is not enqueue work."""
-    import ctypes
-    import threading
-    hip = None
-    try:                                       # the HIP runtime this process already runs on (torch's copy)
-        path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
-        hip = ctypes.CDLL(path)
-    except (StopIteration, OSError):
-        pass
-    blocking = hip is not None and hip.hipSetDeviceFlags(ctypes.c_uint(4)) == 0      # hipDeviceScheduleBlockingSync
-    for _ in range(2):
-        trainer.step(batch)
-    torch.cuda.synchronize()
-    c0, w0 = _thread_cpu_seconds(), time.perf_counter()
-    for _ in range(steps):
-        trainer.step(batch)
-    torch.cuda.synchronize()
-    w1, c1 = time.perf_counter(), _thread_cpu_seconds()
-    if hip is not None:
-        hip.hipSetDeviceFlags(ctypes.c_uint(0))                                      # hipDeviceScheduleAuto
-    main_tid = threading.get_native_id()
-    ms = {"main": 0.0, "autograd": 0.0, "runtime_and_other": 0.0}
-    for tid, (name, t) in c1.items():
-        d = (t - c0.get(tid, (name, 0.0))[1]) / steps * 1e3
-        ms["main" if tid == main_tid else "autograd" if name.startswith("pt_autograd") else "runtime_and_other"] += d
-    return {"host_enqueue_ms": ms["main"] + ms["autograd"], "main_thread_ms": ms["main"],
-            "autograd_thread_ms": ms["autograd"], "runtime_and_other_threads_ms": ms["runtime_and_other"],
-            "wall_ms": (w1 - w0) / steps * 1e3, "steps": steps,
-            "sync_mode": "blocking" if blocking else "spin (flag refused: waits are counted)",
-            "note": "per-thread CPU time from /proc/self/task (10 ms ticks over %d steps); host_enqueue_ms = main + autograd "
-                    "thread" % steps}
+    optimizer) and the autograd engine's thread (backward); they run one after the other, so their sum is the host's critical
+    path per step: a step is host-bound when it approaches ms_per_step (8 ranks on one host: this, not xGMI, bounds the
+    scaling).  Measured in a CHILD process (tools/host_threads.py --json) because the runtime's synchronisation has to be
+    switched from spinning to blocking BEFORE the first launch for the GPU waits not to count; the HIP runtime's own polling
+    thread is listed separately."""
+    import subprocess
+    env = dict(os.environ, WL=workload, B=str(batch), AC="bf16" if bf16 else "f32")
+    try:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_threads.py"), "--json"], env=env,
+                             capture_output=True, text=True, timeout=600)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        out["note"] = ("per-thread CPU time from /proc/self/task (10 ms ticks over %d steps) in a child process; "
+                       "host_enqueue_ms = main + autograd thread" % out["steps"])
+        return out
+    except Exception as e:          # never fail the benchmark line over the side measurement
+        return {"host_enqueue_ms": None, "error": repr(e)[:200]}
 
 
 def assert_fracs(obj, path="line"):
@@ -607,7 +575,6 @@ def main():
     dt, loss = timed_steps(trainer, batch, args, world, device)
     # second precision + the MFMA legs take extra (collective) training steps: EVERY rank runs them
     bf16, mfma, mfma32 = None, None, None
-    host = host_enqueue_leg(trainer, batch)          # collective steps: every rank
     if ac is None and not args.no_roofline:
         mfma32 = mfma_leg(trainer, batch, fp32=True)
     if ac is None and not args.no_bf16_leg:
@@ -621,7 +588,6 @@ def main():
                 "final_loss": loss16, "precision": PRECISION_NOTE[torch.bfloat16],
                 "note": "same workload, batch and step as the headline under bf16 autocast + channels-last "
                         "(BASELINE.json configs[4]-style mixed precision; NOT the headline: the reference trains in fp32)"}
-        bf16["host_enqueue"] = host_enqueue_leg(trainer16, batch)
         if not args.no_roofline:
             mfma = mfma_leg(trainer16, batch, fp32=False)
         del trainer16
@@ -643,7 +609,6 @@ def main():
                        "precision": PRECISION_NOTE[ac],
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
                        "executor": "eager+DDP"},
-            "host_enqueue_ms": host["host_enqueue_ms"], "host_enqueue": host,
         }
         if bf16 is not None:
             line["bf16_mixed_precision"] = bf16
@@ -656,6 +621,11 @@ def main():
                 line["roofline_spconv"] = spconv_leg(device, batch)
             if mfma is not None:
                 line["roofline_mfma"] = mfma
+        if world == 1 and not args.no_roofline and wl["kind"] == "distill":
+            host = host_enqueue_leg(args.workload, args.batch, False)
+            line["host_enqueue_ms"], line["host_enqueue"] = host.get("host_enqueue_ms"), host
+            if bf16 is not None:
+                line["bf16_mixed_precision"]["host_enqueue"] = host_enqueue_leg(args.workload, args.batch, True)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(device)
         assert_fracs(line)

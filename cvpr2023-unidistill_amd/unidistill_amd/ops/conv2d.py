@@ -288,6 +288,17 @@ class _Conv1x1Fn(torch.autograd.Function):
                 gskip = _nhwc(gskip.to(torch.bfloat16))
             if ctx.hip and cout % 64 == 0:       # the kernel's reduction dimension comes in 64-channel slices
                 gx = _launch1x1(gy, _w1x1_t(weight), cin, residual=gskip)
+            elif ctx.hip:
+                # Cout not a multiple of 64 (the depth net, 512 -> 368): zero-pad dy and the transposed weights to the next
+                # multiple (one copy of dy) instead of leaving the hand-written path for a library GEMM
+                pad = (-cout) % 64
+                gyp = torch.empty((B, cout + pad, H, W), dtype=torch.bfloat16, device=gy.device,
+                                  memory_format=torch.channels_last)
+                gyp[:, :cout] = gy
+                gyp[:, cout:] = 0
+                wt = torch.zeros((cin, cout + pad), dtype=torch.bfloat16, device=gy.device)
+                wt[:, :cout] = weight.detach().view(cout, cin).t()
+                gx = _launch1x1(gyp, wt, cin, residual=gskip)
             elif ctx.gemm:
                 g2, w2 = gy.permute(0, 2, 3, 1).reshape(B * H * W, cout), wb.view(cout, cin)
                 gx = g2 @ w2 if gskip is None else torch.addmm(gskip.permute(0, 2, 3, 1).reshape(B * H * W, cin), g2, w2)

@@ -27,7 +27,9 @@ def thread_cpu():
 dev = torch.device("cuda:0")
 path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
 hip = ctypes.CDLL(path)
-print("blocking sync flag rc:", hip.hipSetDeviceFlags(ctypes.c_uint(4)))
+_rc = hip.hipSetDeviceFlags(ctypes.c_uint(4))
+if "--json" not in sys.argv:
+    print("blocking sync flag rc:", _rc)
 torch.manual_seed(0)
 AC = torch.bfloat16 if os.environ.get("AC") == "bf16" else None
 tr = T.Trainer(T.DistillStep(os.environ.get("WL", "camera_exp_distill_lidar")), device=dev, autocast_dtype=AC, channels_last=True)
@@ -35,13 +37,24 @@ batch = T.synthetic_batch(dev, int(os.environ.get("B", 4)))
 for _ in range(5):
     tr.step(batch)
 torch.cuda.synchronize()
-N = int(os.environ.get("STEPS", 10))
+N = int(os.environ.get("STEPS", 20 if "--json" in sys.argv else 10))
 c0, w0, p0 = thread_cpu(), time.perf_counter(), time.process_time()
 for _ in range(N):
     tr.step(batch)
 p1 = time.process_time()
 torch.cuda.synchronize()
 w1, c1 = time.perf_counter(), thread_cpu()
+if "--json" in sys.argv:        # bench.py's host_enqueue leg: one JSON line, no profile
+    import json
+    main_tid = threading.get_native_id()
+    ms = {"main": 0.0, "autograd": 0.0, "runtime_and_other": 0.0}
+    for tid, (name, t) in c1.items():
+        d = (t - c0.get(tid, (name, 0.0))[1]) / N * 1e3
+        ms["main" if tid == main_tid else "autograd" if name.startswith("pt_autograd") else "runtime_and_other"] += d
+    print(json.dumps({"host_enqueue_ms": ms["main"] + ms["autograd"], "main_thread_ms": ms["main"],
+                      "autograd_thread_ms": ms["autograd"], "runtime_and_other_threads_ms": ms["runtime_and_other"],
+                      "wall_ms": 1e3 * (w1 - w0) / N, "steps": N, "sync_mode": "blocking (hipDeviceScheduleBlockingSync set before the first launch)"}))
+    sys.exit(0)
 print(f"wall {1e3 * (w1 - w0) / N:.2f} ms/step, process CPU {1e3 * (p1 - p0) / N:.2f} ms/step; main tid {threading.get_native_id()}")
 for tid, (name, t) in sorted(c1.items(), key=lambda kv: -(kv[1][1] - c0.get(kv[0], ("", 0))[1])):
     d = t - c0.get(tid, ("", 0.0))[1]
