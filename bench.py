@@ -460,6 +460,8 @@ def cpu_baseline_leg(device):
     except Exception:
         cpu_name = "unknown"
     return {"value": 1.0 / med, "unit": "samples/s", "cores": ncores, "kind": "port",
+            "label": "port with a SCALAR oracle inside: geometry / lift / voxel pooling run as single-thread C + numpy (the "
+                     "oracle is the checker, not a tuned CPU implementation); only the torch CPU ops use all the cores",
             "sample": "BASELINE configs[0]: camera-only student, 1 camera 256x704, batch 1, random weights, "
                       "forward+backward; torch CPU ops (image branch, BEV trunk, head, target assignment, loss) + "
                       "CPU oracle (geometry, lift, voxel pooling fwd/bwd); median of 10 iterations after 2 warm-ups on the "

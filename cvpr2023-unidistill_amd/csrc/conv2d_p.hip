@@ -69,6 +69,11 @@ __device__ __forceinline__ void wait_vm() {
 __device__ __forceinline__ bf16x8 lds_frag(const char* smem, unsigned addr) {
   return *reinterpret_cast<const bf16x8*>(smem + addr);
 }
+// Fragment read the compiler does not track: it would wait lgkmcnt(0) before the first use of ANY outstanding LDS read,
+// i.e. for the reads of the next k-step it has just issued; here the waits are counted by hand (UD_WAITSET).
+__device__ __forceinline__ void lds_read_asm(bf16x8& dst, unsigned addr, int imm) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
+}
 
 // One work item of a workgroup's range: a full tile (two half units) or a half tile.
 struct Tile {
@@ -213,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_p(const unsigned short* __
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) wf[1][nb] = wf[0][nb];
     xf[1][0] = xf[1][1] = xf[0][0];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   bool more = true;
   while (more) {
@@ -247,11 +253,18 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_p(const unsigned short* __
   /* One tap = four k-steps of 16 channels, software-pipelined over two fragment sets: the reads of step k + 1 are issued  \
      before the MFMAs of step k (set 0 enters the tap already loaded -- read during the previous tap -- and leaves it    \
      holding the first step of the next one); the DMA issue of the wave's role comes last, under the draining MFMAs. */     \
-#define UD_LOADSET(S, KS, WSLOT, XBASE, DY, FULL)                                                                       \
+#define UD_LOADSET(S, WBASE, XBASE, DY, FULL)                                                                           \
   if (!(ABL & 2)) {                                                                                                     \
-    _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb) wf[S][nb] = lds_frag(smem, wa[KS] + (WSLOT) + nb * 4096);        \
-    xf[S][0] = lds_frag(smem, (XBASE) + (DY) * kHaloW * 128);                                                           \
-    if (FULL) xf[S][1] = lds_frag(smem, (XBASE) + (2 + (DY)) * kHaloW * 128);                                           \
+    _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb) lds_read_asm(wf[S][nb], (WBASE), nb * 4096);                     \
+    lds_read_asm(xf[S][0], (XBASE), (DY) * kHaloW * 128);                                                               \
+    if (FULL) lds_read_asm(xf[S][1], (XBASE), (2 + (DY)) * kHaloW * 128);                                               \
+  }
+/* wait until at most N LDS reads are outstanding; the set's registers are in / out operands so that no MFMA on them can   \
+   be scheduled above the wait (the compiler knows nothing about the asm loads' latency) */                               \
+#define UD_WAITSET(S, N)                                                                                                \
+  if (!(ABL & 2)) {                                                                                                     \
+    if (NBW == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[S][0]), "+v"(wf[S][NBW - 1]), "+v"(xf[S][0]), "+v"(xf[S][1]) : "n"(N)); \
+    else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(wf[S][0]), "+v"(xf[S][0]), "+v"(xf[S][1]) : "n"(N));               \
   }
 #define UD_MMASET(S, FULL)                                                                                              \
   if (!(ABL & 1)) {                                                                                                     \
@@ -266,30 +279,27 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_p(const unsigned short* __
   {                                                                                                                     \
     constexpr int dy = (T) / 3, dx = (T) % 3;                                                                           \
     constexpr int ndy = (T) < 8 ? ((T) + 1) / 3 : 0, ndx = (T) < 8 ? ((T) + 1) % 3 : 0;                                 \
-    constexpr int kReads = NBW + 1 + ((FULL) ? 1 : 0), kMfma = NBW * ((FULL) ? 2 : 1);                                  \
+    constexpr int kReads = NBW + 1 + ((FULL) ? 1 : 0);                                                                  \
+    constexpr int kReadsNext = NBW + 1 + (((FULL) || (T) == 8) ? 1 : 0);                                                \
     unsigned wslot = (unsigned)((((T) + phase) & 3) * kWBytes);                                                         \
     unsigned nslot = (unsigned)((((T) + 1 + phase) & 3) * kWBytes);                                                     \
     /* opaque: keeps the slot-relative fragment addresses of all nine taps from being precomputed per stage (~30 VGPRs) */ \
     asm volatile("" : "+s"(wslot), "+s"(nslot));                                                                        \
     const unsigned nx = xa[ndx][0] + ((T) < 8 ? 0u : xnext);                                                            \
-    UD_LOADSET(1, 1, wslot, xa[dx][1], dy, FULL)                                                                        \
+    /* set 0 holds k-step 0 (read and awaited during the previous tap) */                                               \
+    UD_LOADSET(1, wa[1] + wslot, xa[dx][1], dy, FULL)                                                                   \
     UD_MMASET(0, FULL)                                                                                                  \
-    UD_LOADSET(0, 2, wslot, xa[dx][2], dy, FULL)                                                                        \
+    UD_LOADSET(0, wa[2] + wslot, xa[dx][2], dy, FULL)                                                                   \
+    UD_WAITSET(1, kReads)                                                                                               \
     UD_MMASET(1, FULL)                                                                                                  \
-    UD_LOADSET(1, 3, wslot, xa[dx][3], dy, FULL)                                                                        \
+    UD_LOADSET(1, wa[3] + wslot, xa[dx][3], dy, FULL)                                                                   \
+    UD_WAITSET(0, kReads)                                                                                               \
     UD_MMASET(0, FULL)                                                                                                  \
     /* first k-step of the next tap (T = 8: tap 0 of the next stage, whose halo was awaited before barrier 7; it may be \
        a full tile while this one is not: always read both blocks then) */                                              \
-    UD_LOADSET(0, 0, nslot, nx, ndy, (FULL) || (T) == 8)                                                                \
+    UD_LOADSET(0, wa[0] + nslot, nx, ndy, (FULL) || (T) == 8)                                                           \
+    UD_WAITSET(1, kReadsNext)                                                                                           \
     UD_MMASET(1, FULL)                                                                                                  \
-    __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);                                                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, kMfma, 0);                                                              \
-    __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);                                                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, kMfma, 0);                                                              \
-    __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);                                                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, kMfma, 0);                                                              \
-    __builtin_amdgcn_sched_group_barrier(0x100, kReads + ((T) == 8 && !(FULL) ? 1 : 0), 0);                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, kMfma, 0);                                                              \
     /* weights three taps ahead (next stage for T >= 6) / two halo pieces of the next stage */                          \
     if (w_wave) {                                                                                                       \
       if (!(ABL & 8)) {                                                                                                 \
@@ -305,6 +315,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_p(const unsigned short* __
       }                                                                                                                 \
       if ((T) == 7) wait_vm<0>();            /* the next stage's halo: visible after this barrier */                   \
     }                                                                                                                   \
+    UD_WAITSET(0, 0)                         /* the next tap's first fragments */                                       \
     if (!(ABL & 16)) __builtin_amdgcn_s_barrier();                                                                      \
   }
 #define UD_TAPS(FULL) UD_TAP(0, FULL) UD_TAP(1, FULL) UD_TAP(2, FULL) UD_TAP(3, FULL) UD_TAP(4, FULL) UD_TAP(5, FULL) \
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_p(const unsigned short* __
 #undef UD_TAPS
 #undef UD_TAP
 #undef UD_MMASET
+#undef UD_WAITSET
 #undef UD_LOADSET
 
     buf ^= 1;
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_p(const unsigned short* __
           }
           const uint4 pk = make_uint4(ud_pack_bf16x2(vv[0], vv[1]), ud_pack_bf16x2(vv[2], vv[3]),
                                       ud_pack_bf16x2(vv[4], vv[5]), ud_pack_bf16x2(vv[6], vv[7]));
-          if (ok) *reinterpret_cast<uint4*>(y + pix + n) = pk;
+          if (ok && !(ABL & 32)) *reinterpret_cast<uint4*>(y + pix + n) = pk;
           if (ep.stats) {
             const unsigned pw[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
@@ -484,7 +496,7 @@ int ud_conv3x3_p_launch(const void* x, const void* w, void* y, int B, int H, int
   if (abl && !narrow) {       // timing ablations (results are wrong): 1 no MFMA, 2 no LDS reads, 4 no halo DMA, 8 no weight DMA, 16 no barrier
 #define UD_ABL(A) case A: UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_p<2, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128)); \
                           k_conv3x3_p<2, A><<<grid, kThreads, lds128, stream>>>(xs, ws, ys, gm, ep); break;
-    switch (abl) { UD_ABL(1) UD_ABL(2) UD_ABL(3) UD_ABL(4) UD_ABL(8) UD_ABL(12) UD_ABL(16) UD_ABL(28) default: break; }
+    switch (abl) { UD_ABL(1) UD_ABL(2) UD_ABL(3) UD_ABL(4) UD_ABL(8) UD_ABL(12) UD_ABL(16) UD_ABL(28) UD_ABL(30) UD_ABL(60) UD_ABL(62) default: break; }
 #undef UD_ABL
     UD_LAUNCH_CHECK();
     return UD_OK;
