@@ -2,9 +2,9 @@
 # Regenerate the rocprofv3 evidence on the GPU box (run through gpurun); summaries land in
 # gpurun_out/profiles_rNN/ and are then copied to profiles/ (tracked), together with profiles/traffic.json, which
 # bench.py reads for its `traffic` figures.
-#   gpurun --timeout 2400 -- 'bash tools/make_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/make_profiles.sh r04'
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -48,6 +48,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc6 -- python $T/pmc_conv3x3.
   python $T/rocpd_pmc.py $(ls /tmp/pmc5/*/*.db | head -1) k_conv3x3_taps | tail -1; python $T/rocpd_pmc.py $(ls /tmp/pmc6/*/*.db | head -1) k_conv3x3_taps | tail -1; echo '```'; } > $OUT/${R}_pmc_conv3x3.md
 # 5. MFMA-only loop (the machine's sustained matrix rates)
 { echo "# MFMA-only loop on the MI355X box (tools/mfma_peak.hip, $R)"; echo; echo '```'; hipcc --offload-arch=gfx950 -O3 $T/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && /tmp/mfma_peak | tee /tmp/mfma_peak.txt; echo '```'; } > $OUT/${R}_mfma_peak.md
+{ echo; echo "## v_mfma_f32_32x32x16_bf16 on constant vs RANDOM operands (tools/mfma_rand.hip)"; echo; echo '```'; hipcc --offload-arch=gfx950 -O3 $T/mfma_rand.hip -o /tmp/mfma_rand 2>/dev/null && /tmp/mfma_rand; echo '```'; echo; echo "## LDS-DMA fill rate from L2-resident / HBM windows, alone and beside MFMAs (tools/dma_rate.hip)"; echo; echo '```'; hipcc --offload-arch=gfx950 -O3 $T/dma_rate.hip -o /tmp/dma_rate 2>/dev/null && /tmp/dma_rate | sed 's/ =   0.0 B\/clk\/CU@2.4//'; echo '```'; } >> $OUT/${R}_mfma_peak.md
 python $T/traffic_json.py $R $(ls /tmp/pmc1/*/*.db | head -1) $(ls /tmp/pmc2/*/*.db | head -1) $(ls /tmp/pmc3/*/*.db | head -1) $(ls /tmp/pmc4/*/*.db | head -1) $(ls /tmp/pmc5/*/*.db | head -1) $(ls /tmp/pmc6/*/*.db | head -1) /tmp/mfma_peak.txt > $OUT/traffic.json 2> $OUT/traffic_json.err
 # 6. sparse encoder
 rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T/time_spconv.py > $OUT/spconv_stdout.txt 2>&1
