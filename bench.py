@@ -102,19 +102,28 @@ def roofline_leg(device, batch):
     torch.cuda.synchronize()
     reps = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    op_ms = 0.0
-    # two passes: the op as a whole WITHOUT the per-kernel event brackets (they add ~4 us to each of its five launches),
-    # then the same launches with them for the kernel's own duration
-    for prof in (False, True):
-        _lib.prof_enable(prof)
+    op_ms = op_dirty_ms = 0.0
+    scrub.zero_()
+    scrub64 = scrub.view(torch.int64)
+    # three passes: the op as a whole WITHOUT the per-kernel event brackets (they add ~4 us to each of its launches), evicting
+    # feat from the Infinity Cache first with a READ of 512 MB (clean lines: honest HBM reads, nothing else in flight);
+    # the same after a 512 MB memset instead (rounds 1-3's protocol: the memset's dirty lines are written back WHILE the op
+    # runs -- reported as op_avg_us_dirty_scrub); then the launches with the brackets for the kernel's own duration
+    for mode in ("clean", "dirty", "prof"):
+        _lib.prof_enable(mode == "prof")
         for _ in range(reps):
-            scrub.zero_()                       # evict feat from the Infinity Cache: honest HBM reads
+            if mode == "dirty":
+                scrub.zero_()
+            else:
+                scrub64.sum()
             e0.record()
             bp._pool_fwd(geom, feat, out, pos, B, N, C, nx, ny, 1, bp.POOL_OVERWRITE)
             e1.record()
             torch.cuda.synchronize()
-            if not prof:
+            if mode == "clean":
                 op_ms += e0.elapsed_time(e1)
+            elif mode == "dirty":
+                op_dirty_ms += e0.elapsed_time(e1)
     _lib.prof_enable(False)
     k_ms, k_calls = _lib.prof_read("bev_pool.k_pool")
     alg = B * N * (12 + C * 4 + 12) + B * ny * nx * C * 4          # SURVEY 8d bev_pool fwd row
@@ -132,7 +141,8 @@ def roofline_leg(device, batch):
                             "HBM throughput of the kernel itself = frac_counter_bytes" % (B * N, 100 * in_grid),
             "avg_kernel_us": k_us, "launches": k_calls, "algorithmic_bytes_per_launch": alg,
             "op_avg_us": op_ms / reps * 1e3, "op_GBps": alg / (op_ms / reps * 1e-3) / 1e9,
-            # whole op (memset + k_bin + scan + k_fill + k_pool) against the same algorithmic bytes
+            "op_avg_us_dirty_scrub": op_dirty_ms / reps * 1e3,
+            # whole op (memset of the cell counts + k_bin + k_pool) against the same algorithmic bytes
             "frac_op": alg / (op_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # the kernel against the HBM bytes it really moves (PMC traffic below: out-of-grid rows are never read)
             "frac_counter_bytes": (traffic / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
@@ -140,7 +150,8 @@ def roofline_leg(device, batch):
             "traffic": traffic, "traffic_source": pf.get("source") if traffic else None,
             "note": "measured after the timed region; HIP events bracket each launch, so avg_kernel_us carries "
                     "the ~6 us dispatch latency that rocprofv3's kernel duration (profiles/) does not; op_avg_us is "
-                    "timed in a separate pass without those brackets; the "
+                    "timed in a separate pass without those brackets, feat evicted from the Infinity Cache by a 512 MB read "
+                    "(op_avg_us_dirty_scrub: by a 512 MB memset, whose write-back then overlaps the op); the "
                     "training step itself uses the fused lift+splat (no [B,N,C] tensor), see DESIGN.md"}
 
 

@@ -5,18 +5,19 @@
 // backward gather (lss_fpn.py:64-79).
 //
 // Design (not the reference CUDA op's per-(point,channel) atomicAdd):
-//   k_bin    one thread per frustum point: bounds test, write pos_memo, wave-aggregated
-//            integer atomic to count points per BEV cell (gives an arbitrary in-cell rank)
-//   k_cell_partials / k_cell_offsets   two-level exclusive scan of the per-cell counts (1024 cells
-//            per workgroup) + ordered list of "heavy" cells (> 64 points)
-//   k_fill   scatter point ids into per-cell lists
+//   k_bin    one thread per frustum point: bounds test, write pos_memo; the points of a cell are counted with one
+//            integer atomic per (workgroup, distinct cell), which gives every point an arbitrary in-cell rank, and the
+//            point id goes STRAIGHT into slot `rank` of the cell's fixed 256-slot row of the id table (a light cell's
+//            list is the first 256 bytes of its row: no scan of the counts, no second scatter pass -- rounds 1-3 ran
+//            k_cell_offsets + k_fill here).  Ranks >= 256 (the frustum puts ~200 points into its densest cells) append
+//            (cell, id) to an overflow list; the workgroup whose reservation crosses 64 appends the cell to the heavy list.
 //   k_pool   light role: one WAVE per cell (<= 64 points): in-register rank sort of the cell's
 //            point ids, then each lane owns 4 channels (16 B) of the 1 KiB feature row and adds
 //            the rows in ascending point order -> coalesced 1 KiB reads, one 1 KiB write, no fp
 //            atomics, bit-reproducible and bit-identical to a sequential CPU loop.
 //            heavy role (first kHeavyBlocks workgroups of the same launch, so the long cells
-//            start first and overlap the light ones): LDS bitonic sort of the ids, 4 waves sum
-//            contiguous chunks, partials are combined in wave order.
+//            start first and overlap the light ones): the cell's row + its entries of the overflow list, LDS bitonic
+//            sort of the ids, 4 waves sum contiguous chunks, partials are combined in wave order.
 // HBM traffic = every kept feature row once + the output once; that is the algorithmic minimum.
 #include "ud_common.h"
 #include "ud_prof.h"
@@ -25,15 +26,17 @@
 namespace {
 
 constexpr int kLightMax = 64;      // cells with more points go to k_heavy
+constexpr int kRow = 256;          // slots of a cell's row in the id table (1 KiB); ranks beyond go to the overflow list
 constexpr int kHeavySortMax = 4096;  // LDS sort capacity of the heavy role; above: index-range scan
 constexpr int kHeavyBlocks = 128;    // persistent heavy-role workgroups at the front of k_pool
 constexpr int kLightBlocks = 2048;   // persistent light-role workgroups (256 CUs x 8)
-constexpr int kScanTile = 1024;      // cells per workgroup in the two-level scan
 
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
                                              int32_t* __restrict__ pos, int* __restrict__ count,
-                                             int* __restrict__ rank, int* __restrict__ cellid,
+                                             int* __restrict__ list, int* __restrict__ cellid,
+                                             int* __restrict__ heavy_list, int* __restrict__ heavy_cnt,
+                                             int2* __restrict__ ovf, int* __restrict__ ovf_cnt,
                                              long long total, int N, int nx, int ny, int nz) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   int cell = -1;
@@ -55,7 +58,9 @@ __global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
   // thread per occupied slot reserves the cell's range, and every point takes base + its LDS ticket.
   constexpr int kSlots = 512;
   __shared__ int s_key[kSlots], s_cnt[kSlots], s_base[kSlots];
+  __shared__ int s_ovf, s_ovf_base;
   for (int i = threadIdx.x; i < kSlots; i += 256) s_key[i] = -1, s_cnt[i] = 0;
+  if (threadIdx.x == 0) s_ovf = 0;
   __syncthreads();
   int slot = -1, ticket = 0;
   if (cell >= 0) {
@@ -70,117 +75,29 @@ __global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kSlots; i += 256)
-    if (s_cnt[i] > 0) s_base[i] = atomicAdd(&count[s_key[i]], s_cnt[i]);
+    if (s_cnt[i] > 0) {
+      const int key = s_key[i], c = s_cnt[i];
+      const int b = atomicAdd(&count[key], c);
+      s_base[i] = b;
+      // exactly one reservation per cell crosses the light limit: that workgroup lists the cell as heavy
+      if (b <= kLightMax && b + c > kLightMax) heavy_list[atomicAdd(heavy_cnt, 1)] = key;
+    }
   __syncthreads();
+  int r = -1;
   if (gid < total) {
     cellid[gid] = cell;
-    rank[gid] = cell >= 0 ? s_base[slot] + ticket : 0;
+    if (cell >= 0) r = s_base[slot] + ticket;
   }
-}
-
-// ----------------------------------------------------------------------------------------
-// Two-level exclusive scan over the per-cell counts (count[] is zero-padded to a multiple of
-// kScanTile).  Pass 1: per-tile (sum, #heavy).  Pass 2: every tile reduces the partials of the
-// tiles before it, scans its own 1024 cells and emits offsets + the ordered heavy-cell list.
-__device__ __forceinline__ int2 block_excl_scan2(int2 v, int2* s_w, int2& total) {
-  // exclusive scan of one int2 per thread across a 256-thread block (4 waves)
-  const int lane = ud_lane(), wave = threadIdx.x >> 6;
-  int2 inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int ax = __shfl_up(inc.x, o), ay = __shfl_up(inc.y, o);
-    if (lane >= o) {
-      inc.x += ax;
-      inc.y += ay;
-    }
+  const bool over = r >= kRow;
+  if (r >= 0 && !over) list[(size_t)cell * kRow + r] = (int)gid;
+  // ranks past the row (a cell with hundreds of points): one overflow-list reservation per workgroup
+  int t = 0;
+  if (over) t = atomicAdd(&s_ovf, 1);
+  if (__syncthreads_or(over)) {
+    if (threadIdx.x == 0) s_ovf_base = atomicAdd(ovf_cnt, s_ovf);
+    __syncthreads();
+    if (over) ovf[s_ovf_base + t] = make_int2(cell, (int)gid);
   }
-  if (lane == 63) s_w[wave] = inc;
-  __syncthreads();
-  int2 base = make_int2(0, 0);
-  int2 tot = make_int2(0, 0);
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int2 t = s_w[w];
-    if (w < wave) {
-      base.x += t.x;
-      base.y += t.y;
-    }
-    tot.x += t.x;
-    tot.y += t.y;
-  }
-  total = tot;
-  __syncthreads();
-  return make_int2(base.x + inc.x - v.x, base.y + inc.y - v.y);
-}
-
-__global__ __launch_bounds__(256) void k_cell_partials(const int* __restrict__ count,
-                                                       int2* __restrict__ part) {
-  __shared__ int2 s_w[4];
-  const int4 c = reinterpret_cast<const int4*>(count)[blockIdx.x * 256 + threadIdx.x];
-  int2 v = make_int2(c.x + c.y + c.z + c.w, (c.x > kLightMax) + (c.y > kLightMax) +
-                                                (c.z > kLightMax) + (c.w > kLightMax));
-  int2 tot;
-  block_excl_scan2(v, s_w, tot);
-  if (threadIdx.x == 0) part[blockIdx.x] = tot;
-}
-
-// DIRECT: with few tiles (one or two samples) every workgroup sums the counts of the tiles before it
-// straight from count[] (<= 64 int4 loads per thread, L2 resident) -- one launch less than the partials pass.
-template <bool DIRECT>
-__global__ __launch_bounds__(256) void k_cell_offsets(const int* __restrict__ count,
-                                                      const int2* __restrict__ part,
-                                                      int* __restrict__ off,
-                                                      int* __restrict__ heavy_list,
-                                                      int* __restrict__ heavy_cnt, int ncell) {
-  __shared__ int2 s_w[4];
-  // sum of the partials of all tiles before this one
-  int2 pre = make_int2(0, 0);
-  if (DIRECT) {
-    const int4* c4 = reinterpret_cast<const int4*>(count);
-    for (int i = threadIdx.x; i < (int)blockIdx.x * 256; i += 256) {
-      const int4 c = c4[i];
-      pre.x += c.x + c.y + c.z + c.w;
-      pre.y += (c.x > kLightMax) + (c.y > kLightMax) + (c.z > kLightMax) + (c.w > kLightMax);
-    }
-  } else {
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
-      const int2 p = part[i];
-      pre.x += p.x;
-      pre.y += p.y;
-    }
-  }
-  int2 pre_tot;
-  block_excl_scan2(pre, s_w, pre_tot);
-  const int cell0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int4 c = reinterpret_cast<const int4*>(count)[blockIdx.x * 256 + threadIdx.x];
-  const int hx = c.x > kLightMax, hy = c.y > kLightMax, hz = c.z > kLightMax, hw = c.w > kLightMax;
-  int2 v = make_int2(c.x + c.y + c.z + c.w, hx + hy + hz + hw);
-  int2 tot;
-  const int2 ex = block_excl_scan2(v, s_w, tot);
-  const int o0 = pre_tot.x + ex.x;
-  int4 o = make_int4(o0, o0 + c.x, o0 + c.x + c.y, o0 + c.x + c.y + c.z);
-  reinterpret_cast<int4*>(off)[blockIdx.x * 256 + threadIdx.x] = o;  // off[] is tile-padded too
-  int h = pre_tot.y + ex.y;
-  if (hx) heavy_list[h++] = cell0;
-  if (hy) heavy_list[h++] = cell0 + 1;
-  if (hz) heavy_list[h++] = cell0 + 2;
-  if (hw) heavy_list[h++] = cell0 + 3;
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
-    // padded cells hold 0, so the running total past the last real cell is the grand total
-    off[ncell] = pre_tot.x + tot.x;
-    *heavy_cnt = pre_tot.y + tot.y;
-  }
-}
-
-// ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fill(const int* __restrict__ cellid,
-                                              const int* __restrict__ rank,
-                                              const int* __restrict__ off, int* __restrict__ list,
-                                              long long total) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int c = cellid[gid];
-  if (c >= 0) list[off[c] + rank[gid]] = (int)gid;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -295,23 +212,40 @@ __device__ __forceinline__ void add_rows_wave(const Src& src, const typename Src
 // Heavy role: one 256-thread workgroup per cell with > kLightMax points.
 template <int VEC, class Src>
 __device__ __forceinline__ void pool_heavy_cell(const Src& src, float* __restrict__ out,
-                                                const int* __restrict__ off,
+                                                const int* __restrict__ count,
                                                 const int* __restrict__ list,
+                                                const int2* __restrict__ ovf, int novf,
                                                 const int* __restrict__ cellid, int cell, int N,
                                                 int nynx, int C, unsigned flags, int* s_ids,
-                                                float (*s_part)[64 * VEC]) {
+                                                float (*s_part)[64 * VEC], int* s_n) {
   using V = typename RowVec<VEC>::T;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int base = off[cell];
-  const int k = off[cell + 1] - base;
+  const int k = count[cell];
   float* orow = out + (size_t)cell * C;
   const bool sortable = (k <= kHeavySortMax);
   if (sortable) {
     int npow = 1;
     while (npow < k) npow <<= 1;
-    for (int i = tid; i < npow; i += 256) s_ids[i] = (i < k) ? list[base + i] : INT_MAX;
+    // ranks 0..kRow-1 sit in the cell's row of the id table, the others among the overflow entries (any order: sorted next)
+    if (tid < min(k, kRow)) s_ids[tid] = list[(size_t)cell * kRow + tid];
+    if (k > kRow) {
+      if (tid == 0) *s_n = kRow;
+      __syncthreads();
+      for (int i0 = 0; i0 < novf; i0 += 4 * 256) {
+        int2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 256 + tid;
+          e[u] = i < novf ? ovf[i] : make_int2(-1, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e[u].x == cell) s_ids[atomicAdd(s_n, 1)] = e[u].y;
+      }
+    }
+    for (int i = k + tid; i < npow; i += 256) s_ids[i] = INT_MAX;
     __syncthreads();
     for (int len = 2; len <= npow; len <<= 1) {
       for (int st = len >> 1; st > 0; st >>= 1) {
@@ -389,47 +323,42 @@ __device__ __forceinline__ void pool_heavy_cell(const Src& src, float* __restric
 
 template <int VEC, class Src>
 __global__ __launch_bounds__(256) void k_pool(Src src, float* __restrict__ out,
-                                              const int* __restrict__ off,
+                                              const int* __restrict__ count,
                                               const int* __restrict__ list,
                                               const int* __restrict__ cellid,
                                               const int* __restrict__ heavy_list,
-                                              const int* __restrict__ heavy_cnt, int ncell, int N,
+                                              const int* __restrict__ heavy_cnt,
+                                              const int2* __restrict__ ovf,
+                                              const int* __restrict__ ovf_cnt, int ncell, int N,
                                               int nynx, int C, unsigned flags) {
   using V = typename RowVec<VEC>::T;
   __shared__ int s_ids[kHeavySortMax];
   __shared__ float s_part[4][64 * VEC];
+  __shared__ int s_n;
   if (blockIdx.x < kHeavyBlocks) {
-    const int nheavy = *heavy_cnt;
+    const int nheavy = *heavy_cnt, novf = *ovf_cnt;
     for (int h = blockIdx.x; h < nheavy; h += kHeavyBlocks)
-      pool_heavy_cell<VEC>(src, out, off, list, cellid, heavy_list[h], N, nynx, C, flags, s_ids,
-                           s_part);
+      pool_heavy_cell<VEC>(src, out, count, list, ovf, novf, cellid, heavy_list[h], N, nynx, C, flags, s_ids,
+                           s_part, &s_n);
     return;
   }
-  // Light role: persistent waves stride over the cells; metadata of the next two cells
-  // (offset pair, then id list) is prefetched while the current cell's rows stream in.
+  // Light role: persistent waves stride over the cells; the next cell's id row and the count of the one after it are
+  // prefetched while the current cell's rows stream in.
   const int lane = ud_lane();
   const int nwaves = (gridDim.x - kHeavyBlocks) * 4;
   int cell =
       (blockIdx.x - kHeavyBlocks) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (cell >= ncell) return;
-  int base = __builtin_amdgcn_readfirstlane(off[cell]);
-  int k = __builtin_amdgcn_readfirstlane(off[cell + 1]) - base;
-  int mine = (k <= kLightMax && lane < k) ? list[base + lane] : INT_MAX;
-  int base1 = 0, k1 = 0;
-  if (cell + nwaves < ncell) {
-    base1 = off[cell + nwaves];
-    k1 = off[cell + nwaves + 1] - base1;
-  }
+  int k = __builtin_amdgcn_readfirstlane(count[cell]);
+  int mine = (k <= kLightMax && lane < k) ? list[(size_t)cell * kRow + lane] : INT_MAX;
+  int k1 = 0;
+  if (cell + nwaves < ncell) k1 = count[cell + nwaves];
   while (true) {
     const int cell1 = cell + nwaves, cell2 = cell + 2 * nwaves;
-    base1 = __builtin_amdgcn_readfirstlane(base1);
     k1 = __builtin_amdgcn_readfirstlane(k1);
-    int mine1 = INT_MAX, base2 = 0, k2 = 0;
-    if (cell1 < ncell && k1 <= kLightMax && lane < k1) mine1 = list[base1 + lane];
-    if (cell2 < ncell) {
-      base2 = off[cell2];
-      k2 = off[cell2 + 1] - base2;
-    }
+    int mine1 = INT_MAX, k2 = 0;
+    if (cell1 < ncell && k1 <= kLightMax && lane < k1) mine1 = list[(size_t)cell1 * kRow + lane];
+    if (cell2 < ncell) k2 = count[cell2];
     if (k <= kLightMax) {  // else: heavy role owns this cell
       float* orow = out + (size_t)cell * C;
       if (k == 0) {
@@ -465,10 +394,8 @@ __global__ __launch_bounds__(256) void k_pool(Src src, float* __restrict__ out,
     }
     if (cell1 >= ncell) break;
     cell = cell1;
-    base = base1;
     k = k1;
     mine = mine1;
-    base1 = base2;
     k1 = k2;
   }
 }
@@ -535,16 +462,14 @@ __global__ __launch_bounds__(256) void k_to_nhwc(const float* __restrict__ src, 
 }
 
 struct PoolWs {
-  int* count;
-  int* heavy_cnt;
-  int2* part;
-  int* off;
-  int ntile;
-  int* rank;
-  int* cellid;
-  int* list;
+  int* count;       // points per cell
+  int* heavy_cnt;   // cells with > kLightMax points
+  int* ovf_cnt;     // entries of ovf
+  int* cellid;      // cell of every point (-1: out of grid); read by the > kHeavySortMax fallback
+  int* list;        // [ncell][kRow] point ids by in-cell rank
   int* heavy_list;
-  size_t zero_bytes;  // count + heavy_cnt are contiguous and zeroed together
+  int2* ovf;        // (cell, point id) of the ranks >= kRow
+  size_t zero_bytes;  // count, heavy_cnt and ovf_cnt are contiguous and zeroed together
   size_t total_bytes;
 };
 
@@ -553,16 +478,14 @@ PoolWs carve(void* ws, int B, int N, int nx, int ny) {
   const size_t ncell = (size_t)B * ny * nx;
   const size_t total = (size_t)B * N;
   PoolWs w;
-  w.ntile = (int)((ncell + kScanTile - 1) / kScanTile);
-  w.count = a.take<int>((size_t)w.ntile * kScanTile);  // zero padded to whole scan tiles
+  w.count = a.take<int>(ncell);
   w.heavy_cnt = a.take<int>(1);
+  w.ovf_cnt = a.take<int>(1);
   w.zero_bytes = a.used;
-  w.part = a.take<int2>(w.ntile);
-  w.off = a.take<int>((size_t)w.ntile * kScanTile + 1);
-  w.rank = a.take<int>(total);
   w.cellid = a.take<int>(total);
-  w.list = a.take<int>(total);
+  w.list = a.take<int>(ncell * kRow);
   w.heavy_list = a.take<int>(total / (kLightMax + 1) + 1);
+  w.ovf = a.take<int2>(total);
   w.total_bytes = a.used;
   return w;
 }
@@ -585,23 +508,9 @@ extern "C" size_t ud_bev_pool_workspace_bytes(int B, int N, int C, int nx, int n
 static int build_lists(const int32_t* geom, int32_t* pos, int B, int N, int nx, int ny, int nz,
                        const PoolWs& w, hipStream_t stream) {
   const long long total = (long long)B * N;
-  const int ncell = B * ny * nx;
   UD_HIP_TRY(hipMemsetAsync(w.count, 0, w.zero_bytes, stream));
-  k_bin<<<ud_div_up(total, 256), 256, 0, stream>>>(geom, pos, w.count, w.rank, w.cellid, total, N,
-                                                   nx, ny, nz);
-  UD_LAUNCH_CHECK();
-  if (w.ntile <= 64) {
-    k_cell_offsets<true><<<w.ntile, 256, 0, stream>>>(w.count, w.part, w.off, w.heavy_list, w.heavy_cnt,
-                                                      ncell);
-    UD_LAUNCH_CHECK();
-  } else {
-    k_cell_partials<<<w.ntile, 256, 0, stream>>>(w.count, w.part);
-    UD_LAUNCH_CHECK();
-    k_cell_offsets<false><<<w.ntile, 256, 0, stream>>>(w.count, w.part, w.off, w.heavy_list, w.heavy_cnt,
-                                                       ncell);
-    UD_LAUNCH_CHECK();
-  }
-  k_fill<<<ud_div_up(total, 256), 256, 0, stream>>>(w.cellid, w.rank, w.off, w.list, total);
+  k_bin<<<ud_div_up(total, 256), 256, 0, stream>>>(geom, pos, w.count, w.list, w.cellid, w.heavy_list, w.heavy_cnt,
+                                                   w.ovf, w.ovf_cnt, total, N, nx, ny, nz);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -612,8 +521,8 @@ static int launch_pool(const Src& src, float* out, const PoolWs& w, int B, int N
   const int ncell = B * ny * nx;
   const int grid = kHeavyBlocks + min(ud_div_up(ncell, 4), kLightBlocks);
   UdProfScope prof(prof_name, stream);
-  k_pool<VEC, Src><<<grid, 256, 0, stream>>>(src, out, w.off, w.list, w.cellid, w.heavy_list,
-                                             w.heavy_cnt, ncell, N, ny * nx, C, flags);
+  k_pool<VEC, Src><<<grid, 256, 0, stream>>>(src, out, w.count, w.list, w.cellid, w.heavy_list,
+                                             w.heavy_cnt, w.ovf, w.ovf_cnt, ncell, N, ny * nx, C, flags);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
