@@ -1488,7 +1488,10 @@ __global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__
 // fragments for 8 NT MFMAs (a lane's 16-byte piece feeds four MFMAs, see conv2d_f32.hip).
 __device__ __attribute__((aligned(16))) unsigned int g_zero16s[4];
 
-template <int CIN, int COUT>
+// NBUF = 3 (64 -> 64 only: 3 x 48 KB): a stage's 64 MFMAs per wave are shorter than the DMA round trip, so TWO stages fly while
+// one is multiplied -- the wait is `vmcnt(pieces of one stage)`, and the rulebook words of a stage are read with inline ds_reads
+// (a compiled LDS read after an LDS-DMA issue gets a `vmcnt(0)` from hipcc, which would drain the stage in flight).
+template <int CIN, int COUT, int NBUF>
 __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ in, const int32_t* __restrict__ nbr, int K,
                                                       int mirror, const float* __restrict__ W, WStrides ws,
                                                       const float* __restrict__ bias, float* __restrict__ out, int Mout,
@@ -1498,7 +1501,8 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
   constexpr int kHalves = CIN / 64;
   constexpr int kAPieces = kTM2 / 4, kWPieces = COUT / 4;      // 1-KiB DMA pieces: 4 rows x 256 B
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_nbr = reinterpret_cast<int*>(smem + 2 * kStage);      // [K][kTM2]
+  constexpr int kPieces = kAPieces / 8 + kWPieces / 8;         // DMA instructions per wave and stage
+  int* s_nbr = reinterpret_cast<int*>(smem + NBUF * kStage);   // [K][kTM2]
   unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
   int* s_row = s_nbr + K * kTM2 + 4;                            // [kTM2]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1542,8 +1546,14 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
   auto stage = [&](int k, int half, int buf) {
     char* sb = smem + buf * kStage;
     int rr[kAPieces / 8];
+    {
+      const unsigned na = NBUF * kStage + (unsigned)(k * kTM2 + 4 * wave + g) * 4u;              // one LDS round trip, not four
 #pragma unroll
-    for (int i = 0; i < kAPieces / 8; ++i) rr[i] = s_nbr[k * kTM2 + 4 * (wave + 8 * i) + g];     // one LDS round trip, not four
+      for (int i = 0; i < kAPieces / 8; ++i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rr[i]) : "v"(na), "n"(i * 128));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < kAPieces / 8; ++i) asm volatile("" : "+v"(rr[i]));
+    }
 #pragma unroll
     for (int i = 0; i < kAPieces / 8; ++i) {
       const int p = wave + 8 * i, r = 4 * p + g;
@@ -1564,21 +1574,39 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) fo[cb] = li * 256 + (((4 * cb + g) ^ li) << 4);
 
-  // stage list: (active offset, half) in order; `todo` walks the offsets
-  unsigned todo = active;
-  int k = todo ? (__ffs((int)todo) - 1) : -1, half = 0, buf = 0;
-  if (k >= 0) stage(k, 0, 0);
-  while (k >= 0) {
-    // the stage after this one
-    int kn = k, hn = half + 1;
-    if (hn == kHalves) {
-      hn = 0;
-      const unsigned rest = todo & (todo - 1);
-      kn = rest ? (__ffs((int)rest) - 1) : -1;
+  // stage list: (active offset, half) in order; m walks the offsets (its lowest set bit = the stage's offset)
+  auto succ = [&](int& k, int& half, unsigned& m) {
+    if (++half == kHalves) {
+      half = 0;
+      m &= m - 1;
+      k = m ? (__ffs((int)m) - 1) : -1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // this stage has landed for everybody; everybody is done with the other buffer
-    if (kn >= 0) stage(kn, hn, buf ^ 1);
+  };
+  unsigned m0 = active;
+  int k = m0 ? (__ffs((int)m0) - 1) : -1, half = 0, buf = 0;
+  int k1 = k, h1 = half;
+  unsigned m1 = m0;
+  if (k >= 0) {
+    stage(k, 0, 0);
+    succ(k1, h1, m1);
+    if (NBUF == 3 && k1 >= 0) stage(k1, h1, 1);
+  }
+  while (k >= 0) {
+    // the stage after the next one
+    int k2 = k1, h2 = h1;
+    unsigned m2 = m1;
+    if (k1 >= 0) succ(k2, h2, m2);
+    if (NBUF == 3 && k1 >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // raw barrier: __syncthreads() is lowered to `s_waitcnt vmcnt(0) lgkmcnt(0)` + s_barrier, which would drain the stage in
+    // flight.  The waves' own LDS reads (inline asm) were awaited with lgkmcnt(0) before their last MFMA group.
+    __builtin_amdgcn_s_barrier();          // this stage has landed for everybody; everybody is done with the previous stage's buffer
+    asm volatile("" ::: "memory");
+    if (NBUF == 3) {
+      if (k2 >= 0) stage(k2, h2, buf >= 1 ? buf - 1 : 2);
+    } else if (k1 >= 0) {
+      stage(k1, h1, buf ^ 1);
+    }
     if ((wmask >> k) & 1u) {
       // fragment reads by hand, one 16-channel group ahead of its MFMAs: hipcc puts `s_waitcnt vmcnt(0)` in front of a compiled LDS
       // read that follows an LDS-DMA issue -- i.e. it waited here for the NEXT stage's DMA issued four lines up, and the double
@@ -1617,10 +1645,9 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
       }
 #undef UD_SD_LOADS
     }
-    if (hn == 0) todo &= todo - 1;
-    k = kn;
-    half = hn;
-    buf ^= 1;
+    k = k1, half = h1, m0 = m1;
+    k1 = k2, h1 = h2, m1 = m2;
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
   }
   // epilogue: acc[i][t][r] = out[row(wm * 32 + 16 i + 4 g + r)][wn * COUT / 2 + 16 t + li]
 #pragma unroll
@@ -1649,14 +1676,16 @@ template <int CIN, int COUT>
 int launch_conv_dma_f32(const float* in, const int32_t* nbr, int K, int mirror, const float* W, WStrides ws,
                         const float* bias, float* out, int Mout, const int32_t* order, ConvEpilogue ep,
                         hipStream_t stream) {
-  const size_t lds = 2 * (size_t)(kTM2 * 256 + COUT * 256) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
+  constexpr int NBUF = (CIN == 64 && COUT == 64) ? 3 : 2;
+  const size_t lds = NBUF * (size_t)(kTM2 * 256 + COUT * 256) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
+  if (lds > 160 * 1024) return UD_ERR_UNSUPPORTED;
   static UdDeviceOnce attr_set;
   if (const unsigned long long attr_set_bit = attr_set.pending()) {
-    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_dma_f32<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_dma_f32<CIN, COUT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
     attr_set.mark(attr_set_bit);
   }
-  k_conv_dma_f32<CIN, COUT><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep);
+  k_conv_dma_f32<CIN, COUT, NBUF><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -1754,10 +1783,14 @@ int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror,
   if (K <= 32 && algo == 3)
     return launch_conv_bf16<CIN_P, COUT_P>(in, cin, nbr, K, mirror, W, ws, bias, out, cout, Mout, order, ep, 0, stream);
   // fp32, 64 / 128 channels exactly, channel-contiguous 16-byte-aligned weights: the LDS-DMA kernel
-  // (64 -> 64 stays on k_conv_mfma_v2: its stages are too short to cover the next stage's DMA: 650 vs 700 us)
-  if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128) && !(CIN_P == 64 && COUT_P == 64)) {
+  // 64 -> 64 stays on k_conv_mfma_v2: a stage there is 64 MFMAs per wave, shorter than the DMA round trip and than the skew of
+  // an 8-wave barrier.  Measured on the step's four 64 -> 64 layers (394 k rows, 5.45 M pairs): v2 620 us, this kernel with two
+  // stage buffers 700 us (round 3), with a three-stage ring -- two stages in flight, counted vmcnt, raw s_barrier -- 670 us
+  // (round 4; UD_SPCONV_DMA64=1 selects it, tests/test_spconv_gpu.py covers it).
+  if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128)) {
     static const bool no_dma = getenv("UD_SPCONV_NO_DMA") != nullptr;       // A/B timing
-    if (!no_dma && K <= 32 && algo == 0 && cin == CIN_P && cout == COUT_P && ws.sc == 1 && (ws.sn & 3) == 0 && (ws.sk & 3) == 0)
+    static const bool no_dma64 = getenv("UD_SPCONV_DMA64") == nullptr;
+    if (!no_dma && !(no_dma64 && CIN_P == 64 && COUT_P == 64) && K <= 32 && algo == 0 && cin == CIN_P && cout == COUT_P && ws.sc == 1 && (ws.sn & 3) == 0 && (ws.sk & 3) == 0)
       return launch_conv_dma_f32<CIN_P, COUT_P>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep, stream);
   }
   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles
