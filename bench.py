@@ -260,6 +260,7 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     if not fp32:
         t = pf.get("conv3x3_bf16_trunk_256_128_180x180x4")
         out["traffic_trunk_256_128_180x180x4"] = t      # PMC bytes of ONE shape (the replay mixes 65)
+        out["library_gemm_reference"] = library_gemm_reference(trainer.device)
     else:
         # the fp32 weight gradients of the same step (ud_conv3x3_wgrad_nhwc_f32 + ud_conv1x1_wgrad_mapped_nhwc_f32): in-step HIP events
         w3, n3 = _lib.prof_read("conv2d.k_wgrad_f32")
@@ -269,6 +270,26 @@ def mfma_leg(trainer, batch, fp32, steps=3):
                                                   "k_wgrad_wino_f32": {"ms_per_step": ww / steps, "launches_per_step": nw / steps},
                                                   "k_wgrad_1x1_f32": {"ms_per_step": w1 / steps, "launches_per_step": n1 / steps}}
     return out
+
+
+def library_gemm_reference(device):
+    """What the vendor's own large bf16 GEMM sustains on THIS box with random operands (8192^3 through `torch @`, hipBLASLt): the bf16
+    MFMA kernels run into the 1 400 W package limit and the shader clock drops to ~2.0 GHz (profiles/r04_conv_bf16.md, section 7),
+    so this -- not 2.5 PF -- is what a GEMM-shaped kernel reaches here.  A reference point only: nothing on the product path calls it,
+    `frac` stays priced against the guide's nominal peak."""
+    a = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+    for _ in range(20):
+        a @ a
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 200
+    e0.record()
+    for _ in range(n):
+        a @ a
+    e1.record()
+    torch.cuda.synchronize()
+    tf = 2 * 8192 ** 3 * n / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"TFLOP/s": tf, "frac_of_peak": tf / MFMA_PEAK_TFLOPS, "what": "torch @ (hipBLASLt), 8192^3 bf16, random operands, 200 calls"}
 
 
 def spconv_leg(device, batch):
