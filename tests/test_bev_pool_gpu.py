@@ -85,6 +85,36 @@ def test_random_vs_oracle_bitexact(B, N, C, nx, ny, nz, overwrite):
     np.testing.assert_allclose(out[~light], ref_out[~light], rtol=2e-5, atol=2e-5)
 
 
+def test_cell_counts_at_the_list_boundaries():
+    """Cells holding exactly 0, 1, 63, 64 (last light count), 65 (first heavy: the reservation that crosses 64 lists the cell),
+    255, 256 (a full row of the id table), 257 and 700 points (ranks past the row go through the overflow list), their points
+    interleaved in the input so that every 256-point workgroup of k_bin sees many cells; two samples with different layouts."""
+    rng = np.random.default_rng(21)
+    counts = [0, 1, 63, 64, 65, 255, 256, 257, 700, 64, 65, 300]
+    nx, ny, C = 4, 3, 256
+    geoms, B = [], 2
+    for b in range(B):
+        cells = np.repeat(np.arange(len(counts)), np.roll(counts, b * 5))
+        cells = np.concatenate([cells, np.full(500, -1)])          # + out-of-grid points
+        rng.shuffle(cells)
+        g = np.stack([np.where(cells >= 0, cells % nx, -1), np.where(cells >= 0, cells // nx, 0), np.zeros_like(cells)], -1)
+        geoms.append(g)
+    geom = np.stack(geoms).astype(np.int32)
+    N = geom.shape[1]
+    feat = rng.standard_normal((B, N, C)).astype(np.float32)
+    ref_out, ref_pos = oracle.bev_pool_fwd(geom, feat, nx, ny, 1)
+    for overwrite in (True, False):
+        out, pos = _run_fwd(geom, feat, nx, ny, 1, overwrite)
+        np.testing.assert_array_equal(pos, ref_pos)
+        cnt = np.zeros((B, ny, nx), np.int64)
+        kept = ref_pos[..., 0] >= 0
+        np.add.at(cnt, (ref_pos[..., 0][kept], ref_pos[..., 1][kept], ref_pos[..., 2][kept]), 1)
+        assert sorted(cnt[0].ravel().tolist()) == sorted(counts)
+        light = cnt <= 64
+        np.testing.assert_array_equal(out[light], ref_out[light])
+        np.testing.assert_allclose(out[~light], ref_out[~light], rtol=2e-5, atol=2e-5)
+
+
 def test_ultra_heavy_cell_scan_path():
     """> 8192 points in one cell exceeds the LDS sort and takes the index-range scan."""
     rng = np.random.default_rng(5)
