@@ -21,6 +21,7 @@
 // HBM traffic = every kept feature row once + the output once; that is the algorithmic minimum.
 #include "ud_common.h"
 #include "ud_prof.h"
+#include "lss_geom.h"
 #include <limits.h>
 
 namespace {
@@ -32,7 +33,26 @@ constexpr int kHeavyBlocks = 128;    // persistent heavy-role workgroups at the 
 constexpr int kLightBlocks = 2048;   // persistent light-role workgroups (256 CUs x 8)
 
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
+// Where a point's bin comes from: the geom tensor of the reference boundary, or the frustum geometry itself (fused lift-splat of
+// the training step: the [B,N,3] bins are never written).
+struct BinsLoad {
+  const int32_t* __restrict__ geom;
+  __device__ __forceinline__ void get(long long gid, int& x, int& y, int& z) const {
+    x = geom[gid * 3 + 0];
+    y = geom[gid * 3 + 1];
+    z = geom[gid * 3 + 2];
+  }
+};
+struct BinsFrustum {
+  UdFrustum f;
+  __device__ __forceinline__ void get(long long gid, int& x, int& y, int& z) const {
+    float q[4];
+    ud_frustum_point(f, gid, q, &x, &y, &z);
+  }
+};
+
+template <class Bins>
+__global__ __launch_bounds__(256) void k_bin(Bins bins,
                                              int32_t* __restrict__ pos, int* __restrict__ count,
                                              int* __restrict__ list, int* __restrict__ cellid,
                                              int* __restrict__ heavy_list, int* __restrict__ heavy_cnt,
@@ -42,9 +62,8 @@ __global__ __launch_bounds__(256) void k_bin(const int32_t* __restrict__ geom,
   int cell = -1;
   if (gid < total) {
     const int b = (int)(gid / N);
-    const int x = geom[gid * 3 + 0];
-    const int y = geom[gid * 3 + 1];
-    const int z = geom[gid * 3 + 2];
+    int x, y, z;
+    bins.get(gid, x, y, z);
     const bool kept = (x >= 0) & (x < nx) & (y >= 0) & (y < ny) & (z >= 0) & (z < nz);
     if (kept) cell = (b * ny + y) * nx + x;
     pos[gid * 3 + 0] = kept ? b : -1;
@@ -505,12 +524,13 @@ extern "C" size_t ud_bev_pool_workspace_bytes(int B, int N, int C, int nx, int n
 }
 
 // Build the per-cell point lists for geom (bins) and write pos_memo.
-static int build_lists(const int32_t* geom, int32_t* pos, int B, int N, int nx, int ny, int nz,
+template <class Bins>
+static int build_lists(const Bins& bins, int32_t* pos, int B, int N, int nx, int ny, int nz,
                        const PoolWs& w, hipStream_t stream) {
   const long long total = (long long)B * N;
   UD_HIP_TRY(hipMemsetAsync(w.count, 0, w.zero_bytes, stream));
-  k_bin<<<ud_div_up(total, 256), 256, 0, stream>>>(geom, pos, w.count, w.list, w.cellid, w.heavy_list, w.heavy_cnt,
-                                                   w.ovf, w.ovf_cnt, total, N, nx, ny, nz);
+  k_bin<Bins><<<ud_div_up(total, 256), 256, 0, stream>>>(bins, pos, w.count, w.list, w.cellid, w.heavy_list, w.heavy_cnt,
+                                                         w.ovf, w.ovf_cnt, total, N, nx, ny, nz);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -535,7 +555,7 @@ extern "C" int ud_bev_pool_fwd(const int32_t* geom, const float* feat, float* ou
   PoolWs w = carve(workspace, B, N, nx, ny);
   if (!workspace || workspace_bytes < w.total_bytes) return UD_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  int rc = build_lists(geom, pos, B, N, nx, ny, nz, w, stream);
+  int rc = build_lists(BinsLoad{geom}, pos, B, N, nx, ny, nz, w, stream);
   if (rc != UD_OK) return rc;
   const bool vec4 = (C % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
   if (vec4) {
@@ -560,7 +580,37 @@ extern "C" int ud_lss_splat_fwd(const int32_t* geom, const float* prob, const fl
   PoolWs w = carve(workspace, B, N, nx, ny);
   if (!workspace || workspace_bytes < w.total_bytes) return UD_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  int rc = build_lists(geom, pos, B, N, nx, ny, nz, w, stream);
+  int rc = build_lists(BinsLoad{geom}, pos, B, N, nx, ny, nz, w, stream);
+  if (rc != UD_OK) return rc;
+  const bool vec4 = (C % 4 == 0) && (((uintptr_t)ctx_pm | (uintptr_t)out) % 16 == 0);
+  if (vec4) {
+    SrcLift<4> src{prob, ctx_pm, C, D * fH * fW, fH * fW};
+    return launch_pool<4>(src, out, w, B, N, C, nx, ny, UD_POOL_OVERWRITE, "lss.k_splat", stream);
+  }
+  SrcLift<1> src{prob, ctx_pm, C, D * fH * fW, fH * fW};
+  return launch_pool<1>(src, out, w, B, N, C, nx, ny, UD_POOL_OVERWRITE, "lss.k_splat", stream);
+}
+
+// The same with the binning taken from the frustum geometry itself (ud_lss_geometry's arithmetic, lss_geom.h): the [B,N,3] bins
+// of the training step are never written or read back, and the launch that produced them is gone.
+extern "C" int ud_lss_splat_geom_fwd(const float* mats, const float* frustum_u, const float* frustum_v,
+                                     const float* frustum_d, const float* lo, const float* size, int has_bda,
+                                     const float* prob, const float* ctx_pm, float* out, int32_t* pos, int B,
+                                     int ncam, int D, int fH, int fW, int C, int nx, int ny, int nz,
+                                     void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
+  if (ncam <= 0 || D <= 0 || fH <= 0 || fW <= 0) return UD_ERR_INVALID_ARG;
+  const long long Nll = (long long)ncam * D * fH * fW;
+  if (Nll >= INT_MAX) return UD_ERR_INVALID_ARG;
+  const int N = (int)Nll;
+  if (!sizes_ok(B, N, C, nx, ny, nz) || !mats || !frustum_u || !frustum_v || !frustum_d || !lo || !size || !prob ||
+      !ctx_pm || !out || !pos)
+    return UD_ERR_INVALID_ARG;
+  PoolWs w = carve(workspace, B, N, nx, ny);
+  if (!workspace || workspace_bytes < w.total_bytes) return UD_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const BinsFrustum bins{UdFrustum{mats, frustum_u, frustum_v, frustum_d, D, fH, fW, has_bda, lo[0], lo[1], lo[2], size[0],
+                                   size[1], size[2]}};
+  int rc = build_lists(bins, pos, B, N, nx, ny, nz, w, stream);
   if (rc != UD_OK) return rc;
   const bool vec4 = (C % 4 == 0) && (((uintptr_t)ctx_pm | (uintptr_t)out) % 16 == 0);
   if (vec4) {

@@ -12,6 +12,7 @@
 // bev_pool.hip + k_splat_bwd below) pools depth_prob * context directly.
 #include "ud_common.h"
 #include "ud_prof.h"
+#include "lss_geom.h"
 
 namespace {
 
@@ -101,55 +102,22 @@ __global__ void k_prepare_mats(const float* __restrict__ s2e, const float* __res
     o[32 + k] = bda ? bda[(size_t)b * 16 + k] : ((k % 5 == 0) ? 1.0f : 0.0f);
 }
 
-__device__ __forceinline__ void mat4_apply(const float* __restrict__ m, const float* p, float* q) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    q[r] = dot4_seq(m[r * 4 + 0], p[0], m[r * 4 + 1], p[1], m[r * 4 + 2], p[2], m[r * 4 + 3], p[3]);
-}
-
-// One thread per frustum point (b, cam, d, h, w): ego coordinates + BEV bin.
-__global__ __launch_bounds__(256) void k_geometry(const float* __restrict__ mats,
-                                                  const float* __restrict__ fu,
-                                                  const float* __restrict__ fv,
-                                                  const float* __restrict__ fd, int ncams_total,
-                                                  int D, int fH, int fW, float lo0, float lo1,
-                                                  float lo2, float sz0, float sz1, float sz2,
-                                                  int has_bda, float* __restrict__ geom,
+// One thread per frustum point (b, cam, d, h, w): ego coordinates + BEV bin (arithmetic in lss_geom.h).
+__global__ __launch_bounds__(256) void k_geometry(UdFrustum f, int ncams_total, float* __restrict__ geom,
                                                   int32_t* __restrict__ bins) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long per_cam = (long long)D * fH * fW;
-  if (gid >= per_cam * ncams_total) return;
-  const int cam = (int)(gid / per_cam);
-  int r = (int)(gid - cam * per_cam);
-  const int d = r / (fH * fW);
-  r -= d * fH * fW;
-  const int h = r / fW;
-  const int w = r - h * fW;
-  const float* m = mats + (size_t)cam * 48;
-  float p[4] = {fu[w], fv[h], fd[d], 1.0f};
+  if (gid >= (long long)f.D * f.fH * f.fW * ncams_total) return;
   float q[4];
-  mat4_apply(m, p, q);                    // undo image-space augmentation (lss_fpn.py:221-222)
-  p[0] = __fmul_rn(q[0], q[2]);           // (u*d, v*d, d, 1)                 (:225-231)
-  p[1] = __fmul_rn(q[1], q[2]);
-  p[2] = q[2];
-  p[3] = q[3];
-  mat4_apply(m + 16, p, q);               // camera -> ego                    (:233-234)
-  if (has_bda) {                          // BEV-space augmentation           (:235-239)
-    p[0] = q[0];
-    p[1] = q[1];
-    p[2] = q[2];
-    p[3] = q[3];
-    mat4_apply(m + 32, p, q);
-  }
+  int bx, by, bz;
+  ud_frustum_point(f, gid, q, &bx, &by, &bz);
   if (geom) {
     geom[gid * 3 + 0] = q[0];
     geom[gid * 3 + 1] = q[1];
     geom[gid * 3 + 2] = q[2];
   }
-  // ((geom - (voxel_coord - voxel_size/2)) / voxel_size).int()              (:311-313)
-  bins[gid * 3 + 0] = (int)__fdiv_rn(__fsub_rn(q[0], lo0), sz0);
-  bins[gid * 3 + 1] = (int)__fdiv_rn(__fsub_rn(q[1], lo1), sz1);
-  bins[gid * 3 + 2] = (int)__fdiv_rn(__fsub_rn(q[2], lo2), sz2);
+  bins[gid * 3 + 0] = bx;
+  bins[gid * 3 + 1] = by;
+  bins[gid * 3 + 2] = bz;
 }
 
 // ---- depth softmax --------------------------------------------------------------------------
@@ -353,10 +321,8 @@ extern "C" int ud_lss_geometry(const float* mats, const float* frustum_u, const 
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * ncam * D * fH * fW;
   UdProfScope prof("lss.k_geometry", stream);
-  k_geometry<<<ud_div_up(total, 256), 256, 0, stream>>>(mats, frustum_u, frustum_v, frustum_d,
-                                                        B * ncam, D, fH, fW, lo[0], lo[1], lo[2],
-                                                        size[0], size[1], size[2], has_bda, geom,
-                                                        bins);
+  const UdFrustum f{mats, frustum_u, frustum_v, frustum_d, D, fH, fW, has_bda, lo[0], lo[1], lo[2], size[0], size[1], size[2]};
+  k_geometry<<<ud_div_up(total, 256), 256, 0, stream>>>(f, B * ncam, geom, bins);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

@@ -34,6 +34,7 @@ _SIGS = {
     "ud_lss_depth_ctx": (c_int, [c_void_p] + [c_i64] * 4 + [c_int] * 5 + [c_void_p] * 3),
     "ud_lss_lift_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "ud_lss_splat_fwd": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "ud_lss_splat_geom_fwd": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
     "ud_lss_lift_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_lss_lift_bwd": (c_int, [c_void_p] * 5 + [c_i64] * 4 + [c_int] * 8
                         + [c_void_p, c_size_t, c_void_p]),

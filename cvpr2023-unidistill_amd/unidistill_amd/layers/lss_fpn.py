@@ -37,6 +37,7 @@ class LSSFPN(nn.Module):
         self.final_dim = final_dim
         self.output_channels = output_channels
         self.materialise = materialise
+        self.fuse_binning = True      # bins computed inside the splat's list-building kernel (ud_lss_splat_geom_fwd)
         bounds = [x_bound, y_bound, z_bound]
         self.register_buffer("voxel_size", torch.Tensor([r[2] for r in bounds]))
         self.register_buffer("voxel_coord", torch.Tensor([r[0] + r[2] / 2.0 for r in bounds]))
@@ -74,17 +75,21 @@ class LSSFPN(nn.Module):
         fr = self.frustum
         return fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous()
 
-    def get_geometry_bins(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat, want_geom=False):
-        """-> bins i32[B, N, 3] (and optionally ego coordinates f32[B,ncam,D,fH,fW,3])."""
-        B, ncam = sensor2ego_mat.shape[:2]
+    def _frustum_desc(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat):
+        """(mats, fu, fv, fd, lo, size, has_bda): everything the geometry of a frustum point needs (ops.lss.geometry's arguments)."""
         ai = ki = None
         if self.inverse == "torch":
             ai = torch.linalg.inv_ex(ida_mat.float()).inverse
             ki = torch.linalg.inv_ex(intrin_mat.float()).inverse
         mats = _lss.prepare_mats(sensor2ego_mat, intrin_mat, ida_mat, bda_mat, ai, ki)
         fu, fv, fd = self._frustum_axes()
-        return _lss.geometry(mats, fu, fv, fd, B, ncam, self._lo, self._size,
-                             has_bda=bda_mat is not None, want_geom=want_geom)
+        return mats, fu, fv, fd, self._lo, self._size, bda_mat is not None
+
+    def get_geometry_bins(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat, want_geom=False):
+        """-> bins i32[B, N, 3] (and optionally ego coordinates f32[B,ncam,D,fH,fW,3])."""
+        B, ncam = sensor2ego_mat.shape[:2]
+        mats, fu, fv, fd, lo, size, has_bda = self._frustum_desc(sensor2ego_mat, intrin_mat, ida_mat, bda_mat)
+        return _lss.geometry(mats, fu, fv, fd, B, ncam, lo, size, has_bda=has_bda, want_geom=want_geom)
 
     def get_geometry(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat):
         return self.get_geometry_bins(sensor2ego_mat, intrin_mat, ida_mat, bda_mat, True)[1]
@@ -106,15 +111,18 @@ class LSSFPN(nn.Module):
         feats = self.get_cam_feats(sweep_imgs)[:, 0]
         depth_feature = self.depth_net(feats.reshape(B * ncam, *feats.shape[2:]))
         D, C = self.depth_channels, self.output_channels
-        bins, _ = self.get_geometry_bins(mats_dict["sensor2ego_mats"][:, sweep_index],
-                                         mats_dict["intrin_mats"][:, sweep_index],
-                                         mats_dict["ida_mats"][:, sweep_index],
-                                         mats_dict.get("bda_mat", None))
+        geo = (mats_dict["sensor2ego_mats"][:, sweep_index], mats_dict["intrin_mats"][:, sweep_index],
+               mats_dict["ida_mats"][:, sweep_index], mats_dict.get("bda_mat", None))
         nx, ny, nz = self._nxyz
         if self.materialise:
+            bins, _ = self.get_geometry_bins(*geo)
             lifted = _lss.lift(depth_feature, D, C)                      # [B*ncam, D, fH, fW, C]
             bev = _bp.voxel_pooling(bins, lifted.reshape(B, -1, C), (nx, ny, nz))
+        elif self.fuse_binning:
+            # the bins are computed inside the splat's list-building kernel (same arithmetic, lss_geom.h): never written
+            bev = _lss.lift_splat(depth_feature, self._frustum_desc(*geo), B, ncam, D, C, nx, ny, nz)
         else:
+            bins, _ = self.get_geometry_bins(*geo)
             bev = _lss.lift_splat(depth_feature, bins, B, ncam, D, C, nx, ny, nz)
         if is_return_depth:
             return bev, depth_feature[:, :D].softmax(1)

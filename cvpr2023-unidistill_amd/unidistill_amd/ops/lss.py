@@ -134,26 +134,40 @@ class LiftSplat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, depth_feature, bins, B, ncam, D, C, nx, ny, nz):
-        _lib.require_gpu(depth_feature, bins)
+        """bins: i32[B, N, 3], or a frustum description (mats, fu, fv, fd, lo, size, has_bda) as ops.lss.geometry takes it --
+        the bins are then computed inside the list-building kernel and never written (ud_lss_splat_geom_fwd)."""
+        frustum = bins if isinstance(bins, tuple) else None
+        _lib.require_gpu(depth_feature, *(frustum[:4] if frustum else (bins,)))
         prob, cpm = depth_ctx(depth_feature, D, C)
         BN, _, fH, fW = depth_feature.shape
-        assert BN == B * ncam and bins.dtype == torch.int32 and bins.is_contiguous()
         N = ncam * D * fH * fW
-        assert bins.shape[0] == B and bins.shape[1] == N
+        assert BN == B * ncam
+        if frustum is None:
+            assert bins.dtype == torch.int32 and bins.is_contiguous() and bins.shape[0] == B and bins.shape[1] == N
         dev = depth_feature.device
         out = torch.empty((B, ny, nx, C), dtype=torch.float32, device=dev)
         pos = torch.empty((B, N, 3), dtype=torch.int32, device=dev)
         lib = _lib.load()
         need = lib.ud_bev_pool_workspace_bytes(B, N, C, nx, ny, nz)
         ws = _lib.workspace(dev, need, "bev_pool")
-        _lib.check(lib.ud_lss_splat_fwd(_lib.ptr(bins), _lib.ptr(prob), _lib.ptr(cpm), _lib.ptr(out),
-                                        _lib.ptr(pos), B, ncam, D, fH, fW, C, nx, ny, nz,
-                                        _lib.ptr(ws), ws.numel(), _lib.stream_of(out)),
-                   "ud_lss_splat_fwd")
+        if frustum is not None:
+            mats, fu, fv, fd, lo, size, has_bda = frustum
+            assert fd.numel() == D and fv.numel() == fH and fu.numel() == fW and mats.shape[0] == BN
+            _lib.check(lib.ud_lss_splat_geom_fwd(_lib.ptr(mats), _lib.ptr(fu), _lib.ptr(fv), _lib.ptr(fd), _f3(lo), _f3(size),
+                                                 1 if has_bda else 0, _lib.ptr(prob), _lib.ptr(cpm), _lib.ptr(out),
+                                                 _lib.ptr(pos), B, ncam, D, fH, fW, C, nx, ny, nz,
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_of(out)),
+                       "ud_lss_splat_geom_fwd")
+        else:
+            _lib.check(lib.ud_lss_splat_fwd(_lib.ptr(bins), _lib.ptr(prob), _lib.ptr(cpm), _lib.ptr(out),
+                                            _lib.ptr(pos), B, ncam, D, fH, fW, C, nx, ny, nz,
+                                            _lib.ptr(ws), ws.numel(), _lib.stream_of(out)),
+                       "ud_lss_splat_fwd")
         ctx.save_for_backward(prob, cpm, pos)
         ctx.meta = ((tuple(depth_feature.shape), tuple(depth_feature.stride()), depth_feature.device),
                     ncam, D, C, nx, ny)
-        ctx.mark_non_differentiable(bins)
+        if frustum is None:
+            ctx.mark_non_differentiable(bins)
         return out.permute(0, 3, 1, 2)
 
     @staticmethod

@@ -151,6 +151,18 @@ int ud_lss_splat_fwd(const int32_t* geom, const float* prob, const float* ctx_pm
                      int nz, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /*
+ * ud_lss_splat_fwd with the binning computed from the frustum inside the list-building kernel (the arithmetic of
+ * ud_lss_geometry: mats / frustum axes / lo / size / has_bda as there): what LSSFPN._forward_single_sweep
+ * (lss_fpn.py:277-319) needs from get_geometry is only the bins, so the training step never materialises them.
+ * out, pos and the workspace as ud_lss_splat_fwd; bit-identical to ud_lss_geometry followed by ud_lss_splat_fwd.
+ */
+int ud_lss_splat_geom_fwd(const float* mats, const float* frustum_u, const float* frustum_v,
+                          const float* frustum_d, const float* lo, const float* size, int has_bda,
+                          const float* prob, const float* ctx_pm, float* out, int32_t* pos, int B, int ncam,
+                          int D, int fH, int fW, int C, int nx, int ny, int nz, void* workspace,
+                          size_t workspace_bytes, ud_stream_t stream);
+
+/*
  * Backward of softmax (x) context.  pos == NULL: gsrc is the dense grad of the materialised
  * lifted tensor f32[BN, D, fH*fW, C].  pos != NULL (fused splat backward): gsrc is the dense NHWC
  * BEV grad f32[B, ny, nx, C] and each point gathers its cell's row through pos i32[B*N,3].

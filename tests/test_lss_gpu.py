@@ -178,3 +178,34 @@ def test_lift_oracle_numpy():
     xcl = _cuda(x).contiguous(memory_format=torch.channels_last)
     got2 = lss.lift(xcl, 20, 12)
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("with_bda", [True, False])
+def test_binning_inside_the_splat_equals_geometry_then_splat(with_bda):
+    """ud_lss_splat_geom_fwd (the bins come from the frustum inside the list-building kernel: the training step's path since
+    round 4) == ud_lss_geometry -> ud_lss_splat_fwd, bit for bit: BEV map and input gradient at the
+    BASELINE frustum (6 cameras, D = 112, 16 x 44, 180 x 180)."""
+    from unidistill_amd import synthetic as syn
+    from unidistill_amd.ops import lss
+    d = torch.device("cuda:0")
+    g = syn.rng(11)
+    B, ncam, D, Cc, fH, fW, nx, ny = 2, 6, 112, 64, 16, 44, 180, 180
+    s2e, intr, ida, bda = (torch.as_tensor(np.asarray(t)).to(d) for t in syn.camera_rig(g, B, ncam, bda_aug=True, jitter=0.02))
+    s2e, intr, ida = s2e[:, 0], intr[:, 0], ida[:, 0]
+    mats = lss.prepare_mats(s2e, intr, ida, bda if with_bda else None,
+                            torch.linalg.inv_ex(ida.float()).inverse, torch.linalg.inv_ex(intr.float()).inverse)
+    fu = torch.linspace(0, 703, fW, device=d)
+    fv = torch.linspace(0, 255, fH, device=d)
+    fd = torch.arange(2.0, 58.0, 0.5, device=d)
+    lo, size = lss.bin_origin_fp32([-54.0 + 0.3, -54.0 + 0.3, -5.0 + 4.0], [0.6, 0.6, 8.0])
+    bins, _ = lss.geometry(mats, fu, fv, fd, B, ncam, lo, size, has_bda=with_bda)
+    x = torch.randn(B * ncam, D + Cc, fH, fW, device=d)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    out_a = lss.lift_splat(xa, bins, B, ncam, D, Cc, nx, ny, 1)
+    out_b = lss.lift_splat(xb, (mats, fu, fv, fd, lo, size, with_bda), B, ncam, D, Cc, nx, ny, 1)
+    assert float(out_a.abs().sum()) > 0
+    assert torch.equal(out_a, out_b)
+    gout = torch.randn_like(out_a)
+    out_a.backward(gout)
+    out_b.backward(gout)
+    assert torch.equal(xa.grad, xb.grad)
