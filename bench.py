@@ -549,6 +549,29 @@ def host_enqueue_leg(workload, batch, bf16):
         return {"host_enqueue_ms": None, "error": repr(e)[:200]}
 
 
+def relaunch_ranks(n):
+    """Run this command line as n ranks on this node (127.0.0.1 rendezvous on a free port); rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def frac_violations(obj, path="line"):
+    """Every `frac` in the line must be a roofline fraction in [0, 1]; returns the offenders (the line is printed first)."""
+    bad = []
+    try:
+        assert_fracs(obj, path)
+    except AssertionError as e:
+        bad.append(str(e))
+    return bad
+
+
 def assert_fracs(obj, path="line"):
     """Every emitted `frac` is a roofline fraction: <= 1 by construction (a larger value means the timed kernel does not do
     the counted work)."""
@@ -578,16 +601,25 @@ def main():
     if os.environ.get("UD_FAULT_DUMP"):           # debugging aid: python stacks of a stuck rank after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["UD_FAULT_DUMP"]), exit=False)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: one process per GPU, as the reference's `--gpus N` (Lightning
+        # accelerator="ddp", exps/base_cli.py:40-58, README.md:92) -- re-launch this command line under torch.distributed.run
+        return relaunch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launch does not match the request")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    backend = os.environ.get("UD_DIST_BACKEND", "nccl") if world > 1 else "none"    # "nccl" == RCCL on ROCm
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, {torch.cuda.device_count()} visible "
+                         "(UD_DIST_BACKEND=gloo shares devices: functional test only)")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        backend = os.environ.get("UD_DIST_BACKEND", "nccl")       # "nccl" == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:                                                     # functional test of the N>1 path
@@ -642,7 +674,9 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": loss,
                        "precision": PRECISION_NOTE[ac],
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
-                       "executor": "eager+DDP"},
+                       "executor": "eager+DDP",
+                       "ranks": dist.get_world_size() if world > 1 else 1,
+                       "dist_backend": dist.get_backend() if world > 1 else "none (single process)"},
         }
         if bf16 is not None:
             line["bf16_mixed_precision"] = bf16
@@ -662,8 +696,12 @@ def main():
                 line["bf16_mixed_precision"]["host_enqueue"] = host_enqueue_leg(args.workload, args.batch, True)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(device)
-        assert_fracs(line)
-        print(json.dumps(line))
+        bad = frac_violations(line)
+        if bad:
+            line["frac_violations"] = bad
+        print(json.dumps(line), flush=True)     # the measurements are emitted even if a fraction is out of range
+        if bad:
+            raise SystemExit("bench.py: roofline fraction(s) outside [0, 1]: " + "; ".join(bad))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,6 +29,22 @@ def test_two_rank_bench_completes(hip_lib):
     assert "Grad strides do not match bucket view strides" not in res.stderr, res.stderr[-1500:]
 
 
+def test_bench_gpus_flag_launches_ranks_itself(hip_lib):
+    """`python bench.py --gpus 2` DIRECTLY (no torchrun around it, WORLD_SIZE unset): the script starts its own two ranks,
+    as the reference's `--gpus N` does (exps/base_cli.py:40-58), and the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "lidar", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-bf16-leg"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["dist_backend"] == "gloo"
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+
+
 _GLOO_DISTILL = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path[:0] = [{root!r}, {pkg!r}]

@@ -40,3 +40,14 @@ def test_invalidate_caches_drops_every_weight_relayout():
     assert invalidate_caches(m) == 4
     assert not hasattr(m[0].weight, "_ud_wino") and not hasattr(m[1].running_var, "_ud_bn_eval")
     assert not hasattr(m[0], "_ud_stem_pack") and invalidate_caches(m) == 0
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus 8 under a 1-rank environment must not print a 1-GPU number as an 8-GPU one (the check precedes any GPU use)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr and '{"metric"' not in res.stdout
