@@ -35,6 +35,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "cvpr2023-unidistill_amd")
 os.environ.setdefault("UD_RANDOM_INIT", "1")   # synthetic benchmark: random weights of the reference architecture
+if "--nchw" not in sys.argv:
+    os.environ.setdefault("UD_STRICT", "1")    # no silent fall-through to a library convolution / GEMM in what is timed
 for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
@@ -674,7 +676,7 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": loss,
                        "precision": PRECISION_NOTE[ac],
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
-                       "executor": "eager+DDP",
+                       "executor": "eager+DDP", "strict_no_library_fallthrough": os.environ.get("UD_STRICT") == "1",
                        "ranks": dist.get_world_size() if world > 1 else 1,
                        "dist_backend": dist.get_backend() if world > 1 else "none (single process)"},
         }

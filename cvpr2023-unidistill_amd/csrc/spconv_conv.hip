@@ -1681,8 +1681,10 @@ int launch_conv_dma_f32(const float* in, const int32_t* nbr, int K, int mirror, 
   if (lds > 160 * 1024) return UD_ERR_UNSUPPORTED;
   static UdDeviceOnce attr_set;
   if (const unsigned long long attr_set_bit = attr_set.pending()) {
+    // the request depends on the runtime K (K * kTM2 ints): reserve the chip's 160 KiB once, so a K = 3 layer launched first
+    // does not pin the limit below what a later K = 27 layer needs
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv_dma_f32<CIN, COUT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+                                   160 * 1024));
     attr_set.mark(attr_set_bit);
   }
   k_conv_dma_f32<CIN, COUT, NBUF><<<ud_div_up(Mout, kTM2), 512, lds, stream>>>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep);

@@ -221,6 +221,38 @@ def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+# Strict mode: a branch of the product path that would leave the hand-written kernels for a library convolution / GEMM
+# (nn.Conv2d -> MIOpen, `@` -> hipBLASLt, aten.convolution_backward) raises instead, naming the site and the shape.
+# UD_STRICT=1 (bench.py and the test-suite default); `strict(False)` scopes the lenient behaviour (goldens at shrunk widths).
+STRICT = os.environ.get("UD_STRICT", "0") == "1"
+
+
+class strict:
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global STRICT
+        self.prev, STRICT = STRICT, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global STRICT
+        STRICT = self.prev
+        return False
+
+
+def library_fallthrough(site, *tensors, **info):
+    """Called right before a GPU tensor is handed to a library convolution / GEMM from a module that has a hand-written path."""
+    if not STRICT or not any(t is not None and t.is_cuda for t in tensors):
+        return
+    shapes = ", ".join(f"{tuple(t.shape)} {str(t.dtype).replace('torch.', '')} strides {tuple(t.stride())}"
+                       for t in tensors if t is not None)
+    extra = "".join(f", {k}={v}" for k, v in info.items())
+    raise RuntimeError(f"UD_STRICT: {site} would fall through to a library kernel for {shapes}{extra} "
+                       "(no hand-written kernel accepts this shape / layout; set UD_STRICT=0 to allow the library path)")
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

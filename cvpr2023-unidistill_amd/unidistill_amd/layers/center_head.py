@@ -19,6 +19,7 @@ import math
 import torch
 from torch import nn
 
+from .. import _lib
 from ..dist import reduce_mean, reduce_mean_many
 from ..ops import bn_act as hipbn, conv2d as hipconv, conv2d_f32 as hipconv32, det_loss as hiploss, head_tail, \
     head_tail_f32
@@ -468,6 +469,8 @@ class PackedSepHeads(nn.Module):
             # the BatchNorm over the 2 688-channel hidden tensor (one 1.39 GB read less)
             y = hipconv32.conv3x3(x, self.c1_weight, self.c1_bias, self.training)
         else:
+            if Conv2d.hip_enabled:
+                _lib.library_fallthrough("layers.center_head.PackedSepHeads (first conv)", x, self.c1_weight)
             y = torch.nn.functional.conv2d(x, self.c1_weight, self.c1_bias, padding=pad)
         if self.training:
             self.bn_num_batches_tracked += 1
@@ -495,6 +498,9 @@ class PackedSepHeads(nn.Module):
                                      self.bn_weight, self.bn_bias, None, self.bn_running_mean, self.bn_running_var,
                                      self.training, self.bn_momentum, self.bn_eps, True, None, partial)
             return self._split(head_tail_f32.group_tail(a, self.c2_weight, self.c2_bias, G, self.kmax))
+        if Conv2d.hip_enabled:
+            _lib.library_fallthrough("layers.center_head.PackedSepHeads (BN + second convs)", y, self.c2_weight,
+                                     training=self.training, grad=torch.is_grad_enabled())
         y = torch.nn.functional.batch_norm(y, self.bn_running_mean, self.bn_running_var, self.bn_weight,
                                            self.bn_bias, self.training, self.bn_momentum, self.bn_eps)
         y = torch.relu(y)

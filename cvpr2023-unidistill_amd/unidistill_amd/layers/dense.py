@@ -14,6 +14,7 @@ import os
 import torch
 from torch import nn
 
+from .. import _lib
 from ..ops import bn_act as hipbn, conv2d as hipconv, conv2d_f32 as hipconv32
 from ..ops.spconv import folded_batchnorm, wants_grad
 
@@ -100,6 +101,9 @@ class Conv2d(nn.Conv2d):
                 y = self._hip_permutation_conv(x)       # strided convolutions: fp32 twin of the mapped 1x1 kernel
                 if y is not None:
                     return y
+        if Conv2d.hip_enabled:
+            _lib.library_fallthrough("layers.dense.Conv2d", x, self.weight, kernel=self.kernel_size, stride=self.stride,
+                                     padding=self.padding)
         return super().forward(x)
 
     def _hip_permutation_conv(self, x):
@@ -164,6 +168,8 @@ class ConvTranspose2d(nn.ConvTranspose2d):
             # deblock, base_bev_backbone.py:67-92; the image neck's last level) -- the 1x1 kernels with an output map
             y = hipconv.conv_transpose_patch(x, self.weight, self.stride[0])
             return y if self.bias is None else y + self.bias.to(y.dtype).view(1, -1, 1, 1)
+        if Conv2d.hip_enabled:
+            _lib.library_fallthrough("layers.dense.ConvTranspose2d", x, self.weight, kernel=self.kernel_size, stride=self.stride)
         return super().forward(x, output_size)
 
 
@@ -184,6 +190,8 @@ def batchnorm_act(bn, x, residual=None, relu=True):
     if Conv2d.hip_enabled and _HIP_BN and isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm1d)) \
             and not frozen_grad and hipbn.supported(x, bn):
         return hipbn.bn_act(bn, x, residual, relu)
+    if Conv2d.hip_enabled and _HIP_BN and not frozen_grad:
+        _lib.library_fallthrough("layers.dense.batchnorm_act", x, training=bn.training)
     y = bn(x)
     if residual is not None:
         y = y + residual

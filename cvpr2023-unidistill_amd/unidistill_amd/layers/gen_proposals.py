@@ -129,8 +129,9 @@ class CenterPointGenProposals(nn.Module):
             off += len(names)
         rois, scores, labels, counts = self._run(pred_dicts, offsets, self._alphas(len(pred_dicts)))
         counts = counts.tolist()                               # the one host read of the layer
-        data_dict["pred_dicts"] = [{"pred_boxes": rois[b, :n], "pred_scores": scores[b, :n],
-                                    "pred_labels": labels[b, :n]} for b, n in enumerate(counts)]
+        # independent tensors, as the reference returns them (in-place post-processing of pred_boxes must not reach rois)
+        data_dict["pred_dicts"] = [{"pred_boxes": rois[b, :n].clone(), "pred_scores": scores[b, :n].clone(),
+                                    "pred_labels": labels[b, :n].clone()} for b, n in enumerate(counts)]
         data_dict["rois"] = rois
         data_dict["roi_scores"] = scores
         data_dict["roi_labels"] = labels

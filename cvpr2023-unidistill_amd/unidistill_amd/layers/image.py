@@ -135,9 +135,20 @@ class ResNet(nn.Module):
                     f"ResNet init_cfg checkpoint {spec!r} not found and frozen_stages={self.frozen_stages} freezes "
                     "the stem: load a checkpoint (load_state_dict), point UD_RESNET50_CKPT (or init_cfg['checkpoint']) at a "
                     "local torchvision ResNet-50 state_dict, or set UD_RANDOM_INIT=1 for synthetic benchmarks / tests")
-                self.register_load_state_dict_post_hook(lambda m, _keys: setattr(m, "_missing_pretrained", None))
+                self.register_load_state_dict_post_hook(ResNet._checkpoint_loaded)
             else:
                 warnings.warn(f"ResNet init_cfg checkpoint {spec!r} not found: Kaiming initialisation kept")
+
+    @staticmethod
+    def _checkpoint_loaded(module, incompatible_keys):
+        """load_state_dict post-hook: the refusal to train on a random frozen stem is lifted only by a load that actually
+        carried this network's weights.  The hook also fires for a PARENT's load (strict=False, a checkpoint holding only the
+        LiDAR teacher, ...): if any of this module's own parameters / buffers is among the missing keys, the stem is still random."""
+        own = {k for k in module.state_dict().keys() if not k.endswith("num_batches_tracked")}
+        missing = incompatible_keys.missing_keys
+        if any(m in own or any(m.endswith("." + k) for k in own) for m in missing):
+            return
+        module._missing_pretrained = None
 
     def stem_takes_any_layout(self, x):
         """True when the stem runs on the HIP kernel, which reads x through its strides (no layout copy needed in front)."""

@@ -124,6 +124,8 @@ def weight_grad(x, gy, weight):
                                                   _lib.ptr(ws), ws.numel(), _lib.stream_of(x)),
                    "ud_conv3x3_wgrad_nhwc_bf16")
         return dw.permute(0, 3, 1, 2).to(weight.dtype)
+    if USE_HIP_WGRAD == "auto":
+        _lib.library_fallthrough("ops.conv2d.weight_grad (3x3 bf16)", x, gy, weight)
     wb = library_layout(weight)
     return torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                [False, True, False])[1].to(weight.dtype)
@@ -217,6 +219,17 @@ def _w1x1_t(weight):
                        w.view(w.shape[0], w.shape[1]).t()))
 
 
+def _w1x1_t_padded(weight):
+    """[Cin, Cout rounded up to 64] bf16, zero columns past Cout: the data-gradient weights when Cout is not a multiple of the
+    kernel's 64-channel reduction slices (cached for frozen weights like every other re-layout)."""
+    def make(w):
+        cout, cin = w.shape[0], w.shape[1]
+        wt = torch.zeros((cin, cout + (-cout) % 64), dtype=torch.bfloat16, device=w.device)
+        wt[:, :cout] = w.view(cout, cin).t()
+        return wt
+    return _cached(weight, "_ud_1x1_tp", make)
+
+
 HIP_1X1_MIN_PIXELS = 1         # per image: maps at least this large run the hand-written 1x1 kernel (forward and data
                                # gradient).  With the straight-line slice loop it is within 3 us of the library GEMM on the
                                # 8 x 22 / 16 x 44 maps and ahead everywhere else (tools/time_conv1x1.py), so every 1x1 runs
@@ -263,6 +276,7 @@ class _Conv1x1Fn(torch.autograd.Function):
                 y, part = y
                 holder.append(part)
         elif ctx.gemm:
+            _lib.library_fallthrough("ops.conv2d._Conv1x1Fn.forward (GEMM)", x, weight)
             # a 1x1 convolution of a channels-last map IS a plain GEMM [pixels, Cin] x [Cin, Cout]: on the
             # small maps of the deep ResNet stages the library GEMM is 1.2-2.5x faster than the conv solver
             y = x.permute(0, 2, 3, 1).reshape(B * H * W, cin) @ wb.view(cout, cin).t()
@@ -270,6 +284,7 @@ class _Conv1x1Fn(torch.autograd.Function):
                 y = y + bias.to(torch.bfloat16)
             y = y.view(B, H, W, cout).permute(0, 3, 1, 2)
         else:
+            _lib.library_fallthrough("ops.conv2d._Conv1x1Fn.forward", x, weight)
             y = torch.nn.functional.conv2d(x, wb, None if bias is None else bias.to(torch.bfloat16))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -296,14 +311,14 @@ class _Conv1x1Fn(torch.autograd.Function):
                                   memory_format=torch.channels_last)
                 gyp[:, :cout] = gy
                 gyp[:, cout:] = 0
-                wt = torch.zeros((cin, cout + pad), dtype=torch.bfloat16, device=gy.device)
-                wt[:, :cout] = weight.detach().view(cout, cin).t()
-                gx = _launch1x1(gyp, wt, cin, residual=gskip)
+                gx = _launch1x1(gyp, _w1x1_t_padded(weight), cin, residual=gskip)
             elif ctx.gemm:
+                _lib.library_fallthrough("ops.conv2d._Conv1x1Fn.backward (GEMM)", gy, weight)
                 g2, w2 = gy.permute(0, 2, 3, 1).reshape(B * H * W, cout), wb.view(cout, cin)
                 gx = g2 @ w2 if gskip is None else torch.addmm(gskip.permute(0, 2, 3, 1).reshape(B * H * W, cin), g2, w2)
                 gx = gx.view(B, H, W, cin).permute(0, 3, 1, 2)
             else:
+                _lib.library_fallthrough("ops.conv2d._Conv1x1Fn.backward", gy, weight)
                 gx = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
                 if gskip is not None:
@@ -429,6 +444,7 @@ class _ConvPatchFn(torch.autograd.Function):
             gx = _bf16_cl_empty((B, C, H, W), x.device, zero=(H % s != 0 or W % s != 0), dtype=dt)
             _mapped(gy, wt, gx, P, cout, K, None, pm)          # [P][Cout] x [K][Cout]^T -> rows scattered by the map
         elif ctx.needs_input_grad[0]:
+            _lib.library_fallthrough("ops.conv2d._ConvPatchFn.backward", gy, weight, stride=s)
             gx = torch.ops.aten.convolution_backward(gy, x, weight.detach().to(dt), None, [s, s], [0, 0], [1, 1],
                                                      False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:

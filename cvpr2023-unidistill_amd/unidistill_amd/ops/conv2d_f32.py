@@ -147,6 +147,8 @@ def weight_grad(x, gy, w, ks):
     result comes back in the parameter's channels-last strides (a [Cout, ks, ks, Cin] buffer viewed as [Cout, Cin, ks, ks])."""
     cout, cin = w.shape[0], w.shape[1]
     if not (USE_HIP_WGRAD and wgrad_supported(x, gy)):
+        if USE_HIP_WGRAD:
+            _lib.library_fallthrough("ops.conv2d_f32.weight_grad", x, gy, w, kernel=ks)
         p = ks // 2
         return torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [p, p], [1, 1], False, [0, 0], 1,
                                                    [False, True, False])[1]

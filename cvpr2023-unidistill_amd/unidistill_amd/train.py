@@ -107,8 +107,26 @@ class DistillStep(nn.Module):
         prep["norm"] = norm
         return prep
 
+    def _reset_teacher_buffers(self):
+        """teacher_train_mode: the reference reloads the teacher's checkpoint before every teacher pass
+        (training_step, ..._distill_lidar.py:463: load_state_dict(self.checkpoint_state_dict)), which undoes the running-statistics
+        update of the previous step's train-mode BatchNorms.  Here: a snapshot of the buffers (taken at the first step, dropped
+        by load_state_dict) copied back with one foreach launch."""
+        bufs = [b for b in self.teacher_model.buffers()]
+        snap = getattr(self, "_teacher_snapshot", None)
+        if snap is None or len(snap) != len(bufs) or any(a.device != b.device for a, b in zip(snap, bufs)):
+            self._teacher_snapshot = [b.detach().clone() for b in bufs]
+            return
+        torch._foreach_copy_(bufs, snap)
+
+    def load_state_dict(self, *a, **k):
+        self._teacher_snapshot = None
+        return super().load_state_dict(*a, **k)
+
     @torch.no_grad()
     def teacher(self, batch, prep, lidar_prepared=None):
+        if self.teacher_train_mode and self.teacher_model.training:
+            self._reset_teacher_buffers()
         return self.teacher_model(self._points(batch), batch.get("imgs"), batch.get("mats_dict"),
                                   prep["gt"], return_feature=True, lidar_prepared=lidar_prepared)
 

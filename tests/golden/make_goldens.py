@@ -613,6 +613,51 @@ def gold_model_step():
             out[f"student_after/{k}"] = v.clone()
     _save("model_step", **out)
 
+    # ---- the same step with the teacher in TRAIN mode: Exp.__init__ calls teacher_model.eval()
+    # (camera_exp_distill_lidar.py:424) but the teacher is a registered submodule, so Lightning's model.train() before the
+    # training loop puts it back into train mode -- its BatchNorms then normalise with BATCH statistics and move their running
+    # statistics, which training_step's per-step load_state_dict(self.checkpoint_state_dict) (:463) resets from the checkpoint
+    # (a separate copy of the tensors, as loaded from the file).  Same weights, inputs and seeds as above.
+    student2, teacher2 = build(109), build(110)
+    teacher2.det_head.dense_head.distill = True
+    for p_ in teacher2.parameters():
+        p_.requires_grad = False
+    ckpt = {k: v.clone() for k, v in teacher2.state_dict().items()}
+
+    class _Lightning(torch.nn.Module):          # what `model.train()` reaches in the reference's LightningModule
+        def __init__(self):
+            super().__init__()
+            self.model, self.teacher_model = student2, teacher2
+    teacher2.eval()                             # Exp.__init__ (:424)
+    _Lightning().train()                        # trainer.fit -> model.train()
+    assert teacher2.training and student2.training
+
+    class _Self2:
+        def __init__(self):
+            self.teacher_model, self.checkpoint_state_dict, self.calls = teacher2, ckpt, {}
+
+        def __call__(self, *a, **k):
+            r = student2(*a, **k)
+            self.calls["student"] = r
+            return r
+    me2 = _Self2()
+    batch2 = {"imgs": imgs, "mats_dict": mats, "gt_boxes": gt_boxes.clone(), "gt_labels": gt_labels.clone()}
+    loss2 = dis.Exp.training_step(me2, batch2)
+    loss2.backward()
+    ret2, tbd2 = me2.calls["student"][:2]
+    out2 = {"loss": loss2.detach(), "loss_rpn": ret2["loss"].detach()}
+    for k in ("loss_feature", "loss_bev_rel", "loss_resp_cls", "loss_resp_reg"):
+        out2[k] = tbd2[k].detach()
+    assert abs(float(out2["loss_feature"]) - float(out["loss_feature"])) > 1e-3 * abs(float(out["loss_feature"])), \
+        "the train-mode teacher must change the distillation terms"
+    for n, p_ in student2.named_parameters():
+        if p_.grad is not None:
+            out2[f"grad/{n}"] = p_.grad.clone()
+    for k, v in teacher2.state_dict().items():       # one momentum step away from the checkpoint (reset comes with the NEXT step)
+        if "running_" in k or "num_batches_tracked" in k:
+            out2[f"teacher_after/{k}"] = v.clone()
+    _save("model_step_teacher_train", **out2)
+
 
 ALL["model_step"] = gold_model_step
 

@@ -256,7 +256,7 @@ def _cmp(a, b, tol, name):
 
 
 @pytest.mark.parametrize("cfg", [(2, 256, 128, 4, 16, 44), (3, 512, 128, 2, 8, 22), (1, 64, 64, 2, 10, 18), (2, 128, 72, 2, 9, 7)])
-def test_patch_conv_k_equals_stride(hip_lib, cfg):
+def test_patch_conv_k_equals_stride(hip_lib, cfg, lenient):      # cfg3 (Cout = 72): the data gradient is a library op by design
     """nn.Conv2d(k = s, stride = s) on the mapped 1x1 kernels: forward, data and weight gradient vs PyTorch fp32 on
     the same bf16-valued tensors (odd sizes drop the remainder rows like the reference op)."""
     import torch.nn.functional as F

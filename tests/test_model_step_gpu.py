@@ -55,7 +55,7 @@ def _close(got, ref, rtol=1e-4, atol_frac=1e-5, what=""):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol_frac * max(float(np.abs(ref).max()), 1e-30), err_msg=what)
 
 
-def test_lssfpn_forward_single_sweep_vs_reference(golden, hip_lib):
+def test_lssfpn_forward_single_sweep_vs_reference(golden, hip_lib, lenient):
     from unidistill_amd.ops import lss
     g = golden("model_step")
     m = _model(g, "student").eval()
@@ -85,7 +85,7 @@ def test_lssfpn_forward_single_sweep_vs_reference(golden, hip_lib):
         assert torch.equal(bev2, bev), "fused lift+splat must equal lift -> voxel_pooling bit for bit"
 
 
-def test_model_return_feature_mode_vs_reference(golden, hip_lib):
+def test_model_return_feature_mode_vs_reference(golden, hip_lib, lenient):
     g = golden("model_step")
     t = _model(g, "teacher").eval()
     t.det_head.dense_head.distill = True
@@ -99,7 +99,7 @@ def test_model_return_feature_mode_vs_reference(golden, hip_lib):
 
 
 @pytest.mark.parametrize("channels_last", [False, True])
-def test_distill_training_step_vs_reference(golden, hip_lib, channels_last):
+def test_distill_training_step_vs_reference(golden, hip_lib, channels_last, lenient):
     """channels_last=True is the benchmark's layout: NHWC convolution weights, the head's packed tail output copied to planes for
     the fused detection-loss kernels (layers/center_head.py:_split), strided response distillation."""
     from unidistill_amd import train
@@ -147,7 +147,57 @@ def test_distill_training_step_vs_reference(golden, hip_lib, channels_last):
             _close(sd[k[len("student_after/"):]], g[k], rtol=1e-4, what=k)
 
 
-def test_student_forward_outputs_vs_reference(golden, hip_lib):
+def test_distill_step_with_train_mode_teacher_vs_reference(golden, hip_lib, lenient):
+    """under Lightning the registered teacher is flipped back to train mode by model.train(), so its
+    BatchNorms use batch statistics (make_goldens.py: model_step_teacher_train, executed by the reference's training_step with
+    the teacher in train mode and the per-step checkpoint reload).  DistillStep(teacher_train_mode=True) reproduces that:
+    loss, the four distillation terms, every student gradient, and the teacher's buffers after two steps (the reload keeps
+    them ONE momentum step from the checkpoint, not two)."""
+    from unidistill_amd import train
+    g, gt_ = golden("model_step"), golden("model_step_teacher_train")
+    student, teacher = _model(g, "student"), _model(g, "teacher")
+    step = train.DistillStep("camera_exp_distill_lidar", student=student, teacher=teacher, geometry=S.GEOMETRY,
+                             teacher_train_mode=True)
+    step.overlap_teacher = False
+    step.cuda().train()
+    assert step.teacher_model.training and step.model.training
+    out = step(_batch(g))
+    out["loss"].backward()
+    _close(out["loss"], gt_["loss"], what="total loss, teacher in train mode")
+    for k in ("loss_rpn", "loss_feature", "loss_bev_rel", "loss_resp_cls", "loss_resp_reg"):
+        _close(out["tb"][k], gt_[k], what=k)
+    assert abs(float(out["tb"]["loss_feature"]) - float(g["loss_feature"])) > 1e-3 * abs(float(g["loss_feature"]))
+    params = [p for p in student.parameters()]
+    saved = [p.data for p in params]
+    for p in params:
+        p.data = p.grad if p.grad is not None else torch.zeros_like(p.data)
+    grads_by_ref_key = {k: v.detach().clone() for k, v in student.state_dict().items()}
+    for p, d in zip(params, saved):
+        p.data = d
+    gmax = max(float(np.abs(gt_[k]).max()) for k in gt_.files if k.startswith("grad/"))
+    n = 0
+    for key in [k for k in gt_.files if k.startswith("grad/")]:
+        ref = gt_[key]
+        got = grads_by_ref_key[key[len("grad/"):]].float().cpu().numpy()
+        tol = 2e-3 * float(np.abs(ref).max()) + 1e-6 * gmax
+        assert float(np.abs(got - ref).max()) <= tol, key
+        n += 1
+    assert n >= 90, n
+    # second step on the same batch: the teacher's running statistics are reset first, so they end ONE update from the
+    # checkpoint again (what the reference's state holds after any step)
+    student.zero_grad(set_to_none=True)
+    step(_batch(g))
+    sd = teacher.state_dict()
+    for k in gt_.files:
+        if k.startswith("teacher_after/"):
+            name = k[len("teacher_after/"):]
+            if name.endswith("num_batches_tracked"):
+                assert int(sd[name]) == int(gt_[k]), name
+            else:
+                _close(sd[name], gt_[k], rtol=1e-4, what=k)
+
+
+def test_student_forward_outputs_vs_reference(golden, hip_lib, lenient):
     g = golden("model_step")
     m = _model(g, "student").train()
     b = _batch(g)

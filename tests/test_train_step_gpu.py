@@ -36,7 +36,7 @@ def test_camera_student_lidar_teacher_distill_step():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     step = train.DistillStep("camera_exp_distill_lidar")
-    tr = train.Trainer(step, device=dev)
+    tr = train.Trainer(step, device=dev, channels_last=True)     # the product layout: UD_STRICT holds (no library fall-through)
     batch = train.synthetic_batch(dev, batch_size=1, ncam=6)
     out = tr.step(batch)
     assert torch.isfinite(out["loss"])
@@ -57,7 +57,7 @@ def _distill_step_checks(workload, batch_size, sweeps, ac, ncam=6):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     step = train.DistillStep(workload)
-    tr = train.Trainer(step, device=dev, autocast_dtype=ac, channels_last=ac is not None)
+    tr = train.Trainer(step, device=dev, autocast_dtype=ac, channels_last=True)
     batch = train.synthetic_batch(dev, batch_size=batch_size, ncam=ncam, sweeps=sweeps)
     before = {n: p.detach().clone() for n, p in step.model.named_parameters() if p.requires_grad}
     out = tr.step(batch)
@@ -126,7 +126,7 @@ def test_cfg1_camera_only_student_one_camera():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     step = train.DetectStep("camera")
-    tr = train.Trainer(step, device=dev)
+    tr = train.Trainer(step, device=dev, channels_last=True)
     batch = train.synthetic_batch(dev, batch_size=1, ncam=1, with_points=False)
     assert batch["imgs"].shape == (1, 1, 1, 3, 256, 704)
     before = [p.detach().clone() for p in tr.params]
@@ -163,3 +163,14 @@ def test_the_forward_pass_sees_the_optimizer_updates(autocast):
     tr.step(batch)
     f1 = bev()
     assert not torch.equal(f0, f1)
+
+
+def test_nchw_camera_model_runs_through_the_library_when_not_strict(lenient):
+    """An NCHW (not channels-last) camera model is outside the hand-written kernels' layout: under UD_STRICT it raises (see
+    test_no_library_gpu.py), without it the step runs on the library path and is finite."""
+    from unidistill_amd import train
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tr = train.Trainer(train.DetectStep("camera"), device=dev)
+    out = tr.step(train.synthetic_batch(dev, batch_size=1, ncam=1, with_points=False))
+    assert torch.isfinite(out["loss"])
