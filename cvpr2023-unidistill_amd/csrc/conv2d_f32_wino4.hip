@@ -12,17 +12,23 @@
 //
 // A workgroup (8 waves) owns 32 tiles (TWB x THB, e.g. 8 x 4 -> 32 x 16 output pixels) x 64 output channels: wave (wq, wh) holds
 // the 36 frequencies of 16 tiles x 16 channels (144 accumulator registers), so the output transform never leaves the lane.
-// Frequencies are stored four to a 16-byte word ([f / 4][row][c][f % 4]): ONE ds_read_b128 of V and one of U feed four MFMAs.
+// Frequencies are stored four to a 16-byte word ([f / 4][row / 16][c][row % 16][f % 4]): ONE ds_read_b128 of V and one of U feed four MFMAs.
 // Per 4-input-channel stage the raw (4 THB + 2) x (4 TWB + 2) x 4-channel patch and the 36 KB U stage arrive by LDS-DMA (U is
-// stored in exactly the LDS order), waves 0-5 transform the (tile, channel) patches -- three waves' worth of threads per patch:
-// rows (0, 5), (1, 2), (3, 4) of B^T d, which share their column pass -- and the MFMA loop reads 16-byte fragments one step ahead.
-// Patch, V and U are double-buffered: 132 KB of LDS, one workgroup per CU, two waves per SIMD.
+// stored in exactly the LDS order), every wave transforms its share of the (tile, channel) patches -- four threads per patch, one
+// per row group of B^T d: row 0, row 5, rows (1, 2), rows (3, 4); all four run the SAME instruction sequence on wave-uniform
+// row offsets / coefficients (a branch per role made hipcc copy the 144 accumulators at every merge: 350 spilled registers) --
+// and the MFMA loop reads 16-byte fragments one step ahead.  Patch, V and U are double-buffered: 133 KB of LDS, one workgroup
+// per CU, two waves per SIMD.
 #include "ud_common.h"
 #include "ud_prof.h"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include <algorithm>
+
+#ifndef UD_W4_ABL
+#define UD_W4_ABL 0      // development ablations (tools/_exp/w4): 1 no transform, 2 no stage DMA, 4 no epilogue, 8 no MFMA, 16 no stage barrier
+#endif
 
 namespace {
 
@@ -32,16 +38,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kT = 32, kTN = 64, kKC = 4, kFQ = 9;
 constexpr int kUBytes = kFQ * kTN * kKC * 16;      // 36 864
 constexpr int kVBytes = kFQ * kT * kKC * 16;       // 18 432
-constexpr int kPBytes = 12288;                     // 768 pixel slots of 16 bytes
-// LDS map: [P0 | P1 | U0 | V0 | V1 | U1]: a unit's first stages (P0, U0, P1) sit in the low 60 KB, which the epilogue's second
-// staging pass does not touch (the next unit's first DMA overlaps it)
+constexpr int kPBytes = 21504;                     // a patch buffer holds EIGHT channels (two stages): 21 DMA pieces of 1 KB
+// LDS map: [P0 | P1 | U0 | V0 | V1 | U1 | dump]: a unit's first stages (P0, P1, U0) sit in the low 78 KB, which the epilogue's
+// second staging pass does not touch (the next unit's first DMA overlaps it)
 constexpr int kP0 = 0, kU0 = 2 * kPBytes, kV0 = kU0 + kUBytes, kV1 = kV0 + kVBytes, kU1 = kV1 + kVBytes;
-constexpr int kSmem = kU1 + kUBytes;               // 135 168
-constexpr int kStageA = 0, kStageB = kSmem - 65536;   // output staging: 256 pixel rows x 64 channels per pass
-static_assert(kStageB >= kV0 && kV1 == kV0 + kVBytes, "LDS map");
+constexpr int kDump = kU1 + kUBytes;               // 1 KB that swallows the V words a one-row role does not produce and padding DMA pieces
+constexpr int kSmem = kDump + 1024;                // 154 624
+constexpr int kStageA = 0, kStageB = kDump - 65536;   // output staging: 256 pixel rows x 64 channels per pass
+static_assert(kStageB >= kV0 && kV1 == kV0 + kVBytes && 65536 <= kV0 + kVBytes, "LDS map");
 
 struct W4Geom {
   int B, H, W, Cin, Cout, bx, by;   // bx x by tile blocks per image
+  unsigned u_bytes;                 // size of the transformed filters
   int n_items;                      // units (tile block, cout block): a workgroup walks items blockIdx.x, + gridDim.x, ...
 };
 struct W4Ep {
@@ -53,16 +61,20 @@ struct W4Ep {
   float* stats;                     // [blocks][Cout][2] per-workgroup (sum, sum of squares) of the stored outputs, or nullptr
 };
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero16w4[4];
-
-__device__ __forceinline__ void dma16(const float* src, unsigned lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)(size_t)lds_wave_base, 16, 0, 0);
+// LDS-DMA of 16 bytes per lane through a raw buffer descriptor: LDS[lds_wave_base + lane * 16] = buffer[voff + soff]; a byte
+// offset past the descriptor's size reads zeros (image borders, padding pieces) -- no pointer select, no per-lane 64-bit address
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(size_t)lds_wave_base, 16, voff, soff, 0, 0);
 }
+constexpr unsigned kOob = 0xFFF00000u;                // a voffset no tensor reaches (the launcher checks): reads zeros
 
 // frequency order: f' = 6 * slot(i) + j for the element (row i, column j) of the 6 x 6 transform, slot = position of i in
 // (0, 5, 1, 2, 3, 4) -- the three row pairs that share their arithmetic are 12 consecutive frequencies = three 16-byte words
 __host__ __device__ constexpr int w4_slot(int i) { return i == 0 ? 0 : i == 5 ? 1 : i + 1; }
+// ... and within a row the columns in the order (0, 5, 1, 3, 2, 4): the row pass produces the pairs (v0, v5), (v1, v3), (v2, v4) with
+// packed fp32 instructions (fp32 MFMAs run on the vector ALUs -- every VALU instruction beside them costs its full issue time)
+__host__ __device__ constexpr int w4_cpos(int j) { return j == 0 ? 0 : j == 5 ? 1 : j == 1 ? 2 : j == 3 ? 3 : j == 2 ? 4 : 5; }
+__host__ __device__ constexpr int w4_f(int i, int j) { return 6 * w4_slot(i) + w4_cpos(j); }
 
 // U[nb][cc][fq][nl][cl][fp] from g'[n][ky][kx][c] = w[n * s_n + c * s_c + ky' * s_y + kx' * s_x] (ky' = flip ? 2 - ky : ky): the forward
 // transform takes (n, c) = (Cout, Cin) of the parameter, the data gradient (n, c) = (Cin, Cout) with flip = 1.  Rows / channels
@@ -94,7 +106,9 @@ __global__ void k_wino4_weights(const float* __restrict__ w, long long s_n, long
     t[4][kx] = (1.f / 24.f) * a - (1.f / 12.f) * b + (1.f / 6.f) * cc2;
     t[5][kx] = cc2;
   }
-  float* out = U + blk * (kFQ * 64 * 16) + nl * 16 + cl * 4;
+  // [fq][wq = nl / 16][c][li = nl % 16][f % 4]: the 64 lanes (li, c) of an MFMA B fragment read 1 KB contiguous (lane * 16 bytes:
+  // ds_read_b128 is bank-conflict-free on linear addresses, 4-way conflicted on a [row][c] order)
+  float* out = U + blk * (kFQ * 64 * 16) + (nl >> 4) * 256 + cl * 64 + (nl & 15) * 4;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     const float a = t[r][0], b = t[r][1], cc2 = t[r][2];
@@ -107,7 +121,7 @@ __global__ void k_wino4_weights(const float* __restrict__ w, long long s_n, long
     u[5] = cc2;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const int f = 6 * w4_slot(r) + j;
+      const int f = w4_f(r, j);
       out[(f >> 2) * (64 * 16) + (f & 3)] = u[j];
     }
   }
@@ -126,22 +140,25 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::forward<F>(f), std::make_integer_sequence<int, N>{});
 }
 
-// LDS operations a transform wave issues in MFMA step fq (after the step's fragment loads): patch-row reads (3 ds_read2_b32
-// each) and V writes (ds_write_b128).  Role 0 = rows (0, 5) of B^T d, role 1 = rows (1, 2) and (3, 4), role 2 = no transform.
-__device__ constexpr int kStepOps[3][9] = {{3, 3, 3, 3, 3, 3, 1, 0, 0}, {3, 3, 3, 3, 0, 0, 0, 2, 1}, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
-__host__ __device__ constexpr int w4_wait(int role, int fq) {   // LDS operations issued after the fragment loads of step fq
-  return (fq > 0 ? kStepOps[role][fq - 1] : 0) + (fq < 8 ? 2 : 0) + kStepOps[role][fq];
+// LDS operations of the input transform that ride in MFMA step fq (after the step's fragment loads): four patch-row reads
+// (3 ds_read2_b32 each) in steps 0-3, the four V writes in step 7
+__device__ constexpr int kStepOps[9] = {3, 3, 3, 3, 0, 0, 0, 4, 0};
+__host__ __device__ constexpr int w4_wait(int fq) {   // LDS operations issued after the fragment loads of step fq (fq < 8)
+  return (fq > 0 ? kStepOps[fq - 1] : 0) + 2 + kStepOps[fq];
 }
 
 template <int TWB, int THB>
 __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restrict__ x, const float* __restrict__ U,
                                                            float* __restrict__ y, W4Geom gm, W4Ep ep) {
   constexpr int PW = 4 * TWB + 2, PH = 4 * THB + 2;
-  // row pitch in 16-byte slots: rows of tiles are 4 patch rows apart; 4 * RP * 16 bytes should step the 256-byte bank period by
-  // the width of a tile row's 16-byte slots (TWB * 16 bytes), so that the 16 tiles of a wave read 16 different slots
-  constexpr int RP = (TWB == 4) ? PW + 1 : PW;
-  constexpr int PP = PH * RP, kPInstr = (PP + 63) / 64;
-  static_assert(TWB * THB <= kT && PP * 16 <= kPBytes && kPInstr <= 16, "tile block");
+  // A patch row in LDS = [channel half h][RP slots of 16 bytes]: the DMA fetches 32 bytes per pixel (two lanes RP apart), so a
+  // 128-byte line of x is requested four times per unit instead of eight (with 16 bytes per pixel and stage the patch DMA alone
+  // cost 13 % of the kernel: the L2 -> CU path, not the MFMA pipe, set the pace).  Rows of tiles are 4 patch rows apart:
+  // 4 * 2 RP * 16 bytes must step the 256-byte bank period by half of it for the two tile rows of an 8 x 4 block -> RP odd.
+  constexpr int RP = (TWB == 16) ? PW : (PW | 1);
+  constexpr int RB = 2 * RP * 16;                                   // bytes per patch row
+  constexpr int PP = PH * 2 * RP, kPInstr = (PP + 63) / 64;
+  static_assert(TWB * THB <= kT && kPInstr * 1024 <= kPBytes && kPInstr <= 24, "tile block");
   constexpr int O0 = 0, O1 = TWB + 1, O2 = 2 * TWB + 2, O3 = 3 * TWB + 2;    // column planes x % 4 = 0 / 1 / 2 / 3 of a patch row
   static_assert((O3 + 0) * 4 <= 255 && (O1 + 1) * 4 <= 255, "ds_read2 offsets");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,21 +168,22 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
   const int g = lane >> 4, li = lane & 15;
   const int wq = wave & 3, wh = wave >> 2;
   const int nblocks = gm.B * gm.bx * gm.by;
-  const int nchunks = gm.Cin / kKC;
-  const float* zero = reinterpret_cast<const float*>(g_zero16w4);
+  const int nchunks = gm.Cin / kKC;                    // even (Cin % 8 == 0)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)gm.B * gm.H * gm.W * gm.Cin * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)gm.u_bytes, 0x00020000);
 
   int unit, cbi, blk_lin, b, ty0, tx0, n0;
-  const float* pp[2];
-  int pinc[2];
-  const float* up;
+  unsigned po[3];                  // byte offset of this lane's 16 bytes of patch piece wave + 8 i within x (channels 0-3 / 4-7), kOob: zeros
+  unsigned uo;                     // wave-uniform byte offset of this wave's first piece of the next U stage
+  unsigned pair_off;               // byte offset of the next patch pair's channels
   auto setup = [&](int item) {
     unit = item;
     cbi = unit / nblocks;
-    const int ru = unit - cbi * nblocks;
+    const int ru_ = unit - cbi * nblocks;
     int blk;
     {   // consecutive items go round the 8 XCDs: XCD k walks its own contiguous range of tile blocks (shared halos stay in its L2)
-      const int base = nblocks >> 3, extra = nblocks & 7, k = ru & 7;
-      blk = k * base + min(k, extra) + (ru >> 3);
+      const int base = nblocks >> 3, extra = nblocks & 7, k = ru_ & 7;
+      blk = k * base + min(k, extra) + (ru_ >> 3);
     }
     blk_lin = blk;
     b = blk / (gm.bx * gm.by);
@@ -173,207 +191,220 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
     ty0 = (blk / gm.bx) * THB, tx0 = (blk % gm.bx) * TWB;      // in tiles
     n0 = cbi * kTN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      // patch DMA instruction pi fills slots [64 pi, 64 pi + 64): slot -> (row, plane position) -> pixel
-      const int pi = ((wave + 4) & 7) + 8 * i;
+    for (int i = 0; i < 3; ++i) {
+      // patch DMA piece pi fills 16-byte slots [64 pi, 64 pi + 64): slot -> (row, channel half, plane position) -> pixel
+      const int pi = wave + 8 * i;
       const int qq = pi * 64 + lane;
-      const int qy = qq / RP, qs = qq - qy * RP;
+      const int qy = qq / (2 * RP), qr = qq - qy * (2 * RP);
+      const int qh = qr >= RP ? 1 : 0, qs = qr - qh * RP;
       const int qx = qs < O1 ? 4 * qs : qs < O2 ? 4 * (qs - O1) + 1 : qs < O3 ? 4 * (qs - O2) + 2 : 4 * (qs - O3) + 3;
       const int gy = 4 * ty0 + qy - 1, gx = 4 * tx0 + qx - 1;
-      const bool ok = qq < PP && qs < PW && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
-      pp[i] = ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin : zero;
-      pinc[i] = ok ? kKC : 0;
+      const bool ok = qq < PP && qs < PW && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && !(UD_W4_ABL & (2 | 128));
+      po[i] = ok ? (unsigned)(((b * gm.H + gy) * gm.W + gx) * gm.Cin + qh * 4) * 4u : kOob;
     }
-    up = U + (size_t)cbi * nchunks * (kUBytes / 4) + wave * 256 + lane * 4;
+    uo = (unsigned)(cbi * nchunks) * (unsigned)kUBytes + wave * 1024;
+    pair_off = 0;
   };
-  auto stage_p = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pi = ((wave + 4) & 7) + 8 * i;
-      if (pi < kPInstr) dma16(pp[i], sbase + kP0 + buf * kPBytes + pi * 1024);
-      pp[i] += pinc[i];
-    }
+  // patch pair (8 channels) -> patch buffer `buf`: ALWAYS three pieces per wave (a constant count lets the stage wait with
+  // vmcnt(3) for everything older); pieces past the patch land in the dump
+  auto patch_piece = [&](int i, int buf) {
+    const int pi = wave + 8 * i;
+    dma16(rx, po[i], pair_off, pi < kPInstr ? sbase + kP0 + buf * kPBytes + pi * 1024 : sbase + kDump);
   };
+  const unsigned lane16 = lane * 16;
   auto stage_u = [&](int buf) {
     const unsigned ub = sbase + (buf ? kU1 : kU0) + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
-      if (wave + 8 * i < 36) dma16(up + i * 2048, ub + i * 8192);
-    up += kUBytes / 4;
+      if (i < 4 || wave < 4) dma16(ru, lane16, uo + i * 8192, ub + i * 8192);
   };
 
-  // ---- input transform: waves 0-5, thread = (row-pair role, tile, channel)
-  const int role = wave >> 1;                          // 0: rows (0, 5); 1: rows (1, 2); 2: rows (3, 4); 3: none
-  const int ttile = (wave & 1) * 16 + (lane >> 2), tc = lane & 3;
+  // ---- input transform: thread = (row group of B^T d, tile, channel); wave w: group w >> 1, tiles 16 (w & 1) .. + 15.
+  // Every group evaluates  X = a1 r1 + a2 r2,  Y = b3 r3 + b4 r4,  out_a = X + Y,  out_b = X - Y  over patch rows r1..r4:
+  //   group 0 (row 0 of B^T d):   X = 4 d0 - 5 d2, Y = d4          -> out_a (out_b is not stored)
+  //   group 1 (row 5):            X = 4 d1 - 5 d3, Y = -d5         -> out_b
+  //   group 2 (rows 1, 2):        X = d4 - 4 d2,   Y = d3 - 4 d1   -> out_a = row 1, out_b = row 2
+  //   group 3 (rows 3, 4):        X = d4 - d2,     Y = 2 d3 - 2 d1 -> out_a = row 3, out_b = row 4
+  // then the row pass on out_a / out_b.  Frequencies: group 0 -> f' 0..5, group 1 -> 6..11, group 2 -> 12..23, group 3 -> 24..35.
+  const int grp = wave >> 1;
+  const int ttile = (wave & 1) * 16 + (lane & 15), tc = lane >> 4;       // the MFMA A-fragment lane order: V words land lane-linear
   const int ttc = min(ttile, TWB * THB - 1);
   const int tyl = ttc / TWB, txl = ttc - tyl * TWB;
-  // byte address of patch row k of this thread's tile, buffer 0: tprow + k * RP * 16
-  const unsigned tprow = sbase + kP0 + ((4 * tyl) * RP + txl) * 16 + tc * 4;
-  // V word of this thread: quads 3 role .. 3 role + 2, [fq][tile][c][4]
-  const unsigned tvw = sbase + kV0 + ((3 * min(role, 2)) * kT * kKC + ttile * kKC + tc) * 16;
-  const float kap = role == 1 ? 4.f : 1.f, lam = role == 1 ? 1.f : 2.f;
+  const unsigned tprow = sbase + kP0 + (4 * tyl) * RB + txl * 16 + tc * 4;     // patch row 0 of this thread's tile, buffer 0, half 0
+  const int rows4 = grp == 0 ? 0x4420 : grp == 1 ? 0x5531 : 0x1324;            // r1 | r2 << 4 | r3 << 8 | r4 << 12
+  const unsigned ro1 = (rows4 & 15) * RB, ro2 = ((rows4 >> 4) & 15) * RB, ro3 = ((rows4 >> 8) & 15) * RB, ro4 = ((rows4 >> 12) & 15) * RB;
+  const float ca1 = grp < 2 ? 4.f : 1.f, ca2 = grp < 2 ? -5.f : grp == 2 ? -4.f : -1.f;
+  const float cb3 = grp == 0 ? 1.f : grp == 1 ? -1.f : grp == 2 ? 1.f : 2.f, cb4 = grp < 2 ? 0.f : grp == 2 ? -4.f : -2.f;
+  // V words [fq][tile / 16][c][tile % 16][4]: A = (a0..a3), B = (a4, a5) low half, C = (b0, b1) high half, D = (b2..b5)
+  const unsigned tvbase = sbase + kV0 + (wave & 1) * 1024 + lane * 16;
+  const unsigned tdump = sbase + kDump + lane * 16;
+  const int q0 = grp < 2 ? 0 : grp == 2 ? 3 : 6;
+  const unsigned wA = grp == 1 ? tdump : tvbase + q0 * (kT * kKC * 16);
+  const unsigned wB = grp == 1 ? tdump : tvbase + (q0 + 1) * (kT * kKC * 16);
+  const unsigned wC = grp == 0 ? tdump : tvbase + (q0 + 1) * (kT * kKC * 16) + 8;
+  const unsigned wD = grp == 0 ? tdump : tvbase + (q0 + 2) * (kT * kKC * 16);
+  const unsigned vdelta01 = (grp == 1 ? 0 : kVBytes), vdelta23 = (grp == 0 ? 0 : kVBytes);   // V buffer 1 - buffer 0 (0 for the dump)
 
-#define W4_ROWREAD(D, K, POFF)                                                                                          \
+#define W4_ROWREAD(D, RO)                                                                                               \
   do {                                                                                                                  \
-    const unsigned a_ = tprow + (K) * (RP * 16) + (POFF);                                                               \
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(D[0]) : "v"(a_), "n"(O0 * 4), "n"((O0 + 1) * 4));  /* j = 0, 4 */ \
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(D[1]) : "v"(a_), "n"(O1 * 4), "n"((O1 + 1) * 4));  /* j = 1, 5 */ \
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(D[2]) : "v"(a_), "n"(O2 * 4), "n"(O3 * 4));        /* j = 2, 3 */ \
+    const unsigned a_ = tprow + (RO);                                                                                   \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(D[0]) : "v"(a_), "n"(O0 * 4), "n"(O1 * 4));              /* j = 0, 1 */ \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(D[1]) : "v"(a_), "n"(O2 * 4), "n"(O3 * 4));              /* j = 2, 3 */ \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(D[2]) : "v"(a_), "n"((O0 + 1) * 4), "n"((O1 + 1) * 4));  /* j = 4, 5 */ \
   } while (0)
-  // columns j = 0..5 of a row held as read above
-#define W4_COL(D, J) ((J) == 0 ? D[0][0] : (J) == 4 ? D[0][1] : (J) == 1 ? D[1][0] : (J) == 5 ? D[1][1] : (J) == 2 ? D[2][0] : D[2][1])
 
-  // 1-D transform along a row: v = w B (B^T of F(4, 3): [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1])
-  auto row_pass = [](const float (&w)[6], float (&v)[6]) {
-    v[0] = fmaf(4.f, w[0], fmaf(-5.f, w[2], w[4]));
-    v[5] = fmaf(4.f, w[1], fmaf(-5.f, w[3], w[5]));
-    const float e1 = fmaf(-4.f, w[2], w[4]), o1 = fmaf(-4.f, w[1], w[3]);
-    v[1] = e1 + o1;
-    v[2] = e1 - o1;
-    const float e2 = w[4] - w[2], o2 = w[3] - w[1];
-    v[3] = fmaf(2.f, o2, e2);
-    v[4] = fmaf(-2.f, o2, e2);
+  // 1-D transform along a row, v = w B (B^T of F(4, 3): [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0;
+  // 0 4 0 -5 0 1]) in six packed instructions: w = pairs (w0, w1), (w2, w3), (w4, w5) -> (v0, v5), (v1, v3), (v2, v4)
+  auto row_pass = [](const f32x2 (&w)[3], f32x2 (&v)[3]) {
+    const f32x2 c4 = {4.f, 4.f}, c5 = {-5.f, -5.f}, c41 = {-4.f, -1.f}, c12 = {1.f, 2.f}, cn12 = {-1.f, -2.f};
+    v[0] = __builtin_elementwise_fma(c4, w[0], __builtin_elementwise_fma(c5, w[1], w[2]));
+    const f32x2 e = __builtin_elementwise_fma(c41, (f32x2){w[1].x, w[1].x}, (f32x2){w[2].x, w[2].x});     // (w4 - 4 w2, w4 - w2)
+    const f32x2 o = __builtin_elementwise_fma(c41, (f32x2){w[0].y, w[0].y}, (f32x2){w[1].y, w[1].y});     // (w3 - 4 w1, w3 - w1)
+    v[1] = __builtin_elementwise_fma(c12, o, e);
+    v[2] = __builtin_elementwise_fma(cn12, o, e);
   };
+  const f32x2 ca1v = {ca1, ca1}, ca2v = {ca2, ca2}, cb3v = {cb3, cb3}, cb4v = {cb4, cb4};
 
-  // plain (not interleaved) transform of the unit's first stage: patch buffer 0 -> V buffer 0
+  // plain (not interleaved) transform of the unit's first stage: patch buffer 0, half 0 -> V buffer 0 (same arithmetic as in the stage)
   auto transform_first = [&]() {
-    if (role > 2) return;
-    const float* P = reinterpret_cast<const float*>(smem + (tprow - sbase));
-    auto px = [&](int k, int j) {
-      const int o = (j & 3) == 0 ? O0 : (j & 3) == 1 ? O1 : (j & 3) == 2 ? O2 : O3;
-      return P[(k * RP + o + (j >> 2)) * 4];
+    auto px2 = [&](unsigned ro, int k) {      // columns (2 k, 2 k + 1) of a patch row
+      const int oa = k == 0 ? O0 : k == 1 ? O2 : O0 + 1, ob = k == 0 ? O1 : k == 1 ? O3 : O1 + 1;
+      const char* q = smem + (tprow - sbase) + ro;
+      return (f32x2){*reinterpret_cast<const float*>(q + oa * 16), *reinterpret_cast<const float*>(q + ob * 16)};
     };
-    float wa[6], wb[6], va[6], vb[6];
-    if (role == 0) {
+    f32x2 wa[3], wb[3], va[3], vb[3];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        wa[j] = fmaf(4.f, px(0, j), fmaf(-5.f, px(2, j), px(4, j)));
-        wb[j] = fmaf(4.f, px(1, j), fmaf(-5.f, px(3, j), px(5, j)));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float e = fmaf(-kap, px(2, j), px(4, j)), o = lam * fmaf(-kap, px(1, j), px(3, j));
-        wa[j] = e + o;
-        wb[j] = e - o;
-      }
+    for (int k = 0; k < 3; ++k) {
+      const f32x2 xx = __builtin_elementwise_fma(ca1v, px2(ro1, k), ca2v * px2(ro2, k));
+      const f32x2 yy = __builtin_elementwise_fma(cb4v, px2(ro4, k), cb3v * px2(ro3, k));
+      wa[k] = xx + yy;
+      wb[k] = xx - yy;
     }
     row_pass(wa, va);
     row_pass(wb, vb);
-    f32x4* V = reinterpret_cast<f32x4*>(smem + (tvw - sbase));
-    V[0] = (f32x4){va[0], va[1], va[2], va[3]};
-    V[kT * kKC] = (f32x4){va[4], va[5], vb[0], vb[1]};
-    V[2 * kT * kKC] = (f32x4){vb[2], vb[3], vb[4], vb[5]};
+    *reinterpret_cast<f32x4*>(smem + (wA - sbase)) = (f32x4){va[0].x, va[0].y, va[1].x, va[1].y};
+    *reinterpret_cast<f32x2*>(smem + (wB - sbase)) = va[2];
+    *reinterpret_cast<f32x2*>(smem + (wC - sbase)) = vb[0];
+    *reinterpret_cast<f32x4*>(smem + (wD - sbase)) = (f32x4){vb[1].x, vb[1].y, vb[2].x, vb[2].y};
   };
 
   f32x4 acc[36];
-  const unsigned fa = sbase + kV0 + ((16 * wh + li) * kKC + g) * 16, fb0 = sbase + ((16 * wq + li) * kKC + g) * 16;
+  f32x4 qa[2], qb[2];                                  // MFMA fragments of step fq of a stage of parity CB: buffer (fq + CB) & 1
+  const unsigned fa = sbase + kV0 + wh * 1024 + lane * 16, fb0 = sbase + wq * 1024 + lane * 16;
 
-  auto first_stages = [&]() {      // the DMA an item needs before its first stage (pointers advance as in the stage loop)
-    stage_p(0);
+  auto first_stages = [&]() {      // the DMA an item needs before its first stages: patch pairs 0 and 1, U(0)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) patch_piece(i, 0);
     stage_u(0);
-    if (nchunks > 1) stage_p(1);
+    uo += kUBytes;
+    pair_off = nchunks > 2 ? 32 : 0;          // (a one-pair unit fetches pair 0 again: never read)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) patch_piece(i, 1);
+    pair_off = 64;
   };
 
-  // One stage = 9 steps of (2 fragment loads one step ahead, 4 MFMAs); the transform of the NEXT stage's patch rides along in
-  // waves 0-5: patch-row reads in the early steps, arithmetic two steps after the rows were requested (LDS returns in order, so
-  // the step's s_waitcnt counts exactly the operations issued after the fragments it needs), V writes at the end.
-  auto stage = [&](auto more_c, auto role_c, int chunk) {
-    constexpr bool MORE = decltype(more_c)::value;
-    constexpr int ROLE = MORE ? decltype(role_c)::value : 2;       // role class: 0, 1 (rows (1,2) / (3,4)), 2 (no transform)
-    const int cb = chunk & 1;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();      // V(chunk) written, U(chunk) and patch(chunk + 1) landed
-    const unsigned pa = fa + cb * kVBytes, pb = fb0 + (cb ? kU1 : kU0);
-    const unsigned poff = (cb ^ 1) * kPBytes;                      // the patch of chunk + 1
-    const unsigned vw = tvw + (cb ^ 1) * kVBytes;
-    f32x4 qa[2], qb[2];
-    f32x2 d0[3], d1[3], d2[3], d3[3], d4[3], d5[3];
-    float wa[6], wb[6], va[6], vb[6], ee[6];
-    asm volatile("ds_read_b128 %0, %1" : "=v"(qa[0]) : "v"(pa));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(qb[0]) : "v"(pb));
-    if (MORE) stage_u(cb ^ 1);
-    if (chunk + 2 < nchunks) stage_p(cb);
+  // One stage = 9 steps of (2 fragment loads one step ahead, 4 MFMAs) on V / U of parity CB = chunk & 1.  Riding along:
+  //   * the input transform of chunk + 1 (patch pair (chunk + 1) / 2, channel half CB ^ 1) -> V[CB ^ 1]: patch-row reads in steps
+  //     0-3, arithmetic from two steps after a row was requested (LDS returns in order, so the step's s_waitcnt counts exactly
+  //     the operations issued after the fragments it needs), V writes in step 7;
+  //   * this wave's LDS-DMA pieces, one per step (a piece blocks the wave's issue for 60+ cycles: in a row at the top of the
+  //     stage they idle the MFMA pipe): U(chunk + 1) in steps 0-4; odd stages: patch pair (chunk + 3) / 2 in steps 5-7.  The
+  //     unit's last stages issue them too (no branch in the loop): U from the unit's last stage again, patch channels past Cin
+  //     clamped to the last pair -- into buffers nobody reads any more;
+  //   * the stage barrier BEFORE the last step's MFMAs: by then the wave holds the step-8 fragments in registers, has written its
+  //     share of V[CB ^ 1] and waits for its DMA; right after the barrier the next stage's first fragments are requested and
+  //     arrive under the four MFMAs still to issue -- no bubble at the stage boundary, no barrier at the top of a stage.
+  auto stage = [&](auto cb_c, int chunk) {
+    constexpr int CB = decltype(cb_c)::value;
+    constexpr bool TRF = !(UD_W4_ABL & 1);
+    const unsigned pa = fa + CB * kVBytes, pb = fb0 + (CB ? kU1 : kU0);
+    const unsigned pan = fa + (CB ^ 1) * kVBytes, pbn = fb0 + (CB ? kU0 : kU1);        // the next stage's
+    const unsigned poff = (((chunk + 1) >> 1) & 1) * kPBytes + (CB ^ 1) * (RP * 16);   // patch pair buffer + channel half of chunk + 1
+    f32x2 r1[3], r2[3], r3[3], r4[3];
+    f32x2 wa[3], wb[3], va[3], vb[3];
+    const unsigned ub = sbase + (CB ? kU0 : kU1) + wave * 1024;
+    const int pbuf = ((chunk + 3) >> 1) & 1;
     static_for<9>([&](auto fq_c) {
       constexpr int fq = decltype(fq_c)::value;
-      constexpr int cur = fq & 1, nxt = cur ^ 1;
+      constexpr int cur = (fq + CB) & 1, nxt = cur ^ 1;
       if constexpr (fq < 8) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qa[nxt]) : "v"(pa), "n"((fq + 1) * (kT * kKC * 16)));
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qb[nxt]) : "v"(pb), "n"((fq + 1) * (kTN * kKC * 16)));
       }
-      // ---- LDS operations of the transform in this step
-      if constexpr (ROLE == 0) {
-        if constexpr (fq == 0) W4_ROWREAD(d0, 0, poff);
-        if constexpr (fq == 1) W4_ROWREAD(d2, 2, poff);
-        if constexpr (fq == 2) W4_ROWREAD(d4, 4, poff);
-        if constexpr (fq == 3) W4_ROWREAD(d1, 1, poff);
-        if constexpr (fq == 4) W4_ROWREAD(d3, 3, poff);
-        if constexpr (fq == 5) W4_ROWREAD(d5, 5, poff);
-        if constexpr (fq == 6)
-          asm volatile("ds_write_b128 %0, %1" ::"v"(vw), "v"((f32x4){va[0], va[1], va[2], va[3]}) : "memory");
-      } else if constexpr (ROLE == 1) {
-        if constexpr (fq == 0) W4_ROWREAD(d2, 2, poff);
-        if constexpr (fq == 1) W4_ROWREAD(d4, 4, poff);
-        if constexpr (fq == 2) W4_ROWREAD(d1, 1, poff);
-        if constexpr (fq == 3) W4_ROWREAD(d3, 3, poff);
+      // ---- LDS operations of the transform in this step (kStepOps counts them)
+      if constexpr (TRF) {
+        if constexpr (fq == 0) W4_ROWREAD(r1, ro1 + poff);
+        if constexpr (fq == 1) W4_ROWREAD(r2, ro2 + poff);
+        if constexpr (fq == 2) W4_ROWREAD(r3, ro3 + poff);
+        if constexpr (fq == 3) W4_ROWREAD(r4, ro4 + poff);
         if constexpr (fq == 7) {
-          asm volatile("ds_write_b128 %0, %1" ::"v"(vw), "v"((f32x4){va[0], va[1], va[2], va[3]}) : "memory");
-          asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(vw), "v"((f32x4){va[4], va[5], vb[0], vb[1]}), "n"(kT * kKC * 16) : "memory");
+          asm volatile("ds_write_b128 %0, %1" ::"v"(wA + (CB ? 0 : vdelta01)), "v"((f32x4){va[0].x, va[0].y, va[1].x, va[1].y}) : "memory");
+          asm volatile("ds_write_b64 %0, %1" ::"v"(wB + (CB ? 0 : vdelta01)), "v"(va[2]) : "memory");
+          asm volatile("ds_write_b64 %0, %1" ::"v"(wC + (CB ? 0 : vdelta23)), "v"(vb[0]) : "memory");
+          asm volatile("ds_write_b128 %0, %1" ::"v"(wD + (CB ? 0 : vdelta23)), "v"((f32x4){vb[1].x, vb[1].y, vb[2].x, vb[2].y}) : "memory");
         }
-        if constexpr (fq == 8)
-          asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(vw), "v"((f32x4){vb[2], vb[3], vb[4], vb[5]}), "n"(2 * kT * kKC * 16) : "memory");
       }
-      // ---- wait for this step's fragments (and with them everything requested two steps ago)
-      constexpr int WN = w4_wait(ROLE, fq);
-      if constexpr (ROLE == 0 && fq == 4)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d2[0]), "+v"(d2[1]), "+v"(d2[2]) : "n"(WN));
-      else if constexpr (ROLE == 0 && fq == 5)      // row 4 (requested in step 2) arrived with step 4's fragments; bind it here
-        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(d4[0]), "+v"(d4[1]), "+v"(d4[2]) : "n"(WN));
-      else if constexpr (ROLE == 0 && fq == 7)
-        asm volatile("s_waitcnt lgkmcnt(%11)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d3[0]), "+v"(d3[1]), "+v"(d3[2]), "+v"(d5[0]), "+v"(d5[1]), "+v"(d5[2]) : "n"(WN));
-      else if constexpr (ROLE == 1 && fq == 3)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(d2[0]), "+v"(d2[1]), "+v"(d2[2]), "+v"(d4[0]), "+v"(d4[1]), "+v"(d4[2]) : "n"(WN));
-      else if constexpr (ROLE == 1 && fq == 5)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d3[0]), "+v"(d3[1]), "+v"(d3[2]) : "n"(WN));
-      else
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(qa[cur]), "+v"(qb[cur]) : "n"(WN));
+      // ---- wait for this step's fragments; a patch row requested in step i has arrived by the wait of step i + 2 and is bound
+      // to that wait (an in/out operand), from which on the compiler may read it
+      if constexpr (fq == 8) {
+        // fragments of step 8 and the V writes of step 7 are done; DMA: an even stage needs everything it issued (U(chunk + 1)),
+        // an odd one may leave its three patch pieces (needed two stages on) in flight
+        if constexpr (CB == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(qa[cur]), "+v"(qb[cur])::"memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" : "+v"(qa[cur]), "+v"(qb[cur])::"memory");
+        if (!(UD_W4_ABL & 16)) __builtin_amdgcn_s_barrier();
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qa[nxt]) : "v"(pan));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qb[nxt]) : "v"(pbn));
+      } else {
+        constexpr int WN = TRF ? w4_wait(fq) : 2;
+        if constexpr (TRF && fq == 3)
+          asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]) : "n"(WN));
+        else if constexpr (TRF && fq == 4)
+          asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(r3[0]), "+v"(r3[1]), "+v"(r3[2]) : "n"(WN));
+        else if constexpr (TRF && fq == 5)
+          asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(qa[cur]), "+v"(qb[cur]), "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]) : "n"(WN));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(qa[cur]), "+v"(qb[cur]) : "n"(WN));
+      }
       // ---- the step's four MFMAs
 #pragma unroll
       for (int p = 0; p < 4; ++p)
-        acc[4 * fq + p] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[cur][p], qb[cur][p], acc[4 * fq + p], 0, 0, 0);
-      // ---- transform arithmetic that became possible with this step's wait
-      if constexpr (ROLE == 0) {
-        if constexpr (fq == 5) {     // rows 0, 2, 4 are in: column pass of row 0 of B^T d
-#pragma unroll
-          for (int j = 0; j < 6; ++j) wa[j] = fmaf(4.f, W4_COL(d0, j), fmaf(-5.f, W4_COL(d2, j), W4_COL(d4, j)));
-          row_pass(wa, va);
+        if (!(UD_W4_ABL & 8) || fq == 0)
+          acc[4 * fq + p] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[cur][p], qb[cur][p], acc[4 * fq + p], 0, 0, 0);
+      if (!(UD_W4_ABL & (2 | 64))) {
+        if constexpr (fq < 4) dma16(ru, lane16, uo + fq * 8192, ub + fq * 8192);
+        else if constexpr (fq == 4) {
+          if (wave < 4) dma16(ru, lane16, uo + fq * 8192, ub + fq * 8192);
         }
-        if constexpr (fq == 7) {     // rows 1, 3, 5: row 5 of B^T d
-#pragma unroll
-          for (int j = 0; j < 6; ++j) wb[j] = fmaf(4.f, W4_COL(d1, j), fmaf(-5.f, W4_COL(d3, j), W4_COL(d5, j)));
-        }
-        if constexpr (fq == 8) row_pass(wb, vb);
-      } else if constexpr (ROLE == 1) {
+      }
+      if constexpr (fq >= 5 && fq < 8 && CB == 1) patch_piece(fq - 5, pbuf);
+      // ---- transform arithmetic that became possible with this step's wait (packed fp32: two columns per instruction)
+      if constexpr (TRF) {
         if constexpr (fq == 3) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) ee[j] = fmaf(-kap, W4_COL(d2, j), W4_COL(d4, j));
+          for (int k = 0; k < 3; ++k) wa[k] = __builtin_elementwise_fma(ca1v, r1[k], ca2v * r2[k]);          // X
+        }
+        if constexpr (fq == 4) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) wb[k] = cb3v * r3[k];
         }
         if constexpr (fq == 5) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            const float o = lam * fmaf(-kap, W4_COL(d1, j), W4_COL(d3, j));
-            wa[j] = ee[j] + o;
-            wb[j] = ee[j] - o;
+          for (int k = 0; k < 3; ++k) {
+            const f32x2 yy = __builtin_elementwise_fma(cb4v, r4[k], wb[k]);                                  // Y
+            wb[k] = wa[k] - yy;
+            wa[k] = wa[k] + yy;
           }
-          row_pass(wa, va);
         }
-        if constexpr (fq == 6) row_pass(wb, vb);
+        if constexpr (fq == 6) {
+          row_pass(wa, va);
+          row_pass(wb, vb);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (ROLE == 0) {
-      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(vw), "v"((f32x4){va[4], va[5], vb[0], vb[1]}), "n"(kT * kKC * 16) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(vw), "v"((f32x4){vb[2], vb[3], vb[4], vb[5]}), "n"(2 * kT * kKC * 16) : "memory");
-    }
+    // next U stage (the unit's last two stages stay on the last one); odd stages: next patch pair (clamped to the last one)
+    uo += chunk + 2 < nchunks ? kUBytes : 0;
+    if constexpr (CB == 1) pair_off += chunk + 5 < nchunks ? 32 : 0;
   };
 
   int item = blockIdx.x;
@@ -382,19 +413,25 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 1
   for (;;) {
-#pragma unroll
-    for (int f = 0; f < 36; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA (and the previous item's stores) are done
     __syncthreads();                                       // first stages in LDS; everybody has left the previous item's epilogue
     transform_first();
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                       // V(0) complete
+    asm volatile("ds_read_b128 %0, %1" : "=v"(qa[0]) : "v"(fa));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(qb[0]) : "v"(fb0 + kU0));
 #pragma unroll 1
-    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
-      if (role == 0) stage(std::true_type{}, IC<0>{}, chunk);
-      else if (role < 3) stage(std::true_type{}, IC<1>{}, chunk);
-      else stage(std::true_type{}, IC<2>{}, chunk);
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      stage(IC<0>{}, chunk);
+      stage(IC<1>{}, chunk + 1);
     }
-    stage(std::false_type{}, IC<2>{}, nchunks - 1);
-    __syncthreads();                  // everybody is done with U / V / the patches of this item
+    // (the last stage's barrier came before its last MFMAs: nobody reads U / V any more, except for the fragments that stage
+    // requested for a stage that does not exist -- wait for them before their registers are reused)
+    // -- and for the DMA pieces the last stages issued into buffers nobody reads (they must not land in the output staging)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(qa[0]), "+v"(qb[0]), "+v"(qa[1]), "+v"(qb[1])::"memory");
+    __syncthreads();
     const int e_b = b, e_ty0 = ty0, e_tx0 = tx0, e_n0 = n0, e_blk = blk_lin;
     const int next = item + gridDim.x;
     // ---- epilogue: output transform in registers -> fp32 pixel rows in LDS (two passes of 16 tiles: accumulator rows r = 2 pass,
@@ -409,31 +446,33 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
     }
     s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = (UD_W4_ABL & 4) ? 1 : 0; pass < 2; ++pass) {
       float* Os = reinterpret_cast<float*>(smem + (pass ? kStageB : kStageA));
+      {
+        // A^T M A for the accumulator rows r = 2 pass, 2 pass + 1 together (a register pair of every accumulator): packed fp32
+        auto m2 = [&](int i, int j) { return (f32x2){acc[w4_f(i, j)][2 * pass], acc[w4_f(i, j)][2 * pass + 1]}; };
+        const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+        f32x2 t[4][6];
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int r = 2 * pass + rr;
-        float t[4][6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {       // A^T M: rows of M in frequency slots (0, 5, 1, 2, 3, 4) -> m0 = slot 0, m5 = slot 1, m1..m4 = slots 2..5
-          const float m0 = acc[0 + j][r], m5 = acc[6 + j][r], m1 = acc[12 + j][r], m2 = acc[18 + j][r], m3 = acc[24 + j][r],
-                      m4 = acc[30 + j][r];
-          const float sa = m1 + m2, da = m1 - m2, sb = m3 + m4, db = m3 - m4;
-          t[0][j] = m0 + sa + sb;
-          t[1][j] = fmaf(2.f, db, da);
-          t[2][j] = fmaf(4.f, sb, sa);
-          t[3][j] = fmaf(8.f, db, da) + m5;
+        for (int j = 0; j < 6; ++j) {
+          const f32x2 m1 = m2(1, j), mm2 = m2(2, j), m3 = m2(3, j), m4 = m2(4, j);
+          const f32x2 sa = m1 + mm2, da = m1 - mm2, sb = m3 + m4, db = m3 - m4;
+          t[0][j] = m2(0, j) + sa + sb;
+          t[1][j] = __builtin_elementwise_fma(c2, db, da);
+          t[2][j] = __builtin_elementwise_fma(c4, sb, sa);
+          t[3][j] = __builtin_elementwise_fma(c8, db, da) + m2(5, j);
         }
-        const int tl = wh * 8 + g * 2 + rr;
-        float* o = Os + (tl * 16) * 64 + (16 * (wq ^ g) + li);
+        // rows of tile tl = wh * 8 + g * 2 (+ 1 for the pair's second half: 16 rows = 4 096 bytes on)
+        const unsigned o = sbase + (pass ? kStageB : kStageA) + ((wh * 8 + g * 2) * 16 * 64 + (16 * (wq ^ g) + li)) * 4;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const float sa = t[a][1] + t[a][2], da = t[a][1] - t[a][2], sb = t[a][3] + t[a][4], db = t[a][3] - t[a][4];
-          o[(a * 4 + 0) * 64] = t[a][0] + sa + sb;
-          o[(a * 4 + 1) * 64] = fmaf(2.f, db, da);
-          o[(a * 4 + 2) * 64] = fmaf(4.f, sb, sa);
-          o[(a * 4 + 3) * 64] = fmaf(8.f, db, da) + t[a][5];
+          const f32x2 sa = t[a][1] + t[a][2], da = t[a][1] - t[a][2], sb = t[a][3] + t[a][4], db = t[a][3] - t[a][4];
+          const f32x2 y0 = t[a][0] + sa + sb, y1 = __builtin_elementwise_fma(c2, db, da), y2 = __builtin_elementwise_fma(c4, sb, sa),
+                      y3 = __builtin_elementwise_fma(c8, db, da) + t[a][5];
+          asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(o), "v"(y0.x), "v"(y0.y), "n"(a * 4 + 0), "n"(a * 4 + 16) : "memory");
+          asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(o), "v"(y1.x), "v"(y1.y), "n"(a * 4 + 1), "n"(a * 4 + 17) : "memory");
+          asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(o), "v"(y2.x), "v"(y2.y), "n"(a * 4 + 2), "n"(a * 4 + 18) : "memory");
+          asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(o), "v"(y3.x), "v"(y3.y), "n"(a * 4 + 3), "n"(a * 4 + 19) : "memory");
         }
       }
       __syncthreads();
@@ -558,13 +597,15 @@ extern "C" int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* 
                                          int flags, float* partial, size_t partial_bytes, int* slices, ud_stream_t stream_) {
   if (!x || !U || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
-  if (Cin % kKC != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;
+  if (Cin % (2 * kKC) != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;     // stages come in pairs (8-channel patch fetches)
   hipStream_t stream = (hipStream_t)stream_;
   const W4Plan p = w4_plan(H, W);
   const int nblocks = B * p.bx * p.by;
   const long long units = (long long)nblocks * ud_div_up(Cout, kTN);
-  if (units > 0x7fffffffll) return UD_ERR_UNSUPPORTED;
-  W4Geom gm{B, H, W, Cin, Cout, p.bx, p.by, (int)units};
+  if (units > 0x7fffffffll || (long long)B * H * W * Cin * 4 >= (long long)kOob ||
+      ud_conv3x3_wino4_f32_weight_bytes(Cin, Cout) >= (size_t)kOob)
+    return UD_ERR_UNSUPPORTED;    // 32-bit byte offsets into x / U (buffer descriptors)
+  W4Geom gm{B, H, W, Cin, Cout, p.bx, p.by, (unsigned)ud_conv3x3_wino4_f32_weight_bytes(Cin, Cout), (int)units};
   W4Ep ep{bias, scale, shift, residual, flags & 1, partial};
   if (partial) {
     if (!slices || partial_bytes < (size_t)nblocks * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;

@@ -36,6 +36,18 @@ WINO_MIN_FILL = 0.7
 USE_WINOGRAD_WGRAD = os.environ.get("UD_F32_WINOGRAD_WGRAD", "1") != "0"
 
 
+# Winograd F(4x4, 3x3) (csrc/conv2d_f32_wino4.hip): 1.78x fewer MFMA flops again; taken where the map fills its 32-tile blocks
+USE_WINO4 = os.environ.get("UD_F32_WINO4", "0") != "0"      # off until the per-shape routing is settled
+WINO4_MIN_FILL = float(os.environ.get("UD_F32_WINO4_FILL", "0.7"))
+
+
+def wino4_pays(H, W, cin, cout):
+    if not (USE_WINOGRAD and USE_WINO4) or cin % 8 or cout % 4:
+        return False
+    blocks = _lib.load().ud_conv3x3_wino4_f32_blocks(H, W)
+    return ((H + 3) // 4) * ((W + 3) // 4) >= WINO4_MIN_FILL * 32 * blocks
+
+
 def wino_pays(H, W, cin, cout):
     if not USE_WINOGRAD or cin % 8 or cout % 4:
         return False
@@ -43,7 +55,7 @@ def wino_pays(H, W, cin, cout):
     return ((H + 1) // 2) * ((W + 1) // 2) >= WINO_MIN_FILL * 64 * blocks
 
 
-def _wino_weights(weight, transposed):
+def _wino_weights(weight, transposed, f4=False):
     """U = G g G^T in the kernel's stage order.  transposed: the data gradient's filter (Cin <-> Cout, taps reversed).  Cached on
     the tensor object for FROZEN weights only (requires_grad False: the distillation teacher), keyed by version + storage;
     trainable weights are transformed on every call -- fused optimizers update parameters without moving the version counter
@@ -54,16 +66,18 @@ def _wino_weights(weight, transposed):
     def make():
         n, c = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
         sn, sc = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
-        U = torch.empty(lib.ud_conv3x3_wino_f32_weight_bytes(c, n) // 4, dtype=torch.float32, device=w.device)
-        _lib.check(lib.ud_conv3x3_wino_f32_weights(_lib.ptr(w), sn, sc, w.stride(2), w.stride(3), n, c, 1 if transposed else 0,
-                                                   _lib.ptr(U), _lib.stream_of(w)), "ud_conv3x3_wino_f32_weights")
+        nbytes, fn = ((lib.ud_conv3x3_wino4_f32_weight_bytes, lib.ud_conv3x3_wino4_f32_weights) if f4 else
+                      (lib.ud_conv3x3_wino_f32_weight_bytes, lib.ud_conv3x3_wino_f32_weights))
+        U = torch.empty(nbytes(c, n) // 4, dtype=torch.float32, device=w.device)
+        _lib.check(fn(_lib.ptr(w), sn, sc, w.stride(2), w.stride(3), n, c, 1 if transposed else 0,
+                      _lib.ptr(U), _lib.stream_of(w)), "ud_conv3x3_wino4_f32_weights" if f4 else "ud_conv3x3_wino_f32_weights")
         return U
 
     if weight.requires_grad or torch.cuda.is_current_stream_capturing():
         if weight.requires_grad and getattr(weight, "_ud_wino", None) is not None:
             weight._ud_wino = None          # a weight that is trained now and frozen again later must not find its old filters
         return make()
-    key = (bool(transposed), weight._version, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+    key = (bool(transposed), bool(f4), weight._version, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
     cache = getattr(weight, "_ud_wino", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -86,6 +100,16 @@ def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False,
         SHAPE_LOG.append((B, cin, H, W, cout, bool(transposed)))
     lib = _lib.load()
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if wino4_pays(H, W, cin, cout):
+        U = _wino_weights(weight, transposed, f4=True)
+        part, ns = (None, ctypes.c_int(0))
+        if bn_stats:
+            part, ns = _bn_partial(lib.ud_conv3x3_wino4_bnstats_bytes(B, H, W, cout), x.device)
+        _lib.check(lib.ud_conv3x3_wino4_nhwc_f32(_lib.ptr(x), _lib.ptr(U), _lib.ptr(y), B, H, W, cin, cout, _lib.ptr(bias),
+                                                 _lib.ptr(scale), _lib.ptr(shift), None, 1 if relu else 0, _lib.ptr(part),
+                                                 part.numel() * 4 if bn_stats else 0, ctypes.addressof(ns), _lib.stream_of(x)),
+                   "ud_conv3x3_wino4_nhwc_f32")
+        return (y, (part, ns.value, B * H * W)) if bn_stats else y
     if wino_pays(H, W, cin, cout):
         U = _wino_weights(weight, transposed)
         part, ns = (None, ctypes.c_int(0))

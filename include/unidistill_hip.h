@@ -586,6 +586,20 @@ int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y, int B, in
                              const float* bias, const float* scale, const float* shift, const float* residual, int flags,
                              float* partial, size_t partial_bytes, int* slices, ud_stream_t stream);
 
+/* The same layers as Winograd F(4x4, 3x3) (csrc/conv2d_f32_wino4.hip): 36 multiplications per 4 x 4 outputs, 4x fewer matrix flops than
+ * the direct form and 1.78x fewer than F(2x2, 3x3); rounding 3-5e-6 of the output's max against fp64 (tested per layer shape).  Same
+ * contract as the ud_conv3x3_wino_* entry points; U from ud_conv3x3_wino4_f32_weights (ud_conv3x3_wino4_f32_weight_bytes(C, N) bytes);
+ * ud_conv3x3_wino4_f32_blocks: 32-tile blocks per image of the launch plan (fill = ceil(H/4) ceil(W/4) / (32 blocks)).
+ * Cin % 8 == 0, Cout % 4 == 0. */
+size_t ud_conv3x3_wino4_f32_weight_bytes(int Cin, int Cout);
+size_t ud_conv3x3_wino4_bnstats_bytes(int B, int H, int W, int Cout);
+int ud_conv3x3_wino4_f32_blocks(int H, int W);
+int ud_conv3x3_wino4_f32_weights(const float* w, int64_t s_n, int64_t s_c, int64_t s_y, int64_t s_x, int N, int C, int flip,
+                                 float* U, ud_stream_t stream);
+int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* y, int B, int H, int W, int Cin, int Cout,
+                              const float* bias, const float* scale, const float* shift, const float* residual, int flags,
+                              float* partial, size_t partial_bytes, int* slices, ud_stream_t stream);
+
 /* Weight gradient of the same layers through the Winograd form (gradient of ud_conv3x3_wino_nhwc_f32: 16 instead of 36 multiplications
  * per 2 x 2 tile and (n, c)); same contract as ud_conv3x3_wgrad_nhwc_f32: dw [Cout][3][3][Cin], tile slices reduced in a fixed order. */
 size_t ud_conv3x3_wino_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout);
