@@ -50,7 +50,14 @@ static_assert(kStageB >= kV0 && kV1 == kV0 + kVBytes && 65536 <= kV0 + kVBytes, 
 struct W4Geom {
   int B, H, W, Cin, Cout, bx, by;   // bx x by tile blocks per image
   unsigned u_bytes;                 // size of the transformed filters
-  int n_items;                      // units (tile block, cout block): a workgroup walks items blockIdx.x, + gridDim.x, ...
+  // Schedule: units (tile block, cout block) [0, n_dp) are walked whole, unit = blockIdx.x, + gridDim.x, ... (data parallel); the
+  // stages of units [n_dp, n_units) form ONE sequence of (n_units - n_dp) * Cin / 4 stages that is cut into gridDim.x equal
+  // ranges of sk_len stages (stream-K): a workgroup runs its range unit by unit; a unit it covers completely is stored as usual,
+  // a piece of a unit goes to the workspace as a partial tile (slot 2 * workgroup + (0: first unit of its range, 1: last)) and
+  // k_wino4_fixup adds the pieces in ascending stage order.  A layer of 276 units on 256 CUs takes 1.08 unit times this way
+  // instead of 2, a 552-unit layer 2.4 instead of 3.
+  int n_dp, n_units, sk_len;
+  float* partial;                   // [2 * gridDim.x][512 rows][64] fp32 partial tiles (before bias / BatchNorm / ReLU)
 };
 struct W4Ep {
   const float* bias;
@@ -140,6 +147,71 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::forward<F>(f), std::make_integer_sequence<int, N>{});
 }
 
+// The fused tail of an output row (4 channels of one pixel): bias, folded BatchNorm, residual, ReLU, store, BatchNorm partial sums.
+// Row numbering of a pass (256 rows): row = tl * 16 + py * 4 + px, tl = wh * 8 + g * 2 + (r & 1) <-> tile slot 16 wh + 4 g + 2 pass + (r & 1).
+template <int TWB, int THB>
+struct W4Tail {
+  const W4Geom& gm;
+  const W4Ep& ep;
+  int b, ty0, tx0, n0, tid, c4, n;
+  float4 bv, scv, shv, s1, s2;
+  __device__ W4Tail(const W4Geom& gm_, const W4Ep& ep_, int b_, int ty0_, int tx0_, int n0_, int tid_)
+      : gm(gm_), ep(ep_), b(b_), ty0(ty0_), tx0(tx0_), n0(n0_), tid(tid_) {
+    c4 = (tid & 15) * 4, n = n0 + c4;
+    bv = make_float4(0.f, 0.f, 0.f, 0.f), scv = make_float4(1.f, 1.f, 1.f, 1.f), shv = bv, s1 = bv, s2 = bv;
+    if (ep.bias && n < gm.Cout) bv = *reinterpret_cast<const float4*>(ep.bias + n);
+    if (ep.scale && n < gm.Cout) {
+      scv = *reinterpret_cast<const float4*>(ep.scale + n);
+      shv = *reinterpret_cast<const float4*>(ep.shift + n);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ y, int pass, int row, float4 v) {
+    static_assert((TWB & (TWB - 1)) == 0, "tile-block width: a power of two (shift / mask below)");
+    const int tl = row >> 4, p = row & 15;
+    const int slot = 16 * (tl >> 3) + 4 * ((tl >> 1) & 3) + 2 * pass + (tl & 1);      // = 4 k + 2 pass + (tid >> 8) for row = (tid >> 4) + 32 k
+    const int sy = slot / TWB, sx = slot & (TWB - 1);
+    const int gy = 4 * (ty0 + sy) + (p >> 2), gx = 4 * (tx0 + sx) + (p & 3);
+    if (slot >= TWB * THB || gy >= gm.H || gx >= gm.W || n >= gm.Cout) return;
+    if (ep.bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (ep.scale) {
+      v.x = v.x * scv.x + shv.x; v.y = v.y * scv.y + shv.y; v.z = v.z * scv.z + shv.z; v.w = v.w * scv.w + shv.w;
+    }
+    const size_t off = ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
+    if (ep.residual) {
+      const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
+      v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+    }
+    if (ep.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + off) = v;
+    if (ep.stats) {
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    }
+  }
+  // a thread keeps ONE 4-channel piece over its 16 rows: reduce the 32 row groups through LDS (red: 16 KB), fixed order
+  __device__ void reduce_stats(float* red, int blk_lin) {
+    const int grp = tid >> 4;
+    const float a4[4] = {s1.x, s1.y, s1.z, s1.w}, q4[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[(grp * 64 + c4 + e) * 2] = a4[e];
+      red[(grp * 64 + c4 + e) * 2 + 1] = q4[e];
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < gm.Cout) {
+      double ad = 0.0, qd = 0.0;          // the 32 row-group sums combine in double (sum of squares minus mean^2 comes next)
+      for (int k = 0; k < 32; ++k) {
+        ad += (double)red[(k * 64 + tid) * 2];
+        qd += (double)red[(k * 64 + tid) * 2 + 1];
+      }
+      ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2] = (float)ad;
+      ep.stats[((size_t)blk_lin * gm.Cout + n0 + tid) * 2 + 1] = (float)qd;
+    }
+  }
+};
+
 // LDS operations of the input transform that ride in MFMA step fq (after the step's fragment loads): four patch-row reads
 // (3 ds_read2_b32 each) in steps 0-3, the four V writes in step 7
 __device__ constexpr int kStepOps[9] = {3, 3, 3, 3, 0, 0, 0, 4, 0};
@@ -176,8 +248,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
   unsigned po[3];                  // byte offset of this lane's 16 bytes of patch piece wave + 8 i within x (channels 0-3 / 4-7), kOob: zeros
   unsigned uo;                     // wave-uniform byte offset of this wave's first piece of the next U stage
   unsigned pair_off;               // byte offset of the next patch pair's channels
-  auto setup = [&](int item) {
-    unit = item;
+  int nst;                         // stages of the current piece (even)
+  auto setup = [&](int unit_, int c0, int c1) {
+    unit = unit_;
+    nst = c1 - c0;
     cbi = unit / nblocks;
     const int ru_ = unit - cbi * nblocks;
     int blk;
@@ -202,8 +276,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
       const bool ok = qq < PP && qs < PW && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W && !(UD_W4_ABL & (2 | 128));
       po[i] = ok ? (unsigned)(((b * gm.H + gy) * gm.W + gx) * gm.Cin + qh * 4) * 4u : kOob;
     }
-    uo = (unsigned)(cbi * nchunks) * (unsigned)kUBytes + wave * 1024;
-    pair_off = 0;
+    uo = (unsigned)(cbi * nchunks + c0) * (unsigned)kUBytes + wave * 1024;
+    pair_off = c0 * 16;            // 4 channels = 16 bytes per stage
   };
   // patch pair (8 channels) -> patch buffer `buf`: ALWAYS three pieces per wave (a constant count lets the stage wait with
   // vmcnt(3) for everything older); pieces past the patch land in the dump
@@ -297,10 +371,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
     for (int i = 0; i < 3; ++i) patch_piece(i, 0);
     stage_u(0);
     uo += kUBytes;
-    pair_off = nchunks > 2 ? 32 : 0;          // (a one-pair unit fetches pair 0 again: never read)
+    pair_off += nst > 2 ? 32 : 0;             // (a one-pair piece fetches its pair again: never read)
 #pragma unroll
     for (int i = 0; i < 3; ++i) patch_piece(i, 1);
-    pair_off = 64;
+    pair_off += nst > 4 ? 32 : 0;
   };
 
   // One stage = 9 steps of (2 fragment loads one step ahead, 4 MFMAs) on V / U of parity CB = chunk & 1.  Riding along:
@@ -309,8 +383,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
   //     the operations issued after the fragments it needs), V writes in step 7;
   //   * this wave's LDS-DMA pieces, one per step (a piece blocks the wave's issue for 60+ cycles: in a row at the top of the
   //     stage they idle the MFMA pipe): U(chunk + 1) in steps 0-4; odd stages: patch pair (chunk + 3) / 2 in steps 5-7.  The
-  //     unit's last stages issue them too (no branch in the loop): U from the unit's last stage again, patch channels past Cin
-  //     clamped to the last pair -- into buffers nobody reads any more;
+  //     piece's last stages issue them too (no branch in the loop): U of the last stage again, the last patch pair again -- into
+  //     buffers nobody reads any more (`chunk` counts from the piece's first stage);
   //   * the stage barrier BEFORE the last step's MFMAs: by then the wave holds the step-8 fragments in registers, has written its
   //     share of V[CB ^ 1] and waits for its DMA; right after the barrier the next stage's first fragments are requested and
   //     arrive under the four MFMAs still to issue -- no bubble at the stage boundary, no barrier at the top of a stage.
@@ -403,18 +477,38 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
       __builtin_amdgcn_sched_barrier(0);
     });
     // next U stage (the unit's last two stages stay on the last one); odd stages: next patch pair (clamped to the last one)
-    uo += chunk + 2 < nchunks ? kUBytes : 0;
-    if constexpr (CB == 1) pair_off += chunk + 5 < nchunks ? 32 : 0;
+    uo += chunk + 2 < nst ? kUBytes : 0;
+    if constexpr (CB == 1) pair_off += chunk + 5 < nst ? 32 : 0;
   };
 
-  int item = blockIdx.x;
-  setup(item);
+  // ---- the workgroup's pieces: whole units first (data parallel), then its stream-K range
+  const int G = gridDim.x;
+  int dp_next = blockIdx.x;                                   // next data-parallel unit
+  int sk_lo = gm.n_dp * nchunks + blockIdx.x * gm.sk_len;     // rest of this workgroup's stream-K range, in global stage numbers
+  const int sk_hi = min(sk_lo + gm.sk_len, gm.n_units * nchunks);
+  int p_unit, p_c0, p_c1, p_slot;                             // piece: unit, stages [c0, c1), partial slot (-1: the whole unit)
+  auto next_piece = [&]() -> bool {
+    if (dp_next < gm.n_dp) {
+      p_unit = dp_next, p_c0 = 0, p_c1 = nchunks, p_slot = -1;
+      dp_next += G;
+      return true;
+    }
+    if (sk_lo >= sk_hi) return false;
+    p_unit = sk_lo / nchunks;
+    p_c0 = sk_lo - p_unit * nchunks;
+    p_c1 = min(nchunks, p_c0 + sk_hi - sk_lo);
+    const bool first = sk_lo == gm.n_dp * nchunks + (int)blockIdx.x * gm.sk_len;
+    p_slot = (p_c0 == 0 && p_c1 == nchunks) ? -1 : 2 * blockIdx.x + (first ? 0 : 1);
+    sk_lo += p_c1 - p_c0;
+    return true;
+  };
+  if (!next_piece()) return;
+  setup(p_unit, p_c0, p_c1);
   first_stages();
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 1
   for (;;) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA (and the previous item's stores) are done
-    __syncthreads();                                       // first stages in LDS; everybody has left the previous item's epilogue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA (and the previous piece's stores) are done
+    __syncthreads();                                       // first stages in LDS; everybody has left the previous piece's epilogue
     transform_first();
 #pragma unroll
     for (int f = 0; f < 36; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -423,7 +517,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
     asm volatile("ds_read_b128 %0, %1" : "=v"(qa[0]) : "v"(fa));
     asm volatile("ds_read_b128 %0, %1" : "=v"(qb[0]) : "v"(fb0 + kU0));
 #pragma unroll 1
-    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    for (int chunk = 0; chunk < nst; chunk += 2) {
       stage(IC<0>{}, chunk);
       stage(IC<1>{}, chunk + 1);
     }
@@ -432,19 +526,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
     // -- and for the DMA pieces the last stages issued into buffers nobody reads (they must not land in the output staging)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(qa[0]), "+v"(qb[0]), "+v"(qa[1]), "+v"(qb[1])::"memory");
     __syncthreads();
-    const int e_b = b, e_ty0 = ty0, e_tx0 = tx0, e_n0 = n0, e_blk = blk_lin;
-    const int next = item + gridDim.x;
+    const int e_b = b, e_ty0 = ty0, e_tx0 = tx0, e_n0 = n0, e_blk = blk_lin, e_slot = p_slot;
+    const bool more = next_piece();
     // ---- epilogue: output transform in registers -> fp32 pixel rows in LDS (two passes of 16 tiles: accumulator rows r = 2 pass,
     // 2 pass + 1 of every wave), then coalesced 16-byte stores with the fused tail.  Row = tl * 16 + py * 4 + px with
     // tl = wh * 8 + g * 2 + (r & 1); the 16-channel group is XOR-ed with g (the four lane groups write rows 8 KB apart otherwise).
-    const int c4 = (tid & 15) * 4, n = e_n0 + c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), scv = make_float4(1.f, 1.f, 1.f, 1.f), shv = bv;
-    if (ep.bias && n < gm.Cout) bv = *reinterpret_cast<const float4*>(ep.bias + n);
-    if (ep.scale && n < gm.Cout) {
-      scv = *reinterpret_cast<const float4*>(ep.scale + n);
-      shv = *reinterpret_cast<const float4*>(ep.shift + n);
-    }
-    s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    W4Tail<TWB, THB> tail(gm, ep, e_b, e_ty0, e_tx0, e_n0, tid);
 #pragma unroll
     for (int pass = (UD_W4_ABL & 4) ? 1 : 0; pass < 2; ++pass) {
       float* Os = reinterpret_cast<float*>(smem + (pass ? kStageB : kStageA));
@@ -476,63 +563,74 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
         }
       }
       __syncthreads();
+      if (e_slot < 0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int row = (tid >> 4) + 32 * k;
-        const int tl = row >> 4, p = row & 15;
-        const int slot = 16 * (tl >> 3) + 4 * ((tl >> 1) & 3) + 2 * pass + (tl & 1);
-        const int sy = slot / TWB, sx = slot - sy * TWB;
-        const int gy = 4 * (e_ty0 + sy) + (p >> 2), gx = 4 * (e_tx0 + sx) + (p & 3);
-        if (slot >= TWB * THB || gy >= gm.H || gx >= gm.W || n >= gm.Cout) continue;
-        float4 v = *reinterpret_cast<const float4*>(Os + row * 64 + (c4 ^ (16 * ((tl >> 1) & 3))));
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (ep.scale) {
-          v.x = v.x * scv.x + shv.x; v.y = v.y * scv.y + shv.y; v.z = v.z * scv.z + shv.z; v.w = v.w * scv.w + shv.w;
+        for (int k = 0; k < 8; ++k) {
+          const int row = (tid >> 4) + 32 * k;
+          tail.store(y, pass, row, *reinterpret_cast<const float4*>(Os + row * 64 + (tail.c4 ^ (16 * ((row >> 5) & 3)))));
         }
-        const size_t off = ((size_t)(e_b * gm.H + gy) * gm.W + gx) * gm.Cout + n;
-        if (ep.residual) {
-          const float4 h = *reinterpret_cast<const float4*>(ep.residual + off);
-          v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+      } else {      // a piece of a unit: the raw rows go to the workspace, k_wino4_fixup adds the pieces and applies the tail
+        float* dst = gm.partial + ((size_t)e_slot * 512 + pass * 256) * 64;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int row = (tid >> 4) + 32 * k;
+          *reinterpret_cast<float4*>(dst + row * 64 + tail.c4) =
+              *reinterpret_cast<const float4*>(Os + row * 64 + (tail.c4 ^ (16 * ((row >> 5) & 3))));
         }
-        if (ep.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(y + off) = v;
-        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
       }
       if (pass == 0) {
-        __syncthreads();               // staging A has been read: the next item's first stages may land there
-        if (next < gm.n_items) {
-          setup(next);
+        __syncthreads();               // staging A has been read: the next piece's first stages may land there
+        if (more) {
+          setup(p_unit, p_c0, p_c1);
           first_stages();
         }
       }
     }
-    if (ep.stats) {     // a thread keeps ONE 4-channel piece over its 16 rows: reduce the 32 row groups through LDS, fixed order
+    if (ep.stats && e_slot < 0) {
       __syncthreads();
-      float* Os = reinterpret_cast<float*>(smem + kStageB);
-      const int grp = tid >> 4;
-      const float a4[4] = {s1.x, s1.y, s1.z, s1.w}, q4[4] = {s2.x, s2.y, s2.z, s2.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Os[(grp * 64 + c4 + e) * 2] = a4[e];
-        Os[(grp * 64 + c4 + e) * 2 + 1] = q4[e];
-      }
-      __syncthreads();
-      if (tid < 64 && e_n0 + tid < gm.Cout) {
-        double ad = 0.0, qd = 0.0;          // the 32 row-group sums combine in double (sum of squares minus mean^2 comes next)
-        for (int k = 0; k < 32; ++k) {
-          ad += (double)Os[(k * 64 + tid) * 2];
-          qd += (double)Os[(k * 64 + tid) * 2 + 1];
-        }
-        ep.stats[((size_t)e_blk * gm.Cout + e_n0 + tid) * 2] = (float)ad;
-        ep.stats[((size_t)e_blk * gm.Cout + e_n0 + tid) * 2 + 1] = (float)qd;
-      }
+      tail.reduce_stats(reinterpret_cast<float*>(smem + kStageB), e_blk);
     }
-    if (next >= gm.n_items) break;
-    item = next;
+    if (!more) break;
   }
+}
+
+// Sum of the pieces of the units the stream-K schedule cut (ascending stage order: deterministic) + the fused tail.  One
+// workgroup per stream-K unit; a unit that one workgroup covered completely was stored by k_conv3x3_wino4_f32 itself.
+template <int TWB, int THB>
+__global__ __launch_bounds__(512) void k_wino4_fixup(float* __restrict__ y, W4Geom gm, W4Ep ep, int G) {
+  __shared__ float red[32 * 64 * 2];
+  const int tid = threadIdx.x;
+  const int nblocks = gm.B * gm.bx * gm.by, nchunks = gm.Cin / kKC;
+  const int u = gm.n_dp + blockIdx.x;
+  const int base = gm.n_dp * nchunks;
+  const int a = u * nchunks - base, e = a + nchunks - 1;              // the unit's stages within the stream-K sequence
+  const int j0 = a / gm.sk_len, j1 = e / gm.sk_len;
+  if (j0 == j1) return;
+  const int cbi = u / nblocks, ru = u - cbi * nblocks;
+  int blk;
+  {
+    const int bs = nblocks >> 3, extra = nblocks & 7, k = ru & 7;
+    blk = k * bs + min(k, extra) + (ru >> 3);
+  }
+  const int blk_lin = blk;
+  const int b = blk / (gm.bx * gm.by);
+  blk -= b * gm.bx * gm.by;
+  W4Tail<TWB, THB> tail(gm, ep, b, (blk / gm.bx) * THB, (blk % gm.bx) * TWB, cbi * kTN, tid);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass)
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+      const int row = (tid >> 4) + 32 * k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = j0; j <= j1; ++j) {
+        const int first_unit = (base + j * gm.sk_len) / nchunks;     // the first unit workgroup j touched
+        const int slot = 2 * j + (first_unit == u ? 0 : 1);
+        const float4 p = *reinterpret_cast<const float4*>(gm.partial + ((size_t)slot * 512 + pass * 256 + row) * 64 + tail.c4);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      tail.store(y, pass, row, v);
+    }
+  if (ep.stats) tail.reduce_stats(red, blk_lin);
 }
 
 #undef W4_ROWREAD
@@ -543,12 +641,12 @@ struct W4Plan {
 };
 // tile-block shape (<= 32 tiles of 4 x 4 outputs) with the fewest blocks for this map
 W4Plan w4_plan(int H, int W) {
-  static const int shapes[][2] = {{8, 4}, {4, 8}, {16, 2}, {11, 2}};
+  static const int shapes[][2] = {{8, 4}, {4, 8}, {16, 2}};
   static const int force = getenv("UD_WINO4_SHAPE") ? atoi(getenv("UD_WINO4_SHAPE")) : -1;
   const int TX = (W + 3) / 4, TY = (H + 3) / 4;
   W4Plan best{};
   long long cost = -1;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 3; ++i) {
     if (force >= 0 && i != force) continue;
     const int bx = ud_div_up(TX, shapes[i][0]), by = ud_div_up(TY, shapes[i][1]);
     const long long cst = (long long)bx * by;
@@ -589,12 +687,48 @@ extern "C" int ud_conv3x3_wino4_f32_weights(const float* w, int64_t s_n, int64_t
   return UD_OK;
 }
 
+namespace {
+std::atomic<int> g_sk_mode{-1};        // ud_conv3x3_wino4_stream_k: -1 default rule, 0 never, 1 deep reductions only, 2 whenever a tail exists
+constexpr int kGrid = 256;             // persistent workgroups: one per CU
+struct W4Sched {
+  int grid, n_dp, sk_len;
+};
+// data-parallel rounds + a stream-K tail where that beats one more (mostly idle) round; a piece costs ~8 stages of prologue + epilogue
+W4Sched w4_schedule(long long units, int nchunks, bool have_ws) {
+  static const int env_mode = getenv("UD_WINO4_SK") ? atoi(getenv("UD_WINO4_SK")) : 1;
+  const int forced = g_sk_mode.load(std::memory_order_relaxed);
+  const int mode = forced >= 0 ? forced : env_mode;
+  static const int persist = getenv("UD_WINO4_GRID") ? atoi(getenv("UD_WINO4_GRID")) : kGrid;
+  const int G = (int)std::min<long long>(units, persist);
+  const int r = (int)(units % G);
+  W4Sched sc{G, (int)units, 0};
+  // measured (tools/time_wino4.py): the tail pays on deep reductions (Cin >= 256: 512 -> 64 @180^2 407 -> 324 us, 2688 -> 64 2121 ->
+  // 1277 us); with 16 or 32 stages per unit its pieces are mostly prologue + epilogue (128 -> 128 @180^2: 168 -> 182 us)
+  if (r == 0 || !have_ws || !mode || (nchunks < 64 && mode < 2)) return sc;
+  int len = (int)(((long long)r * nchunks + G - 1) / G);
+  len += len & 1;
+  if (len + 16 >= (nchunks + 8) * 9 / 10) return sc;
+  sc.n_dp = (int)(units - r), sc.sk_len = len;
+  return sc;
+}
+}  // namespace
+
+// tests / tuning: the stream-K rule (-1: default = UD_WINO4_SK or 1; 0: whole units only; 1: tails of layers with Cin >= 256; 2: every tail)
+extern "C" void ud_conv3x3_wino4_stream_k(int mode) { g_sk_mode.store(mode, std::memory_order_relaxed); }
+
+// workspace for the stream-K partial tiles (2 per persistent workgroup)
+extern "C" size_t ud_conv3x3_wino4_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  (void)B; (void)H; (void)W; (void)Cin; (void)Cout;
+  return (size_t)2 * kGrid * 512 * 64 * sizeof(float);
+}
+
 // y = conv3x3(x) (+ bias) (* scale + shift: a folded eval-mode BatchNorm) (+ residual) (ReLU if flags & 1) with U from
 // ud_conv3x3_wino4_f32_weights(N = Cout, C = Cin); partial != nullptr: also the per-workgroup BatchNorm partial sums
 // ([*slices][Cout][2], same contract as ud_conv3x3_bnstats_nhwc_f32).
 extern "C" int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* y, int B, int H, int W, int Cin, int Cout,
                                          const float* bias, const float* scale, const float* shift, const float* residual,
-                                         int flags, float* partial, size_t partial_bytes, int* slices, ud_stream_t stream_) {
+                                         int flags, float* partial, size_t partial_bytes, int* slices, void* workspace,
+                                         size_t workspace_bytes, ud_stream_t stream_) {
   if (!x || !U || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UD_ERR_INVALID_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return UD_ERR_INVALID_ARG;
   if (Cin % (2 * kKC) != 0 || Cout % 4 != 0) return UD_ERR_UNSUPPORTED;     // stages come in pairs (8-channel patch fetches)
@@ -605,7 +739,10 @@ extern "C" int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* 
   if (units > 0x7fffffffll || (long long)B * H * W * Cin * 4 >= (long long)kOob ||
       ud_conv3x3_wino4_f32_weight_bytes(Cin, Cout) >= (size_t)kOob)
     return UD_ERR_UNSUPPORTED;    // 32-bit byte offsets into x / U (buffer descriptors)
-  W4Geom gm{B, H, W, Cin, Cout, p.bx, p.by, (unsigned)ud_conv3x3_wino4_f32_weight_bytes(Cin, Cout), (int)units};
+  const bool have_ws = workspace && workspace_bytes >= ud_conv3x3_wino4_f32_workspace_bytes(B, H, W, Cin, Cout);
+  const W4Sched sc = w4_schedule(units, Cin / kKC, have_ws);
+  W4Geom gm{B, H, W, Cin, Cout, p.bx, p.by, (unsigned)ud_conv3x3_wino4_f32_weight_bytes(Cin, Cout), sc.n_dp, (int)units,
+            sc.sk_len > 0 ? sc.sk_len : 2, (float*)workspace};
   W4Ep ep{bias, scale, shift, residual, flags & 1, partial};
   if (partial) {
     if (!slices || partial_bytes < (size_t)nblocks * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;
@@ -615,18 +752,21 @@ extern "C" int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* 
   if (const unsigned long long attr_set_bit = attr_set.pending()) {
 #define UD_W4_ATTR(A, Bq) \
   UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_wino4_f32<A, Bq>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem))
-    UD_W4_ATTR(8, 4); UD_W4_ATTR(4, 8); UD_W4_ATTR(16, 2); UD_W4_ATTR(11, 2);
+    UD_W4_ATTR(8, 4); UD_W4_ATTR(4, 8); UD_W4_ATTR(16, 2);
 #undef UD_W4_ATTR
     attr_set.mark(attr_set_bit);
   }
   UdProfScope prof("conv2d.k_conv3x3_wino4_f32", stream);
-  static const int persist = getenv("UD_WINO4_GRID") ? atoi(getenv("UD_WINO4_GRID")) : 256;      // one workgroup per CU
-  const dim3 grid((unsigned)std::min<long long>(units, persist > 0 ? persist : units));
-#define UD_W4_LAUNCH(A, Bq) k_conv3x3_wino4_f32<A, Bq><<<grid, 512, kSmem, stream>>>(x, U, y, gm, ep)
+  const dim3 grid((unsigned)sc.grid);
+  const int n_sk = (int)units - sc.n_dp;
+#define UD_W4_LAUNCH(A, Bq)                                                                    \
+  do {                                                                                         \
+    k_conv3x3_wino4_f32<A, Bq><<<grid, 512, kSmem, stream>>>(x, U, y, gm, ep);                 \
+    if (n_sk > 0) k_wino4_fixup<A, Bq><<<n_sk, 512, 0, stream>>>(y, gm, ep, sc.grid);          \
+  } while (0)
   if (p.twb == 8) UD_W4_LAUNCH(8, 4);
   else if (p.twb == 4) UD_W4_LAUNCH(4, 8);
-  else if (p.twb == 16) UD_W4_LAUNCH(16, 2);
-  else UD_W4_LAUNCH(11, 2);
+  else UD_W4_LAUNCH(16, 2);
 #undef UD_W4_LAUNCH
   UD_LAUNCH_CHECK();
   return UD_OK;

@@ -37,15 +37,20 @@ USE_WINOGRAD_WGRAD = os.environ.get("UD_F32_WINOGRAD_WGRAD", "1") != "0"
 
 
 # Winograd F(4x4, 3x3) (csrc/conv2d_f32_wino4.hip): 1.78x fewer MFMA flops again; taken where the map fills its 32-tile blocks
-USE_WINO4 = os.environ.get("UD_F32_WINO4", "0") != "0"      # off until the per-shape routing is settled
+USE_WINO4 = os.environ.get("UD_F32_WINO4", "1") != "0"
 WINO4_MIN_FILL = float(os.environ.get("UD_F32_WINO4_FILL", "0.7"))
 
 
 def wino4_pays(H, W, cin, cout):
+    """Measured per shape against F(2x2) (tools/time_wino4.py, profiles/r05_conv_f32_wino4.md): a unit pays ~8 stages of prologue
+    + epilogue, so F(4x4) wins where the reduction is deep (Cin >= 256: 1.1-1.5x), on the 180 x 180 BEV maps (1.08-1.27x) and
+    on maps too small for F(2x2)'s 64-tile blocks; the 64- / 128-channel ResNet maps stay on F(2x2)."""
     if not (USE_WINOGRAD and USE_WINO4) or cin % 8 or cout % 4:
         return False
     blocks = _lib.load().ud_conv3x3_wino4_f32_blocks(H, W)
-    return ((H + 3) // 4) * ((W + 3) // 4) >= WINO4_MIN_FILL * 32 * blocks
+    if ((H + 3) // 4) * ((W + 3) // 4) < WINO4_MIN_FILL * 32 * blocks:
+        return False
+    return WINO4_MIN_FILL == 0.0 or cin >= 256 or H * W >= 128 * 128
 
 
 def wino_pays(H, W, cin, cout):
@@ -105,9 +110,11 @@ def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False,
         part, ns = (None, ctypes.c_int(0))
         if bn_stats:
             part, ns = _bn_partial(lib.ud_conv3x3_wino4_bnstats_bytes(B, H, W, cout), x.device)
+        ws = _lib.workspace(x.device, lib.ud_conv3x3_wino4_f32_workspace_bytes(B, H, W, cin, cout), "conv_w4")
         _lib.check(lib.ud_conv3x3_wino4_nhwc_f32(_lib.ptr(x), _lib.ptr(U), _lib.ptr(y), B, H, W, cin, cout, _lib.ptr(bias),
                                                  _lib.ptr(scale), _lib.ptr(shift), None, 1 if relu else 0, _lib.ptr(part),
-                                                 part.numel() * 4 if bn_stats else 0, ctypes.addressof(ns), _lib.stream_of(x)),
+                                                 part.numel() * 4 if bn_stats else 0, ctypes.addressof(ns), _lib.ptr(ws),
+                                                 ws.numel(), _lib.stream_of(x)),
                    "ud_conv3x3_wino4_nhwc_f32")
         return (y, (part, ns.value, B * H * W)) if bn_stats else y
     if wino_pays(H, W, cin, cout):

@@ -281,9 +281,9 @@ def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
     gy = _cl(torch.randn(B, cout, H, W, device="cuda"))
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     gref = F.conv_transpose2d(gy.double(), w.double(), padding=1)
-    old = (c.USE_WINOGRAD, c.WINO_MIN_FILL)
+    old = (c.USE_WINOGRAD, c.WINO_MIN_FILL, c.USE_WINO4)
     try:
-        c.USE_WINOGRAD, c.WINO_MIN_FILL = True, 0.0
+        c.USE_WINOGRAD, c.WINO_MIN_FILL, c.USE_WINO4 = True, 0.0, False       # F(2x2) here; F(4x4): the next test
         assert c.wino_pays(H, W, cin, cout)
         y, (part, slices, rows) = c._launch3(x, w, b, bn_stats=True)
         y2 = c._launch3(x, w, b, relu=True)
@@ -292,7 +292,7 @@ def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
         c.USE_WINOGRAD = False
         yd = c._launch3(x, w, b) if cin % 32 == 0 else None
     finally:
-        c.USE_WINOGRAD, c.WINO_MIN_FILL = old
+        c.USE_WINOGRAD, c.WINO_MIN_FILL, c.USE_WINO4 = old
     tol = 2e-5 * float(ref.abs().max())
     err = float((y.double() - ref).abs().max())
     assert err <= tol, (err, tol)
@@ -303,6 +303,58 @@ def test_conv3x3_winograd_kernel_vs_direct_and_fp64(hip_lib, shape):
         assert float((gx.double() - gref).abs().max()) <= 2e-5 * float(gref.abs().max())
     gwref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)
     assert float((gw.double() - gwref).abs().max()) <= 1e-4 * float(gwref.abs().max())      # the direct weight-gradient kernels' bound
+    st = part[:slices * cout * 2].view(slices, cout, 2).double().sum(0)
+    assert rows == B * H * W
+    ys = y.double()
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), ys.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st[:, 1].cpu().numpy(), (ys * ys).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("sk", [0, 2], ids=["whole-units", "stream-k-tail"])
+@pytest.mark.parametrize("shape", [(1, 64, 64, 16, 16), (2, 128, 128, 180, 180), (1, 256, 256, 90, 90), (3, 64, 192, 64, 176),
+                                   (2, 128, 64, 32, 88), (5, 256, 256, 16, 44), (1, 512, 64, 8, 22), (2, 72, 100, 27, 35),
+                                   (1, 64, 2688, 36, 28), (1, 64, 64, 1, 1), (1, 8, 4, 5, 3), (2, 2688, 64, 20, 12),
+                                   (9, 64, 128, 64, 64), (5, 128, 64, 126, 90), (4, 512, 64, 180, 180), (1, 24, 40, 13, 19)])
+def test_conv3x3_winograd_f4_kernel_vs_fp64(hip_lib, shape, sk):
+    """ud_conv3x3_wino4_nhwc_f32 -- Winograd F(4x4, 3x3): forward (+ bias, BatchNorm partial sums, ReLU) and data gradient on the
+    shapes of the F(2x2) test above + a 276-unit layer (stream-K over all units) against an fp64 convolution.  Tolerance
+    1e-4 of the output's max (F(4x4)'s transforms round ~5x coarser than F(2x2)'s: measured 0.3-5e-5, the direct kernel 1-3e-6);
+    both schedules -- whole units, and a stream-K tail with partial tiles + k_wino4_fixup -- must agree to that bound and the
+    stream-K result must be reproducible bit for bit (fixed summation order of the pieces)."""
+    from unidistill_amd import _lib
+    from unidistill_amd.ops import conv2d_f32 as c
+    B, cin, cout, H, W = shape
+    torch.manual_seed(sum(shape))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda"))
+    w = torch.randn(cout, cin, 3, 3, device="cuda") * (9 * cin) ** -0.5
+    b = torch.randn(cout, device="cuda")
+    gy = _cl(torch.randn(B, cout, H, W, device="cuda"))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    gref = F.conv_transpose2d(gy.double(), w.double(), padding=1)
+    old = (c.USE_WINOGRAD, c.WINO4_MIN_FILL, c.USE_WINO4)
+    lib = _lib.load()
+    try:
+        c.USE_WINOGRAD, c.WINO4_MIN_FILL, c.USE_WINO4 = True, 0.0, True
+        lib.ud_conv3x3_wino4_stream_k(sk)
+        assert c.wino4_pays(H, W, cin, cout)
+        _lib.prof_enable(True)
+        _lib.prof_read("conv2d.k_conv3x3_wino4_f32", reset=True)
+        y, (part, slices, rows) = c._launch3(x, w, b, bn_stats=True)
+        assert _lib.prof_read("conv2d.k_conv3x3_wino4_f32")[1] == 1
+        _lib.prof_enable(False)
+        y2 = c._launch3(x, w, b, relu=True)
+        y3 = c._launch3(x, w, b)
+        gx = c._launch3(gy, w, transposed=True) if cout % 8 == 0 else None
+    finally:
+        _lib.prof_enable(False)
+        lib.ud_conv3x3_wino4_stream_k(-1)
+        c.USE_WINOGRAD, c.WINO4_MIN_FILL, c.USE_WINO4 = old
+    tol = 1e-4 * float(ref.abs().max())
+    err = float((y.double() - ref).abs().max())
+    assert err <= tol, (err, tol)
+    assert torch.equal(y2, torch.relu(y)) and torch.equal(y3, y)
+    if gx is not None:
+        assert float((gx.double() - gref).abs().max()) <= 1e-4 * float(gref.abs().max())
     st = part[:slices * cout * 2].view(slices, cout, 2).double().sum(0)
     assert rows == B * H * W
     ys = y.double()
