@@ -594,14 +594,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
   }
 }
 
-// Sum of the pieces of the units the stream-K schedule cut (ascending stage order: deterministic) + the fused tail.  One
-// workgroup per stream-K unit; a unit that one workgroup covered completely was stored by k_conv3x3_wino4_f32 itself.
+// Sum of the pieces of the units the stream-K schedule cut (ascending stage order: deterministic) + the fused tail.  Two
+// workgroups per stream-K unit (one per staging pass = 16 of its 32 tiles), eight independent rows in flight per thread; a unit
+// that one workgroup covered completely was stored by k_conv3x3_wino4_f32 itself.  BatchNorm partial sums of a cut unit go to
+// the extra rows nblocks + 2 * (unit - n_dp) + pass (zeroed by the launcher); its own row is cleared here.
 template <int TWB, int THB>
-__global__ __launch_bounds__(512) void k_wino4_fixup(float* __restrict__ y, W4Geom gm, W4Ep ep, int G) {
+__global__ __launch_bounds__(512) void k_wino4_fixup(float* __restrict__ y, W4Geom gm, W4Ep ep) {
   __shared__ float red[32 * 64 * 2];
   const int tid = threadIdx.x;
   const int nblocks = gm.B * gm.bx * gm.by, nchunks = gm.Cin / kKC;
-  const int u = gm.n_dp + blockIdx.x;
+  const int u = gm.n_dp + (blockIdx.x >> 1), pass = blockIdx.x & 1;
   const int base = gm.n_dp * nchunks;
   const int a = u * nchunks - base, e = a + nchunks - 1;              // the unit's stages within the stream-K sequence
   const int j0 = a / gm.sk_len, j1 = e / gm.sk_len;
@@ -616,21 +618,27 @@ __global__ __launch_bounds__(512) void k_wino4_fixup(float* __restrict__ y, W4Ge
   const int b = blk / (gm.bx * gm.by);
   blk -= b * gm.bx * gm.by;
   W4Tail<TWB, THB> tail(gm, ep, b, (blk / gm.bx) * THB, (blk % gm.bx) * TWB, cbi * kTN, tid);
+  float4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass)
-#pragma unroll 1
+  for (int j = j0; j <= j1; ++j) {
+    const int first_unit = (base + j * gm.sk_len) / nchunks;     // the first unit workgroup j touched
+    const int slot = 2 * j + (first_unit == u ? 0 : 1);
+    const float* src = gm.partial + ((size_t)slot * 512 + pass * 256 + (tid >> 4)) * 64 + tail.c4;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int row = (tid >> 4) + 32 * k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j = j0; j <= j1; ++j) {
-        const int first_unit = (base + j * gm.sk_len) / nchunks;     // the first unit workgroup j touched
-        const int slot = 2 * j + (first_unit == u ? 0 : 1);
-        const float4 p = *reinterpret_cast<const float4*>(gm.partial + ((size_t)slot * 512 + pass * 256 + row) * 64 + tail.c4);
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-      }
-      tail.store(y, pass, row, v);
+      const float4 p = ud_ldg_stream(src + (size_t)k * 32 * 64);
+      v[k].x += p.x; v[k].y += p.y; v[k].z += p.z; v[k].w += p.w;
     }
-  if (ep.stats) tail.reduce_stats(red, blk_lin);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tail.store(y, pass, (tid >> 4) + 32 * k, v[k]);
+  if (ep.stats) {
+    tail.reduce_stats(red, nblocks + 2 * (u - gm.n_dp) + pass);
+    if (pass == 0 && tid < 64 && tail.n0 + tid < gm.Cout)
+      ep.stats[((size_t)blk_lin * gm.Cout + tail.n0 + tid) * 2] = ep.stats[((size_t)blk_lin * gm.Cout + tail.n0 + tid) * 2 + 1] = 0.f;
+  }
 }
 
 #undef W4_ROWREAD
@@ -657,36 +665,6 @@ W4Plan w4_plan(int H, int W) {
 
 }  // namespace
 
-extern "C" size_t ud_conv3x3_wino4_f32_weight_bytes(int Cin, int Cout) {
-  if (Cin <= 0 || Cout <= 0) return 0;
-  return (size_t)ud_div_up(Cout, 64) * ud_div_up(Cin, 4) * kUBytes;
-}
-
-// tile blocks per image of the plan for an H x W map (each 32 tile slots of 4 x 4 outputs): callers compare with
-// ceil(H / 4) * ceil(W / 4) to decide whether the map fills the blocks well enough
-extern "C" int ud_conv3x3_wino4_f32_blocks(int H, int W) {
-  if (H <= 0 || W <= 0) return 0;
-  const W4Plan p = w4_plan(H, W);
-  return p.bx * p.by;
-}
-
-extern "C" size_t ud_conv3x3_wino4_bnstats_bytes(int B, int H, int W, int Cout) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
-  const W4Plan p = w4_plan(H, W);
-  return (size_t)B * p.bx * p.by * Cout * 2 * sizeof(float);
-}
-
-extern "C" int ud_conv3x3_wino4_f32_weights(const float* w, int64_t s_n, int64_t s_c, int64_t s_y, int64_t s_x, int N, int C,
-                                            int flip, float* U, ud_stream_t stream_) {
-  if (!w || !U || N <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  UdProfScope prof("conv2d.k_wino4_weights", stream);
-  const long long total = (long long)ud_div_up(N, 64) * ud_div_up(C, 4) * 256;
-  k_wino4_weights<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(w, s_n, s_c, s_y, s_x, N, C, flip, U, total);
-  UD_LAUNCH_CHECK();
-  return UD_OK;
-}
-
 namespace {
 std::atomic<int> g_sk_mode{-1};        // ud_conv3x3_wino4_stream_k: -1 default rule, 0 never, 1 deep reductions only, 2 whenever a tail exists
 constexpr int kGrid = 256;             // persistent workgroups: one per CU
@@ -712,6 +690,36 @@ W4Sched w4_schedule(long long units, int nchunks, bool have_ws) {
   return sc;
 }
 }  // namespace
+
+extern "C" size_t ud_conv3x3_wino4_f32_weight_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (size_t)ud_div_up(Cout, 64) * ud_div_up(Cin, 4) * kUBytes;
+}
+
+// tile blocks per image of the plan for an H x W map (each 32 tile slots of 4 x 4 outputs): callers compare with
+// ceil(H / 4) * ceil(W / 4) to decide whether the map fills the blocks well enough
+extern "C" int ud_conv3x3_wino4_f32_blocks(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  const W4Plan p = w4_plan(H, W);
+  return p.bx * p.by;
+}
+
+extern "C" size_t ud_conv3x3_wino4_bnstats_bytes(int B, int H, int W, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const W4Plan p = w4_plan(H, W);
+  return ((size_t)B * p.bx * p.by + 2 * kGrid) * Cout * 2 * sizeof(float);      // + two rows per stream-K unit (< kGrid of them)
+}
+
+extern "C" int ud_conv3x3_wino4_f32_weights(const float* w, int64_t s_n, int64_t s_c, int64_t s_y, int64_t s_x, int N, int C,
+                                            int flip, float* U, ud_stream_t stream_) {
+  if (!w || !U || N <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  UdProfScope prof("conv2d.k_wino4_weights", stream);
+  const long long total = (long long)ud_div_up(N, 64) * ud_div_up(C, 4) * 256;
+  k_wino4_weights<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(w, s_n, s_c, s_y, s_x, N, C, flip, U, total);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
 
 // tests / tuning: the stream-K rule (-1: default = UD_WINO4_SK or 1; 0: whole units only; 1: tails of layers with Cin >= 256; 2: every tail)
 extern "C" void ud_conv3x3_wino4_stream_k(int mode) { g_sk_mode.store(mode, std::memory_order_relaxed); }
@@ -745,8 +753,11 @@ extern "C" int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* 
             sc.sk_len > 0 ? sc.sk_len : 2, (float*)workspace};
   W4Ep ep{bias, scale, shift, residual, flags & 1, partial};
   if (partial) {
-    if (!slices || partial_bytes < (size_t)nblocks * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;
-    *slices = nblocks;
+    const size_t rows = (size_t)nblocks + 2 * (size_t)(units - sc.n_dp);
+    if (!slices || partial_bytes < rows * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;
+    *slices = (int)rows;
+    if (rows > (size_t)nblocks)
+      UD_HIP_TRY(hipMemsetAsync(partial + (size_t)nblocks * Cout * 2, 0, (rows - nblocks) * Cout * 2 * sizeof(float), stream));
   }
   static UdDeviceOnce attr_set;
   if (const unsigned long long attr_set_bit = attr_set.pending()) {
@@ -762,7 +773,7 @@ extern "C" int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* 
 #define UD_W4_LAUNCH(A, Bq)                                                                    \
   do {                                                                                         \
     k_conv3x3_wino4_f32<A, Bq><<<grid, 512, kSmem, stream>>>(x, U, y, gm, ep);                 \
-    if (n_sk > 0) k_wino4_fixup<A, Bq><<<n_sk, 512, 0, stream>>>(y, gm, ep, sc.grid);          \
+    if (n_sk > 0) k_wino4_fixup<A, Bq><<<2 * n_sk, 512, 0, stream>>>(y, gm, ep);               \
   } while (0)
   if (p.twb == 8) UD_W4_LAUNCH(8, 4);
   else if (p.twb == 4) UD_W4_LAUNCH(4, 8);
