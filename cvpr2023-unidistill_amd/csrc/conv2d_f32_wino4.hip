@@ -666,22 +666,23 @@ W4Plan w4_plan(int H, int W) {
 }  // namespace
 
 namespace {
-std::atomic<int> g_sk_mode{-1};        // ud_conv3x3_wino4_stream_k: -1 default rule, 0 never, 1 deep reductions only, 2 whenever a tail exists
+std::atomic<int> g_sk_mode{-1};        // ud_conv3x3_wino4_stream_k: -1 default (UD_WINO4_SK or 2), 0 never, 1 deep reductions only, 2 whenever a tail exists and beats a whole round
 constexpr int kGrid = 256;             // persistent workgroups: one per CU
 struct W4Sched {
   int grid, n_dp, sk_len;
 };
 // data-parallel rounds + a stream-K tail where that beats one more (mostly idle) round; a piece costs ~8 stages of prologue + epilogue
 W4Sched w4_schedule(long long units, int nchunks, bool have_ws) {
-  static const int env_mode = getenv("UD_WINO4_SK") ? atoi(getenv("UD_WINO4_SK")) : 1;
+  static const int env_mode = getenv("UD_WINO4_SK") ? atoi(getenv("UD_WINO4_SK")) : 2;
   const int forced = g_sk_mode.load(std::memory_order_relaxed);
   const int mode = forced >= 0 ? forced : env_mode;
   static const int persist = getenv("UD_WINO4_GRID") ? atoi(getenv("UD_WINO4_GRID")) : kGrid;
   const int G = (int)std::min<long long>(units, persist);
   const int r = (int)(units % G);
   W4Sched sc{G, (int)units, 0};
-  // measured (tools/time_wino4.py): the tail pays on deep reductions (Cin >= 256: 512 -> 64 @180^2 407 -> 324 us, 2688 -> 64 2121 ->
-  // 1277 us); with 16 or 32 stages per unit its pieces are mostly prologue + epilogue (128 -> 128 @180^2: 168 -> 182 us)
+  // measured (tools/time_wino4.py, fix-up with two workgroups per unit): the tail pays on every layer shape of the step -- 512 -> 64
+  // @180^2 407 -> 262 us, 2688 -> 64 2121 -> 1236 us, 128 -> 128 @180^2 179 -> 161 us, 128 -> 128 @32 x 88 x 24 113 -> 88 us
+  // (mode 1 keeps it to Cin >= 256)
   if (r == 0 || !have_ws || !mode || (nchunks < 64 && mode < 2)) return sc;
   int len = (int)(((long long)r * nchunks + G - 1) / G);
   len += len & 1;
@@ -721,7 +722,7 @@ extern "C" int ud_conv3x3_wino4_f32_weights(const float* w, int64_t s_n, int64_t
   return UD_OK;
 }
 
-// tests / tuning: the stream-K rule (-1: default = UD_WINO4_SK or 1; 0: whole units only; 1: tails of layers with Cin >= 256; 2: every tail)
+// tests / tuning: the stream-K rule (-1: default = UD_WINO4_SK or 2; 0: whole units only; 1: tails of layers with Cin >= 256; 2: every tail that beats one more round)
 extern "C" void ud_conv3x3_wino4_stream_k(int mode) { g_sk_mode.store(mode, std::memory_order_relaxed); }
 
 // workspace for the stream-K partial tiles (2 per persistent workgroup)

@@ -42,9 +42,12 @@ WINO4_MIN_FILL = float(os.environ.get("UD_F32_WINO4_FILL", "0.7"))
 
 
 def wino4_pays(H, W, cin, cout):
-    """Measured per shape against F(2x2) (tools/time_wino4.py, profiles/r05_conv_f32_wino4.md): a unit pays ~8 stages of prologue
-    + epilogue, so F(4x4) wins where the reduction is deep (Cin >= 256: 1.1-1.5x), on the 180 x 180 BEV maps (1.08-1.27x) and
-    on maps too small for F(2x2)'s 64-tile blocks; the 64- / 128-channel ResNet maps stay on F(2x2)."""
+    """Measured per shape against F(2x2) (tools/time_wino4.py, profiles/r05_conv_f32_wino4.md): with the stream-K tail F(4x4) is
+    ahead on every 3x3 shape of the step whose map fills the 32-tile blocks -- 1.04x (64 -> 64 @64x176) to 1.54x (2688 -> 64
+    @180^2).  Routed to it: the BEV maps (trunk, head) and every layer with Cin >= 256.  The 64- / 128-channel ResNet layers
+    (1.04x / 1.19x, 0.1 ms per step together) stay on F(2x2): with all sixteen 3x3 layers of the image branch on F(4x4) the
+    branch's forward ends 1.07e-4 of its max from the library path -- past the 1e-4 of tests/test_image_branch_f32_gpu.py, which
+    is kept as it was."""
     if not (USE_WINOGRAD and USE_WINO4) or cin % 8 or cout % 4:
         return False
     blocks = _lib.load().ud_conv3x3_wino4_f32_blocks(H, W)

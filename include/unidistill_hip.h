@@ -597,7 +597,7 @@ int ud_conv3x3_wino4_f32_blocks(int H, int W);
 int ud_conv3x3_wino4_f32_weights(const float* w, int64_t s_n, int64_t s_c, int64_t s_y, int64_t s_x, int N, int C, int flip,
                                  float* U, ud_stream_t stream);
 size_t ud_conv3x3_wino4_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout);   /* stream-K partial tiles (optional: NULL = whole units only) */
-void ud_conv3x3_wino4_stream_k(int mode);   /* schedule rule: -1 default, 0 whole units only, 1 stream-K tail when Cin >= 256, 2 every tail (tests) */
+void ud_conv3x3_wino4_stream_k(int mode);   /* schedule rule: -1 default (= 2), 0 whole units only, 1 stream-K tail when Cin >= 256, 2 every tail that beats one more round */
 int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* y, int B, int H, int W, int Cin, int Cout,
                               const float* bias, const float* scale, const float* shift, const float* residual, int flags,
                               float* partial, size_t partial_bytes, int* slices, void* workspace, size_t workspace_bytes,
