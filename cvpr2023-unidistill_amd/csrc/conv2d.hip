@@ -24,7 +24,6 @@
 #include "ud_prof.h"
 #include "conv_pixmap.h"
 #include "wgrad_sum.h"
-#include "conv3x3_p.h"
 
 namespace {
 
@@ -479,142 +478,6 @@ __global__ __launch_bounds__(256) void k_conv3x3_taps(const unsigned short* __re
 // share their k-group, so the slot is XORed with (halo column >> 1) & 7 / (channel >> 1) & 7 instead of the row index & 7
 // (16 different rows then fall into 16 different 16-byte slots of the 256-byte bank row: 0 conflicts in SQ_LDS_BANK_CONFLICT).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <int TN, int RW>
-__global__ __launch_bounds__(256) void k_conv3x3_taps32(const unsigned short* __restrict__ x,
-                                                        const unsigned short* __restrict__ w,
-                                                        unsigned short* __restrict__ y, ConvGeom gm, ConvEp ep) {
-  static_assert(RW % 2 == 0, "32-pixel blocks = two image rows");
-  constexpr int WM = TN == 128 ? 2 : 4;
-  constexpr int TH = WM * RW, TM = TH * kTW, MB = RW / 2;
-  constexpr int kHQ = kHW * (TH + 2), kHQP = (kHQ + 7) / 8 * 8, kAInstr = kHQP / 8;
-  constexpr int NB = TN / 32;
-  constexpr int kBBytes = TN * 128, kABytes = kHQP * 128, kAOff = 2 * kBBytes;
-  constexpr int kAPer = (kAInstr + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, kh = lane >> 5, col = lane & 15, rsel = (lane >> 4) & 1;
-  const int wm = TN == 128 ? (wave >> 1) : wave, wn = TN == 128 ? (wave & 1) : 0;
-  const int ntiles = gm.B * gm.tiles_x * gm.tiles_y;
-  const int per = (ntiles + 7) / 8;
-  int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (tile >= ntiles) return;
-  const int tile_lin = tile;
-  const int b = tile / (gm.tiles_x * gm.tiles_y);
-  tile -= b * gm.tiles_x * gm.tiles_y;
-  const int ty0 = (tile / gm.tiles_x) * TH, tx0 = (tile % gm.tiles_x) * kTW;
-  const int n0 = blockIdx.y * TN;
-  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero16);
-
-  f32x16 acc[MB][2];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int r8 = lane >> 3, slot = lane & 7;
-  const unsigned short* pa[kAPer];
-  int inca[kAPer];
-#pragma unroll
-  for (int i = 0; i < kAPer; ++i) {
-    const int q = (wave + 4 * i) * 8 + r8;
-    const int qy = q / kHW, qx = q - qy * kHW;
-    const int gy = ty0 + qy - 1, gx = tx0 + qx - 1;
-    const bool ok = q < kHQ && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
-    pa[i] = ok ? x + ((size_t)(b * gm.H + gy) * gm.W + gx) * gm.Cin + ((slot ^ ((qx >> 1) & 7)) << 3) : zero;
-    inca[i] = ok ? kKC : 0;
-  }
-  auto stage_a = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < kAPer; ++i) {
-      if (wave + 4 * i < kAInstr)
-        dma16(pa[i], reinterpret_cast<unsigned short*>(smem + kAOff + buf * kABytes + (wave + 4 * i) * 1024));
-      pa[i] += inca[i];
-    }
-  };
-  unsigned voffb[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int n = (wave + 4 * j) * 8 + r8;
-    const int nn = min(n0 + n, gm.Cout - 1);
-    voffb[j] = (unsigned)(((size_t)nn * 9 * gm.Cin + ((slot ^ ((n >> 1) & 7)) << 3)) * 2);
-  }
-  auto stage_b = [&](int chunk, int tap, int buf) {
-    const int te = ep.reverse_taps ? 8 - tap : tap;
-    const char* wb = reinterpret_cast<const char*>(w) + ((size_t)te * gm.Cin + (size_t)chunk * kKC) * 2;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      dma16(reinterpret_cast<const unsigned short*>(wb + voffb[j]),
-            reinterpret_cast<unsigned short*>(smem + buf * kBBytes + (wave + 4 * j) * 1024));
-  };
-  // fragment addresses (bytes in LDS): pixels [dx][ks], weights [ks][buffer parity]
-  unsigned sa[3][4], sb[4][2];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-      sa[dx][ks] = kAOff + ((RW * wm + rsel) * kHW + col + dx) * 128 + (((2 * ks + kh) ^ (((col + dx) >> 1) & 7)) << 4);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) sb[ks][p] = p * kBBytes + (64 * wn + l31) * 128 + (((2 * ks + kh) ^ ((l31 >> 1) & 7)) << 4);
-  }
-
-  const int nchunks = gm.Cin / kKC;
-  stage_a(0);
-  stage_b(0, 0, 0);
-  __syncthreads();
-  int adelta = kABytes;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int cpar = chunk & 1;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap < 8) stage_b(chunk, tap + 1, ((tap + 1) & 1) ^ cpar);
-      else if (chunk + 1 < nchunks) stage_b(chunk + 1, 0, cpar ^ 1);
-      if (tap == 0 && chunk + 1 < nchunks) stage_a(cpar ^ 1);
-      const int dy = tap / 3, dx = tap % 3;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 a[MB], bb[2];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-          a[mb] = *reinterpret_cast<const bf16x8*>(smem + sa[dx][ks] + (2 * mb + dy) * kHW * 128);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          bb[nb] = *reinterpret_cast<const bf16x8*>(smem + sb[ks][tap & 1] + nb * 4096);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bb[nb], acc[mb][nb], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const unsigned t = sb[ks][0];
-      sb[ks][0] = sb[ks][1];
-      sb[ks][1] = t;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) sa[dx][ks] += adelta;
-    }
-    adelta = -adelta;
-  }
-  // accumulators -> fp32 tile in LDS: block (mb, nb), register r of lane (l31, kh) = pixel (r & 3) + 8 (r >> 2) + 4 kh of the
-  // block's 32 (two image rows x 16: contiguous in the tile's pixel order), channel l31
-  float* Os = reinterpret_cast<float*>(smem);
-  constexpr int kLDO = TN + 4;
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Os[(16 * RW * wm + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * kh) * kLDO + 64 * wn + 32 * nb + l31] = acc[mb][nb][r];
-  __syncthreads();
-  conv_store_rows<TN, 3, TM>(Os, tid, b, ty0, tx0, n0, y, gm, ep, tile_lin);
-}
 
 // ---- plain 1x1 (no pixel map): straight-line slice loop -------------------------------------------------------------------
 // k_conv1x1_mapped rebuilds every DMA source through PixMap::off and every fragment address per 64-channel slice; for
@@ -1207,24 +1070,10 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
     UD_TAPS_ATTR(128, 4); UD_TAPS_ATTR(128, 3); UD_TAPS_ATTR(128, 2);
     UD_TAPS_ATTR(64, 2); UD_TAPS_ATTR(64, 1);
 #undef UD_TAPS_ATTR
-#define UD_TAPS32_ATTR(TN, RW)                                                                                        \
-  UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv3x3_taps32<TN, RW>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                 (int)conv_taps_smem_bytes(TN, RW)))
-    UD_TAPS32_ATTR(128, 4); UD_TAPS32_ATTR(128, 2); UD_TAPS32_ATTR(64, 2);
-#undef UD_TAPS32_ATTR
     if (const char* r = getenv("UD_CONV_RW")) force_rw = atoi(r);
     attr_set.mark(attr_set_bit);
   }
   UdProfScope prof("conv2d.k_conv3x3", stream);
-  if (ud_conv3x3_p_supported(B, H, W, Cin, Cout)) {       // persistent 32x32x16 kernel (csrc/conv2d_p.hip)
-    if (stats) {
-      const int slices = ud_conv3x3_p_slices(B, H, W);
-      if (stats_bytes < (size_t)slices * Cout * 2 * sizeof(float) || !slices_out) return UD_ERR_WORKSPACE;
-      *slices_out = slices;
-    }
-    return ud_conv3x3_p_launch(x, w, y, B, H, W, Cin, Cout, bias, scale, shift, residual, relu & 1, (relu >> 1) & 1, stats,
-                               stream);
-  }
   const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
   const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
   unsigned short* ys = reinterpret_cast<unsigned short*>(y);
@@ -1255,19 +1104,14 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
   const dim3 grid((B * gm.tiles_x * gm.tiles_y + 7) / 8 * 8, ntn);
 #define UD_TAPS_LAUNCH(TN, RW)                                                                                        \
   k_conv3x3_taps<TN, RW><<<grid, 256, conv_taps_smem_bytes(TN, RW), stream>>>(xs, ws, ys, gm, ep)
-#define UD_TAPS32_LAUNCH(TN, RW)                                                                                      \
-  k_conv3x3_taps32<TN, RW><<<grid, 256, conv_taps_smem_bytes(TN, RW), stream>>>(xs, ws, ys, gm, ep)
-  static const int mfma32 = getenv("UD_CONV_MFMA32") ? atoi(getenv("UD_CONV_MFMA32")) : 0;   // 1: 32x32x16 blocks on even tile heights (A/B: 808 vs 824 TFLOP/s over the step's shapes, profiles/r04_conv_bf16.md)
   if (narrow) {
     if (rw == 1) UD_TAPS_LAUNCH(64, 1);
-    else if (mfma32) UD_TAPS32_LAUNCH(64, 2);
     else UD_TAPS_LAUNCH(64, 2);
   } else {
     if (rw == 3) UD_TAPS_LAUNCH(128, 3);
-    else if (rw == 2) { if (mfma32) UD_TAPS32_LAUNCH(128, 2); else UD_TAPS_LAUNCH(128, 2); }
-    else { if (mfma32) UD_TAPS32_LAUNCH(128, 4); else UD_TAPS_LAUNCH(128, 4); }
+    else if (rw == 2) UD_TAPS_LAUNCH(128, 2);
+    else UD_TAPS_LAUNCH(128, 4);
   }
-#undef UD_TAPS32_LAUNCH
 #undef UD_TAPS_LAUNCH
   UD_LAUNCH_CHECK();
   return UD_OK;

@@ -1488,9 +1488,8 @@ __global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__
 // fragments for 8 NT MFMAs (a lane's 16-byte piece feeds four MFMAs, see conv2d_f32.hip).
 __device__ __attribute__((aligned(16))) unsigned int g_zero16s[4];
 
-// NBUF = 3 (64 -> 64 only: 3 x 48 KB): a stage's 64 MFMAs per wave are shorter than the DMA round trip, so TWO stages fly while
-// one is multiplied -- the wait is `vmcnt(pieces of one stage)`, and the rulebook words of a stage are read with inline ds_reads
-// (a compiled LDS read after an LDS-DMA issue gets a `vmcnt(0)` from hipcc, which would drain the stage in flight).
+// (A three-buffer ring for the 64 -> 64 layers -- two stages in flight under a counted vmcnt -- was measured in round 4 and
+// removed in round 5: 670 us against k_conv_mfma_v2's 620 us on the step's four layers.)
 template <int CIN, int COUT, int NBUF>
 __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ in, const int32_t* __restrict__ nbr, int K,
                                                       int mirror, const float* __restrict__ W, WStrides ws,
@@ -1501,7 +1500,6 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
   constexpr int kHalves = CIN / 64;
   constexpr int kAPieces = kTM2 / 4, kWPieces = COUT / 4;      // 1-KiB DMA pieces: 4 rows x 256 B
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kPieces = kAPieces / 8 + kWPieces / 8;         // DMA instructions per wave and stage
   int* s_nbr = reinterpret_cast<int*>(smem + NBUF * kStage);   // [K][kTM2]
   unsigned& s_active = *reinterpret_cast<unsigned*>(s_nbr + K * kTM2);
   int* s_row = s_nbr + K * kTM2 + 4;                            // [kTM2]
@@ -1589,24 +1587,18 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
   if (k >= 0) {
     stage(k, 0, 0);
     succ(k1, h1, m1);
-    if (NBUF == 3 && k1 >= 0) stage(k1, h1, 1);
   }
   while (k >= 0) {
     // the stage after the next one
     int k2 = k1, h2 = h1;
     unsigned m2 = m1;
     if (k1 >= 0) succ(k2, h2, m2);
-    if (NBUF == 3 && k1 >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // raw barrier: __syncthreads() is lowered to `s_waitcnt vmcnt(0) lgkmcnt(0)` + s_barrier, which would drain the stage in
     // flight.  The waves' own LDS reads (inline asm) were awaited with lgkmcnt(0) before their last MFMA group.
     __builtin_amdgcn_s_barrier();          // this stage has landed for everybody; everybody is done with the previous stage's buffer
     asm volatile("" ::: "memory");
-    if (NBUF == 3) {
-      if (k2 >= 0) stage(k2, h2, buf >= 1 ? buf - 1 : 2);
-    } else if (k1 >= 0) {
-      stage(k1, h1, buf ^ 1);
-    }
+    if (k1 >= 0) stage(k1, h1, buf ^ 1);
     if ((wmask >> k) & 1u) {
       // fragment reads by hand, one 16-channel group ahead of its MFMAs: hipcc puts `s_waitcnt vmcnt(0)` in front of a compiled LDS
       // read that follows an LDS-DMA issue -- i.e. it waited here for the NEXT stage's DMA issued four lines up, and the double
@@ -1676,7 +1668,7 @@ template <int CIN, int COUT>
 int launch_conv_dma_f32(const float* in, const int32_t* nbr, int K, int mirror, const float* W, WStrides ws,
                         const float* bias, float* out, int Mout, const int32_t* order, ConvEpilogue ep,
                         hipStream_t stream) {
-  constexpr int NBUF = (CIN == 64 && COUT == 64) ? 3 : 2;
+  constexpr int NBUF = 2;
   const size_t lds = NBUF * (size_t)(kTM2 * 256 + COUT * 256) + (size_t)K * kTM2 * sizeof(int) + 16 + kTM2 * sizeof(int);
   if (lds > 160 * 1024) return UD_ERR_UNSUPPORTED;
   static UdDeviceOnce attr_set;
@@ -1787,12 +1779,10 @@ int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror,
   // fp32, 64 / 128 channels exactly, channel-contiguous 16-byte-aligned weights: the LDS-DMA kernel
   // 64 -> 64 stays on k_conv_mfma_v2: a stage there is 64 MFMAs per wave, shorter than the DMA round trip and than the skew of
   // an 8-wave barrier.  Measured on the step's four 64 -> 64 layers (394 k rows, 5.45 M pairs): v2 620 us, this kernel with two
-  // stage buffers 700 us (round 3), with a three-stage ring -- two stages in flight, counted vmcnt, raw s_barrier -- 670 us
-  // (round 4; UD_SPCONV_DMA64=1 selects it, tests/test_spconv_gpu.py covers it).
-  if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128)) {
+  // stage buffers 700 us (round 3), with a three-stage ring 670 us (round 4; removed).
+  if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128) && !(CIN_P == 64 && COUT_P == 64)) {
     static const bool no_dma = getenv("UD_SPCONV_NO_DMA") != nullptr;       // A/B timing
-    static const bool no_dma64 = getenv("UD_SPCONV_DMA64") == nullptr;
-    if (!no_dma && !(no_dma64 && CIN_P == 64 && COUT_P == 64) && K <= 32 && algo == 0 && cin == CIN_P && cout == COUT_P && ws.sc == 1 && (ws.sn & 3) == 0 && (ws.sk & 3) == 0)
+    if (!no_dma && K <= 32 && algo == 0 && cin == CIN_P && cout == COUT_P && ws.sc == 1 && (ws.sn & 3) == 0 && (ws.sk & 3) == 0)
       return launch_conv_dma_f32<CIN_P, COUT_P>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep, stream);
   }
   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles

@@ -92,7 +92,6 @@ _SIGS = {
     "ud_voxelize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int]
                     + [c_void_p] * 5 + [c_void_p, c_size_t, c_int, c_void_p]),
     "ud_conv3x3_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
-    "ud_conv3x3_persistent": (c_int, [c_int]),
     "ud_conv1x1_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
     "ud_conv3x3_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_void_p]),
     "ud_conv1x1_nhwc_f32": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p]),

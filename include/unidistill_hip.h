@@ -472,11 +472,6 @@ int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const float* y, con
 int ud_conv3x3_nhwc_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
                          const float* bias, const float* scale, const float* shift,
                          const void* residual, int relu, ud_stream_t stream);
-/* Dispatch of ud_conv3x3_nhwc_bf16 / ud_conv3x3_bnstats_nhwc_bf16 to the persistent v_mfma_f32_32x32x16_bf16 kernel
- * (csrc/conv2d_p.hip: 512-thread workgroups, one per CU, halo + weight prefetch across tiles) on maps with at least 384 work
- * units: mode 1 = on, 0 = off (default; UD_CONV_P in the environment sets the initial value), < 0 = query only.
- * Returns the previous mode.  Same results contract as the default kernel (tests/test_conv2d_p_gpu.py). */
-int ud_conv3x3_persistent(int mode);
 /* 1x1 / stride-1 convolution (the ResNet bottleneck 1x1 convs of the reference's image branch) on the same
  * kernel family: x [P][Cin] bf16 (P = B*H*W channels-last pixels), w [Cout][Cin] bf16, y [P][Cout] bf16,
  * same fused epilogue (bit 0 of `relu` only).  The data gradient is the same call on dy with w^T

@@ -384,17 +384,3 @@ def test_mask_order_vs_numpy(M, K):
     ref = np.argsort(mask, kind="stable")
     assert order.dtype == np.int32 and np.array_equal(order, ref)
     assert sp.mask_order(nbr, True) is sp.mask_order(nbr, False)          # cached on the rulebook, shared with the mirrored pass
-
-
-def test_dma_ring_64_to_64_opt_in_equals_oracle():
-    """k_conv_dma_f32<64, 64, 3> (three-stage LDS-DMA ring; UD_SPCONV_DMA64=1, read once per process, default off because
-    k_conv_mfma_v2 is faster on these layers): the 64 -> 64 forward / data-gradient / weight-gradient case of
-    test_conv_dgrad_wgrad_vs_oracle run again in a child process that selects it."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, UD_SPCONV_DMA64="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__, "-k",
-                        "test_conv_dgrad_wgrad_vs_oracle and 64-64"], env=env, capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
