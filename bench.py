@@ -173,7 +173,7 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     from unidistill_amd import _lib
     from unidistill_amd.ops import conv2d as c16, conv2d_f32 as c32
     c2 = c32 if fp32 else c16
-    prof_names = ("conv2d.k_conv3x3_f32", "conv2d.k_conv3x3_wino_f32") if fp32 else ("conv2d.k_conv3x3",)
+    prof_names = ("conv2d.k_conv3x3_f32", "conv2d.k_conv3x3_wino_f32", "conv2d.k_conv3x3_wino4_f32") if fp32 else ("conv2d.k_conv3x3",)
     peak = MFMA_PEAK_TFLOPS_F32 if fp32 else MFMA_PEAK_TFLOPS
     c2.FLOP_COUNTER = [0]
     for nm in prof_names + ("conv2d.k_wgrad_f32", "conv2d.k_wgrad_wino_f32", "conv2d.k_wgrad_1x1_f32"):
@@ -225,9 +225,15 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     # fp32: launches whose map fills the tile blocks run as Winograd F(2x2,3x3) -- 16 instead of 36 multiplications per 2 x 2
     # outputs: `achieved` stays ALGORITHMIC (direct-form) flops / time as the contract defines it, `executed` is what the MFMA
     # pipe actually ran
-    ex_flops = sum(2 * B * H * W * cout * 9 * cin * ((16.0 / 36.0) if fp32 and c32.wino_pays(H, W, cin, cout) else 1.0)
-                   for (B, cin, H, W, cout, _) in log)
-    n_wino = sum(1 for (B, cin, H, W, cout, _) in log if fp32 and c32.wino_pays(H, W, cin, cout))
+    def mult_frac(H, W, cin, cout):      # multiplications the routed kernel executes / the direct form's
+        if not fp32:
+            return 1.0
+        if c32.wino4_pays(H, W, cin, cout):
+            return 36.0 / 144.0          # F(4x4,3x3): 36 per 4 x 4 outputs
+        return (16.0 / 36.0) if c32.wino_pays(H, W, cin, cout) else 1.0
+    ex_flops = sum(2 * B * H * W * cout * 9 * cin * mult_frac(H, W, cin, cout) for (B, cin, H, W, cout, _) in log)
+    n_wino = sum(1 for (B, cin, H, W, cout, _) in log if mult_frac(H, W, cin, cout) < 1.0)
+    n_wino4 = sum(1 for (B, cin, H, W, cout, _) in log if fp32 and c32.wino4_pays(H, W, cin, cout))
     executed = ex_flops / (rp_ms * 1e-3) / 1e12
     in_step = flops / (ms * 1e-3) / 1e12
     if fp32:                                   # in-step events: priced by executed flops as well
@@ -236,19 +242,20 @@ def mfma_leg(trainer, batch, fp32, steps=3):
     loop = pf.get("mfma_only_loop_tflops", {})
     instr = "v_mfma_f32_16x16x4_f32" if fp32 else "v_mfma_f32_16x16x32_bf16"
     out = {"bound": "mfma",
-           "kernel": ("conv2d_f32_wino.k_conv3x3_wino_f32 / conv2d_f32.k_conv_f32_taps (ud_conv3x3_wino_nhwc_f32, ud_conv3x3_nhwc_f32"
+           "kernel": ("conv2d_f32_wino4.k_conv3x3_wino4_f32 / conv2d_f32_wino.k_conv3x3_wino_f32 / conv2d_f32.k_conv_f32_taps "
+                      "(ud_conv3x3_wino4_nhwc_f32, ud_conv3x3_wino_nhwc_f32, ud_conv3x3_nhwc_f32"
                       if fp32 else "conv2d.k_conv3x3_taps (ud_conv3x3_nhwc_bf16") + ": BEV trunk, head, ResNet 3x3 convs; fwd + dgrad)",
-           # fp32: achieved / frac = the flops the MFMA pipe EXECUTES (Winograd launches run 16/36 of the direct-form
-           # multiplications) / time: a roofline fraction, always <= 1; the direct-form rate is kept beside it
+           # fp32: achieved / frac = the flops the MFMA pipe EXECUTES (Winograd launches run 16/36 -- F(2x2) -- or 36/144 -- F(4x4) --
+           # of the direct-form multiplications) / time: a roofline fraction, always <= 1; the direct-form rate is kept beside it
            "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak, "dtype": "f32" if fp32 else "bf16",
            "launches": len(log), "avg_kernel_us": rp_ms / len(log) * 1e3, "algorithmic_flops_per_step": rp_flops,
            "kernel_ms_per_step": rp_ms, "traffic": None,
-           "executed": ({"winograd_launches": n_wino, "flops_per_step": ex_flops, "TFLOP/s": executed,
+           "executed": ({"winograd_launches": n_wino, "of_them_F4x4": n_wino4, "flops_per_step": ex_flops, "TFLOP/s": executed,
                          "frac_of_peak": executed / peak} if fp32 else None),
            "algorithmic_equivalent": ({"TFLOP/s": achieved, "x_matrix_peak": achieved / peak,
                                        "note": "direct-form flops (2 B H W Cout 9 Cin) of the same launches / time: what a direct "
                                                "convolution would have to sustain to match; NOT a roofline fraction (Winograd "
-                                               "F(2x2,3x3) executes 16/36 of these multiplications)"} if fp32 else None),
+                                               "F(2x2,3x3) executes 16/36, F(4x4,3x3) 36/144 of these multiplications)"} if fp32 else None),
            # what an MFMA-only loop sustains on the same machine with the instruction this kernel uses (tools/mfma_peak.hip;
            # profiles/traffic.json): informational, `frac` stays priced against the guide's nominal peak
            "mfma_only_loop": ({"instruction": instr, "TFLOP/s": loop[instr], "frac_of_loop": executed / loop[instr],
@@ -383,12 +390,18 @@ def voxelize_leg(device):
         coords = torch.empty(cap, 4, dtype=torch.int32, device=device)
         num = torch.empty(cap, dtype=torch.int32, device=device)
         m = torch.empty(B + 2, dtype=torch.int32, device=device)
-        ALGO = 0       # hash partition + LDS sort (no global atomics); the synthetic clouds never overflow a partition
+        # what the product wrapper picks (ops/voxelize.py): below 160 k points the three-launch atomic hash on its own clean
+        # workspace (algo 3 after one algo-2 call), else the hash partition + LDS sort (algo 0: no global atomics; the
+        # synthetic clouds never overflow a partition)
+        small = B * N < 160000
+        ALGO = 3 if small else 0
         vs, rg, st = _f3(syn.VOXEL_SIZE), _f3(syn.POINT_CLOUD_RANGE), _lib.stream_of(pts)
 
-        def run():
+        def run(algo=ALGO):
             _lib.check(lib.ud_voxelize(_lib.ptr(pts), B, N, F, vs, rg, P, maxM, _lib.ptr(vox), _lib.ptr(coords),
-                                       _lib.ptr(num), None, _lib.ptr(m), _lib.ptr(ws), ws.numel(), ALGO, st), "ud_voxelize")
+                                       _lib.ptr(num), None, _lib.ptr(m), _lib.ptr(ws), ws.numel(), algo, st), "ud_voxelize")
+        if small:
+            run(2)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -405,7 +418,7 @@ def voxelize_leg(device):
         torch.cuda.synchronize()
         _lib.prof_enable(False)
         kern = {}
-        for k in ("k_partition", "k_bucket", "k_flags", "k_emit", "k_gather"):
+        for k in (("k_insert2", "k_first_assign", "k_gather") if small else ("k_partition", "k_bucket", "k_flags", "k_rows", "k_gather")):
             ms, n = _lib.prof_read("voxelize." + k)
             kern[k] = ms / max(n, 1) * 1e3
         M = int(m[B])
@@ -414,7 +427,7 @@ def voxelize_leg(device):
                                "complete voxelization (the product wrapper would repeat with algo 1)")
         alg = B * N * F * 4 + M * (P * F * 4 + 12 + 4)          # N*20 + M*216 bytes
         dom = max(kern, key=kern.get)
-        cases.append({"points": B * N, "voxels": M, "algorithmic_bytes": alg, "op_us": op_us,
+        cases.append({"points": B * N, "voxels": M, "algo": ALGO, "algorithmic_bytes": alg, "op_us": op_us,
                       "op_GBps": alg / op_us / 1e3, "frac_op": alg / op_us / 1e3 / HBM_PEAK_GBS,
                       "kernel_us": kern, "dominant_kernel": "voxelize." + dom})
     big = cases[-1]
@@ -427,9 +440,12 @@ def voxelize_leg(device):
             # (gfx950 correction) + WRITE_SIZE, KB): 4.7x the algorithmic bytes -- the random 8-byte hash-table accesses of
             # k_insert / k_first move whole sectors
             "traffic": vox_traffic, "traffic_source": pv.get("source") if vox_traffic else None, "cases": cases,
-            "note": "op-level, algo 0 (hash partition + per-partition LDS hash / counting sort: no global atomics; 7 launches); "
-                    "per-kernel times are HIP-event brackets incl. ~6 us dispatch.  Random-access bound (gathers of 20-byte "
-                    "points, 4-16-byte scattered stores), not streaming-bound: see DESIGN.md"}
+            "traffic_ratio": (vox_traffic / big["algorithmic_bytes"]) if vox_traffic else None,
+            "small_cloud_us": cases[0]["op_us"],
+            "note": "op-level; cases[1] (headline of this object): algo 0 (hash partition + per-partition LDS hash / counting "
+                    "sort: no global atomics; 6 launches); cases[0]: the 30 k cloud on the three-launch atomic hash with a "
+                    "self-cleaning workspace (algo 3).  Per-kernel times are HIP-event brackets incl. ~6 us dispatch.  "
+                    "Random-access bound (gathers of 20-byte points, 4-16-byte scattered stores), not streaming-bound: see DESIGN.md"}
 
 
 def usable_cores():
@@ -685,6 +701,11 @@ def main():
         if not args.no_roofline:
             line["roofline"] = roofline_leg(device, 1)
             line["roofline_voxelize"] = voxelize_leg(device)
+            # flat copies inside `roofline` (BASELINE.json's metric names "bev_pool+voxelize HBM GB/s"; the driver's parsed record
+            # keeps the `roofline` object)
+            rv = line["roofline_voxelize"]
+            line["roofline"].update(voxelize_frac=rv["frac"], voxelize_GBps=rv["achieved"], voxelize_traffic_ratio=rv["traffic_ratio"],
+                                    voxelize_small_cloud_us=rv["small_cloud_us"])
             if mfma32 is not None:
                 line["roofline_mfma_f32"] = mfma32
             if "points" in batch:

@@ -74,6 +74,22 @@ __device__ __forceinline__ unsigned hash_slot(unsigned key, int shift) {
   return (key * 2654435761u) >> shift;
 }
 
+// voxel key of the point at q (global point index gid); false: outside the grid / NaN
+template <typename P>
+__device__ __forceinline__ bool point_key_at(const float* __restrict__ q, const P& p, long long gid, unsigned& key) {
+  int c[3];
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float f = floorf(__fdiv_rn(__fsub_rn(q[a], p.lo[a]), p.vs[a]));
+    ok = ok && (f >= 0.0f) && (f < (float)p.grid[a]);  // false for NaN
+    c[a] = ok ? (int)f : 0;
+  }
+  const int b = (int)(gid / p.N);
+  key = (unsigned)(((b * p.grid[2] + c[2]) * p.grid[1] + c[1])) * (unsigned)p.grid[0] + (unsigned)c[0];
+  return ok;
+}
+
 __global__ __launch_bounds__(256) void k_insert(const float* __restrict__ pts, VoxParams p,
                                                 unsigned long long* __restrict__ table,
                                                 int* __restrict__ pslot) {
@@ -299,13 +315,14 @@ __global__ __launch_bounds__(256) void k_assign(const float* __restrict__ pts, V
 // max(n, 1) in slot order, like MeanVFE's sum over the slot axis.
 constexpr int kGatherPMax = 16;  // ids staged in LDS up to this many slots per voxel
 
-__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, VoxParams p,
-                                                const unsigned* __restrict__ top, int TS,
-                                                const unsigned* __restrict__ cnt,
-                                                const int32_t* __restrict__ m_out,
-                                                float* __restrict__ voxels,
-                                                int32_t* __restrict__ num,
-                                                float* __restrict__ mean) {
+template <bool CLEAN>
+__device__ __forceinline__ void gather_rows(const float* __restrict__ pts, const VoxParams& p,
+                                            unsigned* __restrict__ top, int TS,
+                                            unsigned* __restrict__ cnt,
+                                            const int32_t* __restrict__ m_out,
+                                            float* __restrict__ voxels,
+                                            int32_t* __restrict__ num,
+                                            float* __restrict__ mean) {
   __shared__ unsigned s_id[4][64 * kGatherPMax];
   __shared__ int s_n[4][64];
   const int lane = ud_lane(), wv = threadIdx.x >> 6;
@@ -322,6 +339,7 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, V
   s_n[wv][lane] = n_l;
   const bool staged = TS <= kGatherPMax;
   const unsigned* trow = top + (size_t)row0 * TS;      // id lists, TS words per row (TS = P, or P rounded up to 4)
+  if (CLEAN && !staged) __builtin_trap();              // (the cleaning variant is only launched with P <= kGatherPMax)
   if (staged)
     for (int i = lane; i < rows * TS; i += 64) s_id[wv][i] = trow[i];
   __builtin_amdgcn_wave_barrier();
@@ -371,8 +389,226 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, V
       mrow[e] = __fdiv_rn(acc, (float)max(n, 1));
     }
   }
+  if (CLEAN) {      // algo 2: leave the id lists / counts of the rows this wave consumed as the 0xFF state the next call starts from
+    unsigned* wrow = top + (size_t)row0 * TS;
+    for (int i = lane; i < rows * TS; i += 64) wrow[i] = kEmpty;
+    if (lane < rows) cnt[row0 + lane] = kEmpty;
+  }
 }
 
+__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ pts, VoxParams p,
+                                                const unsigned* __restrict__ top, int TS,
+                                                const unsigned* __restrict__ cnt,
+                                                const int32_t* __restrict__ m_out,
+                                                float* __restrict__ voxels,
+                                                int32_t* __restrict__ num,
+                                                float* __restrict__ mean) {
+  gather_rows<false>(pts, p, const_cast<unsigned*>(top), TS, const_cast<unsigned*>(cnt), m_out, voxels, num, mean);
+}
+
+
+// ---- algo 2: the atomic hash in THREE launches for small clouds (<= 256 tiles of 1 024 points) ------------------------------
+// At 30 k points every kernel of algo 1 runs 2-3 us and the op is its chain of launches (2 memsets + 5 kernels: 44 us).  Here:
+//   k_insert2        = k_insert (+ the overflow word; checks the caller's claim that the workspace is in its clean state)
+//   k_first_assign   = k_first + k_scan + k_assign in one launch: a tile publishes its first-point bitmap words, their in-tile
+//                      prefixes and its count with device-scope stores (ordered by completion, not by a release fence: a fence
+//                      would write the L2 back), then waits for the counts of the tiles BEFORE it -- a first point always lies
+//                      in an earlier (or the same) tile, and workgroups are dispatched in index order, so the wait cannot
+//                      deadlock -- scans them in LDS and assigns rows / counts / kept ids exactly like k_assign
+//   k_gather_clean   = k_gather; every wave then restores the 0xFF state of the id lists / counts it consumed, the point tiles
+//                      reset their hash slots and the header word is stamped: the next call needs no memset (the caller passes
+//                      algo 3 = "the workspace still holds what my last algo-2/3 call with these sizes left"; k_insert2
+//                      verifies the stamp and reports m_out[B + 1] = 2 otherwise -> repeat with algo 2).
+constexpr unsigned kAggValid = 0x80000000u;
+
+__global__ __launch_bounds__(256) void k_insert2(const float* __restrict__ pts, VoxParams p,
+                                                 unsigned long long* __restrict__ table, int* __restrict__ pslot,
+                                                 const unsigned* __restrict__ hdr, unsigned expect, int check,
+                                                 int32_t* __restrict__ m_out) {
+  const bool bad = check && __hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect;
+  if (blockIdx.x == 0 && threadIdx.x == 0) m_out[p.B + 1] = bad ? 2 : 0;
+  if (bad) return;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)p.B * p.N;
+  if (gid >= total) return;
+  unsigned key;
+  const bool ok = point_key_at(pts + gid * p.F, p, gid, key);
+  int slot = -1;
+  if (ok) {
+    const unsigned long long mine = ((unsigned long long)key << 32) | (unsigned long long)(unsigned)gid;
+    unsigned h = hash_slot(key, p.tshift);
+    while (true) {
+      // small clouds: most points open their own voxel -- the CAS goes first (one round trip), no peek
+      const unsigned long long cur = atomicCAS(&table[h], kEmpty64, mine);
+      if (cur == kEmpty64) break;
+      if ((unsigned)(cur >> 32) == key) {
+        if (cur > mine) atomicMin(&table[h], mine);
+        break;
+      }
+      h = (h + 1) & p.tmask;
+    }
+    slot = (int)h;
+  }
+  pslot[gid] = slot;
+}
+
+__global__ __launch_bounds__(256) void k_first_assign(const float* __restrict__ pts, VoxParams p,
+                                                      const unsigned long long* __restrict__ table,
+                                                      const int* __restrict__ pslot,
+                                                      unsigned long long* __restrict__ bitmap, unsigned* __restrict__ wl32,
+                                                      unsigned* __restrict__ agg, unsigned* __restrict__ top,
+                                                      unsigned* __restrict__ cnt, int32_t* __restrict__ coords,
+                                                      int32_t* __restrict__ m_out, unsigned* __restrict__ hdr, int ntile) {
+  __shared__ int s_cnt[16];
+  __shared__ int s_E[258];          // s_E[i] = first points in tiles < i
+  __shared__ int s_w[4];
+  __shared__ int s_samp[66];        // first-appearance rank at the start of sample b (b <= B), as far as this tile can know it
+  const long long total = (long long)p.B * p.N;
+  const int lane = ud_lane(), wv = threadIdx.x >> 6, tid = threadIdx.x;
+  const int t = blockIdx.x;
+  const long long base = (long long)t * kFirstTile;
+  if (t == 0 && tid == 0) __hip_atomic_store(&hdr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // state: in use
+  if (m_out[p.B + 1] != 0) return;                                     // k_insert2 refused the workspace
+  int sl[4];
+  unsigned fp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long g = base + k * 256 + tid;
+    sl[k] = (g < total) ? pslot[g] : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) fp[k] = (sl[k] >= 0) ? (unsigned)table[sl[k]] : kEmpty;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long g = base + k * 256 + tid;
+    const unsigned long long bits = __ballot(fp[k] == (unsigned)g && g < total);
+    if (lane == 0) {
+      const long long w = (base >> 6) + k * 4 + wv;
+      if (w * 64 < total) __hip_atomic_store(&bitmap[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_cnt[k * 4 + wv] = __popcll(bits);
+    }
+  }
+  __syncthreads();
+  int tot = 0;
+  if (tid < 16) {
+    int pre = 0;
+    for (int i = 0; i < 16; ++i) pre += (i < tid) ? s_cnt[i] : 0;
+    const long long w = (base >> 6) + tid;
+    if (w * 64 < total) __hip_atomic_store(&wl32[w], (unsigned)pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 15) s_w[0] = pre + s_cnt[15];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's device-scope stores have completed ...
+  __syncthreads();                                       // ... everybody's have
+  tot = s_w[0];
+  if (tid == 0) __hip_atomic_store(&agg[t], (unsigned)tot | kAggValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // counts of the tiles before this one
+  int a = 0;
+  if (tid < t) {
+    unsigned v;
+    do {
+      v = __hip_atomic_load(&agg[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(v & kAggValid)) __builtin_amdgcn_s_sleep(1);
+    } while (!(v & kAggValid));
+    a = (int)(v & ~kAggValid);
+  } else if (tid == t) {
+    a = tot;
+  }
+  __syncthreads();
+  {
+    int inc = a;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int pre = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pre += (k < wv) ? s_w[k] : 0;
+    s_E[tid + 1] = pre + inc;
+    if (tid == 0) s_E[0] = 0;
+  }
+  __syncthreads();
+  auto rank_at = [&](unsigned g) -> int {       // first points before point g (g in a tile <= t, or g == total in the last tile)
+    if ((long long)g >= total) return s_E[ntile];
+    const unsigned long long bw = __hip_atomic_load(&bitmap[g >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned wl = __hip_atomic_load(&wl32[g >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return s_E[g >> 10] + (int)wl + __popcll(bw & ((1ull << (g & 63)) - 1ull));
+  };
+  const long long tile_end = min(base + kFirstTile, total);
+  if (tid <= p.B) {
+    const long long g = (long long)tid * p.N;
+    s_samp[tid] = (g < tile_end || (g == total && t == ntile - 1)) ? rank_at((unsigned)g) : 0x3fffffff;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const long long gid = base + k * 256 + tid;
+    int row = -1;
+    if (gid < total && fp[k] != kEmpty) {
+      const unsigned first = fp[k];
+      const int b = (int)(gid / p.N);
+      const int r = rank_at(first) - s_samp[b];
+      if (r < p.maxM) {
+        int rb = 0;
+        for (int i = 0; i < b; ++i) rb += min(s_samp[i + 1] - s_samp[i], p.maxM);
+        row = rb + r;
+        if (first == (unsigned)gid) {  // first point of the voxel writes its coordinates
+          const float* q = pts + gid * p.F;
+          int c[3];
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) c[ax] = (int)floorf(__fdiv_rn(__fsub_rn(q[ax], p.lo[ax]), p.vs[ax]));
+          *reinterpret_cast<int4*>(coords + (size_t)row * 4) = make_int4(b, c[2], c[1], c[0]);
+        }
+      }
+    }
+    // counts and kept ids: as k_assign (one integer atomic per run of equal rows inside the wave; atomicMin insertion chain)
+    const int prev = __shfl_up(row, 1);
+    const bool start = (lane == 0) || (prev != row);
+    const unsigned long long starts = __ballot(start);
+    const unsigned long long upto = starts & ((2ull << lane) - 1ull);
+    const int lead = 63 - __clzll(upto);
+    const unsigned long long after = starts & ~((2ull << lead) - 1ull);
+    const int end = after ? (__ffsll((long long)after) - 1) : 64;
+    if (row >= 0 && lane == lead) atomicAdd(&cnt[row], (unsigned)(end - lead));
+    if (row >= 0 && (lane - lead) < p.P) {
+      unsigned* tt = top + (size_t)row * p.P;
+      unsigned carry = (unsigned)gid;
+      for (int j = 0; j < p.P; ++j) {          // (no peek at the last slot first: one round trip for a voxel's only point)
+        const unsigned old = atomicMin(&tt[j], carry);
+        if (old == kEmpty) break;
+        carry = max(old, carry);
+      }
+    }
+  }
+  if (t == ntile - 1 && tid == 0) {      // per-sample voxel counts (capped) and their total
+    int tot_m = 0;
+    for (int b = 0; b < p.B; ++b) {
+      const int m = min(s_samp[b + 1] - s_samp[b], p.maxM);
+      m_out[b] = m;
+      tot_m += m;
+    }
+    m_out[p.B] = tot_m;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_clean(const float* __restrict__ pts, VoxParams p, unsigned* __restrict__ top,
+                                                      unsigned* __restrict__ cnt, const int32_t* __restrict__ m_out,
+                                                      float* __restrict__ voxels, int32_t* __restrict__ num,
+                                                      float* __restrict__ mean, unsigned long long* __restrict__ table,
+                                                      const int* __restrict__ pslot, unsigned* __restrict__ agg, int ntile,
+                                                      unsigned* __restrict__ hdr, unsigned stamp) {
+  if (m_out[p.B + 1] != 0) return;
+  const long long total = (long long)p.B * p.N;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+    const int sl = pslot[g];
+    if (sl >= 0) table[sl] = kEmpty64;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ntile; i += gridDim.x * 256) agg[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = stamp;      // read by the NEXT call's k_insert2: a launch boundary away
+  gather_rows<true>(pts, p, top, p.P, cnt, m_out, voxels, num, mean);
+}
 
 // ---- algo 0: hash partition + LDS sort (see the header) -------------------------------------------------------------
 constexpr int kCH = 2048;        // points per partition chunk
@@ -735,6 +971,8 @@ struct VoxWs {
   unsigned* top;
   unsigned* cnt;
   unsigned* ticket;
+  unsigned* wl32;              // algo 2: in-tile prefixes of the bitmap words, 32-bit (device-scope stores)
+  unsigned* hdr;               // algo 2: state stamp of the workspace
   size_t ff_bytes;
   unsigned long long* bitmap;  // ---- fully written by k_first (no initialisation)
   unsigned short* wlocal;
@@ -778,6 +1016,8 @@ VoxWs carve(void* ws, int B, int N, int P, int maxM) {
   w.fpid = a.take<unsigned>(total);
   w.pslot = a.take<int>(total);
   w.samp_rank = a.take<int>(B + 1);
+  w.wl32 = a.take<unsigned>(w.nwords);
+  w.hdr = a.take<unsigned>(4);
   w.total_bytes = a.used;
   return w;
 }
@@ -863,7 +1103,7 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
                            int32_t* coords, int32_t* num_points, float* mean_feats,
                            int32_t* m_out, void* workspace, size_t workspace_bytes, int algo,
                            ud_stream_t stream_) {
-  if (!points || !voxel_size || !range || !coords || !m_out || (algo != 0 && algo != 1)) return UD_ERR_INVALID_ARG;
+  if (!points || !voxel_size || !range || !coords || !m_out || algo < 0 || algo > 3) return UD_ERR_INVALID_ARG;
   VoxParams p;
   for (int a = 0; a < 3; ++a) {
     p.lo[a] = range[a];
@@ -907,7 +1147,7 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
       UD_LAUNCH_CHECK();
     }
     {
-      UdProfScope prof("voxelize.k_emit", stream);
+      UdProfScope prof("voxelize.k_rows", stream);
       k_vp_rows<<<ud_div_up(total, 256), 256, 0, stream>>>(p, v.rec, v.nrec, v.vtop, v.bitmap, v.bprefix, v.wlocal,
                                                            v.samp_rank, v.TS, v.top, v.cnt, coords);
       UD_LAUNCH_CHECK();
@@ -922,6 +1162,34 @@ extern "C" int ud_voxelize(const float* points, int B, int N, int F, const float
   VoxWs w = carve(workspace, B, N, P, max_voxels);
   p.tmask = w.T - 1;
   p.tshift = w.tshift;
+  if (algo >= 2) {
+    if (w.ntile > 256 || P > kGatherPMax || B > 64) return UD_ERR_UNSUPPORTED;
+    const unsigned stamp = 0xC1EA0000u ^ (unsigned)(B * 0x9E3779B1u) ^ (unsigned)(N * 0x85EBCA77u) ^ (unsigned)(P * 0xC2B2AE3Du) ^
+                           (unsigned)max_voxels;
+    if (algo == 2) {      // unknown workspace contents: the one memset (hash entries, id lists, counts: 0xFF; tile counts: 0)
+      UD_HIP_TRY(hipMemsetAsync(w.table, 0xFF, w.ff_bytes, stream));
+      UD_HIP_TRY(hipMemsetAsync(w.part, 0, (size_t)w.ntile * sizeof(int), stream));
+    }
+    {
+      UdProfScope prof("voxelize.k_insert2", stream);
+      k_insert2<<<ud_div_up(total, 256), 256, 0, stream>>>(points, p, w.table, w.pslot, w.hdr, stamp, algo == 3, m_out);
+      UD_LAUNCH_CHECK();
+    }
+    {
+      UdProfScope prof("voxelize.k_first_assign", stream);
+      k_first_assign<<<w.ntile, 256, 0, stream>>>(points, p, w.table, w.pslot, w.bitmap, w.wl32, (unsigned*)w.part, w.top, w.cnt,
+                                                  coords, m_out, w.hdr, w.ntile);
+      UD_LAUNCH_CHECK();
+    }
+    {
+      UdProfScope prof("voxelize.k_gather", stream);
+      const int blocks = std::max(ud_div_up(w.cap, 256), std::min(w.ntile, 64));
+      k_gather_clean<<<blocks, 256, 0, stream>>>(points, p, w.top, w.cnt, m_out, voxels, num_points, mean_feats, w.table,
+                                                 w.pslot, (unsigned*)w.part, w.ntile, w.hdr, stamp);
+      UD_LAUNCH_CHECK();
+    }
+    return UD_OK;
+  }
   UD_HIP_TRY(hipMemsetAsync(m_out + B + 1, 0, sizeof(int32_t), stream));
   UD_HIP_TRY(hipMemsetAsync(w.table, 0xFF, w.ff_bytes, stream));
   {

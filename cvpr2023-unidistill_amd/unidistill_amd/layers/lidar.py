@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from ..ops import spconv as sp
-from ..ops.voxelize import MeanVFE, Voxelization, voxelize_deferred
+from ..ops.voxelize import MeanVFE, Voxelization, voxelize_deferred, voxelize_dirty
 
 
 def _conv_bn_relu(cin, cout, kernel, norm_fn, *, stride=1, padding=0, key=None, kind="subm"):
@@ -170,6 +170,7 @@ class LidarEncoder(nn.Module):
                 sites = pyr.finalize(M, host[2:].tolist())
                 return sp.SparseConvTensor(mean_cap[:M], None, None, None, _sites=sites)
             overflowed = True                                               # seen the fast path overflow: straight to the hash path
+            voxelize_dirty(batch.device)
         voxels, coords, num = self.voxelizer(lidar_points, algo=1 if overflowed else None)
         feats = self.vfe(voxels, num)
         x = sp.SparseConvTensor(feats, coords.int(), bb.sparse_shape, len(lidar_points))

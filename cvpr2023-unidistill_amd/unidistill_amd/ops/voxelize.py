@@ -17,8 +17,28 @@ def _f3(v):
     return (ctypes.c_float * len(v))(*[float(x) for x in v])
 
 
-ALGO = None      # None: by size (below), hash fallback on overflow; 0 / 1: force one algorithm (tests, timing)
-SMALL_CLOUD = 160000   # points: below this the atomic hash (5 launches, ~15 us of atomics) beats the 6-launch partition path
+ALGO = None      # None: by size (below), hash fallback on overflow; 0 / 1 / 2: force one algorithm (tests, timing)
+SMALL_CLOUD = 160000   # points: below this the atomic hash (3 launches, ~15 us of atomics) beats the 6-launch partition path
+SMALL_TILES = 256      # algo 2 (three launches, self-cleaning workspace): at most this many 1 024-point tiles, P <= 16, B <= 64
+
+# algo 2 leaves its workspace in the clean state its next call starts from: (buffer address, bytes) -> sizes of the last algo-2/3
+# call on it.  Any other algorithm on the buffer, or an exception, drops the entry (the next small call then pays the memset).
+_CLEAN = {}
+
+
+def _small_algo(ws, B, N, P, max_voxels):
+    """2 (memset first) or 3 (the workspace is known clean) for the three-launch small-cloud path, or None if it does not apply."""
+    if B * N >= SMALL_CLOUD or (B * N + 1023) // 1024 > SMALL_TILES or P > 16 or B > 64:
+        return None
+    return 3 if _CLEAN.get((ws.data_ptr(), ws.numel())) == (B, N, P, max_voxels) else 2
+
+
+def _note_algo(ws, algo, B, N, P, max_voxels):
+    key = (ws.data_ptr(), ws.numel())
+    if algo in (2, 3):
+        _CLEAN[key] = (B, N, P, max_voxels)
+    else:
+        _CLEAN.pop(key, None)
 
 
 def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_voxels=True,
@@ -47,16 +67,23 @@ def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_vo
     mean = torch.empty((cap, F), dtype=torch.float32, device=dev) if want_mean else None
     m_out = torch.empty((B + 2,), dtype=torch.int32, device=dev)
     algo = ALGO if algo is None else algo
-    for a in (((1,) if B * N < SMALL_CLOUD else (0, 1)) if algo is None else (algo,)):
+    small = _small_algo(ws, B, N, int(max_points), int(max_voxels))
+    if algo == 2 and small is None:
+        raise ValueError("ud_voxelize: algo 2 takes at most 256 tiles of 1 024 points, P <= 16, B <= 64")
+    order = (algo if algo != 2 else small,) if algo is not None else ((small, 2) if small is not None else
+                                                                      ((1,) if B * N < SMALL_CLOUD else (0, 1)))
+    for a in order:
+        _CLEAN.pop((ws.data_ptr(), ws.numel()), None)        # unknown until the call has returned
         _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range),
                                    int(max_points), int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords),
                                    _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m_out), _lib.ptr(ws),
                                    ws.numel(), a, _lib.stream_of(points)), "ud_voxelize")
         m_host = m_out.cpu()
         if int(m_host[B + 1]) == 0:
+            _note_algo(ws, a, B, N, int(max_points), int(max_voxels))
             break
     else:
-        raise RuntimeError("ud_voxelize: a hash partition overflowed (algo 0 forced)")
+        raise RuntimeError("ud_voxelize: a hash partition overflowed (algo 0 forced) or the workspace state was refused")
     M = int(m_host[B])
     return (voxels[:M] if want_voxels else None, coords[:M], num[:M],
             mean[:M] if want_mean else None, m_host[:B])
@@ -86,12 +113,25 @@ def voxelize_deferred(points, voxel_size, pc_range, max_points, max_voxels, want
     mean = torch.empty((cap, F), dtype=torch.float32, device=dev) if want_mean else None
     m_out = torch.empty((B + 2,), dtype=torch.int32, device=dev)
     algo = ALGO if algo is None else algo
+    small = _small_algo(ws, B, N, int(max_points), int(max_voxels))
     if algo is None:
-        algo = 1 if B * N < SMALL_CLOUD else 0
+        algo = small if small is not None else (1 if B * N < SMALL_CLOUD else 0)
+    elif algo == 2:
+        if small is None:
+            raise ValueError("ud_voxelize: algo 2 takes at most 256 tiles of 1 024 points, P <= 16, B <= 64")
+        algo = small
+    _CLEAN.pop((ws.data_ptr(), ws.numel()), None)
     _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range), int(max_points),
                                int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(num), _lib.ptr(mean),
                                _lib.ptr(m_out), _lib.ptr(ws), ws.numel(), algo, _lib.stream_of(points)), "ud_voxelize")
+    # (the caller reads m_out[B + 1]; a refused / overflowed call leaves the workspace dirty: voxelize_dirty() below)
+    _note_algo(ws, algo, B, N, int(max_points), int(max_voxels))
     return voxels, coords, num, mean, m_out, algo
+
+
+def voxelize_dirty(device):
+    """A deferred call reported a non-zero overflow word: forget every clean-state note of this device's workspaces."""
+    _CLEAN.clear()
 
 
 class PointToVoxel:

@@ -1,6 +1,7 @@
-"""GPU parity: HIP voxelize(+MeanVFE) through the C ABI vs the CPU oracle (bit-exact indices), for both algorithms behind
+"""GPU parity: HIP voxelize(+MeanVFE) through the C ABI vs the CPU oracle (bit-exact indices), for the algorithms behind
 ud_voxelize: 0 = hash partition + per-partition LDS sort (no global atomics; reports an overflow when one partition gets more
-than 8 192 points), 1 = atomic open-addressing hash; None = the product default (0, falling back to 1 on overflow)."""
+than 8 192 points), 1 = atomic open-addressing hash (5 launches), 2 / 3 = the same hash in three launches with a self-cleaning
+workspace (small clouds); None = the product default (2 / 3 below 160 k points, else 0 falling back to 1 on overflow)."""
 import numpy as np
 import pytest
 import torch
@@ -129,3 +130,58 @@ def test_deterministic_rerun():
     b = _gpu(pts)
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_three_launch_path_cleans_its_workspace_and_refuses_a_foreign_one():
+    """algo 2 / 3 (small clouds): the first call memsets the workspace (algo 2), the following ones start from the state the
+    previous call's last kernel restored (algo 3): five different clouds of one shape in a row, each bit-exact against the
+    oracle (a slot, id list or count that was not restored would leak into the next cloud).  A workspace that was NOT left by
+    such a call is refused on the device (m_out[B + 1] = 2) instead of being trusted."""
+    import ctypes
+    from unidistill_amd import _lib
+    from unidistill_amd.ops import voxelize as V
+    g = syn.rng(31)
+    V._CLEAN.clear()
+    seen = []
+    orig = V._note_algo
+
+    def spy(ws, algo, *a):
+        seen.append(algo)
+        return orig(ws, algo, *a)
+    V._note_algo = spy
+    try:
+        clouds = syn.pad_clouds([syn.lidar_cloud(g, 30000, 1) for _ in range(5)])       # one shape
+        for i in range(5):
+            pts = clouds[i:i + 1]
+            ref = oracle.voxelize(pts, VS, RG, 10, 120000)
+            vox, coords, num, mean, m = _gpu(pts, algo=None)
+            np.testing.assert_array_equal(coords, ref["coords"], err_msg=f"call {i}")
+            np.testing.assert_array_equal(num, ref["num"], err_msg=f"call {i}")
+            np.testing.assert_array_equal(vox, ref["voxels"], err_msg=f"call {i}")
+            np.testing.assert_array_equal(mean, ref["mean"], err_msg=f"call {i}")
+    finally:
+        V._note_algo = orig
+    assert seen == [2, 3, 3, 3, 3], seen
+    # a foreign workspace under the "known clean" claim
+    lib = _lib.load()
+    t = torch.from_numpy(syn.lidar_cloud(g, 30000, 1)[None]).cuda()
+    B, N, F = t.shape
+    ws = torch.randint(0, 255, (lib.ud_voxelize_workspace_bytes(B, N, 10, 120000),), dtype=torch.uint8, device="cuda")
+    cap = lib.ud_voxelize_capacity(B, N, 120000)
+    coords = torch.empty(cap, 4, dtype=torch.int32, device="cuda")
+    num = torch.empty(cap, dtype=torch.int32, device="cuda")
+    mean = torch.empty(cap, F, device="cuda")
+    m = torch.zeros(B + 2, dtype=torch.int32, device="cuda")
+    _lib.check(lib.ud_voxelize(_lib.ptr(t), B, N, F, V._f3(VS), V._f3(RG), 10, 120000, None, _lib.ptr(coords), _lib.ptr(num),
+                               _lib.ptr(mean), _lib.ptr(m), _lib.ptr(ws), ws.numel(), 3, _lib.stream_of(t)), "ud_voxelize")
+    assert int(m[B + 1]) == 2
+
+
+def test_three_launch_path_on_a_batch_with_caps_and_padding():
+    """algo 2 on 4 x 30 k points (the LiDAR teacher's batch: 118 tiles, tiles straddle the sample boundaries) with a small
+    max_voxels cap and zero-padded tails (thousands of points in one voxel)."""
+    g = syn.rng(32)
+    clouds = [syn.lidar_cloud(g, 30000 - 700 * i, 1) for i in range(4)]
+    pts = syn.pad_clouds(clouds)
+    _check(pts, maxM=9000, algos=[2, 1])
+    _check(pts, algos=[2])

@@ -9,7 +9,7 @@ from unidistill_amd.ops.voxelize import _f3
 
 lib = _lib.load()
 d = torch.device("cuda:0")
-ALGO = int(os.environ.get("ALGO", "0"))      # 0: partition + LDS sort, 1: atomic hash
+ALGO = int(os.environ.get("ALGO", "0"))      # 0: partition + LDS sort, 1: atomic hash, 2: three-launch hash with its memsets, 3: the same on its own clean workspace
 def bench(B, sweeps, fused):
     g = syn.rng()
     pts = torch.from_numpy(syn.pad_clouds([syn.lidar_cloud(g, 30000, sweeps) for _ in range(B)])).to(d)
@@ -22,9 +22,12 @@ def bench(B, sweeps, fused):
     mean = torch.empty(cap, F, device=d); m = torch.empty(B + 2, dtype=torch.int32, device=d)
     vs, rg = _f3(syn.VOXEL_SIZE), _f3(syn.POINT_CLOUD_RANGE)
     st = _lib.stream_of(pts)
-    def run():
+    if ALGO >= 2 and (B * N + 1023) // 1024 > 256:
+        return
+    def run(algo=ALGO):
         _lib.check(lib.ud_voxelize(_lib.ptr(pts), B, N, F, vs, rg, P, maxM, _lib.ptr(vox), _lib.ptr(coords),
-                                   _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m), _lib.ptr(ws), ws.numel(), ALGO, st), "vox")
+                                   _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m), _lib.ptr(ws), ws.numel(), algo, st), "vox")
+    if ALGO == 3: run(2)      # leaves the workspace clean
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -38,10 +41,10 @@ def bench(B, sweeps, fused):
     for _ in range(10): run()
     torch.cuda.synchronize(); _lib.prof_enable(False)
     parts = []
-    for k in (("k_partition", "k_bucket", "k_flags", "k_emit", "k_gather") if ALGO == 0 else ("k_insert", "k_first", "k_assign", "k_gather")):
+    for k in (("k_partition", "k_bucket", "k_flags", "k_emit", "k_gather") if ALGO == 0 else ("k_insert", "k_first", "k_assign", "k_gather") if ALGO == 1 else ("k_insert2", "k_first_assign", "k_gather")):
         ms, n = _lib.prof_read("voxelize." + k)
         parts.append(f"{k} {ms / max(n, 1) * 1e3:.1f}")
     print("    per-kernel us (HIP events, incl. ~6 us dispatch each): " + ", ".join(parts))
-for B, sw in ((1, 1), (1, 10), (4, 10)):
+for B, sw in ((1, 1), (4, 1), (1, 10), (4, 10)):
     for fused in (False, True):
         bench(B, sw, fused)
