@@ -129,6 +129,8 @@ _SIGS = {
                                                                                               c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_conv3x3_wino_f32_weight_bytes": (c_size_t, [c_int, c_int]),
     "ud_conv3x3_wino_bnstats_bytes": (c_size_t, [c_int] * 4),
+    "ud_conv3x3_wino4_wgrad_f32_workspace_bytes": (c_size_t, [c_int] * 5),
+    "ud_conv3x3_wino4_wgrad_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_conv3x3_wino_wgrad_f32_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_conv3x3_wino_wgrad_nhwc_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_conv3x3_wino_f32_blocks": (c_int, [c_int, c_int]),

@@ -56,6 +56,17 @@ def wino4_pays(H, W, cin, cout):
     return WINO4_MIN_FILL == 0.0 or cin >= 256 or H * W >= 128 * 128
 
 
+USE_WINO4_WGRAD = os.environ.get("UD_F32_WINO4_WGRAD", "1") != "0"
+WINO4_WGRAD_ALL = False      # tests: every shape the kernel takes
+
+
+def wino4_wgrad_pays(B, H, W, cin, cout):
+    """Weight gradient through the F(4x4) form (ud_conv3x3_wino4_wgrad_nhwc_f32): same routing idea as the forward pass."""
+    if not (USE_WINO4 and USE_WINO4_WGRAD) or cin % 32 or cout % 64 or B * H * W * max(cin, cout) * 4 >= 2 ** 31 - 1:
+        return False
+    return WINO4_WGRAD_ALL or wino4_pays(H, W, cin, cout)
+
+
 def wino_pays(H, W, cin, cout):
     if not USE_WINOGRAD or cin % 8 or cout % 4:
         return False
@@ -190,6 +201,12 @@ def weight_grad(x, gy, w, ks):
     B, _, H, W = x.shape
     if ks == 3:
         wino = USE_WINOGRAD and USE_WINOGRAD_WGRAD
+        if wino and wino4_wgrad_pays(B, H, W, cin, cout):
+            ws = _lib.workspace(x.device, lib.ud_conv3x3_wino4_wgrad_f32_workspace_bytes(B, H, W, cin, cout), "conv_wgrad")
+            dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ud_conv3x3_wino4_wgrad_nhwc_f32(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), B, H, W, cin, cout, _lib.ptr(ws),
+                                                           ws.numel(), _lib.stream_of(x)), "ud_conv3x3_wino4_wgrad_nhwc_f32")
+            return dw.permute(0, 3, 1, 2)
         nbytes, fn = ((lib.ud_conv3x3_wino_wgrad_f32_workspace_bytes, lib.ud_conv3x3_wino_wgrad_nhwc_f32) if wino else
                       (lib.ud_conv3x3_wgrad_f32_workspace_bytes, lib.ud_conv3x3_wgrad_nhwc_f32))
         ws = _lib.workspace(x.device, nbytes(B, H, W, cin, cout), "conv_wgrad")

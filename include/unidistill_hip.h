@@ -604,6 +604,12 @@ size_t ud_conv3x3_wino_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, i
 int ud_conv3x3_wino_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                                    void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
+/* ... and through the F(4x4, 3x3) form (csrc/conv2d_f32_wino4_wgrad.hip: 36 multiplications per 16 output pixels and (n, c) instead of
+ * 64): same contract; Cin % 32 == 0, Cout % 64 == 0, both tensors below 2 GB, else UD_ERR_UNSUPPORTED. */
+size_t ud_conv3x3_wino4_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ud_conv3x3_wino4_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                    void* workspace, size_t workspace_bytes, ud_stream_t stream);
+
 /* ---- LiDAR input side ------------------------------------------------------------------
  * Replaces the numpy point transforms of the reference's data pipeline:
  * CollectLidarSweeps.forward (unidistill/data/multisensorfusion/transforms3d.py:379-414) and the point part
