@@ -86,9 +86,19 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
   constexpr int O0 = 0, O1 = 5, O2 = 10, O3 = 14;                  // column planes x % 4 = 0 / 1 / 2 / 3 of a patch row (5, 5, 4, 4 columns)
   const long long xbytes = (long long)gm.B * gm.H * gm.W * gm.Cin * 4, dbytes = (long long)gm.B * gm.H * gm.W * gm.Cout * 4;
 
-  // ---- stage geometry (wave-uniform): stage s = (image b, tile row ty, four tiles from tile column 4 sx)
+  // ---- stage geometry (wave-uniform): stage s = (image b, tile row ty, four tiles from tile column 4 sx).  The byte offsets of
+  // its first pixel in x (channel c0) and dy travel with it and are stepped by constants (the scalar unit is not free beside
+  // fp32 MFMAs: re-deriving them with 64-bit multiplies cost ~140 scalar instructions per wave and stage).
   struct StageAt {
     int b, ty, sx;
+    bool inner;                     // every pixel the stage touches lies inside the image (x patch rows 4 ty - 1 .. + 4, columns 16 sx - 1 .. + 16)
+    long long xoff, doff;           // bytes: x pixel (b, 4 ty - 1, 16 sx - 1) channel c0; dy pixel (b, 4 ty, 16 sx) channel 0 (images past B: image 0)
+  };
+  const long long x_sx = 16ll * gm.Cin * 4, d_sx = 16ll * gm.Cout * 4;                       // next stage in the tile row
+  const long long x_ty = (4ll * gm.W - 16ll * gm.SX) * gm.Cin * 4, d_ty = (4ll * gm.W - 16ll * gm.SX) * gm.Cout * 4;   // + row wrap
+  const long long x_b = ((long long)gm.H - 4ll * gm.TY) * gm.W * gm.Cin * 4, d_b = ((long long)gm.H - 4ll * gm.TY) * gm.W * gm.Cout * 4;
+  auto classify = [&](StageAt& a) {
+    a.inner = a.b < gm.B && a.ty > 0 && 4 * a.ty + 4 < gm.H && a.sx > 0 && 16 * a.sx + 16 < gm.W;
   };
   auto decode = [&](int s) {
     StageAt a;
@@ -97,18 +107,26 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
     const int r = s - a.b * per;
     a.ty = r / gm.SX;
     a.sx = r - a.ty * gm.SX;
+    const long long bb = a.b < gm.B ? a.b : 0;
+    a.xoff = (((bb * gm.H + 4 * a.ty - 1) * gm.W + 16 * a.sx - 1) * gm.Cin + c0) * 4;
+    a.doff = (((bb * gm.H + 4 * a.ty) * gm.W + 16 * a.sx) * gm.Cout) * 4;
+    classify(a);
     return a;
   };
   auto advance = [&](StageAt& a) {
+    a.xoff += x_sx, a.doff += d_sx;
     if (++a.sx == gm.SX) {
       a.sx = 0;
-      if (++a.ty == gm.TY) a.ty = 0, ++a.b;
+      a.xoff += x_ty, a.doff += d_ty;
+      if (++a.ty == gm.TY) {
+        a.ty = 0, ++a.b;
+        a.xoff += x_b, a.doff += d_b;
+        if (a.b >= gm.B) a.xoff = ((-(long long)gm.W - 1) * gm.Cin + c0) * 4, a.doff = 0;   // stages past the last image: image 0 again (all masked)
+      }
     }
+    classify(a);
   };
-  // every pixel the stage touches lies inside the image (x patch rows 4 ty - 1 .. + 4, columns 16 sx - 1 .. + 16)?
-  auto interior = [&](const StageAt& a) {
-    return a.b < gm.B && a.ty > 0 && 4 * a.ty + 4 < gm.H && a.sx > 0 && 16 * a.sx + 16 < gm.W;
-  };
+  auto interior = [&](const StageAt& a) { return a.inner; };
 
   // ---- x patch DMA: piece p (two per wave: wave, wave + 8 < 14) fills 16-byte slots [64 p, 64 p + 64) of the patch buffer;
   // slot -> (row, channel half, column position in its plane, 4-channel group); lane constants: the byte offset from the patch's
@@ -128,9 +146,9 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
   }
   auto issue_x = [&](const StageAt& a, int buf) {
     // descriptor based at the patch's top-left pixel (clamped to the tensor for the masked path)
-    const long long base = (((long long)(a.b < gm.B ? a.b : 0) * gm.H + 4 * a.ty - 1) * gm.W + 16 * a.sx - 1) * gm.Cin + c0;
     if (interior(a)) {
-      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(x + base), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(x) + a.xoff), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; ++i)      // always two pieces per wave (a constant count for the vmcnt waits); pieces 14, 15: zeros into the dump
         dma16(r, xo[i], 0, wave + 8 * i < 14 ? sbase + kX0 + buf * kXBytes + (wave + 8 * i) * 1024 : sbase + kDump);
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
         const int qy = xq[i] >> 8, qx = xq[i] & 255;
         const int gy = 4 * a.ty - 1 + qy, gx = 16 * a.sx - 1 + qx;
         const bool ok = xq[i] >= 0 && a.b < gm.B && gy >= 0 && gy < gm.H && gx >= 0 && gx < gm.W;
-        const unsigned vo = ok ? (unsigned)(base * 4) + xo[i] : kInv;
+        const unsigned vo = ok ? (unsigned)a.xoff + xo[i] : kInv;
         dma16(r, vo, 0, wave + 8 * i < 14 ? sbase + kX0 + buf * kXBytes + (wave + 8 * i) * 1024 : sbase + kDump);
       }
     }
@@ -156,9 +174,9 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
   f32x2 rd00, rd01, rd10, rd11, rd20, rd21, rd30, rd31;
   __amdgpu_buffer_rsrc_t rdy_cur;
   auto dy_rsrc = [&](const StageAt& a) {
-    const long long base = (((long long)(a.b < gm.B ? a.b : 0) * gm.H + 4 * a.ty) * gm.W + 16 * a.sx) * gm.Cout;
-    const long long left = dbytes - base * 4;          // bytes from there to the end of the tensor: later pixels read zeros
-    rdy_cur = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + base), 0, (int)(left > 0x7fffffffll ? 0x7fffffffll : left), 0x00020000);
+    const long long left = dbytes - a.doff;             // bytes from there to the end of the tensor: later pixels read zeros
+    rdy_cur = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(dy) + a.doff), 0,
+                                                (int)(left > 0x7fffffffll ? 0x7fffffffll : left), 0x00020000);
   };
 #define G4_LOAD_DY(PY, A, B_)                                                                                                  \
   do {                                                                                                                         \
@@ -388,10 +406,14 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
         dy_rsrc(s1);
       }
       // dy of stage + 2 (the registers are free: the transform has read them)
-      if constexpr (fq == 1) G4_LOAD_DY(0, rd00, rd01);
-      if constexpr (fq == 2) G4_LOAD_DY(1, rd10, rd11);
-      if constexpr (fq == 3) G4_LOAD_DY(2, rd20, rd21);
-      if constexpr (fq == 4) G4_LOAD_DY(3, rd30, rd31);
+      if constexpr (fq == 1) {
+        G4_LOAD_DY(0, rd00, rd01);
+        G4_LOAD_DY(1, rd10, rd11);
+      }
+      if constexpr (fq == 2) {
+        G4_LOAD_DY(2, rd20, rd21);
+        G4_LOAD_DY(3, rd30, rd31);
+      }
       if constexpr (fq == 3) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) wa[k] = __builtin_elementwise_fma(ca1v, r1[k], ca2v * r2[k]);          // X

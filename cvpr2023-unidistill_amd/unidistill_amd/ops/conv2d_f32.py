@@ -64,7 +64,10 @@ def wino4_wgrad_pays(B, H, W, cin, cout):
     """Weight gradient through the F(4x4) form (ud_conv3x3_wino4_wgrad_nhwc_f32): same routing idea as the forward pass."""
     if not (USE_WINO4 and USE_WINO4_WGRAD) or cin % 32 or cout % 64 or B * H * W * max(cin, cout) * 4 >= 2 ** 31 - 1:
         return False
-    return WINO4_WGRAD_ALL or wino4_pays(H, W, cin, cout)
+    # measured against the F(2x2) weight-gradient kernel (tools/time_wino4_wgrad.py): ahead on the large maps -- 64 -> 2688 @180^2
+    # 1.87 -> 1.65 ms, 256 -> 128 0.40 -> 0.36, 64 -> 64 @64x176 x24 0.177 -> 0.138 -- level or behind on the small ones (its
+    # transforms wait on a one-stage prefetch of dy; the F(2x2) kernel keeps two stages of raw tiles in registers)
+    return WINO4_WGRAD_ALL or (wino4_pays(H, W, cin, cout) and H * W >= 11000)
 
 
 def wino_pays(H, W, cin, cout):

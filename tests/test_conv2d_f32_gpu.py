@@ -362,6 +362,41 @@ def test_conv3x3_winograd_f4_kernel_vs_fp64(hip_lib, shape, sk):
     np.testing.assert_allclose(st[:, 1].cpu().numpy(), (ys * ys).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64, 16, 16), (2, 128, 128, 180, 180), (1, 256, 256, 90, 90), (3, 64, 192, 64, 176),
+                                   (2, 128, 64, 32, 88), (5, 256, 256, 16, 44), (1, 512, 64, 8, 22), (1, 64, 2688, 36, 28),
+                                   (1, 64, 64, 1, 1), (2, 2688, 64, 20, 12), (9, 64, 128, 64, 64), (5, 128, 64, 126, 90),
+                                   (2, 32, 64, 13, 19), (3, 96, 128, 37, 5)])
+def test_conv3x3_winograd_f4_weight_gradient_vs_fp64(hip_lib, shape):
+    """ud_conv3x3_wino4_wgrad_nhwc_f32 -- the weight gradient through the F(4x4, 3x3) form: dW against an fp64 weight gradient on
+    the F(2x2) test's shapes the kernel takes (Cin % 32 == 0, Cout % 64 == 0), odd / ragged maps (edge stages: masked patch
+    pieces, zeroed dy pixels), a one-pixel map, slice counts from 1 to 128.  Tolerance 1e-4 of max |dW| (the direct weight-gradient
+    kernels' bound; measured 2e-6 .. 2.5e-5); two runs bit-identical (ordered slice sum)."""
+    from unidistill_amd import _lib
+    from unidistill_amd.ops import conv2d_f32 as c
+    B, cin, cout, H, W = shape
+    torch.manual_seed(sum(shape))
+    x = _cl(torch.randn(B, cin, H, W, device="cuda"))
+    gy = _cl(torch.randn(B, cout, H, W, device="cuda"))
+    w = torch.randn(cout, cin, 3, 3, device="cuda")
+    old = (c.USE_WINO4_WGRAD, c.WINO4_WGRAD_ALL, c.USE_WINO4, c.USE_WINOGRAD)
+    try:
+        c.USE_WINO4_WGRAD, c.WINO4_WGRAD_ALL, c.USE_WINO4, c.USE_WINOGRAD = True, True, True, True
+        assert c.wino4_wgrad_pays(B, H, W, cin, cout)
+        _lib.prof_enable(True)
+        _lib.prof_read("conv2d.k_wgrad_wino4_f32", reset=True)
+        gw = c.weight_grad(x, gy, w, 3)
+        assert _lib.prof_read("conv2d.k_wgrad_wino4_f32")[1] == 1
+        _lib.prof_enable(False)
+        gw2 = c.weight_grad(x, gy, w, 3)
+    finally:
+        _lib.prof_enable(False)
+        c.USE_WINO4_WGRAD, c.WINO4_WGRAD_ALL, c.USE_WINO4, c.USE_WINOGRAD = old
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)
+    assert gw.shape == ref.shape
+    assert float((gw.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    assert torch.equal(gw, gw2)
+
+
 def test_winograd_filters_follow_parameter_updates_that_skip_the_version_counter(hip_lib):
     """torch's fused optimizers step parameters without moving ``_version`` (measured on torch._fused_adamw_): the transformed
     Winograd filters of a TRAINABLE weight must therefore never come from a version-keyed cache; a frozen weight's may, and
