@@ -75,6 +75,51 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
 }
 constexpr unsigned kOob = 0xFFF00000u;                // a voffset no tensor reaches (the launcher checks): reads zeros
 
+// Packed fp32 arithmetic by hand: hipcc splits about half of the f32x2 expressions of the transforms into scalar pairs (47 VALU
+// instructions per stage instead of 30), and beside fp32 MFMAs every VALU instruction costs its issue time.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));      // a: a wave-uniform coefficient pair (SGPRs)
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "s"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// c * (w.lo, w.lo) + (z.lo, z.lo) / the same on the high halves of w and z
+__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 c, f32x2 w, f32x2 z) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "s"(c), "v"(w), "v"(z));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 c, f32x2 w, f32x2 z) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(c), "v"(w), "v"(z));
+  return d;
+}
+// c * (w.hi, w.hi) + z
+__device__ __forceinline__ f32x2 pk_fma_whi(f32x2 c, f32x2 w, f32x2 z) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(c), "v"(w), "v"(z));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul_whi(f32x2 c, f32x2 w) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "s"(c), "v"(w));
+  return d;
+}
+
 // frequency order: f' = 6 * slot(i) + j for the element (row i, column j) of the 6 x 6 transform, slot = position of i in
 // (0, 5, 1, 2, 3, 4) -- the three row pairs that share their arithmetic are 12 consecutive frequencies = three 16-byte words
 __host__ __device__ constexpr int w4_slot(int i) { return i == 0 ? 0 : i == 5 ? 1 : i + 1; }
@@ -331,11 +376,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
   // 0 4 0 -5 0 1]) in six packed instructions: w = pairs (w0, w1), (w2, w3), (w4, w5) -> (v0, v5), (v1, v3), (v2, v4)
   auto row_pass = [](const f32x2 (&w)[3], f32x2 (&v)[3]) {
     const f32x2 c4 = {4.f, 4.f}, c5 = {-5.f, -5.f}, c41 = {-4.f, -1.f}, c12 = {1.f, 2.f}, cn12 = {-1.f, -2.f};
-    v[0] = __builtin_elementwise_fma(c4, w[0], __builtin_elementwise_fma(c5, w[1], w[2]));
-    const f32x2 e = __builtin_elementwise_fma(c41, (f32x2){w[1].x, w[1].x}, (f32x2){w[2].x, w[2].x});     // (w4 - 4 w2, w4 - w2)
-    const f32x2 o = __builtin_elementwise_fma(c41, (f32x2){w[0].y, w[0].y}, (f32x2){w[1].y, w[1].y});     // (w3 - 4 w1, w3 - w1)
-    v[1] = __builtin_elementwise_fma(c12, o, e);
-    v[2] = __builtin_elementwise_fma(cn12, o, e);
+    v[0] = pk_fma(c4, w[0], pk_fma(c5, w[1], w[2]));
+    const f32x2 e = pk_fma_lo(c41, w[1], w[2]);       // (w4 - 4 w2, w4 - w2)
+    const f32x2 o = pk_fma_hi(c41, w[0], w[1]);       // (w3 - 4 w1, w3 - w1)
+    v[1] = pk_fma(c12, o, e);
+    v[2] = pk_fma(cn12, o, e);
   };
   const f32x2 ca1v = {ca1, ca1}, ca2v = {ca2, ca2}, cb3v = {cb3, cb3}, cb4v = {cb4, cb4};
 
@@ -455,18 +500,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4_f32(const float* __restri
       if constexpr (TRF) {
         if constexpr (fq == 3) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) wa[k] = __builtin_elementwise_fma(ca1v, r1[k], ca2v * r2[k]);          // X
+          for (int k = 0; k < 3; ++k) wa[k] = pk_fma(ca1v, r1[k], pk_mul(ca2v, r2[k]));          // X
         }
         if constexpr (fq == 4) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) wb[k] = cb3v * r3[k];
+          for (int k = 0; k < 3; ++k) wb[k] = pk_mul(cb3v, r3[k]);
         }
         if constexpr (fq == 5) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const f32x2 yy = __builtin_elementwise_fma(cb4v, r4[k], wb[k]);                                  // Y
-            wb[k] = wa[k] - yy;
-            wa[k] = wa[k] + yy;
+            const f32x2 yy = pk_fma(cb4v, r4[k], wb[k]);                                  // Y
+            wb[k] = pk_sub(wa[k], yy);
+            wa[k] = pk_add(wa[k], yy);
           }
         }
         if constexpr (fq == 6) {
