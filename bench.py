@@ -486,12 +486,18 @@ def cpu_baseline_leg(device):
             cpu_step.step(model, batch)
             ts.append(time.perf_counter() - t0)
         return ts
+    import oracle
     prev = torch.get_num_threads()
     torch.set_num_threads(ncores)
+    os.environ["OMP_NUM_THREADS"] = str(ncores)
+    was = oracle.use_openmp(True)   # lift + voxel pooling fwd / bwd from the OpenMP build of the oracle source
     t_all = timed(10, 2)            # 2 warm-up + 10 timed iterations
+    oracle.use_openmp(False)
+    t_scalar = timed(3, 1)          # the same with the scalar checker inside (rounds 1-4's figure)
     torch.set_num_threads(1)
     t_one = timed(3, 1)             # one thread: 1 + 3 (a step takes ~7 s there; keeps the default run within minutes)
     torch.set_num_threads(prev)
+    oracle.use_openmp(was)
     # the product path on the same configuration (camera detector, 1 camera, batch 1, fp32, fwd+bwd+AdamW)
     torch.manual_seed(1234)
     tr = train.Trainer(train.DetectStep("camera"), device=device)
@@ -510,8 +516,12 @@ def cpu_baseline_leg(device):
     except Exception:
         cpu_name = "unknown"
     return {"value": 1.0 / med, "unit": "samples/s", "cores": ncores, "kind": "port",
-            "label": "port with a SCALAR oracle inside: geometry / lift / voxel pooling run as single-thread C + numpy (the "
-                     "oracle is the checker, not a tuned CPU implementation); only the torch CPU ops use all the cores",
+            "label": "port: torch CPU ops on all cores + the OpenMP build of the oracle source for the lift and voxel pooling "
+                     "forward / backward (oracle/Makefile: libud_oracle_omp.so, bit-identical to the scalar checker); the frustum "
+                     "geometry stays numpy",
+            "scalar_oracle_inside": {"value": 1.0 / sorted(t_scalar)[len(t_scalar) // 2],
+                                     "seconds_per_step": sorted(t_scalar)[len(t_scalar) // 2], "iterations": 3, "warmup": 1,
+                                     "note": "same step with the single-thread checker build inside (rounds 1-4)"},
             "sample": "BASELINE configs[0]: camera-only student, 1 camera 256x704, batch 1, random weights, "
                       "forward+backward; torch CPU ops (image branch, BEV trunk, head, target assignment, loss) + "
                       "CPU oracle (geometry, lift, voxel pooling fwd/bwd); median of 10 iterations after 2 warm-ups on the "

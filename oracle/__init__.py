@@ -18,14 +18,33 @@ _lib = None
 def build(force=False):
     """Compile ud_oracle.c with gcc (idempotent)."""
     src = os.path.join(_DIR, "ud_oracle.c")
-    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    so_omp = _SO.replace("libud_oracle.so", "libud_oracle_omp.so")
+    stale = any((not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) for so in (_SO, so_omp))
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _DIR])
     return _SO
 
 
+_SO_OMP = _SO.replace("libud_oracle.so", "libud_oracle_omp.so")
+_lib_omp = None
+_use_omp = False
+
+
+def use_openmp(on):
+    """bench.py's cpu_baseline only: route bev_pool_fwd / bev_pool_bwd / lss_lift to the OpenMP build of the same source
+    (same bits: the per-cell summation order is kept).  The checker (tests, smoke) always uses the scalar build."""
+    global _use_omp
+    prev, _use_omp = _use_omp, bool(on)
+    return prev
+
+
 def lib():
-    global _lib
+    global _lib, _lib_omp
+    if _use_omp:
+        if _lib_omp is None:
+            build()
+            _lib_omp = ctypes.CDLL(_SO_OMP)
+        return _lib_omp
     if _lib is None:
         build()
         _lib = ctypes.CDLL(_SO)
@@ -156,8 +175,20 @@ def lss_geometry(sensor2ego, intrin, ida, bda, u, v, d, voxel_coord, voxel_size,
     return geom, bins
 
 
+def lss_lift_c(depth_feature, D, C):
+    """The C twin of lss_lift (ud_oracle.c:oracle_lss_lift; OpenMP in the baseline build)."""
+    x = _f32(depth_feature)
+    BN, _, fH, fW = x.shape
+    lifted = np.empty((BN, D, fH, fW, C), np.float32)
+    prob = np.empty((BN, D, fH, fW), np.float32)
+    lib().oracle_lss_lift(_p(x, F), BN, D, C, fH, fW, _p(lifted, F), _p(prob, F))
+    return lifted, prob
+
+
 def lss_lift(depth_feature, D, C):
     """softmax(depth) (x) context, permuted to [BN, D, fH, fW, C] (lss_fpn.py:289-310)."""
+    if _use_omp:
+        return lss_lift_c(depth_feature, D, C)
     x = depth_feature.astype(np.float32)
     z = x[:, :D]
     e = np.exp(z - z.max(1, keepdims=True))

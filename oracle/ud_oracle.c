@@ -11,6 +11,9 @@
  * absent from the reference tree (voxel_pooling_ext, spconv) follow the call-site contract and
  * the published algorithm; see the per-function notes and DESIGN.md ("parity pinning").
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,6 +33,28 @@
  * ------------------------------------------------------------------------------------- */
 void oracle_bev_pool_fwd(const int32_t* geom, const float* feat, float* out, int32_t* pos, int B,
                          int N, int C, int nx, int ny, int nz) {
+#ifdef _OPENMP
+  /* OpenMP build (bench.py's cpu_baseline only; the checker is the scalar build): thread t owns the BEV rows y % T == t, walks
+   * ALL points in input order and adds those that land in its rows -- every cell still sums in ascending point order, so the
+   * result is bit-identical to the loop below. */
+#pragma omp parallel
+  {
+    const int T = omp_get_num_threads(), t = omp_get_thread_num();
+    for (int b = 0; b < B; ++b)
+      for (int n = 0; n < N; ++n) {
+        const size_t p = (size_t)b * N + n;
+        const int x = geom[p * 3 + 0], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
+        if (x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz || y % T != t) continue;
+        pos[p * 3 + 0] = b;
+        pos[p * 3 + 1] = y;
+        pos[p * 3 + 2] = x;
+        float* o = out + (((size_t)b * ny + y) * nx + x) * C;
+        const float* f = feat + p * C;
+        for (int c = 0; c < C; ++c) o[c] += f[c];
+      }
+  }
+  return;
+#endif
   for (int b = 0; b < B; ++b) {
     for (int n = 0; n < N; ++n) {
       const size_t p = (size_t)b * N + n;
@@ -45,11 +70,42 @@ void oracle_bev_pool_fwd(const int32_t* geom, const float* feat, float* out, int
   }
 }
 
+/* The lift of LSSFPN._forward_single_sweep (lss_fpn.py:289-310): prob = softmax over the D depth bins, lifted[n][d][h][w][c] =
+ * prob[n][d][h][w] * ctx[n][c][h][w].  x = depth net output [BN][D + C][fH][fW].  (numpy formulation: oracle.lss_lift; this C
+ * twin exists for the OpenMP baseline and is checked against it in tests/test_oracle_golden.py.) */
+void oracle_lss_lift(const float* x, int BN, int D, int C, int fH, int fW, float* lifted, float* prob) {
+  const size_t HW = (size_t)fH * fW;
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static)
+#endif
+  for (int n = 0; n < BN; ++n)
+    for (size_t q = 0; q < HW; ++q) {
+      const float* z = x + (size_t)n * (D + C) * HW + q;
+      float m = z[0];
+      for (int d = 1; d < D; ++d) m = z[d * HW] > m ? z[d * HW] : m;
+      float sum = 0.f;
+      float* pr = prob + (size_t)n * D * HW + q;
+      for (int d = 0; d < D; ++d) {
+        pr[d * HW] = expf(z[d * HW] - m);
+        sum += pr[d * HW];
+      }
+      for (int d = 0; d < D; ++d) {
+        pr[d * HW] = pr[d * HW] / sum;
+        float* o = lifted + (((size_t)n * D + d) * HW + q) * C;
+        const float pv = pr[d * HW];
+        for (int c = 0; c < C; ++c) o[c] = pv * z[(size_t)(D + c) * HW];
+      }
+    }
+}
+
 /* BEV pool backward.  Reference: lss_fpn.py:64-79 (VoxelPooling.backward):
  * grad_feat[kept] = grad_out[b, :, y, x]; zero elsewhere.  gout is NCHW [B, C, ny, nx]. */
 void oracle_bev_pool_bwd(const float* gout_nchw, const int32_t* pos, float* gfeat, int B, int N,
                          int C, int nx, int ny) {
   memset(gfeat, 0, (size_t)B * N * C * sizeof(float));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (size_t p = 0; p < (size_t)B * N; ++p) {
     const int b = pos[p * 3 + 0], y = pos[p * 3 + 1], x = pos[p * 3 + 2];
     if (b == -1) continue;

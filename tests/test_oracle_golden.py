@@ -146,3 +146,30 @@ def test_collate_oracle_matches_reference_golden(golden):
     g = golden("collate")
     for k in ("imgs", "points", "gt_boxes", "gt_labels"):
         np.testing.assert_array_equal(oracle.collate_fill([g[f"in{i}_{k}"] for i in range(3)]), g["out_" + k])
+
+
+def test_openmp_build_of_the_oracle_equals_the_scalar_checker():
+    """bench.py's cpu_baseline runs bev_pool forward / backward and the lift from the OpenMP build of oracle/ud_oracle.c
+    (oracle.use_openmp): same bits as the scalar checker (rows are owned by threads, every cell still sums in point order); the
+    C lift equals the numpy formulation."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(3)
+    B, N, C, nx, ny = 2, 5000, 16, 12, 10
+    geom = np.stack([rng.integers(-2, nx + 2, (B, N)), rng.integers(-2, ny + 2, (B, N)), rng.integers(0, 2, (B, N))], -1).astype(np.int32)
+    feat = rng.standard_normal((B, N, C)).astype(np.float32)
+    out0, pos0 = oracle.bev_pool_fwd(geom, feat, nx, ny, 1)
+    g = rng.standard_normal((B, C, ny, nx)).astype(np.float32)
+    gf0 = oracle.bev_pool_bwd(g, pos0)
+    x = rng.standard_normal((3, 7 + 5, 4, 6)).astype(np.float32)
+    l0, p0 = oracle.lss_lift(x, 7, 5)
+    prev = oracle.use_openmp(True)
+    try:
+        out1, pos1 = oracle.bev_pool_fwd(geom, feat, nx, ny, 1)
+        gf1 = oracle.bev_pool_bwd(g, pos1)
+        l1, p1 = oracle.lss_lift(x, 7, 5)
+    finally:
+        oracle.use_openmp(prev)
+    assert np.array_equal(out0, out1) and np.array_equal(pos0, pos1) and np.array_equal(gf0, gf1)
+    np.testing.assert_allclose(l1, l0, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(p1, p0, rtol=2e-6, atol=1e-7)
