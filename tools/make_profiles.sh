@@ -4,7 +4,7 @@
 # bench.py reads for its `traffic` figures.
 #   gpurun --timeout 2400 -- 'bash tools/make_profiles.sh r04'
 set -u
-R=${1:-r04}
+R=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -15,7 +15,7 @@ DB=$(ls /tmp/p_bench/*/*.db | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo; echo "The JSON line below was measured UNDER the tracer (about 8 us added per launch, ~2 000 launches per step: ms_per_step is ~15 ms above the un-instrumented run that bench.py / the driver reports); it is kept for the kernel table's context, not as the result."; echo;
   echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt | cut -c1-3000; echo '```'; echo;
   echo "## Roofline kernels of the bench legs (rocprofv3 durations; bench.py's own HIP-event figures are in the JSON above)"; echo;
-  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_vp_|k_scan|k_gather|k_bin|k_cell|k_fill|k_conv_f32_taps|k_conv3x3_wino_f32|k_wino_wgrad|k_conv3x3_taps|k_conv_mfma_v2|k_conv_dma_f32|k_conv3x3_wgrad_f32|k_conv1x1_wgrad_f32";
+  python $T/rocpd_summary.py $DB | grep -E "^\| kernel|^\|---|k_pool<4|k_vp_|k_scan|k_gather|k_bin|k_cell|k_fill|k_conv_f32_taps|k_conv3x3_wino4_f32|k_wino4_fixup|k_wino4_wgrad|k_conv3x3_wino_f32|k_wino_wgrad|k_insert2|k_first_assign|k_gather_clean|k_conv3x3_taps|k_conv_mfma_v2|k_conv_dma_f32|k_conv3x3_wgrad_f32|k_conv1x1_wgrad_f32";
   echo; echo "## Kernels by total time, naive_conv / find-mode kernels excluded"; echo;
   python $T/rocpd_summary.py $DB | grep -v "naive_conv\|MIOpenConvUni\|Im2d2Col\|Col2Im" | head -45; } > $OUT/${R}_bench_kernel_stats.md
 # 2. steady-state training step by category (marker-delimited window): fp32 (headline) and bf16
@@ -26,9 +26,9 @@ for AC in "" bf16; do
     TOP=30 python $T/rocpd_categories.py $(ls /tmp/p_step/*/*.db | head -1) 6 --top | cut -c1-180; } > $OUT/${R}_step_categories_$TAG.md
 done
 # 3. bev_pool / voxelize / dense() op level + the streaming reference points
-{ echo "# bev_pool + voxelize + dense() op-level timings ($R)"; echo; echo '```'; python $T/time_bev_pool.py 2>&1 | tail -4; echo "-- voxelize, algo 0 (hash partition + LDS):"; python $T/time_voxelize.py 2>&1 | tail -12; echo "-- voxelize, algo 1 (atomic hash):"; ALGO=1 python $T/time_voxelize.py 2>&1 | tail -12; python $T/time_dense.py 2>&1 | tail -2; python $T/time_stream.py 2>&1 | tail -5; echo "-- device-scope atomics vs plain accesses (tools/atomic_rate.hip):"; hipcc --offload-arch=gfx950 -O3 $T/atomic_rate.hip -o /tmp/atomic_rate 2>/dev/null && /tmp/atomic_rate; echo '```'; } > $OUT/${R}_bevpool_voxelize_ops.md
+{ echo "# bev_pool + voxelize + dense() op-level timings ($R)"; echo; echo '```'; python $T/time_bev_pool.py 2>&1 | tail -4; echo "-- voxelize, algo 0 (hash partition + LDS):"; python $T/time_voxelize.py 2>&1 | tail -16; echo "-- voxelize, algo 1 (atomic hash):"; ALGO=1 python $T/time_voxelize.py 2>&1 | tail -16; echo "-- voxelize, algo 3 (atomic hash in three launches, self-cleaning workspace; clouds of at most 256 tiles):"; ALGO=3 python $T/time_voxelize.py 2>&1 | grep -A1 "^B="; python $T/time_dense.py 2>&1 | tail -2; python $T/time_stream.py 2>&1 | tail -5; echo "-- device-scope atomics vs plain accesses (tools/atomic_rate.hip):"; hipcc --offload-arch=gfx950 -O3 $T/atomic_rate.hip -o /tmp/atomic_rate 2>/dev/null && /tmp/atomic_rate; echo '```'; } > $OUT/${R}_bevpool_voxelize_ops.md
 rm -rf /tmp/p_vox; rocprofv3 --kernel-trace --stats -d /tmp/p_vox -- python $T/time_voxelize.py > /dev/null 2>&1
-{ echo; echo "## voxelize kernels (algo 0; all six configurations of tools/time_voxelize.py pooled; rocprofv3 kernel durations)"; echo; python $T/rocpd_summary.py $(ls /tmp/p_vox/*/*.db | head -1) namespace; } >> $OUT/${R}_bevpool_voxelize_ops.md
+{ echo; echo "## voxelize kernels (algo 0; all eight configurations of tools/time_voxelize.py pooled; rocprofv3 kernel durations)"; echo; python $T/rocpd_summary.py $(ls /tmp/p_vox/*/*.db | head -1) namespace; } >> $OUT/${R}_bevpool_voxelize_ops.md
 # 4. HBM traffic of the dominant kernels (separate --pmc passes, as MI355X_MICROARCH.md prescribes)
 rm -rf /tmp/pmc1 /tmp/pmc2
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc1 -- python $T/pmc_pool.py > /dev/null 2>&1
@@ -39,7 +39,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc2 -- python $T/pmc_pool.py 
 rm -rf /tmp/pmc3 /tmp/pmc4
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc3 -- python $T/time_voxelize.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc4 -- python $T/time_voxelize.py > /dev/null 2>&1
-{ echo "# HBM traffic of the voxelize kernels (algo 0) from PMC counters ($R; all six configurations of tools/time_voxelize.py pooled; KB)"; echo; echo '```';
+{ echo "# HBM traffic of the voxelize kernels (algo 0) from PMC counters ($R; all eight configurations of tools/time_voxelize.py pooled; KB)"; echo; echo '```';
   for k in k_vp_partition k_vp_bucket k_vp_flags k_scan k_vp_rows k_gather; do python $T/rocpd_pmc.py $(ls /tmp/pmc3/*/*.db | head -1) $k | tail -1; python $T/rocpd_pmc.py $(ls /tmp/pmc4/*/*.db | head -1) $k | tail -1; done; echo '```'; } > $OUT/${R}_pmc_voxelize.md
 rm -rf /tmp/pmc5 /tmp/pmc6
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc5 -- python $T/pmc_conv3x3.py > /dev/null 2>&1
@@ -53,6 +53,8 @@ python $T/traffic_json.py $R $(ls /tmp/pmc1/*/*.db | head -1) $(ls /tmp/pmc2/*/*
 # 6. sparse encoder
 rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T/time_spconv.py > $OUT/spconv_stdout.txt 2>&1
 { echo "# LiDAR sparse encoder forward, B=4 x 30k points ($R)"; echo; echo '```'; grep "encoder fwd" $OUT/spconv_stdout.txt; echo '```'; echo; python $T/rocpd_summary.py $(ls /tmp/p_sp/*/*.db | head -1) namespace | head -30; } > $OUT/${R}_spconv_encoder.md
+# 6b. Winograd F(4x4,3x3): per-shape table (forward / data gradient, weight gradient) and the SQ counters of the forward kernel
+{ echo "# Winograd F(4x4,3x3) fp32 kernels vs F(2x2,3x3) and the direct fp32 MFMA kernel ($R)"; echo; echo "Forward launches at the 3x3 shapes of the distillation step (tools/time_wino4.py; err = max |y - fp64| / max |fp64|; F4 with its stream-K tail):"; echo; echo '```'; python $T/time_wino4.py 2>&1 | grep "^3x3"; echo '```'; echo; echo "Weight gradient (tools/time_wino4_wgrad.py):"; echo; echo '```'; python $T/time_wino4_wgrad.py 2>&1 | grep "^wgrad"; echo '```'; echo; echo "SQ counters of k_conv3x3_wino4_f32 at 128 -> 128 @180^2 x 4 (tools/pmc_kernel.sh; sums over the chip, *_CYCLES of waves in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles):"; echo; echo '```'; bash $T/pmc_kernel.sh k_conv3x3_wino4_f32 python $T/pmc_wino4.py 2>&1 | sed "s/void (anonymous namespace):://" | cut -c1-40,100-170; echo '```'; } > $OUT/${R}_conv_f32_wino4.md
 # 7. fp32 convolutions: ours vs library (forward / data gradient, and the weight gradients of one step)
-{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels (direct and Winograd F(2x2,3x3)) vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py; 3x3: Winograd form, last column = the direct kernel):"; python $T/time_f32_wgrad.py 2>&1 | tail -22; echo; echo "-- plain 1x1 launches of one step (tools/time_f32_1x1.py):"; python $T/time_f32_1x1.py 2>&1 | grep -E "kind|line|total"; echo; echo "-- frozen ResNet stem, 24 x 256 x 704 (tools/time_stem.py):"; python $T/time_stem.py 2>&1 | grep "us "; echo '```'; } > $OUT/${R}_conv_f32.md
+{ echo "# fp32 convolutions: hand-written fp32 MFMA kernels (direct and Winograd: the launcher's routing) vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py; 3x3: Winograd form, last column = the direct kernel):"; python $T/time_f32_wgrad.py 2>&1 | tail -22; echo; echo "-- plain 1x1 launches of one step (tools/time_f32_1x1.py):"; python $T/time_f32_1x1.py 2>&1 | grep -E "kind|line|total"; echo; echo "-- frozen ResNet stem, 24 x 256 x 704 (tools/time_stem.py):"; python $T/time_stem.py 2>&1 | grep "us "; echo '```'; } > $OUT/${R}_conv_f32.md
 ls -la $OUT
