@@ -500,7 +500,7 @@ def cpu_baseline_leg(device):
     oracle.use_openmp(was)
     # the product path on the same configuration (camera detector, 1 camera, batch 1, fp32, fwd+bwd+AdamW)
     torch.manual_seed(1234)
-    tr = train.Trainer(train.DetectStep("camera"), device=device)
+    tr = train.Trainer(train.DetectStep("camera"), device=device, channels_last=True)
     gb = train.synthetic_batch(device, 1, ncam=1, with_points=False)
     for _ in range(3):
         tr.step(gb)
