@@ -17,6 +17,8 @@
 // the nine shifted GEMMs: per 4-pixel step a wave issues 1 + 9 LDS reads for 36 MFMAs (1 152 MFMA cycles) -- the kernel
 // is MFMA-bound by construction.  LDS is double-buffered (2 x 77 KB), one workgroup per CU.
 #include "ud_common.h"
+#include <cstdlib>
+#include <utility>
 #include "ud_prof.h"
 #include "conv_pixmap.h"
 #include "wgrad_sum.h"
@@ -36,10 +38,25 @@ struct WgTile {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16w[4];
+constexpr unsigned kOobW = 0xFFF00000u;     // a buffer offset no tensor reaches (the launchers check): reads zeros
+
+template <class F, int... Is>
+__device__ __forceinline__ void wg_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  wg_static_for_impl(std::forward<F>(f), std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ void dma16(const float* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// (a __device__ wrapper: the builtin called directly in a kernel template makes hipcc 7.2 drop the kernel's host stub)
+__device__ __forceinline__ void dma16b(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(size_t)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
 struct WgGeom {
@@ -190,7 +207,11 @@ int wg3_slices(int B, int H, int W, int Cin, int Cout, int* tiles_per_slice) {
 // three workgroups per CU), wave w owns NT / 4 dy channels x 64 x channels.  These layers have few channels (64 <-> 256
 // ...), i.e. 21-32 flops per byte streamed: the kernel runs at the HBM / L2 rate as much as at the MFMA rate.
 constexpr int kPS = 32;                          // pixels per step
-template <int NT>
+// PLAIN (both operands plain [P][C] rows, tensors < 4 GB -- the ResNet / FPN 1x1 layers, most launches of a step): staged through
+// buffer descriptors whose base moves with the pixel step, so a lane's offsets are fixed for the whole slice (no address
+// arithmetic per piece: that was ~90 VALU instructions per 64 MFMAs, and on this chip every issued instruction is paid for in
+// MFMA issue time) and rows past the last pixel read zeros through the range check.
+template <int NT, bool PLAIN>
 __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ partial, long long P, int Cin, int Cout,
                                                            int c_tiles, int steps_per_slice, PixMap xmap, PixMap ymap) {
@@ -215,6 +236,34 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[i][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // PLAIN: the lane's fixed byte offsets within a 32-pixel step (kOobW: a channel past the end -> zeros)
+  constexpr int kDP = kPS / kDRowsPer / 4, kXP = kPS / 4 / 4;       // dy / x pieces per wave and step
+  unsigned vd[kDP], vx[kXP];
+  if (PLAIN) {
+#pragma unroll
+    for (int k = 0; k < kDP; ++k) {
+      const int piece = wave + 4 * k, r = piece * kDRowsPer + lane / kDSlots, slot = lane % kDSlots;
+      const int n = n0 + 4 * (slot ^ ((r & 1) << 2));
+      vd[k] = n < Cout ? (unsigned)(r * Cout + n) * 4u : kOobW;
+    }
+#pragma unroll
+    for (int k = 0; k < kXP; ++k) {
+      const int r = (wave + 4 * k) * 4 + g, c = c0 + 4 * li;
+      vx[k] = c < Cin ? (unsigned)(r * Cin + c) * 4u : kOobW;
+    }
+  }
+#define UD_WG_STAGE_PLAIN(STEP, BUF)                                                                                          \
+  do {                                                                                                                        \
+    const long long p0_ = (long long)(STEP) * kPS;                                                                            \
+    const unsigned lb = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (BUF) * kBuf) + wave * 1024;        \
+    const unsigned long long left = (unsigned long long)(P - p0_); /* > 0: the step exists */                                 \
+    const __amdgpu_buffer_rsrc_t rd =                                                                                         \
+        __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p0_ * Cout), 0, (int)(unsigned)(left * Cout * 4), 0x00020000);          \
+    const __amdgpu_buffer_rsrc_t rxs =                                                                                        \
+        __builtin_amdgcn_make_buffer_rsrc((void*)(x + p0_ * Cin), 0, (int)(unsigned)(left * Cin * 4), 0x00020000);            \
+    _Pragma("unroll") for (int k = 0; k < kDP; ++k) dma16b(rd, vd[k], lb + k * 4096);                                         \
+    _Pragma("unroll") for (int k = 0; k < kXP; ++k) dma16b(rxs, vx[k], lb + kDTile + k * 4096);                               \
+  } while (0)
   auto stage = [&](int step, int buf) {
     char* sb = smem + buf * kBuf;
     const long long p0 = (long long)step * kPS;
@@ -246,36 +295,42 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
   unsigned pb = lds0 + kDTile + g * kRowB + li * 16;
   float fa[2][TI];
   f32x4 fb[2];
-  auto loads = [&](int b2, int ks) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[b2]) : "v"(pb + 4 * ks * kRowB) : "memory");
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
-      asm volatile("ds_read_b32 %0, %1" : "=v"(fa[b2][ti]) : "v"(pa[ti] + 4 * ks * kDRow) : "memory");
-  };
+  // (macros, not generic lambdas: with the step offset as an asm immediate hipcc 7.2 loses the host stub of a kernel whose body
+  // holds a generic lambda around it)
+#define UD_WG_LOADS(B2, KS)                                                                                          \
+  do {                                                                                                               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[B2]) : "v"(pb), "n"(4 * (KS) * kRowB) : "memory");       \
+    _Pragma("unroll") for (int ti = 0; ti < TI; ++ti)                                                                \
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[B2][ti]) : "v"(pa[ti]), "n"(4 * (KS) * kDRow) : "memory"); \
+  } while (0)
+#define UD_WG_STEP(KS)                                                                                               \
+  do {                                                                                                               \
+    constexpr int cur = (KS) & 1;                                                                                    \
+    if constexpr ((KS) + 1 < kPS / 4) {                                                                              \
+      UD_WG_LOADS(cur ^ 1, ((KS) + 1) % (kPS / 4));                                                                  \
+      if (TI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));    \
+      else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[cur]), "+v"(fa[cur][0]));                                   \
+    } else {                                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));                 \
+    }                                                                                                                \
+    _Pragma("unroll") for (int ti = 0; ti < TI; ++ti)                                                                \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
+        acc[ti][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][ti], fb[cur][e], acc[ti][e], 0, 0, 0);            \
+  } while (0)
+  static_assert(kPS / 4 == 8, "eight 4-pixel steps per staged step");
 
-  if (s_begin < s_end) stage(s_begin, 0);
+  if (s_begin < s_end) {
+    if (PLAIN) UD_WG_STAGE_PLAIN(s_begin, 0); else stage(s_begin, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
   for (int step = s_begin; step < s_end; ++step) {
-    if (step + 1 < s_end) stage(step + 1, buf ^ 1);
-    loads(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < kPS / 4; ++ks) {
-      const int cur = ks & 1;
-      if (ks + 1 < kPS / 4) {
-        loads(cur ^ 1, ks + 1);
-        if (TI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));
-        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[cur]), "+v"(fa[cur][0]));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));
-      }
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[ti][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][ti], fb[cur][e], acc[ti][e], 0, 0, 0);
+    if (step + 1 < s_end) {
+      if (PLAIN) UD_WG_STAGE_PLAIN(step + 1, buf ^ 1); else stage(step + 1, buf ^ 1);
     }
+    UD_WG_LOADS(0, 0);
+    UD_WG_STEP(0); UD_WG_STEP(1); UD_WG_STEP(2); UD_WG_STEP(3); UD_WG_STEP(4); UD_WG_STEP(5); UD_WG_STEP(6); UD_WG_STEP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();            // the next step has landed; everybody is done reading this one
     const unsigned d = buf ? (unsigned)-kBuf : (unsigned)kBuf;
@@ -284,6 +339,9 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
     pb += d;
     buf ^= 1;
   }
+#undef UD_WG_STEP
+#undef UD_WG_LOADS
+#undef UD_WG_STAGE_PLAIN
   const int c = c0 + 4 * li;
   if (c < Cin) {
 #pragma unroll
@@ -381,12 +439,17 @@ extern "C" int ud_conv1x1_wgrad_mapped_nhwc_f32(const float* x, const float* dy,
   {
     UdProfScope prof("conv2d.k_wgrad_1x1_f32", stream);
     const dim3 grid(pl.slices, pl.n_tiles * pl.c_tiles);
-    if (pl.nt == 128)
-      k_conv1x1_wgrad_f32<128><<<grid, 256, 2 * kPS * (512 + 256), stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
-                                                                            pl.steps_per_slice, xm, ym);
-    else
-      k_conv1x1_wgrad_f32<64><<<grid, 256, 2 * kPS * (256 + 256), stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles,
-                                                                           pl.steps_per_slice, xm, ym);
+    static const int no_plain = getenv("UD_F32_WGRAD_PLAIN") ? !atoi(getenv("UD_F32_WGRAD_PLAIN")) : 0;
+    const bool plain = !no_plain && xm.mode == 0 && ym.mode == 0 && (size_t)P * Cin * 4 < (size_t)kOobW &&
+                       (size_t)P * Cout * 4 < (size_t)kOobW;
+#define UD_WG1(NTv, PL, LDSB) \
+  k_conv1x1_wgrad_f32<NTv, PL><<<grid, 256, LDSB, stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles, pl.steps_per_slice, xm, ym)
+    if (pl.nt == 128) {
+      if (plain) UD_WG1(128, true, 2 * kPS * (512 + 256)); else UD_WG1(128, false, 2 * kPS * (512 + 256));
+    } else {
+      if (plain) UD_WG1(64, true, 2 * kPS * (256 + 256)); else UD_WG1(64, false, 2 * kPS * (256 + 256));
+    }
+#undef UD_WG1
     UD_LAUNCH_CHECK();
   }
   return ud_wgrad_sum(partial, pl.slices, (size_t)Cout * Cin, dw, stream);

@@ -547,6 +547,21 @@ int ud_conv1x1_mapped_nhwc_bf16(const void* x, const void* w, void* y, int64_t P
  * mode on v_mfma_f32_16x16x4_f32; map channels % 4 == 0, Cin % 32 == 0, Cout % 4 == 0, a 32-channel slice inside one tap. */
 int ud_conv1x1_mapped_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout,
                                const int* in_map, const int* out_map, ud_stream_t stream);
+/* Persistent form of the fp32 1x1 family (plain and mapped, csrc/conv2d_f32_1x1p.hip; the same layers as ud_conv1x1_nhwc_f32 /
+ * ud_conv1x1_mapped_nhwc_f32): 512 resident workgroups walk (128-pixel tile, 64-channel block) units data parallel + a stream-K
+ * tail of 32-channel slices (pieces of a cut unit are summed in slice order by a fix-up launch: deterministic), slices flowing
+ * through a three-stage LDS ring two ahead of the MFMAs, epilogue (bias, folded BN, residual, ReLU if flags & 1) from registers.
+ * partial != NULL: BatchNorm partial sums [*slices = ceil(P / 128)][Cout][2] (ud_conv1x1_bnstats_bytes).  in_map / out_map as in
+ * ud_conv1x1_mapped_nhwc_f32 (NULL = plain; mapped launches take no epilogue inputs); x_elems = elements of the mapped input
+ * tensor, y_elems of the mapped output tensor (ignored for plain sides).  workspace (ud_conv1x1p_f32_workspace_bytes) enables the stream-K tail.  Tensors < 4 GB.
+ * ud_conv1x1_f32_persistent(mode): -1 default (UD_F32_1X1P or 1), 0 = callers use the grid-per-tile kernels, 1 = this one. */
+size_t ud_conv1x1p_f32_workspace_bytes(void);
+void ud_conv1x1_f32_persistent(int mode);
+int ud_conv1x1_f32_persistent_enabled(void);
+int ud_conv1x1p_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout, const float* bias,
+                         const float* scale, const float* shift, const float* residual, int flags, float* partial,
+                         size_t partial_bytes, int* slices, const int* in_map, const int* out_map, size_t x_elems,
+                         size_t y_elems, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, float* dw, int64_t P, int Cin, int Cout,
                                       const int* x_map, const int* dy_map, void* workspace,
                                       size_t workspace_bytes, ud_stream_t stream);
