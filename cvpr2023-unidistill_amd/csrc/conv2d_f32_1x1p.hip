@@ -23,6 +23,7 @@
 #include "ud_common.h"
 #include "ud_prof.h"
 #include "conv_pixmap.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -551,22 +552,34 @@ __global__ __launch_bounds__(256) void k_conv1x1p_fixup(float* __restrict__ y, P
   }
 }
 
+std::atomic<int> g_p_sk{-1};        // ud_conv1x1p_stream_k: -1 default (UD_F32_1X1P_SK or 1: where the cost model says so), 0 never, 2 whenever a tail can be cut
 std::atomic<int> g_p_mode{-1};      // ud_conv1x1_f32_persistent: -1 default (UD_F32_1X1P or 1), 0 grid-per-tile kernels, 1 persistent
 
 struct PSched {
   int grid, n_dp, sk_len;
 };
-// Whole rounds data parallel + a stream-K tail where that beats one more, partly filled, round.  A piece costs about two slices
-// of fill / drain; a cut unit a fix-up pass.
+// Whole rounds data parallel + a stream-K tail where that beats one more, partly filled, round.  The tail's slices are cut into
+// ranges of >= 4 slices and a unit into <= 8 pieces (a piece costs a fill / drain and a 32 KB partial tile; the fix-up pass reads
+// every piece); ranges go to workgroups in launch order, i.e. one per CU while there are fewer than 256.  Both tails are priced
+// with the measured slice times (tools/_exp/p1: 2.3 us per slice for the two workgroups of a CU together, 1.25 us for one alone)
+// and the fix-up pass at 6 us + its bytes at 3 TB/s.
 PSched p_schedule(long long units, int nchunks, bool have_ws) {
-  static const int env_sk = getenv("UD_F32_1X1P_SK") ? atoi(getenv("UD_F32_1X1P_SK")) : 1;
+  static const int env_mode = getenv("UD_F32_1X1P_SK") ? atoi(getenv("UD_F32_1X1P_SK")) : 1;
+  const int forced = g_p_sk.load(std::memory_order_relaxed);
+  const int env_sk = forced >= 0 ? forced : env_mode;
   const int G = kGridP;
   PSched sc{G, (int)units, 0};
   if (units <= 0) return sc;
   const int r = (int)(units % G);
-  if (r == 0 || !have_ws || !env_sk || nchunks < 4) return sc;
-  const int len = (int)(((long long)r * nchunks + G - 1) / G);
-  if (len + 3 >= nchunks) return sc;       // the tail is nearly a whole round anyway
+  if (r == 0 || !have_ws || !env_sk || nchunks < 8) return sc;
+  int len = (int)(((long long)r * nchunks + G - 1) / G);
+  len = std::max(len, std::max(4, (nchunks + 7) / 8));
+  if (len >= nchunks) return sc;
+  const long long pieces = ((long long)r * nchunks + len - 1) / len;
+  const double t_dp = nchunks * (r <= G / 2 ? 1.25 : 2.3);
+  const int fan = (nchunks + len - 1) / len + 1;
+  const double t_sk = len * (pieces <= G / 2 ? 1.25 : 2.3) + 6.0 + (double)r * (fan + 1) * 32768.0 / 3.0e6;
+  if (env_sk < 2 && t_sk >= t_dp) return sc;
   sc.n_dp = (int)(units - r), sc.sk_len = len;
   return sc;
 }
@@ -574,6 +587,7 @@ PSched p_schedule(long long units, int nchunks, bool have_ws) {
 }  // namespace
 
 extern "C" void ud_conv1x1_f32_persistent(int mode) { g_p_mode.store(mode, std::memory_order_relaxed); }
+extern "C" void ud_conv1x1p_stream_k(int mode) { g_p_sk.store(mode, std::memory_order_relaxed); }
 
 extern "C" int ud_conv1x1_f32_persistent_enabled(void) {
   static const int env_mode = getenv("UD_F32_1X1P") ? atoi(getenv("UD_F32_1X1P")) : 1;

@@ -108,6 +108,7 @@ _SIGS = {
     "ud_conv1x1_mapped_nhwc_f32": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 3),
     "ud_conv1x1p_f32_workspace_bytes": (c_size_t, []),
     "ud_conv1x1_f32_persistent": (None, [c_int]),
+    "ud_conv1x1p_stream_k": (None, [c_int]),
     "ud_conv1x1_f32_persistent_enabled": (c_int, []),
     "ud_conv1x1p_nhwc_f32": (c_int, [c_void_p] * 3 + [c_i64, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_void_p]
                              + [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p]),

@@ -162,11 +162,40 @@ def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False,
 LOG_1X1 = None           # set to [] to record ("line", P, Cin, Cout) of every plain 1x1 launch (tools/time_f32_1x1.py)
 
 
+# Reductions of at least this many channels go to the persistent stream-K kernel (csrc/conv2d_f32_1x1p.hip): measured per shape of
+# one distillation step (tools/time_1x1p.py) it wins from 12 slices of 32 channels on (16 896 x 1024 -> 256: 114 -> 89 us,
+# 4 224 x 2048 -> 512: 142 -> 89 us) and loses below (270 336 x 64 -> 256: 115 vs 130 us: a unit is two slices there)
+P1X1_MIN_K = int(os.environ.get("UD_F32_1X1P_MIN_K", "384"))
+
+
+def persistent_1x1(K):
+    return K >= P1X1_MIN_K and _lib.load().ud_conv1x1_f32_persistent_enabled() == 1
+
+
+def launch_1x1p(x, w, y, P, K, N, bias=None, residual=None, part=None, imap=None, omap=None):
+    """ud_conv1x1p_nhwc_f32 on torch tensors; -> number of BatchNorm partial rows (0 without `part`)."""
+    lib = _lib.load()
+    ws = _lib.workspace(x.device, lib.ud_conv1x1p_f32_workspace_bytes(), "conv_1x1p")
+    ns = ctypes.c_int(0)
+    _lib.check(lib.ud_conv1x1p_nhwc_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), P, K, N, _lib.ptr(bias), None, None,
+                                        _lib.ptr(residual), 0, _lib.ptr(part), part.numel() * 4 if part is not None else 0,
+                                        ctypes.addressof(ns), imap, omap, x.numel(), y.numel(), _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_of(x)), "ud_conv1x1p_nhwc_f32")
+    return ns.value
+
+
 def _launch1(x, w, cout, bias=None, residual=None, bn_stats=False):
     B, cin, H, W = x.shape
     if LOG_1X1 is not None:
         LOG_1X1.append(("line", B * H * W, cin, cout, None, None))
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if persistent_1x1(cin) and x.numel() < (1 << 30) - (1 << 18) and y.numel() < (1 << 30) - (1 << 18):
+        if bn_stats:
+            part, _ = _bn_partial(_lib.load().ud_conv1x1_bnstats_bytes(B * H * W, cout), x.device)
+            ns = launch_1x1p(x, w, y, B * H * W, cin, cout, bias=bias, part=part)
+            return y, (part, ns, B * H * W)
+        launch_1x1p(x, w, y, B * H * W, cin, cout, bias=bias, residual=residual)
+        return y
     if bn_stats:
         lib = _lib.load()
         part, ns = _bn_partial(lib.ud_conv1x1_bnstats_bytes(B * H * W, cout), x.device)

@@ -557,6 +557,7 @@ int ud_conv1x1_mapped_nhwc_f32(const float* x, const float* w, float* y, int64_t
  * ud_conv1x1_f32_persistent(mode): -1 default (UD_F32_1X1P or 1), 0 = callers use the grid-per-tile kernels, 1 = this one. */
 size_t ud_conv1x1p_f32_workspace_bytes(void);
 void ud_conv1x1_f32_persistent(int mode);
+void ud_conv1x1p_stream_k(int mode);   /* tests / tuning: -1 default (the launcher's cost model), 0 whole units only, 2 cut every tail that can be cut */
 int ud_conv1x1_f32_persistent_enabled(void);
 int ud_conv1x1p_nhwc_f32(const float* x, const float* w, float* y, int64_t P, int Cin, int Cout, const float* bias,
                          const float* scale, const float* shift, const float* residual, int flags, float* partial,
