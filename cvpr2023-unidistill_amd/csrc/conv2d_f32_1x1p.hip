@@ -485,6 +485,157 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
 #undef UD_P_RD
 }
 
+// Short reductions (fewer than kShortK slices: the 64 / 128 / 256-channel ResNet layers over 67 k - 270 k pixels) -- a unit is a
+// few hundred MFMAs, so what a workgroup spends around them decides: one workgroup per (pixel tile, 64-channel block) with no
+// schedule to walk, two LDS stages (three workgroups per CU cover each other's fill), and the same epilogue from registers
+// as above (the grid-per-tile kernel of conv2d_f32.hip stages its tile through LDS: ~1 300 instructions per wave against the
+// 128 - 512 MFMAs of such a unit).  Plain input and output only.
+constexpr int kShortK = 12;
+constexpr int kSmemT = 2 * kStage + 4 * 64 * 2 * 4;
+__global__ __launch_bounds__(256, 3) void k_conv1x1t_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, PGeom gm, PEp ep, unsigned x_bytes,
+                                                         unsigned w_bytes, unsigned y_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned sbase = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int r8 = lane >> 3, slot8 = lane & 7;
+  const int ntiles = (int)((gm.npix + kTM - 1) / kTM), per = (ntiles + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // an XCD walks consecutive pixel tiles
+  if (tile >= ntiles) return;
+  const int ng = blockIdx.y, n0 = ng * kTN;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(ep.residual ? ep.residual : y), 0, (int)y_bytes, 0x00020000);
+  const unsigned sw4 = (unsigned)((slot8 ^ r8) << 4);
+  unsigned xv[4], wv[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)          // rows past P lie past the descriptor's end: zeros
+    xv[i] = ((unsigned)tile * kTM + (wave + 4 * i) * 8 + r8) * (unsigned)gm.Cin * 4u + sw4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)          // channels past Cout re-read the last one (never stored)
+    wv[j] = (unsigned)min(n0 + (wave + 4 * j) * 8 + r8, gm.Cout - 1) * (unsigned)gm.Cin * 4u + sw4;
+  const unsigned lb = sbase + wave * 1024;
+  auto stage = [&](int c, int buf) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)c * (kKC * 4), xb = lb + buf * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(rx, xv[i], so, xb + i * 4096);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(rw, wv[j], so, xb + kXBytes + j * 4096);
+  };
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned fwo[2], fxo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const unsigned piece = (unsigned)(((4 * ks + g) ^ (li & 7)) << 4);
+    fwo[ks] = kXBytes + li * 128 + piece;
+    fxo[ks] = (32 * wave + li) * 128 + piece;
+  }
+  auto mma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 wf[4], xf[2];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) wf[ci] = *reinterpret_cast<const f32x4*>(smem + fwo[ks] + buf * kStage + ci * 2048);
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) xf[pj] = *reinterpret_cast<const f32x4*>(smem + fxo[ks] + buf * kStage + pj * 2048);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+          for (int pj = 0; pj < 2; ++pj)
+            acc[ci][pj] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ci][e], xf[pj][e], acc[ci][pj], 0, 0, 0);
+    }
+  };
+  // output offsets of the lane's 4 x 2 pieces (kOob, or a row past P on the fast path: not stored) and the residual, requested
+  // before the multiplications it hides under
+  unsigned ov[4][2];
+  {
+    const unsigned p0 = (unsigned)tile * kTM + 32 * wave + li;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const int n = n0 + 16 * ci + 4 * g;
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj)
+        ov[ci][pj] = (n >= gm.Cout || (long long)(p0 + 16 * pj) >= gm.npix) ? kOob : ((p0 + 16 * pj) * (unsigned)gm.Cout + n) * 4u;
+    }
+  }
+  u32x4 rres[4][2];
+  if (ep.residual) {
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) rres[ci][pj] = __builtin_amdgcn_raw_buffer_load_b128(rr, ov[ci][pj], 0, 0);
+  }
+  const int nchunks = gm.nchunks;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nchunks; c += 2) {
+    if (c + 1 < nchunks) stage(c + 1, 1);
+    mma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c + 1 < nchunks) {
+      if (c + 2 < nchunks) stage(c + 2, 0);
+      mma(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  float s1[16], s2[16];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) {
+    const int n = min(n0 + 16 * ci + 4 * g, gm.Cout - 4);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (ep.bias) bv = *reinterpret_cast<const f32x4*>(ep.bias + n);
+    if (ep.scale) {
+      sc = *reinterpret_cast<const f32x4*>(ep.scale + n);
+      sh = *reinterpret_cast<const f32x4*>(ep.shift + n);
+    }
+    f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pj = 0; pj < 2; ++pj) {
+      f32x4 v = acc[ci][pj];
+      if (ep.bias) v += bv;
+      if (ep.scale) v = v * sc + sh;
+      if (ep.residual) v += __builtin_bit_cast(f32x4, rres[ci][pj]);
+      if (ep.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, ov[ci][pj], 0, 0);
+      if (ep.stats) {
+        const float m = ov[ci][pj] == kOob ? 0.f : 1.f;
+        t1 += v * m;
+        t2 += (v * v) * m;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[4 * ci + r] = t1[r], s2[4 * ci + r] = t2[r];
+  }
+  if (ep.stats) {
+    float* red = reinterpret_cast<float*>(smem + 2 * kStage);
+    const float a = row16_transpose_sum(s1, li), q = row16_transpose_sum(s2, li);
+    const int ch = 16 * (li >> 2) + 4 * g + (li & 3);
+    red[(wave * 64 + ch) * 2] = a;
+    red[(wave * 64 + ch) * 2 + 1] = q;
+    __syncthreads();
+    if (tid < 128) {
+      const int chn = tid >> 1, which = tid & 1;
+      const float v = ((red[(0 * 64 + chn) * 2 + which] + red[(1 * 64 + chn) * 2 + which]) +
+                       red[(2 * 64 + chn) * 2 + which]) + red[(3 * 64 + chn) * 2 + which];
+      if (n0 + chn < gm.Cout) ep.stats[((size_t)tile * gm.Cout + n0 + chn) * 2 + which] = v;
+    }
+  }
+}
+
 // Sum of the pieces of the units the stream-K schedule cut, in slice order, + the epilogue.  One workgroup per cut unit; a
 // thread owns one 4-channel piece over 8 pixel rows (rows tid / 16 + 16 k).
 template <bool MAPPED>
@@ -640,6 +791,7 @@ extern "C" int ud_conv1x1p_nhwc_f32(const float* x, const float* w, float* y, in
   }
   static UdDeviceOnce attr_set;
   if (const unsigned long long attr_set_bit = attr_set.pending()) {
+    UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1t_f32, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemT));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1p_f32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
     UD_HIP_TRY(hipFuncSetAttribute((const void*)k_conv1x1p_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
     attr_set.mark(attr_set_bit);
@@ -647,7 +799,11 @@ extern "C" int ud_conv1x1p_nhwc_f32(const float* x, const float* w, float* y, in
   UdProfScope prof("conv2d.k_conv1x1_f32", stream);
   const int n_sk = (int)units - sc.n_dp;
   const unsigned xb = (unsigned)(xe * 4), wb = (unsigned)(we * 4), yb = (unsigned)(ye * 4);
-  if (mapped) {
+  static const int short_k = getenv("UD_F32_1X1T_K") ? atoi(getenv("UD_F32_1X1T_K")) : kShortK;
+  if (!mapped && Cin / kKC < short_k) {
+    const dim3 grid((ntiles + 7) / 8 * 8, ngroups);
+    k_conv1x1t_f32<<<grid, 256, kSmemT, stream>>>(x, w, y, gm, ep, xb, wb, yb);
+  } else if (mapped) {
     k_conv1x1p_f32<true><<<sc.grid, 256, kSmem, stream>>>(x, w, y, gm, ep, xb, wb, yb);
     if (n_sk > 0) k_conv1x1p_fixup<true><<<n_sk, 256, 0, stream>>>(y, gm, ep);
   } else {

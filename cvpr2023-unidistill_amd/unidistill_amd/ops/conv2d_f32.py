@@ -162,14 +162,17 @@ def _launch3(x, weight, bias=None, relu=False, transposed=False, bn_stats=False,
 LOG_1X1 = None           # set to [] to record ("line", P, Cin, Cout) of every plain 1x1 launch (tools/time_f32_1x1.py)
 
 
-# Reductions of at least this many channels go to the persistent stream-K kernel (csrc/conv2d_f32_1x1p.hip): measured per shape of
-# one distillation step (tools/time_1x1p.py) it wins from 12 slices of 32 channels on (16 896 x 1024 -> 256: 114 -> 89 us,
-# 4 224 x 2048 -> 512: 142 -> 89 us) and loses below (270 336 x 64 -> 256: 115 vs 130 us: a unit is two slices there)
-P1X1_MIN_K = int(os.environ.get("UD_F32_1X1P_MIN_K", "384"))
+# ud_conv1x1p_nhwc_f32 (csrc/conv2d_f32_1x1p.hip) takes the 1x1 launches it measured faster on, per shape of one distillation step
+# (tools/time_1x1p.py): the persistent stream-K kernel from 12 slices of 32 channels on (16 896 x 1024 -> 256: 114 -> 89 us,
+# 4 224 x 2048 -> 512: 142 -> 89 us; plain and mapped), its per-tile kernel with the epilogue from registers for the shorter plain
+# reductions (16 896 x 256 -> 1024: 96 -> 90 us, 129 600 x 256 -> 128: 90 -> 75 us); 64-channel reductions stay on the
+# grid-per-tile kernel of conv2d_f32.hip (270 336 x 64 -> 256: 116 vs 120 us: those launches are store-bound).
+P1X1_MIN_K = int(os.environ.get("UD_F32_1X1P_MIN_K", "96"))
+P1X1_MIN_K_MAPPED = int(os.environ.get("UD_F32_1X1P_MIN_K_MAPPED", "384"))
 
 
-def persistent_1x1(K):
-    return K >= P1X1_MIN_K and _lib.load().ud_conv1x1_f32_persistent_enabled() == 1
+def persistent_1x1(K, mapped=False):
+    return K >= (P1X1_MIN_K_MAPPED if mapped else P1X1_MIN_K) and _lib.load().ud_conv1x1_f32_persistent_enabled() == 1
 
 
 def launch_1x1p(x, w, y, P, K, N, bias=None, residual=None, part=None, imap=None, omap=None):
