@@ -1332,5 +1332,6 @@ extern "C" int ud_conv1x1_wgrad_mapped_nhwc_bf16(const void* x, const void* dy, 
   if (xm.mode == 4 || ym.mode >= 3) return UD_ERR_UNSUPPORTED;
   if (ym.mode == 1 && ym.s * ym.s * ym.C != Cout) return UD_ERR_INVALID_ARG;
   if (ym.mode == 2 && ym.C != Cout) return UD_ERR_INVALID_ARG;
+  if (P > (int64_t)1 << 30) return UD_ERR_UNSUPPORTED;                       // PixMap::off divides in 32 bits
   return wgrad1x1_impl(x, dy, dw, P, Cin, Cout, workspace, workspace_bytes, xm, ym, stream);
 }

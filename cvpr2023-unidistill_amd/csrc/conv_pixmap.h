@@ -25,9 +25,10 @@ struct PixMap {
   int mode, s, Ho, Wo, H, W, C, a, b;
   __device__ __forceinline__ size_t off(long long p, int k, int K) const {
     if (mode == 0) return (size_t)p * K + k;
-    const int ox = (int)(p % Wo);
-    const long long t = p / Wo;
-    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    // rows < 2^30 (every launcher checks): 32-bit divisions (a 64-bit one is a ~100-instruction loop per DMA piece)
+    const unsigned pu = (unsigned)p, t = pu / (unsigned)Wo;
+    const int ox = (int)(pu - t * (unsigned)Wo);
+    const int b = (int)(t / (unsigned)Ho), oy = (int)(t - (unsigned)b * (unsigned)Ho);
     if (mode == 4) {
       const int tapi = k / C, c = k - tapi * C, nx = 1 + this->b;
       const int jy = tapi / nx, jx = tapi - jy * nx;
