@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256) void k_conv1x1_mapped(const unsigned short* __
       pa[i] = x + (size_t)p * gm.Cin + ((slot ^ (r & 7)) << 3);
       continue;
     }
-    const int ox = (int)(p % im.Wo);
-    const long long t = p / im.Wo;
-    const int oy = (int)(t % im.Ho), b = (int)(t / im.Ho);
+    const unsigned pu = (unsigned)p, t = pu / (unsigned)im.Wo;        // rows < 2^30 (launcher): 32-bit divisions
+    const int ox = (int)(pu - t * (unsigned)im.Wo);
+    const int b = (int)(t / (unsigned)im.Ho), oy = (int)(t - (unsigned)b * (unsigned)im.Ho);
     int y0, x0;
     if (mode == 4) { y0 = oy; x0 = ox; }
     else if (mode == 2) { y0 = im.s * oy + im.a; x0 = im.s * ox + im.b; }
@@ -642,7 +642,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const unsigned short* __r
       const long long p = p0 + r;
       rc[j] = make_uint4(0u, 0u, 0u, 0u);
       if (p < P && c0 + c8 < gm.Cin) {
-        const int px = (int)(p % gm.W), py = (int)((p / gm.W) % gm.H);
+        const unsigned pu = (unsigned)p, tq = pu / (unsigned)gm.W;       // B * H * W fits an int
+        const int px = (int)(pu - tq * (unsigned)gm.W), py = (int)(tq % (unsigned)gm.H);
         if (px + sx >= 0 && px + sx < gm.W && py + sy >= 0 && py + sy < gm.H)
           rc[j] = *reinterpret_cast<const uint4*>(x + (size_t)(p + (long long)sy * gm.W + sx) * gm.Cin + c0 + c8);
       }

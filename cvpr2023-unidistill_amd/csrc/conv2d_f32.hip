@@ -386,9 +386,9 @@ __global__ __launch_bounds__(256) void k_conv1x1_mapped_f32(const float* __restr
       pa[i] = x + (size_t)p * gm.Cin + ((slot ^ (r & 7)) << 2);
       continue;
     }
-    const int ox = (int)(p % im.Wo);
-    const long long t = p / im.Wo;
-    const int oy = (int)(t % im.Ho), b = (int)(t / im.Ho);
+    const unsigned pu = (unsigned)p, t = pu / (unsigned)im.Wo;        // rows < 2^30 (launcher): 32-bit divisions
+    const int ox = (int)(pu - t * (unsigned)im.Wo);
+    const int b = (int)(t / (unsigned)im.Ho), oy = (int)(t - (unsigned)b * (unsigned)im.Ho);
     int y0, x0;
     if (mode == 4) { y0 = oy; x0 = ox; }
     else if (mode == 2) { y0 = im.s * oy + im.a; x0 = im.s * ox + im.b; }

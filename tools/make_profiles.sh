@@ -54,7 +54,9 @@ python $T/traffic_json.py $R $(ls /tmp/pmc1/*/*.db | head -1) $(ls /tmp/pmc2/*/*
 rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T/time_spconv.py > $OUT/spconv_stdout.txt 2>&1
 { echo "# LiDAR sparse encoder forward, B=4 x 30k points ($R)"; echo; echo '```'; grep "encoder fwd" $OUT/spconv_stdout.txt; echo '```'; echo; python $T/rocpd_summary.py $(ls /tmp/p_sp/*/*.db | head -1) namespace | head -30; } > $OUT/${R}_spconv_encoder.md
 # 6b. Winograd F(4x4,3x3): per-shape table (forward / data gradient, weight gradient) and the SQ counters of the forward kernel
-{ echo "# Winograd F(4x4,3x3) fp32 kernels vs F(2x2,3x3) and the direct fp32 MFMA kernel ($R)"; echo; echo "Forward launches at the 3x3 shapes of the distillation step (tools/time_wino4.py; err = max |y - fp64| / max |fp64|; F4 with its stream-K tail):"; echo; echo '```'; python $T/time_wino4.py 2>&1 | grep "^3x3"; echo '```'; echo; echo "Weight gradient (tools/time_wino4_wgrad.py):"; echo; echo '```'; python $T/time_wino4_wgrad.py 2>&1 | grep "^wgrad"; echo '```'; echo; echo "SQ counters of k_conv3x3_wino4_f32 at 128 -> 128 @180^2 x 4 (tools/pmc_kernel.sh; sums over the chip, *_CYCLES of waves in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles):"; echo; echo '```'; bash $T/pmc_kernel.sh k_conv3x3_wino4_f32 python $T/pmc_wino4.py 2>&1 | sed "s/void (anonymous namespace):://" | cut -c1-40,100-170; echo '```'; } > $OUT/${R}_conv_f32_wino4.md
+{ echo "# Winograd F(4x4,3x3) fp32 kernels vs F(2x2,3x3) and the direct fp32 MFMA kernel ($R)"; echo; echo "Forward launches at the 3x3 shapes of the distillation step (tools/time_wino4.py; err = max |y - fp64| / max |fp64|; F4 with its stream-K tail):"; echo; echo '```'; python $T/time_wino4.py 2>&1 | grep "^3x3"; echo '```'; echo; echo "Weight gradient (tools/time_wino4_wgrad.py):"; echo; echo '```'; python $T/time_wino4_wgrad.py 2>&1 | grep "^wgrad"; echo '```'; echo; echo "SQ counters of k_conv3x3_wino4_f32 at 128 -> 128 @180^2 x 4 (tools/pmc_kernel.sh; sums over the chip, *_CYCLES of waves in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles):"; echo; echo '```'; bash $T/pmc_kernel.sh k_conv3x3_wino4_f32 python $T/pmc_wino4.py 2>&1 | grep " n=" | sed "s/.*k_conv3x3_wino4_f32[^ ]* [^ ]* [^ ]* [a-z]* */k_conv3x3_wino4_f32  /" | awk '{printf "%-22s %-26s %s %s\n", $1, $2, $3, $4}'; echo '```'; } > $OUT/${R}_conv_f32_wino4.md
+# 6c. fp32 1x1 family: persistent stream-K / per-tile kernels vs the grid-per-tile kernel, per plain shape of one step; SQ counters
+{ echo "# fp32 1x1 convolutions: ud_conv1x1p_nhwc_f32 (persistent stream-K from 12 slices, per-tile with register epilogue below) vs the grid-per-tile kernel ($R)"; echo; echo "tools/time_1x1p.py (plain launches of one distillation step; 'new' = the launcher's own schedule, 'no-SK' = without the workspace; err vs an fp64 matmul with bias + residual + ReLU + BatchNorm sums):"; echo; echo '```'; python $T/time_1x1p.py 2>&1 | grep -E "^ +[0-9P]|per step"; echo '```'; echo; echo "SQ counters of k_conv1x1p_f32 at 16 896 x 1024 -> 256 with its stream-K tail (tools/pmc_kernel.sh k_conv1x1p python tools/pmc_1x1p.py 16896 1024 256 1):"; echo; echo '```'; bash $T/pmc_kernel.sh k_conv1x1p python $T/pmc_1x1p.py 16896 1024 256 1 2>&1 | grep " n=" | grep "k_conv1x1p_f32" | sed "s/.*k_conv1x1p_f32[^ ]* [^ ]* [^ ]* [a-z]* */k_conv1x1p_f32  /" | awk '{printf "%-18s %-26s %s %s\n", $1, $2, $3, $4}'; echo '```'; } > $OUT/${R}_conv_f32_1x1.md
 # 7. fp32 convolutions: ours vs library (forward / data gradient, and the weight gradients of one step)
 { echo "# fp32 convolutions: hand-written fp32 MFMA kernels (direct and Winograd: the launcher's routing) vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py; 3x3: Winograd form, last column = the direct kernel):"; python $T/time_f32_wgrad.py 2>&1 | tail -22; echo; echo "-- plain 1x1 launches of one step (tools/time_f32_1x1.py):"; python $T/time_f32_1x1.py 2>&1 | grep -E "kind|line|total"; echo; echo "-- frozen ResNet stem, 24 x 256 x 704 (tools/time_stem.py):"; python $T/time_stem.py 2>&1 | grep "us "; echo '```'; } > $OUT/${R}_conv_f32.md
 ls -la $OUT

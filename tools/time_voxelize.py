@@ -41,7 +41,7 @@ def bench(B, sweeps, fused):
     for _ in range(10): run()
     torch.cuda.synchronize(); _lib.prof_enable(False)
     parts = []
-    for k in (("k_partition", "k_bucket", "k_flags", "k_emit", "k_gather") if ALGO == 0 else ("k_insert", "k_first", "k_assign", "k_gather") if ALGO == 1 else ("k_insert2", "k_first_assign", "k_gather")):
+    for k in (("k_partition", "k_bucket", "k_flags", "k_rows", "k_gather") if ALGO == 0 else ("k_insert", "k_first", "k_assign", "k_gather") if ALGO == 1 else ("k_insert2", "k_first_assign", "k_gather")):
         ms, n = _lib.prof_read("voxelize." + k)
         parts.append(f"{k} {ms / max(n, 1) * 1e3:.1f}")
     print("    per-kernel us (HIP events, incl. ~6 us dispatch each): " + ", ".join(parts))
