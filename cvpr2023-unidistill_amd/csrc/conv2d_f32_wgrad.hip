@@ -211,7 +211,7 @@ constexpr int kPS = 32;                          // pixels per step
 // buffer descriptors whose base moves with the pixel step, so a lane's offsets are fixed for the whole slice (no address
 // arithmetic per piece: that was ~90 VALU instructions per 64 MFMAs, and on this chip every issued instruction is paid for in
 // MFMA issue time) and rows past the last pixel read zeros through the range check.
-template <int NT, bool PLAIN>
+template <int NT, int PLAIN>     // bit 0: x is plain, bit 1: dy is plain (the other operand goes through its pixel map per piece)
 __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ partial, long long P, int Cin, int Cout,
                                                            int c_tiles, int steps_per_slice, PixMap xmap, PixMap ymap) {
@@ -257,22 +257,28 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
     const long long p0_ = (long long)(STEP) * kPS;                                                                            \
     const unsigned lb = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (BUF) * kBuf) + wave * 1024;        \
     const unsigned long long left = (unsigned long long)(P - p0_); /* > 0: the step exists */                                 \
-    const __amdgpu_buffer_rsrc_t rd =                                                                                         \
-        __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p0_ * Cout), 0, (int)(unsigned)(left * Cout * 4), 0x00020000);          \
-    const __amdgpu_buffer_rsrc_t rxs =                                                                                        \
-        __builtin_amdgcn_make_buffer_rsrc((void*)(x + p0_ * Cin), 0, (int)(unsigned)(left * Cin * 4), 0x00020000);            \
-    _Pragma("unroll") for (int k = 0; k < kDP; ++k) dma16b(rd, vd[k], lb + k * 4096);                                         \
-    _Pragma("unroll") for (int k = 0; k < kXP; ++k) dma16b(rxs, vx[k], lb + kDTile + k * 4096);                               \
+    if (PLAIN & 2) {                                                                                                          \
+      const __amdgpu_buffer_rsrc_t rd =                                                                                       \
+          __builtin_amdgcn_make_buffer_rsrc((void*)(dy + p0_ * Cout), 0, (int)(unsigned)(left * Cout * 4), 0x00020000);        \
+      _Pragma("unroll") for (int k = 0; k < kDP; ++k) dma16b(rd, vd[k], lb + k * 4096);                                       \
+    }                                                                                                                         \
+    if (PLAIN & 1) {                                                                                                          \
+      const __amdgpu_buffer_rsrc_t rxs =                                                                                      \
+          __builtin_amdgcn_make_buffer_rsrc((void*)(x + p0_ * Cin), 0, (int)(unsigned)(left * Cin * 4), 0x00020000);          \
+      _Pragma("unroll") for (int k = 0; k < kXP; ++k) dma16b(rxs, vx[k], lb + kDTile + k * 4096);                             \
+    }                                                                                                                         \
   } while (0)
   auto stage = [&](int step, int buf) {
     char* sb = smem + buf * kBuf;
     const long long p0 = (long long)step * kPS;
+    if (!(PLAIN & 2))
     for (int piece = wave; piece < kPS / kDRowsPer; piece += 4) {      // dy: slots XOR 4 on odd pixels (see the 3x3 kernel)
       const int r = piece * kDRowsPer + lane / kDSlots, slot = lane % kDSlots;
       const int n = n0 + 4 * (slot ^ ((r & 1) << 2));
       const long long p = p0 + r;
       dma16((p < P && n < Cout) ? dy + ymap.off(p, n, Cout) : zero, sb + piece * 1024);
     }
+    if (!(PLAIN & 1))
     for (int piece = wave; piece < kPS / 4; piece += 4) {
       const int r = piece * 4 + g;
       const long long p = p0 + r;
@@ -320,14 +326,16 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
   static_assert(kPS / 4 == 8, "eight 4-pixel steps per staged step");
 
   if (s_begin < s_end) {
-    if (PLAIN) UD_WG_STAGE_PLAIN(s_begin, 0); else stage(s_begin, 0);
+    if (PLAIN) UD_WG_STAGE_PLAIN(s_begin, 0);
+    if (PLAIN != 3) stage(s_begin, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
   for (int step = s_begin; step < s_end; ++step) {
     if (step + 1 < s_end) {
-      if (PLAIN) UD_WG_STAGE_PLAIN(step + 1, buf ^ 1); else stage(step + 1, buf ^ 1);
+      if (PLAIN) UD_WG_STAGE_PLAIN(step + 1, buf ^ 1);
+      if (PLAIN != 3) stage(step + 1, buf ^ 1);
     }
     UD_WG_LOADS(0, 0);
     UD_WG_STEP(0); UD_WG_STEP(1); UD_WG_STEP(2); UD_WG_STEP(3); UD_WG_STEP(4); UD_WG_STEP(5); UD_WG_STEP(6); UD_WG_STEP(7);
@@ -440,15 +448,18 @@ extern "C" int ud_conv1x1_wgrad_mapped_nhwc_f32(const float* x, const float* dy,
     UdProfScope prof("conv2d.k_wgrad_1x1_f32", stream);
     const dim3 grid(pl.slices, pl.n_tiles * pl.c_tiles);
     static const int no_plain = getenv("UD_F32_WGRAD_PLAIN") ? !atoi(getenv("UD_F32_WGRAD_PLAIN")) : 0;
-    const bool plain = !no_plain && xm.mode == 0 && ym.mode == 0 && (size_t)P * Cin * 4 < (size_t)kOobW &&
-                       (size_t)P * Cout * 4 < (size_t)kOobW;
+    const int plain = no_plain ? 0 : ((xm.mode == 0 && (size_t)P * Cin * 4 < (size_t)kOobW) ? 1 : 0) |
+                                     ((ym.mode == 0 && (size_t)P * Cout * 4 < (size_t)kOobW) ? 2 : 0);
 #define UD_WG1(NTv, PL, LDSB) \
   k_conv1x1_wgrad_f32<NTv, PL><<<grid, 256, LDSB, stream>>>(x, dy, partial, P, Cin, Cout, pl.c_tiles, pl.steps_per_slice, xm, ym)
-    if (pl.nt == 128) {
-      if (plain) UD_WG1(128, true, 2 * kPS * (512 + 256)); else UD_WG1(128, false, 2 * kPS * (512 + 256));
-    } else {
-      if (plain) UD_WG1(64, true, 2 * kPS * (256 + 256)); else UD_WG1(64, false, 2 * kPS * (256 + 256));
-    }
+#define UD_WG1P(NTv, LDSB)                                                                    \
+  do {                                                                                        \
+    if (plain == 3) UD_WG1(NTv, 3, LDSB); else if (plain == 2) UD_WG1(NTv, 2, LDSB);          \
+    else if (plain == 1) UD_WG1(NTv, 1, LDSB); else UD_WG1(NTv, 0, LDSB);                     \
+  } while (0)
+    if (pl.nt == 128) UD_WG1P(128, 2 * kPS * (512 + 256));
+    else UD_WG1P(64, 2 * kPS * (256 + 256));
+#undef UD_WG1P
 #undef UD_WG1
     UD_LAUNCH_CHECK();
   }

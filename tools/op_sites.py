@@ -39,7 +39,8 @@ class Count(TorchDispatchMode):
             if site.startswith("(autograd"):
                 engine[name] += 1
             if FILTER and any(f in name for f in FILTER):
-                special[(name, site)] += 1
+                shp = tuple(args[0].shape) if args and isinstance(args[0], torch.Tensor) else (tuple(args[0]) if args and isinstance(args[0], (list, tuple)) else ())
+                special[(name + " " + str(shp), site)] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -54,7 +55,7 @@ for s, n in cnt.items():
 for s, n in by_fn.most_common(40):
     print(f"{n:5d}  {s}")
 for (name, site), n in special.most_common(40):
-    print(f"{n:5d}  {name:40s} {site}")
+    print(f"{n:5d}  {name:60s} {site}")
 print("ops issued outside a package frame (autograd engine, optimizer):")
 for name, n in engine.most_common(25):
     print(f"{n:5d}  {name}")
