@@ -431,7 +431,37 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
   // One slice: [fragments of k-steps 4-7] MFMAs 0-3 | slice q + 1 landed + barrier | [load slice q + 3 into this buffer,
   // fragments 0-3 of slice q + 1] MFMAs 4-7 | epilogue at the end of a piece.  Every fragment read has 32 MFMAs to arrive under;
   // at the barrier every wave holds the whole of slice q in registers, so its buffer is free for the load three slices ahead.
+  const bool affine_in = !MAPPED || imode == 0 || imode == 2;
   for (;;) {
+    // Steady state inside a piece (no epilogue in the last two steps, this one not the piece's last, three slices in flight, the
+    // load side inside its own piece): the same step with every decision taken out -- the general step below spends ~60 scalar
+    // instructions per slice on them (SQ counters, profiles/r05_conv_f32_1x1.md), and each is paid in MFMA issue time.
+    while (c_left >= 2 && eh == 0 && in_flight >= 3 && l_left > 0 && affine_in && !(UD_P_ABL & 256)) {
+      f32x4 wb[4], xb[2];
+      UD_P_RD6(wb, xb, aw1, ax1);
+      if (!(UD_P_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(xa[0]), "+v"(xa[1]) :: "memory");
+      mma(wa, xa);
+      if (!(UD_P_ABL & 4))
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)"
+                     : "+v"(wb[0]), "+v"(wb[1]), "+v"(wb[2]), "+v"(wb[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(acc[0][0]), "+v"(acc[0][1]),
+                       "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1])
+                     :: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (!(UD_P_ABL & 2)) __builtin_amdgcn_s_barrier();
+      const unsigned xb_ = sbase + rd_off + wave * 1024;
+      const int step_b = rd_off == 2 * kStage ? -2 * kStage : kStage;
+      rd_off += step_b;
+      aw0 += step_b, aw1 += step_b, ax0 += step_b, ax1 += step_b;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma16(rx, xv[i], l_so, xb_ + i * 4096);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rw, wv[j], l_so, xb_ + kXBytes + j * 4096);
+      l_so += kKC * 4;
+      --l_left;
+      UD_P_RD6(wa, xa, aw0, ax0);
+      mma(wb, xb);
+      --c_left;
+    }
     f32x4 wb[4], xb[2];
     UD_P_RD6(wb, xb, aw1, ax1);
     if (!(UD_P_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(xa[0]), "+v"(xa[1]) :: "memory");
