@@ -38,7 +38,10 @@ USE_WINOGRAD_WGRAD = os.environ.get("UD_F32_WINOGRAD_WGRAD", "1") != "0"
 
 # Winograd F(4x4, 3x3) (csrc/conv2d_f32_wino4.hip): 1.78x fewer MFMA flops again; taken where the map fills its 32-tile blocks
 USE_WINO4 = os.environ.get("UD_F32_WINO4", "1") != "0"
-WINO4_MIN_FILL = float(os.environ.get("UD_F32_WINO4_FILL", "0.7"))
+# tile blocks must be at least this full: 0.35 since the stream-K tail (measured: 512 -> 512 @8x22x24, 12 of 32 tile slots used,
+# 183 us against 233 us for the direct kernel and 228 us for F(2x2); the whole step 61.8 -> 61.3 ms with the image branch's
+# layer3 / layer4 convolutions on F(4x4), tests/test_image_branch_f32_gpu.py green with its bounds untouched)
+WINO4_MIN_FILL = float(os.environ.get("UD_F32_WINO4_FILL", "0.35"))
 
 
 def wino4_pays(H, W, cin, cout):
@@ -51,7 +54,10 @@ def wino4_pays(H, W, cin, cout):
     if not (USE_WINOGRAD and USE_WINO4) or cin % 8 or cout % 4:
         return False
     blocks = _lib.load().ud_conv3x3_wino4_f32_blocks(H, W)
-    if ((H + 3) // 4) * ((W + 3) // 4) < WINO4_MIN_FILL * 32 * blocks:
+    # (reductions longer than 1024 channels keep the 0.7 of rounds 3-4 on sparse maps: their F(4x4) error, 4.6e-5 at 2688
+    # channels, is past the 2e-5 the small-map cases of tests/test_conv2d_f32_gpu.py allow)
+    fill = WINO4_MIN_FILL if (cin <= 1024 or WINO4_MIN_FILL == 0.0) else max(WINO4_MIN_FILL, 0.7)
+    if ((H + 3) // 4) * ((W + 3) // 4) < fill * 32 * blocks:
         return False
     return WINO4_MIN_FILL == 0.0 or cin >= 256 or H * W >= 128 * 128
 
