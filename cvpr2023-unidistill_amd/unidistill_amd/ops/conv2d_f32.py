@@ -44,6 +44,9 @@ USE_WINO4 = os.environ.get("UD_F32_WINO4", "1") != "0"
 WINO4_MIN_FILL = float(os.environ.get("UD_F32_WINO4_FILL", "0.35"))
 
 
+WINO4_MIN_CIN = int(os.environ.get("UD_F32_WINO4_CIN", "256"))
+
+
 def wino4_pays(H, W, cin, cout):
     """Measured per shape against F(2x2) (tools/time_wino4.py, profiles/r05_conv_f32_wino4.md): with the stream-K tail F(4x4) is
     ahead on every 3x3 shape of the step whose map fills the 32-tile blocks -- 1.04x (64 -> 64 @64x176) to 1.54x (2688 -> 64
@@ -59,7 +62,7 @@ def wino4_pays(H, W, cin, cout):
     fill = WINO4_MIN_FILL if (cin <= 1024 or WINO4_MIN_FILL == 0.0) else max(WINO4_MIN_FILL, 0.7)
     if ((H + 3) // 4) * ((W + 3) // 4) < fill * 32 * blocks:
         return False
-    return WINO4_MIN_FILL == 0.0 or cin >= 256 or H * W >= 128 * 128
+    return WINO4_MIN_FILL == 0.0 or cin >= WINO4_MIN_CIN or H * W >= 128 * 128
 
 
 USE_WINO4_WGRAD = os.environ.get("UD_F32_WINO4_WGRAD", "1") != "0"
