@@ -31,8 +31,8 @@ namespace {
 
 constexpr int kTM = 128, kTN = 64, kKC = 32, kNS = 3;
 constexpr int kXBytes = kTM * 128, kWBytes = kTN * 128, kStage = kXBytes + kWBytes;
-constexpr int kRed = kNS * kStage;                 // BatchNorm partial sums of the four waves: [4][64][2] floats
-constexpr int kSmem = kRed + 4 * 64 * 2 * 4;       // 75 776 bytes: two workgroups per CU
+constexpr int kRed = kNS * kStage;                 // BatchNorm partial sums of the four waves: [4][64][2] doubles
+constexpr int kSmem = kRed + 4 * 64 * 2 * 8;       // 77 824 bytes: two workgroups per CU
 constexpr int kGridP = 512;                        // persistent workgroups (2 per CU on 256 CUs)
 constexpr unsigned kOob = 0xFFF00000u;             // a byte offset no tensor reaches (the launcher checks): reads zeros
 
@@ -139,6 +139,38 @@ __device__ __forceinline__ float row16_transpose_sum(const float (&in)[16], int 
   }
   const float keep = h0 ? c[1] : c[0], send = h0 ? c[0] : c[1];      // partner li ^ 1 (quad_perm [1,0,3,2] = 0xB1)
   return keep + dpp_f<0xB1>(send);
+}
+
+// The same exchange on doubles (two DPP moves per value): the BatchNorm partial sums leave the tile accurate to the final
+// rounding to float -- the statistics kernels downstream combine tiles in double, and a training-mode BatchNorm backward
+// amplifies an inconsistency between its statistics and its input by (mean / std)^2 (tests/test_image_branch_f32_gpu.py).
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double row16_transpose_sum(const double (&in)[16], int li) {
+  double a[8], b[4], c[2];
+  const bool h3 = li & 8, h2 = li & 4, h1 = li & 2, h0 = li & 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const double keep = h3 ? in[i + 8] : in[i], send = h3 ? in[i] : in[i + 8];
+    a[i] = keep + dpp_d<0x140>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double keep = h2 ? a[i + 4] : a[i], send = h2 ? a[i] : a[i + 4];
+    b[i] = keep + dpp_d<0x141>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double keep = h1 ? b[i + 2] : b[i], send = h1 ? b[i] : b[i + 2];
+    c[i] = keep + dpp_d<0x4E>(send);
+  }
+  const double keep = h0 ? c[1] : c[0], send = h0 ? c[0] : c[1];
+  return keep + dpp_d<0xB1>(send);
 }
 
 template <bool MAPPED>
@@ -334,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
       return;
     }
     const int n0 = c_ng * kTN;
-    float s1[16], s2[16];
+    double s1[16], s2[16];
     float vm[2] = {1.f, 1.f};            // BatchNorm sums: rows past the last pixel do not count
     if (ep.stats) {
 #pragma unroll
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
         sc = *reinterpret_cast<const f32x4*>(ep.scale + n);
         sh = *reinterpret_cast<const f32x4*>(ep.shift + n);
       }
-      f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+      double t1[4] = {0.0, 0.0, 0.0, 0.0}, t2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int pj = 0; pj < 2; ++pj) {
         f32x4 v = acc[ci][pj];
@@ -363,16 +395,20 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
         if (!(UD_P_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, ov[ci][pj], 0, 0);
         if (ep.stats) {
           const float m = fast_out ? vm[pj] : (ov[ci][pj] == kOob ? 0.f : 1.f);
-          t1 += v * m;
-          t2 += (v * v) * m;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double d = (double)(v[r] * m);
+            t1[r] += d;
+            t2[r] += d * d;
+          }
         }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) s1[4 * ci + r] = t1[r], s2[4 * ci + r] = t2[r];
     }
     if (ep.stats) {                      // per-channel (sum, sum of squares) of the tile's stored outputs
-      float* red = reinterpret_cast<float*>(smem + kRed);
-      const float a = row16_transpose_sum(s1, li), q = row16_transpose_sum(s2, li);
+      double* red = reinterpret_cast<double*>(smem + kRed);
+      const double a = row16_transpose_sum(s1, li), q = row16_transpose_sum(s2, li);
       // lane li holds value index li = 4 ci + r of its group g: channel 16 ci + 4 g + r
       const int ch = 16 * (li >> 2) + 4 * g + (li & 3);
       red[(wave * 64 + ch) * 2] = a;
@@ -381,9 +417,9 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
       __builtin_amdgcn_s_barrier();      // raw: the slices in flight stay in flight; `red` is next written after a ring barrier
       if (tid < 128) {
         const int chn = tid >> 1, which = tid & 1;
-        const float v = ((red[(0 * 64 + chn) * 2 + which] + red[(1 * 64 + chn) * 2 + which]) +
-                         red[(2 * 64 + chn) * 2 + which]) + red[(3 * 64 + chn) * 2 + which];
-        if (n0 + chn < gm.Cout) ep.stats[((size_t)c_tile * gm.Cout + n0 + chn) * 2 + which] = v;
+        const double v = ((red[(0 * 64 + chn) * 2 + which] + red[(1 * 64 + chn) * 2 + which]) +
+                          red[(2 * 64 + chn) * 2 + which]) + red[(3 * 64 + chn) * 2 + which];
+        if (n0 + chn < gm.Cout) ep.stats[((size_t)c_tile * gm.Cout + n0 + chn) * 2 + which] = (float)v;
       }
     }
   };
@@ -521,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
 // as above (the grid-per-tile kernel of conv2d_f32.hip stages its tile through LDS: ~1 300 instructions per wave against the
 // 128 - 512 MFMAs of such a unit).  Plain input and output only.
 constexpr int kShortK = 12;
-constexpr int kSmemT = 2 * kStage + 4 * 64 * 2 * 4;
+constexpr int kSmemT = 2 * kStage + 4 * 64 * 2 * 8;
 __global__ __launch_bounds__(256, 3) void k_conv1x1t_f32(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, PGeom gm, PEp ep, unsigned x_bytes,
                                                          unsigned w_bytes, unsigned y_bytes) {
@@ -620,7 +656,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1t_f32(const float* __restrict
       __builtin_amdgcn_s_barrier();
     }
   }
-  float s1[16], s2[16];
+  double s1[16], s2[16];
 #pragma unroll
   for (int ci = 0; ci < 4; ++ci) {
     const int n = min(n0 + 16 * ci + 4 * g, gm.Cout - 4);
@@ -630,7 +666,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1t_f32(const float* __restrict
       sc = *reinterpret_cast<const f32x4*>(ep.scale + n);
       sh = *reinterpret_cast<const f32x4*>(ep.shift + n);
     }
-    f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+    double t1[4] = {0.0, 0.0, 0.0, 0.0}, t2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int pj = 0; pj < 2; ++pj) {
       f32x4 v = acc[ci][pj];
@@ -643,25 +679,29 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1t_f32(const float* __restrict
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, ov[ci][pj], 0, 0);
       if (ep.stats) {
         const float m = ov[ci][pj] == kOob ? 0.f : 1.f;
-        t1 += v * m;
-        t2 += (v * v) * m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double d = (double)(v[r] * m);
+          t1[r] += d;
+          t2[r] += d * d;
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[4 * ci + r] = t1[r], s2[4 * ci + r] = t2[r];
   }
   if (ep.stats) {
-    float* red = reinterpret_cast<float*>(smem + 2 * kStage);
-    const float a = row16_transpose_sum(s1, li), q = row16_transpose_sum(s2, li);
+    double* red = reinterpret_cast<double*>(smem + 2 * kStage);
+    const double a = row16_transpose_sum(s1, li), q = row16_transpose_sum(s2, li);
     const int ch = 16 * (li >> 2) + 4 * g + (li & 3);
     red[(wave * 64 + ch) * 2] = a;
     red[(wave * 64 + ch) * 2 + 1] = q;
     __syncthreads();
     if (tid < 128) {
       const int chn = tid >> 1, which = tid & 1;
-      const float v = ((red[(0 * 64 + chn) * 2 + which] + red[(1 * 64 + chn) * 2 + which]) +
-                       red[(2 * 64 + chn) * 2 + which]) + red[(3 * 64 + chn) * 2 + which];
-      if (n0 + chn < gm.Cout) ep.stats[((size_t)tile * gm.Cout + n0 + chn) * 2 + which] = v;
+      const double v = ((red[(0 * 64 + chn) * 2 + which] + red[(1 * 64 + chn) * 2 + which]) +
+                        red[(2 * 64 + chn) * 2 + which]) + red[(3 * 64 + chn) * 2 + which];
+      if (n0 + chn < gm.Cout) ep.stats[((size_t)tile * gm.Cout + n0 + chn) * 2 + which] = (float)v;
     }
   }
 }
@@ -670,7 +710,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1t_f32(const float* __restrict
 // thread owns one 4-channel piece over 8 pixel rows (rows tid / 16 + 16 k).
 template <bool MAPPED>
 __global__ __launch_bounds__(256) void k_conv1x1p_fixup(float* __restrict__ y, PGeom gm, PEp ep) {
-  __shared__ float red[16 * 64 * 2];
+  __shared__ double red[16 * 64 * 2];
   const int tid = threadIdx.x;
   const int u = gm.n_dp + blockIdx.x;
   const int base = gm.n_dp * gm.nchunks;
@@ -700,7 +740,7 @@ __global__ __launch_bounds__(256) void k_conv1x1p_fixup(float* __restrict__ y, P
   }
   const PixMap om = gm.omap;
   const int no = MAPPED ? out_ch_off(om, nok ? n : 0) : n;
-  f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+  double t1[4] = {0.0, 0.0, 0.0, 0.0}, t2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const unsigned p = (unsigned)tile * kTM + row0 + 16 * k;
@@ -714,8 +754,12 @@ __global__ __launch_bounds__(256) void k_conv1x1p_fixup(float* __restrict__ y, P
       t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
     }
     *reinterpret_cast<f32x4*>(y + po + no) = t;
-    t1 += t;
-    t2 += t * t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double d = (double)t[r];
+      t1[r] += d;
+      t2[r] += d * d;
+    }
   }
   if (ep.stats) {
 #pragma unroll
@@ -726,9 +770,9 @@ __global__ __launch_bounds__(256) void k_conv1x1p_fixup(float* __restrict__ y, P
     __syncthreads();
     if (tid < 128) {
       const int chn = tid >> 1, which = tid & 1;
-      float s = 0.f;
+      double s = 0.0;
       for (int k = 0; k < 16; ++k) s += red[(k * 64 + chn) * 2 + which];
-      if (n0 + chn < gm.Cout) ep.stats[((size_t)tile * gm.Cout + n0 + chn) * 2 + which] = s;
+      if (n0 + chn < gm.Cout) ep.stats[((size_t)tile * gm.Cout + n0 + chn) * 2 + which] = (float)s;
     }
   }
 }
