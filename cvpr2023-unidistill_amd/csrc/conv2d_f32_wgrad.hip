@@ -309,19 +309,27 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
     _Pragma("unroll") for (int ti = 0; ti < TI; ++ti)                                                                \
       asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[B2][ti]) : "v"(pa[ti]), "n"(4 * (KS) * kDRow) : "memory"); \
   } while (0)
+// The waits name NO registers: an in/out operand lets hipcc put a register copy of a fragment in front of the wait, i.e. while the
+// asm-issued read is still in flight (seen in the <64, plain> variant: `v_mov v8, v17` one instruction before lgkmcnt(0) -- one
+// wave in ~40 launches multiplied a stale fragment).  Instead a scheduling barrier right after the wait keeps the MFMAs below it.
+#define UD_WG_WAIT(N)                                    \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
 #define UD_WG_STEP(KS)                                                                                               \
   do {                                                                                                               \
     constexpr int cur = (KS) & 1;                                                                                    \
     if constexpr ((KS) + 1 < kPS / 4) {                                                                              \
       UD_WG_LOADS(cur ^ 1, ((KS) + 1) % (kPS / 4));                                                                  \
-      if (TI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));    \
-      else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[cur]), "+v"(fa[cur][0]));                                   \
+      if (TI == 2) UD_WG_WAIT(3); else UD_WG_WAIT(2);                                                                \
     } else {                                                                                                         \
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[cur]), "+v"(fa[cur][0]), "+v"(fa[cur][TI - 1]));                 \
+      UD_WG_WAIT(0);                                                                                                 \
     }                                                                                                                \
     _Pragma("unroll") for (int ti = 0; ti < TI; ++ti)                                                                \
       _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
         acc[ti][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][ti], fb[cur][e], acc[ti][e], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
   } while (0)
   static_assert(kPS / 4 == 8, "eight 4-pixel steps per staged step");
 
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_wgrad_f32(const float* __restri
     buf ^= 1;
   }
 #undef UD_WG_STEP
+#undef UD_WG_WAIT
 #undef UD_WG_LOADS
 #undef UD_WG_STAGE_PLAIN
   const int c = c0 + 4 * li;

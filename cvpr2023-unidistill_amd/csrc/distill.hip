@@ -288,7 +288,7 @@ __device__ __forceinline__ bool term_pixel(const float* __restrict__ corners, co
 
 __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ dkp, const float* __restrict__ corners,
                                                      const unsigned char* __restrict__ valid, int M, int C, int H,
-                                                     int W, MapViewW gs, int T, int tbits) {
+                                                     int W, MapViewW gs, int T, int tbits, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem_sc[];
   unsigned* keys = reinterpret_cast<unsigned*>(smem_sc);                    // [T]
   float* wts = reinterpret_cast<float*>(keys + T);                          // [T]
@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void k_box_scatter(const float* __restrict__ d
       const int t = (int)(keys[i] & tmask);
       acc += dk[(size_t)((t / 36) * 9 + ((t % 36) >> 2)) * C] * wts[t];
     }
-    base[(pix / W) * gs.sy + (pix % W) * gs.sx] = acc;
+    float* dst = base + (pix / W) * gs.sy + (pix % W) * gs.sx;
+    *dst = accumulate ? *dst + acc : acc;       // accumulate: the map already holds the other consumers' gradient
   }
 }
 
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void k_terms_rank(const unsigned long long* __
 __global__ __launch_bounds__(256) void k_box_scatter_sorted(const float* __restrict__ dkp,
                                                             const unsigned long long* __restrict__ sorted,
                                                             const float* __restrict__ wts, int M, int C, int W,
-                                                            int T, MapViewW gs) {
+                                                            int T, MapViewW gs, int accumulate) {
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long* sk = sorted + (size_t)b * T;
   const float* wt = wts + (size_t)b * T;
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(256) void k_box_scatter_sorted(const float* __restr
       const int t = (int)(unsigned)sk[j];
       acc += dk[(size_t)((t / 36) * 9 + ((t % 36) >> 2)) * C] * wt[t];
     }
-    base[((int)pix / W) * gs.sy + ((int)pix % W) * gs.sx] = acc;
+    float* dst = base + ((int)pix / W) * gs.sy + ((int)pix % W) * gs.sx;
+    *dst = accumulate ? *dst + acc : acc;
   }
 }
 
@@ -659,12 +661,11 @@ extern "C" size_t ud_distill_box_bwd_workspace_bytes(int B, int M, int C) {
          2 * ud_align_up((size_t)B * M * 36 * sizeof(unsigned long long)) + ud_align_up((size_t)B * M * 36 * sizeof(float));
 }
 
-extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_strides,
-                                  const float* t, const int64_t* t_strides,
-                                  const float* corners_px, const unsigned char* valid, int B, int M,
-                                  int C, int H, int W, const float* gscale, float* gs,
-                                  const int64_t* gs_strides, void* workspace, size_t workspace_bytes,
-                                  ud_stream_t stream_) {
+namespace {
+int box_bwd_impl(int kind, const float* s, const int64_t* s_strides, const float* t, const int64_t* t_strides,
+                 const float* corners_px, const unsigned char* valid, int B, int M, int C, int H, int W,
+                 const float* gscale, float* gs, const int64_t* gs_strides, void* workspace, size_t workspace_bytes,
+                 ud_stream_t stream_, int accumulate) {
   if (!s || !t || !s_strides || !t_strides || !corners_px || !valid || !gscale || !gs || !gs_strides)
     return UD_ERR_INVALID_ARG;
   if (B <= 0 || M <= 0 || C <= 0 || H <= 0 || W <= 0 || (kind != 0 && kind != 1))
@@ -695,7 +696,7 @@ extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_str
     if (lds > 64 * 1024)
       UD_HIP_TRY(hipFuncSetAttribute((const void*)k_box_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_box_scatter<<<dim3(B, ud_div_up(C, 64), kRunSplit), 256, lds, stream>>>(dkp, corners_px, valid, M, C, H, W, g,
-                                                                                 T, tbits);
+                                                                                 T, tbits, accumulate);
     UD_LAUNCH_CHECK();
     return UD_OK;
   }
@@ -715,9 +716,29 @@ extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_str
   k_terms_rank<<<gt_, 256, 0, stream>>>(keys, nterm, sorted);
   UD_LAUNCH_CHECK();
   k_box_scatter_sorted<<<dim3(B, ud_div_up(C, 64), ud_div_up(nterm, 256)), 256, 0, stream>>>(dkp, sorted, wts, M, C, W,
-                                                                                            nterm, g);
+                                                                                            nterm, g, accumulate);
   UD_LAUNCH_CHECK();
   return UD_OK;
+}
+}  // namespace
+
+extern "C" int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_strides, const float* t, const int64_t* t_strides,
+                                  const float* corners_px, const unsigned char* valid, int B, int M, int C, int H, int W,
+                                  const float* gscale, float* gs, const int64_t* gs_strides, void* workspace,
+                                  size_t workspace_bytes, ud_stream_t stream) {
+  return box_bwd_impl(kind, s, s_strides, t, t_strides, corners_px, valid, B, M, C, H, W, gscale, gs, gs_strides, workspace,
+                      workspace_bytes, stream, 0);
+}
+
+// The same gradient ADDED to a map that already holds the feature's gradient from its other consumer (the BEV trunk / the head):
+// the touched pixels are read, added to and written back once each (same order: deterministic); nothing else is touched, so
+// neither a zeroed map nor autograd's three-pass add of two dense maps is needed (4 x 512 x 180 x 180: 265 MB each).
+extern "C" int ud_distill_box_bwd_acc(int kind, const float* s, const int64_t* s_strides, const float* t,
+                                      const int64_t* t_strides, const float* corners_px, const unsigned char* valid, int B, int M,
+                                      int C, int H, int W, const float* gscale, float* gs, const int64_t* gs_strides,
+                                      void* workspace, size_t workspace_bytes, ud_stream_t stream) {
+  return box_bwd_impl(kind, s, s_strides, t, t_strides, corners_px, valid, B, M, C, H, W, gscale, gs, gs_strides, workspace,
+                      workspace_bytes, stream, 1);
 }
 
 // calculate_box_mask_gaussian on the device: gt f32[B,M,S] -> mask f32[B,H,W].

@@ -74,6 +74,8 @@ _SIGS = {
     "ud_distill_box_bwd_workspace_bytes": (c_size_t, [c_int] * 3),
     "ud_distill_box_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                            + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_distill_box_bwd_acc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+                               + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_distill_mask_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ud_distill_gaussian_mask": (c_int, [c_void_p, c_int, c_int, c_int] + [ctypes.c_double] * 4
                                  + [c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

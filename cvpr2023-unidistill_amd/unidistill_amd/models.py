@@ -14,6 +14,7 @@ from .layers.center_head import CenterHeadIouAware, FCOSAssigner
 from .layers.gen_proposals import IouAwareGenProposals
 from .layers.lidar import LidarEncoder
 from .layers.lss_fpn import LSSFPN
+from .ops.distill import feature_tap
 
 
 class CameraEncoder(nn.Module):
@@ -111,12 +112,16 @@ class BEVFusionCenterHead(nn.Module):
         normalisers (train.py computes them up front so the network pass holds no collective);
         lidar_prepared: LidarEncoder.prepare(lidar_points), when the caller ran it ahead of time."""
         bev = self.extract_bev(lidar_points, cameras_imgs, metas, lidar_prepared)
+        tapped = self.training and not return_feature
+        # the two maps the box distillation losses read: their gradients join the network branch's inside one kernel (ops/distill.py)
+        bev, bev_out = feature_tap(bev) if tapped else (bev, bev)
         trunk, _ = self.bev_encoder(bev)
+        trunk, trunk_out = feature_tap(trunk) if tapped else (trunk, trunk)
         ret = self.det_head(trunk, gt_boxes, targets=targets)
         if return_feature:
             return bev, trunk, ret["multi_head_features"]
         if self.training:
             loss, tb = self.det_head.dense_head.get_loss(ret, norm=loss_norm)
             tb["loss_rpn"] = loss.detach()
-            return {"loss": loss}, tb, bev, trunk, ret["multi_head_features"], {}
+            return {"loss": loss}, tb, bev_out, trunk_out, ret["multi_head_features"], {}
         return ret

@@ -9,6 +9,7 @@ Gradients flow to the STUDENT tensors only, as in the reference (teacher outputs
 because the teacher is frozen).
 """
 import ctypes
+import os
 
 import torch
 
@@ -37,9 +38,64 @@ def box_corners_bev(gt_boxes, pc_range, voxel_size, out_size_scale):
     return corners, valid.bool()
 
 
+FEATURE_TAP = os.environ.get("UD_FEATURE_TAP", "1") != "0"
+
+
+class _Tap:
+    """Side channel of feature_tap: the box losses leave their (sparse) input gradient here instead of materialising it."""
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = []
+
+
+class _FeatureTap(torch.autograd.Function):
+    """x -> (x for the network, x for the distillation losses), both aliases.  In backward the losses' gradients -- a few
+    hundred bilinear footprints per sample -- are ADDED into the dense gradient that came back through the network branch
+    (ud_distill_box_bwd_acc) instead of each being written into a zeroed map of the feature's size and summed by autograd
+    (4 x 512 x 180 x 180: one 265 MB fill + a three-pass add per feature map and step)."""
+
+    @staticmethod
+    def forward(ctx, x, tap):
+        ctx.tap = tap
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_net, g_loss):
+        tap = ctx.tap
+        pending, tap.pending = tap.pending, []
+        if not pending:
+            if g_net is None:
+                return g_loss, None
+            return (g_net if g_loss is None else g_net + g_loss), None
+        g = g_net
+        if g is None or g.dtype != torch.float32 or not g.is_cuda or any(st == 0 for st in g.stride()):
+            g = torch.zeros_like(pending[0][1], dtype=torch.float32) if g is None else g.float().contiguous()
+        lib = _lib.load()
+        for kind, sx, tx, corners, valid_u8, gscale in pending:
+            B, C, H, W = sx.shape
+            M = corners.shape[1]
+            ws = _lib.workspace(sx.device, lib.ud_distill_box_bwd_workspace_bytes(B, M, C), "distill_bwd")
+            _lib.check(lib.ud_distill_box_bwd_acc(kind, _lib.ptr(sx), _strides(sx), _lib.ptr(tx), _strides(tx), _lib.ptr(corners),
+                                                  _lib.ptr(valid_u8), B, M, C, H, W, _lib.ptr(gscale), _lib.ptr(g), _strides(g),
+                                                  _lib.ptr(ws), ws.numel(), _lib.stream_of(sx)), "ud_distill_box_bwd_acc")
+        return g, None
+
+
+def feature_tap(x):
+    """(x_net, x_loss): feed x_net on into the network and x_loss to FeatureDistillLoss / BEVDistillLoss (fp32 CUDA training only;
+    anything else gets (x, x) and the losses their usual dense gradient)."""
+    if not (FEATURE_TAP and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype == torch.float32):
+        return x, x
+    tap = _Tap()
+    x_net, x_loss = _FeatureTap.apply(x, tap)
+    x_loss._ud_tap = tap
+    return x_net, x_loss
+
+
 class _BoxDistill(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, kind, student, teacher, corners, valid_u8, weight):
+    def forward(ctx, kind, student, teacher, corners, valid_u8, weight, tap=None):
         _lib.require_gpu(student, teacher, corners, valid_u8)
         s = student if student.dtype == torch.float32 else student.float()
         t = teacher.detach()
@@ -54,6 +110,7 @@ class _BoxDistill(torch.autograd.Function):
         den = weight + 1e-4
         ctx.save_for_backward(s, t, corners, valid_u8, den)
         ctx.kind = kind
+        ctx.tap = tap if s is student else None
         return box_loss.sum() / den
 
     @staticmethod
@@ -62,6 +119,10 @@ class _BoxDistill(torch.autograd.Function):
         B, C, H, W = s.shape
         M = corners.shape[1]
         gscale = (gloss / den).reshape(1).float().contiguous()
+        if ctx.tap is not None:
+            # the tap adds this gradient into the network branch's map; what autograd gets here is a stride-0 zero of the right shape
+            ctx.tap.pending.append((ctx.kind, s, t, corners, valid_u8, gscale))
+            return None, torch.zeros((), dtype=s.dtype, device=s.device).expand_as(s), None, None, None, None, None
         gs = torch.zeros_like(s)
         lib = _lib.load()
         ws = _lib.workspace(s.device, lib.ud_distill_box_bwd_workspace_bytes(B, M, C), "distill_bwd")
@@ -70,7 +131,7 @@ class _BoxDistill(torch.autograd.Function):
                                           B, M, C, H, W, _lib.ptr(gscale), _lib.ptr(gs),
                                           _strides(gs), _lib.ptr(ws), ws.numel(), _lib.stream_of(s)),
                    "ud_distill_box_bwd")
-        return None, gs, None, None, None, None
+        return None, gs, None, None, None, None, None
 
 
 def _box_loss(kind, student, teacher, coords, indices, weight):
@@ -78,7 +139,7 @@ def _box_loss(kind, student, teacher, coords, indices, weight):
     valid_u8 = indices.to(torch.uint8).contiguous()
     if weight is None:
         weight = reduce_mean(indices.float().sum())
-    return _BoxDistill.apply(kind, student, teacher, corners, valid_u8, weight)
+    return _BoxDistill.apply(kind, student, teacher, corners, valid_u8, weight, getattr(student, "_ud_tap", None))
 
 
 def FeatureDistillLoss(feature_lidar, feature_fuse, gt_boxes_bev_coords, gt_boxes_indices, weight=None):

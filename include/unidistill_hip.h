@@ -361,6 +361,14 @@ int ud_distill_box_bwd(int kind, const float* s, const int64_t* s_strides, const
                        const unsigned char* valid, int B, int M, int C, int H, int W,
                        const float* gscale, float* gs, const int64_t* gs_strides,
                        void* workspace, size_t workspace_bytes, ud_stream_t stream);
+/* ud_distill_box_bwd ADDED to gs instead of written into a zeroed gs: gs already holds the gradient the feature map received from
+ * its other consumer; only the pixels the boxes touch are read and written (deterministic).  Replaces the zero fill + autograd's
+ * dense add of the two maps in the student's backward. */
+int ud_distill_box_bwd_acc(int kind, const float* s, const int64_t* s_strides, const float* t,
+                           const int64_t* t_strides, const float* corners_px,
+                           const unsigned char* valid, int B, int M, int C, int H, int W,
+                           const float* gscale, float* gs, const int64_t* gs_strides,
+                           void* workspace, size_t workspace_bytes, ud_stream_t stream);
 
 /* calculate_box_mask_gaussian (distill_lidar.py:100-178) on the device: mask f32[B,H,W]. */
 size_t ud_distill_mask_workspace_bytes(int B, int M);
