@@ -453,3 +453,30 @@ def test_fp32_frozen_trunk_fuses_conv_bn_relu_and_matches_the_unfused_path(hip_l
         dense._can_fuse_inference = old
     assert (y - yr).abs().max() <= 2e-5 * yr.abs().max()
     assert fused_bn_launches <= 3, fused_bn_launches        # only the strided conv / deblock links keep a separate BatchNorm pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(270336, 256, 64), (270336, 64, 64), (16896, 1024, 256)])
+def test_f32_1x1_weight_gradient_is_the_same_in_150_launches(hip_lib, shape):
+    """A race detector for the hand-scheduled fragment reads of ud_conv1x1_wgrad_mapped_nhwc_f32 (plain staging, both tile widths):
+    150 launches on the same operands give 150 bit-identical gradients.  (Round 5: the 64-wide variant copied a fragment register
+    while its asm-issued LDS read was in flight -- about 1 launch in 40 differed in one wave's 16 x 64 block; the static twin of
+    this test is tests/test_asm_inflight_cpu.py.)"""
+    import ctypes as ct
+    from unidistill_amd import _lib
+    lib = _lib.load()
+    P, K, N = shape
+    torch.manual_seed(P + K + N)
+    x = torch.randn(P, K, device="cuda")
+    gy = torch.randn(P, N, device="cuda")
+    nbytes = lib.ud_conv1x1_wgrad_f32_workspace_bytes(P, K, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(150):
+        dw = torch.empty(N, K, device="cuda")
+        _lib.check(lib.ud_conv1x1_wgrad_mapped_nhwc_f32(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(dw), P, K, N, None, None, _lib.ptr(ws),
+                                                        nbytes, _lib.stream_of(x)), "ud_conv1x1_wgrad_mapped_nhwc_f32")
+        outs.append(dw)
+    torch.cuda.synchronize()
+    different = sum(not torch.equal(outs[0], o) for o in outs[1:])
+    assert different == 0, f"{different} of 149 launches differ from the first"
