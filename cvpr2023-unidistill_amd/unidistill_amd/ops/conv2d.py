@@ -364,7 +364,7 @@ def _mapped(x, w2d, y, P, K, N, imap, omap):
         if _c32.LOG_1X1 is not None:
             _c32.LOG_1X1.append(("mapped", P, K, N, None if imap is None else tuple(imap), None if omap is None else tuple(omap),
                                  tuple(x.shape), tuple(y.shape)))
-        if _c32.persistent_1x1(K, mapped=True) and x.numel() < (1 << 30) - (1 << 18) and y.numel() < (1 << 30) - (1 << 18):
+        if _c32.persistent_1x1(K, mapped=True, P=P, N=N) and x.numel() < (1 << 30) - (1 << 18) and y.numel() < (1 << 30) - (1 << 18):
             _c32.launch_1x1p(x, w2d, y, P, K, N, imap=imap, omap=omap)
             return
         _lib.check(_lib.load().ud_conv1x1_mapped_nhwc_f32(_lib.ptr(x), _lib.ptr(w2d), _lib.ptr(y), P, K, N, imap, omap,

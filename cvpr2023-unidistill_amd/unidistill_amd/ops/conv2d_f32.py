@@ -181,8 +181,23 @@ P1X1_MIN_K_MAPPED = int(os.environ.get("UD_F32_1X1P_MIN_K_MAPPED", "384"))
 P1X1_STATS = os.environ.get("UD_F32_1X1P_STATS", "1") == "1"
 
 
-def persistent_1x1(K, mapped=False):
-    return K >= (P1X1_MIN_K_MAPPED if mapped else P1X1_MIN_K) and _lib.load().ud_conv1x1_f32_persistent_enabled() == 1
+P1X1_KEEP_ONE_ROUND = True     # tests: False sends every mapped launch that qualifies by its reduction length to the new kernel
+
+
+def persistent_1x1(K, mapped=False, P=0, N=0):
+    if not (K >= (P1X1_MIN_K_MAPPED if mapped else P1X1_MIN_K) and _lib.load().ud_conv1x1_f32_persistent_enabled() == 1):
+        return False
+    if mapped and P and N and P1X1_KEEP_ONE_ROUND:
+        # the grid-per-tile kernel keeps the mapped launches whose grid is ONE nearly full round of its 512 slots (the 90 x 90 x 4 BEV
+        # maps: 254 tiles x 2 blocks of 128 channels = 508 workgroups; 32 400 x 1152 -> 256: 174 us against 215 us persistent --
+        # tools/time_f32_1x1.py MAPPED=1), where its 128-wide tiles stage the mapped input half as often
+        tiles = (P + 127) // 128
+        wgs = tiles * ((N + 127) // 128)
+        if N <= 64 or wgs <= 256:
+            wgs = tiles * ((N + 63) // 64)
+        if 460 <= wgs <= 512:
+            return False
+    return True
 
 
 def launch_1x1p(x, w, y, P, K, N, bias=None, residual=None, part=None, imap=None, omap=None):

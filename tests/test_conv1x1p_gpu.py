@@ -103,6 +103,7 @@ def test_persistent_1x1_mapped_convs_vs_library(hip_lib, monkeypatch, kind, cfg,
     from unidistill_amd.ops import conv2d as c, conv2d_f32 as c32
     lib = _lib.load()
     monkeypatch.setattr(c32, "P1X1_MIN_K_MAPPED", 32)
+    monkeypatch.setattr(c32, "P1X1_KEEP_ONE_ROUND", False)
     calls = []
     real = c32.launch_1x1p
     monkeypatch.setattr(c32, "launch_1x1p", lambda *a, **k: (calls.append(1), real(*a, **k))[1])

@@ -53,7 +53,7 @@ for key, n in sorted(cnt.items(), key=lambda kv: -kv[1]):
         xs, ys = key[6], key[7]
         x = torch.randn(xs, device=dev).contiguous(memory_format=torch.channels_last)
         y = torch.empty(ys, device=dev).contiguous(memory_format=torch.channels_last)
-        w = torch.randn(N, K, device=dev) * 0.05
+        w = torch.randn(N, 9 * imap[6] if (imap is not None and imap[0] == 4) else K, device=dev) * 0.05   # mode 4: [C][3][3][Cout]
         im = None if imap is None else (ct.c_int * 9)(*imap)
         om = None if omap is None else (ct.c_int * 9)(*omap)
         ms = timeit(lambda: c2._mapped(x, w, y, P, K, N, im, om))
