@@ -212,6 +212,45 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
   int py[4], px[4];                      // im2col maps: the lane's source pixel (range test per tap)
   int seg = 0, cseg = 0;                 // mapped: tap / block-row index and channel within it of the next slice
   const int seg_len = imode == 1 ? im.s * im.C : (imode >= 3 ? im.C : gm.Cin);
+  // Within a segment (a tap / a block row of the map; the whole reduction for plain and strided inputs) a slice is affine: the
+  // lane's offsets xo[] are fixed and the slice index rides in the scalar offsets.  Recomputed per segment, not per slice.
+  unsigned xo[4];
+  unsigned so_x = 0, so_w = 0;
+  int seg_left = 0x7fffffff;
+  auto seg_setup = [&]() __attribute__((always_inline)) {
+    if (!MAPPED || imode == 0 || imode == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xo[i] = xv[i];
+      so_x = so_w = l_so;
+      seg_left = 0x7fffffff;
+      return;
+    }
+    int koff, dy = 0, dx = 0, wk;
+    if (imode == 1) {
+      koff = seg * im.W * im.C;
+      wk = seg * seg_len;
+    } else if (imode == 3) {
+      const int ty = seg / 3, tx = seg - 3 * ty;
+      dy = ty - 1; dx = tx - 1;
+      koff = (dy * im.W + dx) * im.C;
+      wk = seg * seg_len;
+    } else {
+      const int nx = 1 + im.b, jy = seg / nx, jx = seg - jy * nx;
+      dy = im.a * (1 - jy); dx = im.b * (1 - jx);
+      koff = (dy * im.W + dx) * im.C;
+      const int ty = im.a ? 2 * jy : 1, tx = im.b ? 2 * jx : 1;
+      wk = (ty * 3 + tx) * im.C;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = xv[i] != kOob &&
+                      (imode < 3 || ((unsigned)(py[i] + dy) < (unsigned)im.H && (unsigned)(px[i] + dx) < (unsigned)im.W));
+      xo[i] = ok ? xv[i] + (unsigned)(koff * 4) : kOob;
+    }
+    so_x = (unsigned)cseg * 4u;
+    so_w = (unsigned)(wk + cseg) * 4u;
+    seg_left = (seg_len - cseg) / kKC;
+  };
   auto load_setup = [&]() __attribute__((always_inline)) {
     int tile, ng, c0, c1, slot;
     l_more = lp.next(gm, J, tile, ng, c0, c1, slot);
@@ -223,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
       for (int i = 0; i < 4; ++i) xv[i] = (unsigned)tile * (unsigned)(kTM * gm.Cin * 4) + xrow[i];   // rows past P: past the descriptor
 #pragma unroll
       for (int j = 0; j < 2; ++j) wv[j] = (unsigned)ng * (unsigned)(kTN * gm.Cin * 4) + wrow[j];
+      seg_setup();
       return;
     }
     const int n0 = ng * kTN;
@@ -251,49 +291,31 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
       wv[j] = (unsigned)n * (unsigned)(imode == 4 ? 9 * im.C : gm.Cin) * 4u + sw4;
     }
     if (MAPPED && imode != 0 && imode != 2) { seg = (c0 * kKC) / seg_len; cseg = c0 * kKC - seg * seg_len; }
+    seg_setup();
   };
   int in_flight = 0;                     // slices issued and not yet consumed
+  auto issue_slice = [&](unsigned buf_off) __attribute__((always_inline)) {
+    const unsigned xb = sbase + buf_off + wave * 1024, wb = xb + kXBytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(rx, xo[i], so_x, xb + i * 4096);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(rw, wv[j], so_w, wb + j * 4096);
+    so_x += kKC * 4;
+    so_w += kKC * 4;
+    l_so += kKC * 4;
+    if (MAPPED && --seg_left == 0) {
+      ++seg;
+      cseg = 0;
+      seg_setup();
+    }
+  };
   auto load_slice = [&](unsigned buf_off) __attribute__((always_inline)) {
     if (!l_more) return;
     if (l_left == 0) {
       load_setup();
       if (!l_more) return;
     }
-    const unsigned xb = sbase + buf_off + wave * 1024, wb = xb + kXBytes;
-    if (!MAPPED || imode == 0 || imode == 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma16(rx, xv[i], l_so, xb + i * 4096);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) dma16(rw, wv[j], l_so, wb + j * 4096);
-      l_so += kKC * 4;
-    } else {
-      int koff, dy = 0, dx = 0, wk;
-      if (imode == 1) {
-        koff = seg * im.W * im.C + cseg;
-        wk = seg * seg_len + cseg;
-      } else if (imode == 3) {
-        const int ty = seg / 3, tx = seg - 3 * ty;
-        dy = ty - 1; dx = tx - 1;
-        koff = (dy * im.W + dx) * im.C + cseg;
-        wk = seg * seg_len + cseg;
-      } else {
-        const int nx = 1 + im.b, jy = seg / nx, jx = seg - jy * nx;
-        dy = im.a * (1 - jy); dx = im.b * (1 - jx);
-        koff = (dy * im.W + dx) * im.C + cseg;
-        const int ty = im.a ? 2 * jy : 1, tx = im.b ? 2 * jx : 1;
-        wk = (ty * 3 + tx) * im.C + cseg;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = xv[i] != kOob &&
-                        (imode < 3 || ((unsigned)(py[i] + dy) < (unsigned)im.H && (unsigned)(px[i] + dx) < (unsigned)im.W));
-        dma16(rx, ok ? xv[i] + (unsigned)(koff * 4) : kOob, 0, xb + i * 4096);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) dma16(rw, wv[j], (unsigned)wk * 4u, wb + j * 4096);
-      cseg += kKC;
-      if (cseg == seg_len) { cseg = 0; ++seg; }
-    }
+    issue_slice(buf_off);
     --l_left;
     ++in_flight;
   };
@@ -467,12 +489,11 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
   // One slice: [fragments of k-steps 4-7] MFMAs 0-3 | slice q + 1 landed + barrier | [load slice q + 3 into this buffer,
   // fragments 0-3 of slice q + 1] MFMAs 4-7 | epilogue at the end of a piece.  Every fragment read has 32 MFMAs to arrive under;
   // at the barrier every wave holds the whole of slice q in registers, so its buffer is free for the load three slices ahead.
-  const bool affine_in = !MAPPED || imode == 0 || imode == 2;
   for (;;) {
     // Steady state inside a piece (no epilogue in the last two steps, this one not the piece's last, three slices in flight, the
     // load side inside its own piece): the same step with every decision taken out -- the general step below spends ~60 scalar
     // instructions per slice on them (SQ counters, profiles/r05_conv_f32_1x1.md), and each is paid in MFMA issue time.
-    while (c_left >= 2 && eh == 0 && in_flight >= 3 && l_left > 0 && affine_in && !(UD_P_ABL & 256)) {
+    while (c_left >= 2 && eh == 0 && in_flight >= 3 && l_left > 0 && !(UD_P_ABL & 256)) {
       f32x4 wb[4], xb[2];
       UD_P_RD6(wb, xb, aw1, ax1);
       if (!(UD_P_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(xa[0]), "+v"(xa[1]) :: "memory");
@@ -484,15 +505,11 @@ __global__ __launch_bounds__(256, 2) void k_conv1x1p_f32(const float* __restrict
                      :: "memory");
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       if (!(UD_P_ABL & 2)) __builtin_amdgcn_s_barrier();
-      const unsigned xb_ = sbase + rd_off + wave * 1024;
+      const unsigned freed_ = rd_off;
       const int step_b = rd_off == 2 * kStage ? -2 * kStage : kStage;
       rd_off += step_b;
       aw0 += step_b, aw1 += step_b, ax0 += step_b, ax1 += step_b;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma16(rx, xv[i], l_so, xb_ + i * 4096);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) dma16(rw, wv[j], l_so, xb_ + kXBytes + j * 4096);
-      l_so += kKC * 4;
+      issue_slice(freed_);
       --l_left;
       UD_P_RD6(wa, xa, aw0, ax0);
       mma(wb, xb);

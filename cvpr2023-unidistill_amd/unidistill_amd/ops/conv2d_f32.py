@@ -177,11 +177,13 @@ LOG_1X1 = None           # set to [] to record ("line", P, Cin, Cout) of every p
 # reductions (16 896 x 256 -> 1024: 96 -> 90 us, 129 600 x 256 -> 128: 90 -> 75 us); 64-channel reductions stay on the
 # grid-per-tile kernel of conv2d_f32.hip (270 336 x 64 -> 256: 116 vs 120 us: those launches are store-bound).
 P1X1_MIN_K = int(os.environ.get("UD_F32_1X1P_MIN_K", "96"))
-P1X1_MIN_K_MAPPED = int(os.environ.get("UD_F32_1X1P_MIN_K_MAPPED", "384"))
+P1X1_MIN_K_MAPPED = int(os.environ.get("UD_F32_1X1P_MIN_K_MAPPED", "128"))
 P1X1_STATS = os.environ.get("UD_F32_1X1P_STATS", "1") == "1"
 
 
-P1X1_KEEP_ONE_ROUND = True     # tests: False sends every mapped launch that qualifies by its reduction length to the new kernel
+# "1": mapped launches whose grid-per-tile grid is one nearly full round stay on that kernel (the rule of the per-slice staging;
+# with the per-segment staging of the persistent kernel it no longer pays: 32 400 x 1152 -> 256 177 us against 182 us)
+P1X1_KEEP_ONE_ROUND = os.environ.get("UD_F32_1X1P_ONE_ROUND", "0") == "1"
 
 
 def persistent_1x1(K, mapped=False, P=0, N=0):
