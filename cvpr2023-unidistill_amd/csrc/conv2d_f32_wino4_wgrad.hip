@@ -91,15 +91,18 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
   // fp32 MFMAs: re-deriving them with 64-bit multiplies cost ~140 scalar instructions per wave and stage).
   struct StageAt {
     int b, ty, sx;
+    bool rowin;                     // b < B and the patch rows 4 ty - 1 .. 4 ty + 4 lie inside the image (changes with ty only)
     bool inner;                     // every pixel the stage touches lies inside the image (x patch rows 4 ty - 1 .. + 4, columns 16 sx - 1 .. + 16)
     long long xoff, doff;           // bytes: x pixel (b, 4 ty - 1, 16 sx - 1) channel c0; dy pixel (b, 4 ty, 16 sx) channel 0 (images past B: image 0)
   };
   const long long x_sx = 16ll * gm.Cin * 4, d_sx = 16ll * gm.Cout * 4;                       // next stage in the tile row
   const long long x_ty = (4ll * gm.W - 16ll * gm.SX) * gm.Cin * 4, d_ty = (4ll * gm.W - 16ll * gm.SX) * gm.Cout * 4;   // + row wrap
   const long long x_b = ((long long)gm.H - 4ll * gm.TY) * gm.W * gm.Cin * 4, d_b = ((long long)gm.H - 4ll * gm.TY) * gm.W * gm.Cout * 4;
-  auto classify = [&](StageAt& a) {
-    a.inner = a.b < gm.B && a.ty > 0 && 4 * a.ty + 4 < gm.H && a.sx > 0 && 16 * a.sx + 16 < gm.W;
-  };
+  // interior tile rows are 1 .. ty_in, interior stages of a row 1 .. sx_in (one unsigned compare each; the row's half is
+  // re-evaluated only where ty changes: the classification used to cost ~20 scalar instructions per stage, twice)
+  const unsigned ty_in = (unsigned)max((gm.H - 4 + 3) / 4 - 1, 0), sx_in = (unsigned)max((gm.W - 16 + 15) / 16 - 1, 0);
+  auto classify_row = [&](StageAt& a) { a.rowin = a.b < gm.B && (unsigned)(a.ty - 1) < ty_in; };
+  auto classify = [&](StageAt& a) { a.inner = a.rowin && (unsigned)(a.sx - 1) < sx_in; };
   auto decode = [&](int s) {
     StageAt a;
     const int per = gm.TY * gm.SX;
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
     const long long bb = a.b < gm.B ? a.b : 0;
     a.xoff = (((bb * gm.H + 4 * a.ty - 1) * gm.W + 16 * a.sx - 1) * gm.Cin + c0) * 4;
     a.doff = (((bb * gm.H + 4 * a.ty) * gm.W + 16 * a.sx) * gm.Cout) * 4;
+    classify_row(a);
     classify(a);
     return a;
   };
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
         a.xoff += x_b, a.doff += d_b;
         if (a.b >= gm.B) a.xoff = ((-(long long)gm.W - 1) * gm.Cin + c0) * 4, a.doff = 0;   // stages past the last image: image 0 again (all masked)
       }
+      classify_row(a);
     }
     classify(a);
   };
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(512) void k_wino4_wgrad_f32(const float* __restrict
                      :: "memory");
         mask_dy(s1);
         dy_transform();
-        advance(s1);
+        s1 = s2;                    // (s2 is one stage ahead of s1 until step 6 moves it on)
         dy_rsrc(s1);
       }
       // dy of stage + 2 (the registers are free: the transform has read them)
