@@ -65,7 +65,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const T* __restrict__ x, const T* __restrict__ res,
                                                     const float* __restrict__ scale,
                                                     const float* __restrict__ shift, T* __restrict__ y,
-                                                    long long P, int C, int CH, int relu) {
+                                                    long long P, int C, int CH, int relu, long long y_ld) {
   const int chunk = blockIdx.y * CH + threadIdx.x % CH, lanes = 256 / CH, pl = threadIdx.x / CH;
   if (chunk * 8 >= C) return;
   float s[8], t[8];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const T* __restrict__ x, con
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    st8(y + off, v);
+    st8(y + (size_t)p * y_ld + chunk * 8, v);       // y_ld > C: the rows of a channel slice of a wider map (a fused concatenation)
   }
 }
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ x, 
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ mean, long long P,
-                                                       int C, int relu, float* __restrict__ partial) {
+                                                       int C, int relu, float* __restrict__ partial, long long dy_ld) {
   using M = GroupMap<GW>;
   __shared__ float red[M::kLanes][GW + 1][2];
   const int cg = blockIdx.y, tid = threadIdx.x, chunk = tid % M::kChunks, pl = tid / M::kChunks;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ x, 
     const size_t off = (size_t)p * C + c0;
     float xv[8], dyv[8], dr[8], yv[8];
     ld8(x + off, xv);
-    ld8(dy + off, dyv);
+    ld8(dy + (size_t)p * dy_ld + c0, dyv);
     if (y) ld8(y + off, yv);
     masked_grad(xv, yv, y != nullptr, dyv, s, t, relu, dr);
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const T* __restrict__ x, cons
                                                    const float* __restrict__ k0,
                                                    const float* __restrict__ k2, T* __restrict__ dx,
                                                    T* __restrict__ dres, long long P, int C,
-                                                   int CH, int relu) {
+                                                   int CH, int relu, long long dy_ld) {
   const int chunk = blockIdx.y * CH + threadIdx.x % CH, lanes = 256 / CH, pl = threadIdx.x / CH;
   if (chunk * 8 >= C) return;
   float s[8], t[8], a0[8], a2[8];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const T* __restrict__ x, cons
     const size_t off = (size_t)p * C + chunk * 8;
     float xv[8], dyv[8], dr[8], o[8], yv[8];
     ld8(x + off, xv);
-    ld8(dy + off, dyv);
+    ld8(dy + (size_t)p * dy_ld + chunk * 8, dyv);
     if (y) ld8(y + off, yv);
     masked_grad(xv, yv, y != nullptr, dyv, s, t, relu, dr);
 #pragma unroll
@@ -357,14 +357,14 @@ int bn_stats_impl(const T* x, long long P, int C, const float* gamma, const floa
 
 template <typename T>
 int bn_fwd_impl(const T* x, const T* residual, const float* scale, const float* shift, T* y, long long P, int C,
-                int relu, hipStream_t stream) {
-  if (!x || !scale || !shift || !y || P <= 0 || C <= 0) return UD_ERR_INVALID_ARG;
-  if (C % 8) return UD_ERR_UNSUPPORTED;
+                int relu, long long y_ld, hipStream_t stream) {
+  if (!x || !scale || !shift || !y || P <= 0 || C <= 0 || y_ld < C) return UD_ERR_INVALID_ARG;
+  if (C % 8 || y_ld % 8 || ((size_t)y & 15)) return UD_ERR_UNSUPPORTED;
   int CH;
   dim3 grid;
   stream_grid(P, C, &CH, &grid);
   UdProfScope prof("bn_act.k_fwd", stream);
-  k_bn_act_fwd<T><<<grid, 256, 0, stream>>>(x, residual, scale, shift, y, P, C, CH, relu);
+  k_bn_act_fwd<T><<<grid, 256, 0, stream>>>(x, residual, scale, shift, y, P, C, CH, relu, y_ld);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -372,10 +372,10 @@ int bn_fwd_impl(const T* x, const T* residual, const float* scale, const float* 
 template <typename T>
 int bn_bwd_impl(const T* x, const T* y, const T* dy, const float* scale, const float* shift, const float* mean,
                 const float* invstd, T* dx, T* dresidual, float* dgamma, float* dbeta, long long P, int C, int relu,
-                void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || P <= 0 || C <= 0)
+                long long dy_ld, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || P <= 0 || C <= 0 || dy_ld < C)
     return UD_ERR_INVALID_ARG;
-  if (C % 16) return UD_ERR_UNSUPPORTED;
+  if (C % 16 || dy_ld % 8 || ((size_t)dy & 15)) return UD_ERR_UNSUPPORTED;
   UdArena ar(workspace, workspace_bytes);
   BnWs w;
   carve(ar, C, &w);
@@ -384,11 +384,11 @@ int bn_bwd_impl(const T* x, const T* y, const T* dy, const float* scale, const f
     UdProfScope prof("bn_act.k_bwd_reduce", stream);
     const int slices = slices_for(P, C), gw = group_width(C);
     if (gw == 64)
-      k_bn_bwd_reduce<64, T><<<dim3(slices, C / 64), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial);
+      k_bn_bwd_reduce<64, T><<<dim3(slices, C / 64), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial, dy_ld);
     else if (gw == 32)
-      k_bn_bwd_reduce<32, T><<<dim3(slices, C / 32), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial);
+      k_bn_bwd_reduce<32, T><<<dim3(slices, C / 32), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial, dy_ld);
     else
-      k_bn_bwd_reduce<16, T><<<dim3(slices, C / 16), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial);
+      k_bn_bwd_reduce<16, T><<<dim3(slices, C / 16), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial, dy_ld);
     UD_LAUNCH_CHECK();
     k_bn_bwd_final<<<C, 64, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd, dgamma, dbeta, w.k0, w.k2);
     UD_LAUNCH_CHECK();
@@ -397,7 +397,7 @@ int bn_bwd_impl(const T* x, const T* y, const T* dy, const float* scale, const f
   dim3 grid;
   stream_grid(P, C, &CH, &grid);
   UdProfScope prof("bn_act.k_bwd_dx", stream);
-  k_bn_bwd_dx<T><<<grid, 256, 0, stream>>>(x, y, dy, scale, shift, w.k0, w.k2, dx, dresidual, P, C, CH, relu);
+  k_bn_bwd_dx<T><<<grid, 256, 0, stream>>>(x, y, dy, scale, shift, w.k0, w.k2, dx, dresidual, P, C, CH, relu, dy_ld);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -448,12 +448,24 @@ int ud_bn_stats_from_partials(const float* partial, int slices, long long P, int
 
 int ud_bn_act_fwd(const void* x, const void* residual, const float* scale, const float* shift, void* y,
                   long long P, int C, int relu, ud_stream_t stream) {
-  return bn_fwd_impl<bf16_t>((const bf16_t*)x, (const bf16_t*)residual, scale, shift, (bf16_t*)y, P, C, relu,
+  return bn_fwd_impl<bf16_t>((const bf16_t*)x, (const bf16_t*)residual, scale, shift, (bf16_t*)y, P, C, relu, C,
                              (hipStream_t)stream);
 }
 int ud_bn_act_fwd_f32(const float* x, const float* residual, const float* scale, const float* shift, float* y,
                       long long P, int C, int relu, ud_stream_t stream) {
-  return bn_fwd_impl<float>(x, residual, scale, shift, y, P, C, relu, (hipStream_t)stream);
+  return bn_fwd_impl<float>(x, residual, scale, shift, y, P, C, relu, C, (hipStream_t)stream);
+}
+// y / dy as a channel slice of a wider channels-last map: rows of C elements every `ld` elements (ld >= C, ld % 8 == 0, the
+// slice's first element 16-byte aligned).  The upsampling heads of the BEV trunk write their BatchNorm + ReLU outputs straight
+// into the concatenated map and read its gradient in place (base_bev_backbone.py:117-141: torch.cat of the deblock outputs).
+int ud_bn_act_fwd_ld(const void* x, const void* residual, const float* scale, const float* shift, void* y,
+                     long long P, int C, long long y_ld, int relu, ud_stream_t stream) {
+  return bn_fwd_impl<bf16_t>((const bf16_t*)x, (const bf16_t*)residual, scale, shift, (bf16_t*)y, P, C, relu, y_ld,
+                             (hipStream_t)stream);
+}
+int ud_bn_act_fwd_ld_f32(const float* x, const float* residual, const float* scale, const float* shift, float* y,
+                         long long P, int C, long long y_ld, int relu, ud_stream_t stream) {
+  return bn_fwd_impl<float>(x, residual, scale, shift, y, P, C, relu, y_ld, (hipStream_t)stream);
 }
 
 int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* scale, const float* shift,
@@ -461,15 +473,30 @@ int ud_bn_act_bwd(const void* x, const void* y, const void* dy, const float* sca
                   float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
                   ud_stream_t stream) {
   return bn_bwd_impl<bf16_t>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, scale, shift, mean, invstd,
-                             (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, P, C, relu, workspace, workspace_bytes,
+                             (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, P, C, relu, C, workspace, workspace_bytes,
                              (hipStream_t)stream);
 }
 int ud_bn_act_bwd_f32(const float* x, const float* y, const float* dy, const float* scale, const float* shift,
                       const float* mean, const float* invstd, float* dx, float* dresidual, float* dgamma,
                       float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
                       ud_stream_t stream) {
-  return bn_bwd_impl<float>(x, y, dy, scale, shift, mean, invstd, dx, dresidual, dgamma, dbeta, P, C, relu, workspace,
+  return bn_bwd_impl<float>(x, y, dy, scale, shift, mean, invstd, dx, dresidual, dgamma, dbeta, P, C, relu, C, workspace,
                             workspace_bytes, (hipStream_t)stream);
+}
+int ud_bn_act_bwd_ld(const void* x, const void* y, const void* dy, long long dy_ld, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, void* dx, void* dresidual, float* dgamma,
+                     float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
+                     ud_stream_t stream) {
+  return bn_bwd_impl<bf16_t>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, scale, shift, mean, invstd,
+                             (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, P, C, relu, dy_ld, workspace, workspace_bytes,
+                             (hipStream_t)stream);
+}
+int ud_bn_act_bwd_ld_f32(const float* x, const float* y, const float* dy, long long dy_ld, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float* dx, float* dresidual,
+                         float* dgamma, float* dbeta, long long P, int C, int relu, void* workspace,
+                         size_t workspace_bytes, ud_stream_t stream) {
+  return bn_bwd_impl<float>(x, y, dy, scale, shift, mean, invstd, dx, dresidual, dgamma, dbeta, P, C, relu, dy_ld,
+                            workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -182,6 +182,11 @@ _SIGS = {
                         + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_bn_act_fwd_f32": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_int, c_void_p]),
     "ud_bn_act_bwd_f32": (c_int, [c_void_p] * 11 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ud_bn_act_fwd_ld": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_i64, c_int, c_void_p]),
+    "ud_bn_act_fwd_ld_f32": (c_int, [c_void_p] * 5 + [c_i64, c_int, c_i64, c_int, c_void_p]),
+    "ud_bn_act_bwd_ld": (c_int, [c_void_p] * 3 + [c_i64] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ud_bn_act_bwd_ld_f32": (c_int, [c_void_p] * 3 + [c_i64] + [c_void_p] * 8 + [c_i64, c_int, c_int, c_void_p, c_size_t,
+                                                                                 c_void_p]),
     "ud_head_tail_workspace_bytes": (c_size_t, [c_int]),
     "ud_head_tail_stats": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_float]
                            + [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),

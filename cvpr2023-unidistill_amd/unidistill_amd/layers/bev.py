@@ -7,11 +7,14 @@ Sequential indices (ZeroPad2d at 0, conv at 1, BN at 2, ...) so checkpoints load
 In the bf16 mixed-precision mode the 3x3 stride-1 convs run on the hand-written MFMA kernel
 (layers/dense.py, ops/conv2d.py); strided / transposed convs and the fp32 mode use PyTorch-ROCm.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
 
 from .dense import Conv2d, ConvTranspose2d, FusedSequential
+from ..ops import bn_act as hipbn
 
 
 def _bn(c):
@@ -19,6 +22,8 @@ def _bn(c):
 
 
 class BaseBEVBackbone(nn.Module):
+    fuse_cat = os.environ.get("UD_FUSE_CAT", "1") == "1"      # A/B switch (tests compare the two)
+
     def __init__(self, layer_nums, layer_strides, num_filters, upsample_strides,
                  num_upsample_filters, input_channels, use_scconv=False, upsample_output=False):
         super().__init__()
@@ -63,11 +68,28 @@ class BaseBEVBackbone(nn.Module):
     def forward(self, spatial_features):
         feats, pyramid = [], {}
         x = spatial_features
+        # The upsampling heads write their BatchNorm + ReLU outputs straight into the concatenated map (ud_bn_act_fwd_ld) and
+        # read its gradient in place: no cat kernel, no strided-slice copies (530 MB / step at 4 x 512 x 180 x 180 in fp32).
+        buf = views = None
+        fuse = self.fuse_cat and len(self.deblocks) >= len(self.blocks) > 1 and x.is_cuda and \
+            all(isinstance(d, FusedSequential) and len(d) == 3 and isinstance(d[1], nn.BatchNorm2d) for d in self.deblocks[:len(self.blocks)])
         for lvl, block in enumerate(self.blocks):
             x = block(x)
             pyramid["spatial_features_%dx" % int(spatial_features.shape[2] / x.shape[2])] = x
-            feats.append(self.deblocks[lvl](x) if len(self.deblocks) > 0 else x)
-        x = torch.cat(feats, dim=1) if len(feats) > 1 else feats[0]
+            if not fuse:
+                feats.append(self.deblocks[lvl](x) if len(self.deblocks) > 0 else x)
+                continue
+            if buf is None:
+                up = self.deblocks[lvl][0]
+                st = up.stride[0] if isinstance(up.stride, tuple) else up.stride
+                hw = (x.shape[2] * st, x.shape[3] * st) if isinstance(up, nn.ConvTranspose2d) else (x.shape[2] // st, x.shape[3] // st)
+                ref = x.new_empty((x.shape[0], 1, hw[0], hw[1]))
+                buf, views = hipbn.cat_buffer(ref, [d[1].num_features for d in self.deblocks[:len(self.blocks)]])
+            feats.append(self.deblocks[lvl](x, views[lvl]))          # (a shape / dtype / path mismatch leaves the slice unwritten)
+        if fuse and all(f.data_ptr() == v.data_ptr() and f.stride() == v.stride() for f, v in zip(feats, views)):
+            x = hipbn.cat_slices(buf, feats)
+        else:
+            x = torch.cat(feats, dim=1) if len(feats) > 1 else feats[0]
         if len(self.deblocks) > len(self.blocks):
             x = self.deblocks[-1](x)
         if self.upsample_featuremap:

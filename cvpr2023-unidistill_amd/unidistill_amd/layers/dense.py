@@ -183,13 +183,16 @@ def _can_fuse_inference(x, bn, conv):
 _HIP_BN = os.environ.get("UD_HIP_BN", "1") != "0"      # A/B switch for the streaming BatchNorm kernels
 
 
-def batchnorm_act(bn, x, residual=None, relu=True):
+def batchnorm_act(bn, x, residual=None, relu=True, out=None):
     """relu(bn(x) (+ residual)): the streaming HIP kernels in bf16 channels-last mode (training-mode
-    statistics with autograd, or eval-mode without), the PyTorch ops otherwise."""
+    statistics with autograd, or eval-mode without), the PyTorch ops otherwise.  out: a channel slice of a concatenation
+    buffer (ops/bn_act.cat_buffer) the HIP path writes in place; the other paths ignore it (the caller checks the result)."""
     frozen_grad = (not bn.training) and wants_grad(x, residual, bn)
     if Conv2d.hip_enabled and _HIP_BN and isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm1d)) \
             and not frozen_grad and hipbn.supported(x, bn):
-        return hipbn.bn_act(bn, x, residual, relu)
+        if out is not None and not (x.dim() == 4 and out.shape == x.shape and out.dtype == x.dtype):
+            out = None
+        return hipbn.bn_act(bn, x, residual, relu, out)
     if Conv2d.hip_enabled and _HIP_BN and not frozen_grad:
         _lib.library_fallthrough("layers.dense.batchnorm_act", x, training=bn.training)
     y = bn(x)
@@ -204,7 +207,8 @@ def _feeds_training_bn(mods, j):
 
 
 class FusedSequential(nn.Sequential):
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: where a trailing BatchNorm (+ ReLU) may write its result (see batchnorm_act)."""
         mods = list(self)
         i, n = 0, len(mods)
         while i < n:
@@ -241,7 +245,8 @@ class FusedSequential(nn.Sequential):
             if conv is None:
                 if isinstance(m, nn.BatchNorm2d) and x.dim() == 4:
                     relu = i + 1 < n and isinstance(mods[i + 1], nn.ReLU)
-                    x = batchnorm_act(m, x, None, relu)
+                    last = i + (2 if relu else 1) >= n
+                    x = batchnorm_act(m, x, None, relu, out if last else None)
                     i += 2 if relu else 1
                     continue
                 if (isinstance(m, Conv2d) and Conv2d.hip_enabled and Conv2d.hip_fp32 and x.dim() == 4 and _fp32_mode(x)

@@ -24,6 +24,20 @@ def _like(t, ref):
     return t.contiguous() if ref.dim() == 2 else t.contiguous(memory_format=torch.channels_last)
 
 
+def _row_stride(t, ref):
+    """t [B, C, H, W] addressed as rows of C channels every `ld` elements -- a channel slice of a (wider) channels-last map, e.g.
+    what torch.cat's backward hands to each input: -> ld (== C for a plain channels-last tensor), or None."""
+    if t.dim() != 4 or ref.dim() != 4 or t.dtype != ref.dtype or t.shape != ref.shape or not t.is_cuda:
+        return None
+    B, C, H, W = t.shape
+    s = t.stride()
+    ld = s[3] if W > 1 else (s[2] if H > 1 else C)
+    if ld < C or ld % 8 or t.data_ptr() % 16 or (C > 1 and s[1] != 1) or (W > 1 and s[3] != ld) or (H > 1 and s[2] != W * ld) \
+            or (B > 1 and s[0] != H * W * ld):
+        return None
+    return ld
+
+
 _ws_bytes = {}
 
 
@@ -104,9 +118,9 @@ def batch_stats(x, gamma, beta, running_mean, running_var, training, momentum, e
 class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu,
-                tracked=None, partial=None):
+                tracked=None, partial=None, out=None):
         lib = _lib.load()
-        k_fwd = lib.ud_bn_act_fwd_f32 if x.dtype == torch.float32 else lib.ud_bn_act_fwd
+        k_fwd = lib.ud_bn_act_fwd_ld_f32 if x.dtype == torch.float32 else lib.ud_bn_act_fwd_ld
         C = x.shape[1]
         P = x.numel() // C
         stream = _lib.stream_of(x)
@@ -114,9 +128,13 @@ class _BnActFn(torch.autograd.Function):
         v0, row = vec.data_ptr(), 4 * C
         if residual is not None:
             residual = _like(residual, x)
-        y = torch.empty_like(x)
+        # out: a channel slice of a wider channels-last map (a fused concatenation, see cat_slices) written in place
+        y = torch.empty_like(x) if out is None else out[0]       # (wrapped in a tuple: not an autograd input of this Function)
+        ld = C if out is None else _row_stride(y, x)
+        if ld is None:
+            raise ValueError(f"bn_act: out {tuple(y.shape)} strides {tuple(y.stride())} is not a channel slice of a channels-last map")
         _lib.check(k_fwd(x.data_ptr(), _lib.ptr(residual), v0 + 3 * row, v0 + 4 * row,
-                                     y.data_ptr(), P, C, 1 if relu else 0, stream), "ud_bn_act_fwd")
+                                     y.data_ptr(), P, C, ld, 1 if relu else 0, stream), "ud_bn_act_fwd_ld")
         ctx.cfg = (bool(training), bool(relu), residual is not None)
         ctx.save_for_backward(x, y if (residual is not None and relu) else None, vec)
         return y
@@ -130,7 +148,9 @@ class _BnActFn(torch.autograd.Function):
         lib = _lib.load()
         C = x.shape[1]
         P = x.numel() // C
-        dy = _like(dy, x)
+        ld = _row_stride(dy, x)           # a slice of a concatenation's gradient is read in place
+        if ld is None:
+            dy, ld = _like(dy, x), C
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
         if dres is not None and not relu:
@@ -138,18 +158,61 @@ class _BnActFn(torch.autograd.Function):
         dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
         ws = _workspace(x.device, C)
         v0, row, g0 = vec.data_ptr(), 4 * C, dgb.data_ptr()
-        k_bwd = lib.ud_bn_act_bwd_f32 if x.dtype == torch.float32 else lib.ud_bn_act_bwd
-        _lib.check(k_bwd(x.data_ptr(), _lib.ptr(y), dy.data_ptr(), v0 + 3 * row, v0 + 4 * row,
+        k_bwd = lib.ud_bn_act_bwd_ld_f32 if x.dtype == torch.float32 else lib.ud_bn_act_bwd_ld
+        _lib.check(k_bwd(x.data_ptr(), _lib.ptr(y), dy.data_ptr(), ld, v0 + 3 * row, v0 + 4 * row,
                                      v0, v0 + 2 * row, dx.data_ptr(), _lib.ptr(dres),
                                      g0, g0 + row, P, C, 1 if relu else 0,
-                                     ws.data_ptr(), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd")
+                                     ws.data_ptr(), ws.numel(), _lib.stream_of(x)), "ud_bn_act_bwd_ld")
         if has_res and ctx.needs_input_grad[3] and dres is None:
             dres = dy
-        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None, None
 
 
-def bn_act(bn, x, residual=None, relu=True):
-    """relu(bn(x) + residual) with nn.BatchNorm2d ``bn``'s parameters, buffers and train/eval mode."""
+class _CatSlices(torch.autograd.Function):
+    """The concatenated map whose channel slices the producers have already written (bn_act(..., out=slice)): forward hands the
+    buffer on, backward hands each producer ITS slice of the gradient as a strided view (read in place by ud_bn_act_bwd_ld)."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        ctx.widths = [p.shape[1] for p in parts]
+        return _alias(holder[0], 0, holder[0].size(), holder[0].stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        outs, c0 = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, c0:c0 + w])
+            c0 += w
+        return (None, *outs)
+
+
+def _alias(buf, offset, size, stride):
+    """A tensor on buf's storage that autograd does not know as a view of buf (the producers' outputs and the concatenated map
+    are separate autograd tensors over one allocation; nothing writes it after the producers)."""
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset() + offset, size, stride)
+
+
+def cat_buffer(ref, widths):
+    """Channels-last [B, sum(widths), H, W] buffer + its channel slices, for bn_act(..., out=slice) and cat_slices."""
+    B, _, H, W = ref.shape
+    Ct = sum(widths)
+    buf = torch.empty((B, H, W, Ct), dtype=ref.dtype, device=ref.device).permute(0, 3, 1, 2)
+    slots, c0 = [], 0
+    for w in widths:
+        slots.append(_alias(buf, c0, (B, w, H, W), buf.stride()))
+        c0 += w
+    return buf, slots
+
+
+def cat_slices(buf, parts):
+    """== torch.cat(parts, 1) when parts[i] IS the i-th channel slice of buf (written in place by its producer)."""
+    return _CatSlices.apply((buf,), *parts)
+
+
+def bn_act(bn, x, residual=None, relu=True, out=None):
+    """relu(bn(x) + residual) with nn.BatchNorm2d ``bn``'s parameters, buffers and train/eval mode; out: see cat_buffer."""
     tracked = None
     if bn.training:
         nbt = bn.num_batches_tracked
@@ -159,4 +222,4 @@ def bn_act(bn, x, residual=None, relu=True):
             nbt.add_(1)
     partial = getattr(x, "_ud_bn_partial", None) if bn.training else None    # left by a bn_stats convolution
     return _BnActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.training,
-                          bn.momentum, bn.eps, relu, tracked, partial)
+                          bn.momentum, bn.eps, relu, tracked, partial, None if out is None else (out,))

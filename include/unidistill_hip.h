@@ -719,6 +719,23 @@ int ud_bn_act_bwd_f32(const float* x, const float* y, const float* dy, const flo
                       const float* mean, const float* invstd, float* dx, float* dresidual, float* dgamma,
                       float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
                       ud_stream_t stream);
+/* y (forward) / dy (backward) as a CHANNEL SLICE of a wider channels-last map: rows of C elements every `ld` elements
+ * (ld >= C, ld % 8 == 0, the slice's first element 16-byte aligned); everything else as the functions above.  The upsampling
+ * heads of the BEV trunk (reference base_bev_backbone.py:117-141: `torch.cat(ups, dim=1)` over the deblocks' BatchNorm + ReLU
+ * outputs) write straight into the concatenated map and read its gradient in place: no cat kernel forward, no strided-slice
+ * copies backward. */
+int ud_bn_act_fwd_ld(const void* x, const void* residual, const float* scale, const float* shift, void* y,
+                     long long P, int C, long long y_ld, int relu, ud_stream_t stream);
+int ud_bn_act_fwd_ld_f32(const float* x, const float* residual, const float* scale, const float* shift, float* y,
+                         long long P, int C, long long y_ld, int relu, ud_stream_t stream);
+int ud_bn_act_bwd_ld(const void* x, const void* y, const void* dy, long long dy_ld, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, void* dx, void* dresidual, float* dgamma,
+                     float* dbeta, long long P, int C, int relu, void* workspace, size_t workspace_bytes,
+                     ud_stream_t stream);
+int ud_bn_act_bwd_ld_f32(const float* x, const float* y, const float* dy, long long dy_ld, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float* dx, float* dresidual,
+                         float* dgamma, float* dbeta, long long P, int C, int relu, void* workspace,
+                         size_t workspace_bytes, ud_stream_t stream);
 
 /* ---- Proposal layer: rotated-BEV IoU + greedy NMS -----------------------------------------------------
  * Replaces `iou3d_nms_cuda.nms_gpu(boxes, keep, thresh)` (reference layers/head/det3d/generate_proposals/

@@ -54,3 +54,27 @@ def test_checker_sees_the_hazard(tmp_path):
                     "\t;;#ASMEND\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v8, v17\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v9, v18\n\ts_endpgm\n")
     assert check_asm_inflight.check(str(bad_s)) == 1
     assert check_asm_inflight.check(str(ok_s)) == 0
+
+
+def test_checker_follows_branches_not_the_listing_order(tmp_path):
+    """hipcc rotates loops: a body can be entered in the middle of the listing (round 5: the steady-state loop of the persistent
+    1x1 kernel, whose second half precedes its entry block).  The checker walks the control-flow graph."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_asm_inflight
+    rd = "\t;;#ASMSTART\n\tds_read_b32 v17, v0\n\t;;#ASMEND\n"
+    hazard = tmp_path / "hazard.s"      # the read of v17 is reached through a branch, before the wait that precedes it in the listing
+    hazard.write_text("_Zk:\n" + rd + "\ts_branch .LBB0_2\n.LBB0_1:\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n.LBB0_2:\n\tv_mov_b32_e32 v8, v17\n"
+                      "\ts_branch .LBB0_1\n")
+    fine = tmp_path / "fine.s"          # the listing shows the copy before the wait; the execution order is wait, then copy
+    fine.write_text("_Zk:\n" + rd + "\ts_branch .LBB0_2\n.LBB0_1:\n\tv_mov_b32_e32 v8, v17\n\ts_endpgm\n.LBB0_2:\n\ts_waitcnt lgkmcnt(0)\n"
+                    "\ts_branch .LBB0_1\n")
+    loop = tmp_path / "loop.s"          # around the back edge: the load of iteration i is consumed in iteration i + 1 after its wait
+    loop.write_text("_Zk:\n" + rd + ".LBB0_1:\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v8, v17\n" + rd +
+                    "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n")
+    loop_bad = tmp_path / "loop_bad.s"  # the same loop reading v17 once more after the new load was issued
+    loop_bad.write_text("_Zk:\n" + rd + ".LBB0_1:\n\ts_waitcnt lgkmcnt(0)\n" + rd + "\tv_mov_b32_e32 v8, v17\n"
+                        "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n")
+    assert check_asm_inflight.check(str(hazard)) == 1
+    assert check_asm_inflight.check(str(fine)) == 0
+    assert check_asm_inflight.check(str(loop)) == 0
+    assert check_asm_inflight.check(str(loop_bad)) == 1

@@ -178,3 +178,89 @@ def test_conv_epilogue_statistics_equal_the_separate_pass(hip_lib, dtype, ks, sh
     # the statistics themselves agree far tighter than the bf16 tensors built from them
     np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(outs[1][2].cpu().numpy(), outs[0][2].cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("widths,shape", [((64, 32), (2, 9, 13)), ((256, 256), (2, 20, 36)), ((16, 48, 64), (3, 5, 7))])
+def test_bn_act_into_a_concatenation_and_strided_gradient(hip_lib, dtype, widths, shape):
+    """bn_act(..., out=slice) + cat_slices == torch.cat of separate bn_act calls, bit for bit (forward, dx, dgamma, dbeta, running
+    statistics): ud_bn_act_fwd_ld writes rows of a wider map, ud_bn_act_bwd_ld reads the concatenation's gradient in place; and
+    the plain torch.cat graph, whose backward hands over strided slices, takes the in-place path too (no copy)."""
+    from unidistill_amd.ops import bn_act as hb
+    B, H, W = shape
+    g = torch.Generator().manual_seed(sum(widths) + H)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    xs = [cl((torch.randn(B, c, H, W, generator=g) * 2 + 0.3).cuda().to(dtype)) for c in widths]
+    gy = cl(torch.randn(B, sum(widths), H, W, generator=g).cuda().to(dtype))
+
+    def run(fused):
+        bns = []
+        for c in widths:
+            bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda()
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+            bns.append(bn)
+        xin = [x.clone().requires_grad_(True) for x in xs]
+        if fused:
+            buf, slots = hb.cat_buffer(xin[0], list(widths))
+            parts = [hb.bn_act(bn, x, None, True, out=s) for bn, x, s in zip(bns, xin, slots)]
+            assert all(p.data_ptr() == s.data_ptr() for p, s in zip(parts, slots))
+            y = hb.cat_slices(buf, parts)
+        else:
+            y = torch.cat([hb.bn_act(bn, x, None, True) for bn, x in zip(bns, xin)], 1)
+        y.backward(gy)
+        return [y.detach()] + [x.grad for x in xin] + [bn.weight.grad for bn in bns] + [bn.bias.grad for bn in bns] + \
+            [bn.running_var for bn in bns]
+
+    real = hb._like
+    copies = []
+    hb._like = lambda t, ref: (copies.append(tuple(t.shape)) if not t.is_contiguous(memory_format=torch.channels_last) else None,
+                               real(t, ref))[1]
+    try:
+        a, b = run(True), run(False)
+    finally:
+        hb._like = real
+    assert not copies, f"a strided gradient slice was copied: {copies}"
+    assert a[0].is_contiguous(memory_format=torch.channels_last)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_bn_act_ld_argument_checks(hip_lib):
+    from unidistill_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(64, 32, device="cuda")
+    y = torch.empty(64, 64, device="cuda")
+    sc = torch.ones(32, device="cuda")
+    s = _lib.stream_of(x)
+    assert lib.ud_bn_act_fwd_ld_f32(x.data_ptr(), None, sc.data_ptr(), sc.data_ptr(), y.data_ptr(), 64, 32, 64, 1, s) == 0
+    assert lib.ud_bn_act_fwd_ld_f32(x.data_ptr(), None, sc.data_ptr(), sc.data_ptr(), y.data_ptr(), 64, 32, 16, 1, s) != 0   # ld < C
+    assert lib.ud_bn_act_fwd_ld_f32(x.data_ptr(), None, sc.data_ptr(), sc.data_ptr(), y.data_ptr(), 64, 32, 36, 1, s) != 0   # ld % 8
+    assert lib.ud_bn_act_fwd_ld_f32(x.data_ptr(), None, sc.data_ptr(), sc.data_ptr(), y.data_ptr() + 4, 64, 32, 64, 1, s) != 0  # alignment
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, :32], torch.relu(x + 1))
+
+
+@pytest.mark.parametrize("autocast", [None, torch.bfloat16])
+def test_bev_backbone_fused_concatenation_equals_torch_cat(hip_lib, autocast):
+    """BaseBEVBackbone (base_bev_backbone.py:117-141) with the deblock outputs written into the concatenated map vs torch.cat."""
+    from unidistill_amd.layers.bev import BaseBEVBackbone
+    torch.manual_seed(3)
+    net = BaseBEVBackbone([1, 1], [1, 2], [64, 128], [1, 2], [128, 128], 64).cuda().train()
+    x = torch.randn(2, 64, 24, 40, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fuse in (True, False):
+        BaseBEVBackbone.fuse_cat = fuse
+        try:
+            for p in net.parameters():
+                p.grad = None
+            xin = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=autocast, enabled=autocast is not None):
+                y, _ = net(xin)
+            y.float().square().mean().backward()
+            outs.append([y.detach().float(), xin.grad] + [p.grad.clone() for p in net.parameters()])
+        finally:
+            BaseBEVBackbone.fuse_cat = True
+    assert outs[0][0].shape == (2, 256, 24, 40)
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)

@@ -16,11 +16,14 @@ torch.cuda.synchronize()
 cnt, byt = collections.Counter(), collections.Counter()
 
 
+DEEP = int(os.environ.get("DEEP", "1"))      # package frames per site (DEEP=3: the callers of a helper such as bn_act._like)
+
+
 def site():
-    for fr in reversed(traceback.extract_stack()[:-2]):
-        if "unidistill_amd/" in fr.filename:
-            return f"{fr.filename.split('unidistill_amd/')[-1]}:{fr.lineno} {fr.line[:70]}"
-    return "?"
+    frames = [fr for fr in reversed(traceback.extract_stack()[:-2]) if "unidistill_amd/" in fr.filename][:DEEP]
+    if not frames:
+        return "?"
+    return " <- ".join(f"{fr.filename.split('unidistill_amd/')[-1]}:{fr.lineno} {fr.line[:70 if DEEP == 1 else 30]}" for fr in frames)
 
 
 def wrap(name):
@@ -29,7 +32,7 @@ def wrap(name):
     def f(self, *a, **k):
         out = orig(self, *a, **k)
         if torch.is_tensor(out) and out.is_cuda and (name == "copy_" or out.data_ptr() != self.data_ptr()):
-            s = site()
+            s = site() + (f"  {tuple(out.shape)} strides {tuple(self.stride())}" if DEEP > 1 else "")
             cnt[(name, s)] += 1
             byt[(name, s)] += out.numel() * out.element_size()
         return out
