@@ -59,4 +59,8 @@ rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T
 { echo "# fp32 1x1 convolutions: ud_conv1x1p_nhwc_f32 (persistent stream-K from 12 slices, per-tile with register epilogue below) vs the grid-per-tile kernel ($R)"; echo; echo "tools/time_1x1p.py (plain launches of one distillation step; 'new' = the launcher's own schedule, 'no-SK' = without the workspace; err vs an fp64 matmul with bias + residual + ReLU + BatchNorm sums):"; echo; echo '```'; python $T/time_1x1p.py 2>&1 | grep -E "^ +[0-9P]|per step"; echo '```'; echo; echo "SQ counters of k_conv1x1p_f32 at 16 896 x 1024 -> 256 with its stream-K tail (tools/pmc_kernel.sh k_conv1x1p python tools/pmc_1x1p.py 16896 1024 256 1):"; echo; echo '```'; bash $T/pmc_kernel.sh k_conv1x1p python $T/pmc_1x1p.py 16896 1024 256 1 2>&1 | grep " n=" | grep "k_conv1x1p_f32" | sed "s/.*k_conv1x1p_f32[^ ]* [^ ]* [^ ]* [a-z]* */k_conv1x1p_f32  /" | awk '{printf "%-18s %-26s %s %s\n", $1, $2, $3, $4}'; echo '```'; } > $OUT/${R}_conv_f32_1x1.md
 # 7. fp32 convolutions: ours vs library (forward / data gradient, and the weight gradients of one step)
 { echo "# fp32 convolutions: hand-written fp32 MFMA kernels (direct and Winograd: the launcher's routing) vs MIOpen ($R)"; echo; echo '```'; python $T/time_conv2d_f32.py 2>&1 | tail -13; echo; echo "-- weight gradients of one distillation step (tools/time_f32_wgrad.py; 3x3: Winograd form, last column = the direct kernel):"; python $T/time_f32_wgrad.py 2>&1 | tail -22; echo; echo "-- plain 1x1 launches of one step (tools/time_f32_1x1.py):"; python $T/time_f32_1x1.py 2>&1 | grep -E "kind|line|total"; echo; echo "-- frozen ResNet stem, 24 x 256 x 704 (tools/time_stem.py):"; python $T/time_stem.py 2>&1 | grep "us "; echo '```'; } > $OUT/${R}_conv_f32.md
+# 8. host lead: how far the enqueueing threads run ahead of the GPU at the phase boundaries of a step (fp32 and bf16)
+{ echo "# Host lead over the GPU inside a training step (tools/host_lead.py, $R)"; echo; echo "Host timestamps and HIP events at the same points of Trainer.step; lead = GPU time - host time at that point (ms since the loop start). A positive lead at every boundary = the step is GPU-bound, the host enqueue cost is hidden."; echo; echo "fp32:"; echo '```'; python $T/host_lead.py 2>&1 | tail -11; echo '```'; echo; echo "bf16 autocast:"; echo '```'; AC=bf16 python $T/host_lead.py 2>&1 | tail -11; echo '```'; } > $OUT/${R}_host_lead.md
+# 8b. the mapped (strided / transposed / im2col / dgrad-class) 1x1 launches of one step through their routing, and SQ counters of the spconv kernel
+{ echo "# Mapped 1x1 launches of one distillation step (tools/time_f32_1x1.py MAPPED=1, $R)"; echo; echo '```'; MAPPED=1 python $T/time_f32_1x1.py 2>&1 | grep -E "kind|mapped|total"; echo '```'; echo; echo "SQ counters of k_conv_dma_f32 (sparse 128 -> 128 layers, B=4 encoder pass; tools/pmc_kernel.sh):"; echo; echo '```'; B=4 bash $T/pmc_kernel.sh k_conv_dma_f32 python $T/time_spconv.py 2>&1 | grep " n=" | grep "128, 128" | awk '{printf "k_conv_dma_f32<128,128>  %-26s %s %s\n", $(NF-4), $(NF-3), $(NF-2)}'; echo '```'; } > $OUT/${R}_conv_f32_mapped.md
 ls -la $OUT

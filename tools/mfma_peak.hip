@@ -42,6 +42,44 @@ __global__ __launch_bounds__(256) void k_mfma32(float* out, int iters) {
     for (int e = 0; e < 16; ++e) s += acc[t][e];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+__global__ __launch_bounds__(256) void k_mfma32_f32(float* out, int iters) {
+  f32x16 acc[4];
+  for (int t = 0; t < 4; ++t)
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const float a = (float)(threadIdx.x & 7) * 0.125f, b = 1.0f / (float)(1 + (threadIdx.x & 3));
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int t = 0; t < 4; ++t)
+    for (int e = 0; e < 16; ++e) s += acc[t][e];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+void run32_f32(int wgs_per_cu) {
+  hipDeviceProp_t p;
+  (void)hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount, grid = cus * wgs_per_cu, iters = 20000;
+  float* out;
+  (void)hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  k_mfma32_f32<<<grid, 256>>>(out, 1000);
+  (void)hipDeviceSynchronize();
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0);
+    k_mfma32_f32<<<grid, 256>>>(out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double fl = (double)grid * 4 * iters * 4 * 2.0 * 32 * 32 * 2;
+    printf("fp32 v_mfma_f32_32x32x2_f32   %d CUs x %d workgroups: %.3f ms  %.1f TFLOP/s  (%.1f %% of the nominal 157)\n", cus, wgs_per_cu, ms,
+           fl / ms / 1e9, 100.0 * fl / ms / 1e9 / 157.3);
+  }
+  (void)hipFree(out);
+}
 void run32(int wgs_per_cu) {
   hipDeviceProp_t p;
   (void)hipGetDeviceProperties(&p, 0);
@@ -102,6 +140,9 @@ int main() {
   run<true>("bf16 v_mfma_f32_16x16x32_bf16", 2.0 * 16 * 16 * 32, 2516.6, 4);
   run<true>("bf16 v_mfma_f32_16x16x32_bf16", 2.0 * 16 * 16 * 32, 2516.6, 8);
   run<false>("fp32 v_mfma_f32_16x16x4_f32 ", 2.0 * 16 * 16 * 4, 157.3, 4);
+  run32_f32(1);
+  run32_f32(2);
+  run32_f32(4);
   run32(2);
   run32(4);
   // a few workgroups only (the chip draws little power): is the rate per CU the same?  (one workgroup per XCD-round-robin slot)
