@@ -62,5 +62,5 @@ rm -rf /tmp/p_sp; B=4 rocprofv3 --kernel-trace --stats -d /tmp/p_sp -- python $T
 # 8. host lead: how far the enqueueing threads run ahead of the GPU at the phase boundaries of a step (fp32 and bf16)
 { echo "# Host lead over the GPU inside a training step (tools/host_lead.py, $R)"; echo; echo "Host timestamps and HIP events at the same points of Trainer.step; lead = GPU time - host time at that point (ms since the loop start). A positive lead at every boundary = the step is GPU-bound, the host enqueue cost is hidden."; echo; echo "fp32:"; echo '```'; python $T/host_lead.py 2>&1 | tail -11; echo '```'; echo; echo "bf16 autocast:"; echo '```'; AC=bf16 python $T/host_lead.py 2>&1 | tail -11; echo '```'; } > $OUT/${R}_host_lead.md
 # 8b. the mapped (strided / transposed / im2col / dgrad-class) 1x1 launches of one step through their routing, and SQ counters of the spconv kernel
-{ echo "# Mapped 1x1 launches of one distillation step (tools/time_f32_1x1.py MAPPED=1, $R)"; echo; echo '```'; MAPPED=1 python $T/time_f32_1x1.py 2>&1 | grep -E "kind|mapped|total"; echo '```'; echo; echo "SQ counters of k_conv_dma_f32 (sparse 128 -> 128 layers, B=4 encoder pass; tools/pmc_kernel.sh):"; echo; echo '```'; B=4 bash $T/pmc_kernel.sh k_conv_dma_f32 python $T/time_spconv.py 2>&1 | grep " n=" | grep "128, 128" | awk '{printf "k_conv_dma_f32<128,128>  %-26s %s %s\n", $(NF-4), $(NF-3), $(NF-2)}'; echo '```'; } > $OUT/${R}_conv_f32_mapped.md
+{ echo "# Mapped 1x1 launches of one distillation step (tools/time_f32_1x1.py MAPPED=1, $R; the total line counts the plain launches of profiles/${R}_conv_f32.md too)"; echo; echo '```'; MAPPED=1 python $T/time_f32_1x1.py 2>&1 | grep -E "kind|mapped|total"; echo '```'; echo; echo "SQ counters of k_conv_dma_f32 (sparse 128 -> 128 layers, B=4 encoder pass; tools/pmc_kernel.sh):"; echo; echo '```'; B=4 bash $T/pmc_kernel.sh k_conv_dma_f32 python $T/time_spconv.py 2>&1 | grep " n=" | grep "128, 128" | awk '{printf "k_conv_dma_f32<128,128>  %-26s %s %s\n", $(NF-4), $(NF-3), $(NF-2)}'; echo '```'; } > $OUT/${R}_conv_f32_mapped.md
 ls -la $OUT
