@@ -12,6 +12,7 @@ import ctypes
 import torch
 
 from .. import _lib
+from . import wgrad_stream
 
 
 def supported(x, weight, stride=1, padding=1, dilation=1, groups=1):
@@ -153,7 +154,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _launch(gy, tap_major_transposed(weight), weight.shape[1], reverse_taps=True)
         if ctx.needs_input_grad[1]:
-            gw = weight_grad(x, gy, weight)
+            gw = wgrad_stream.defer(weight, lambda: weight_grad(x, gy, weight), x, gy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32)
         return gx, gw, gb, None
@@ -324,7 +325,7 @@ class _Conv1x1Fn(torch.autograd.Function):
                 if gskip is not None:
                     gx = gx + gskip
         if ctx.needs_input_grad[1]:
-            gw = weight_grad_1x1(x, gy, weight)
+            gw = wgrad_stream.defer(weight, lambda: weight_grad_1x1(x, gy, weight), x, gy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32)
         return gx, gw, gb, None, None
@@ -451,8 +452,8 @@ class _ConvPatchFn(torch.autograd.Function):
             gx = torch.ops.aten.convolution_backward(gy, x, weight.detach().to(dt), None, [s, s], [0, 0], [1, 1],
                                                      False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = _mapped_wgrad(x, gy, P, K, cout, pm, None)    # [Cout][s][s][C]
-            gw = dw.view(cout, s, s, C).permute(0, 3, 1, 2).to(weight.dtype)
+            gw = wgrad_stream.defer(weight, lambda: _mapped_wgrad(x, gy, P, K, cout, pm, None)    # [Cout][s][s][C]
+                                    .view(cout, s, s, C).permute(0, 3, 1, 2).to(weight.dtype), x, gy)
         return gx, gw, None
 
 
@@ -492,8 +493,8 @@ class _ConvTPatchFn(torch.autograd.Function):
             gx = _bf16_cl_empty((B, cin, H, W), x.device, dtype=dt)
             _mapped(gy, w2, gx, P, N, cin, pm, None)            # rows of dy gathered by the map: [P][N] x [Cin][N]^T
         if ctx.needs_input_grad[1]:
-            dw = _mapped_wgrad(x, gy, P, cin, N, None, pm)      # [s][s][Cout][Cin]
-            gw = dw.view(s, s, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
+            gw = wgrad_stream.defer(weight, lambda: _mapped_wgrad(x, gy, P, cin, N, None, pm)      # [s][s][Cout][Cin]
+                                    .view(s, s, cout, cin).permute(3, 2, 0, 1).to(weight.dtype), x, gy)
         return gx, gw, None
 
 
@@ -532,7 +533,8 @@ class _Conv1x1StrideFn(torch.autograd.Function):
             wt = weight.detach().reshape(cout, cin).t().contiguous() if dt == torch.float32 else _w1x1_t(weight)
             _mapped(gy, wt, gx, P, cout, cin, None, pm)
         if ctx.needs_input_grad[1]:
-            gw = _mapped_wgrad(x, gy, P, cin, cout, pm, None).view(cout, cin, 1, 1).to(weight.dtype)
+            gw = wgrad_stream.defer(weight, lambda: _mapped_wgrad(x, gy, P, cin, cout, pm, None).view(cout, cin, 1, 1).to(weight.dtype),
+                                    x, gy)
         return gx, gw, None
 
 
@@ -590,8 +592,8 @@ class _Conv3x3S2Fn(torch.autograd.Function):
                     _mapped(gy, wtt, gx, B * Hc * Wc, K, C, _pmap(4, 2, Hc, Wc, Ho, Wo, cout, a, b),
                             _pmap(2, 2, Hc, Wc, H, W, C, a, b))
         if ctx.needs_input_grad[1]:
-            dw = _mapped_wgrad(x, gy, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)   # [Cout][9][C]
-            gw = dw.view(cout, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype)
+            gw = wgrad_stream.defer(weight, lambda: _mapped_wgrad(x, gy, B * Ho * Wo, 9 * C, cout, _pmap(3, 2, Ho, Wo, H, W, C), None)   # [Cout][9][C]
+                                    .view(cout, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype), x, gy)
         return gx, gw
 
 

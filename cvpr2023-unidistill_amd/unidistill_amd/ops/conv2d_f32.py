@@ -10,6 +10,7 @@ import os
 import torch
 
 from .. import _lib
+from . import wgrad_stream
 
 
 def _nhwc(t):
@@ -353,7 +354,7 @@ class _ConvF32(torch.autograd.Function):
                 gx = _launch1(gy, w.reshape(weight.shape[0], weight.shape[1]).t().contiguous(), weight.shape[1],
                               residual=gskip)
         if ctx.needs_input_grad[1]:
-            gw = weight_grad(x, gy, w, ks)
+            gw = wgrad_stream.defer(weight, lambda: weight_grad(x, gy, w, ks), x, gy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
         return gx, gw, gb, None, None, None

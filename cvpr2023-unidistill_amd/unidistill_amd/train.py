@@ -17,7 +17,7 @@ from . import config as C
 from . import _lib
 from .dist import get_world_size, is_distributed, reduce_mean_many
 from .models import BEVFusionCenterHead
-from .ops import distill as D
+from .ops import distill as D, wgrad_stream
 
 
 def build_model(modality, **kw):
@@ -262,6 +262,7 @@ class Trainer:
         else:
             out = fn(batch)
         out["loss"].backward()
+        wgrad_stream.join()                        # (already done by the engine callback of ops/wgrad_stream.py; idempotent)
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip, foreach=True)
         self.opt.step()
