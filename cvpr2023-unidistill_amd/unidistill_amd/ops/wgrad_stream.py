@@ -12,8 +12,10 @@ fp32 distillation step: 60.1 -> 58.6 ms.
   * x / dy / the result are recorded on the streams that use them (caching-allocator reuse);
   * one callback queued on the autograd engine makes the caller's stream wait for the side stream when the backward pass ends,
     whoever started it (Trainer.step, torch.autograd.grad in a test).
-It computes inline -- the behaviour of rounds 1-5 -- when the parameter already has a gradient (accumulation steps, DDP's bucket
-views: AccumulateGrad then adds / copies on the caller's stream), under create_graph, on CPU, or with ``UD_WGRAD_STREAM=0``.
+It computes inline -- the behaviour of rounds 1-5 -- when the parameter already has a gradient (accumulation steps:
+AccumulateGrad then adds on the caller's stream) or carries a hook, under create_graph, on CPU, with ``UD_WGRAD_STREAM=0``, and
+under DistributedDataParallel (``disable()``, called by train.Trainer: DDP's reducer hook copies every gradient into its bucket
+on the caller's stream as soon as AccumulateGrad has run, i.e. before the join).
 (An engine-level variant -- an identity node recorded on the side stream so that autograd orders the streams itself -- was built
 first and gave non-reproducible losses; it was not pursued.)"""
 import os
@@ -36,11 +38,20 @@ def join():
     _pending.clear()
 
 
+def disable():
+    """Inline weight gradients for the rest of the process (DistributedDataParallel: see the module text)."""
+    global ENABLED
+    ENABLED = False
+
+
 def defer(weight, thunk, *keep):
     """dW of ``weight`` = thunk(), computed on the weight-gradient stream when that is safe (see the module text)."""
+    if ENABLED and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        disable()           # a process group with peers: assume a gradient reducer (DDP) hangs on the parameters
     if not (ENABLED and weight.is_cuda and weight.is_leaf and weight.grad is None and not torch.is_grad_enabled()
+            and not weight._backward_hooks and not getattr(weight, "_post_accumulate_grad_hooks", None)
             and not torch.cuda.is_current_stream_capturing()):
-        return thunk()
+        return thunk()      # (a hook on the parameter would read the gradient on the caller's stream)
     idx = weight.device.index
     side = _streams.get(idx)
     if side is None:

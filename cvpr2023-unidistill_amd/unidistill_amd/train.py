@@ -240,6 +240,7 @@ class Trainer:
                     p.register_hook(lambda g, st=p.stride(): g.as_strided(g.shape, st)
                                     if (g.stride() != st and g.is_contiguous()) else g)
             # gradients are all-reduced over RCCL/xGMI in ~64 MB buckets, overlapped with backward
+            wgrad_stream.disable()          # DDP's reducer hook reads each gradient on this stream right after AccumulateGrad
             self.ddp = nn.parallel.DistributedDataParallel(
                 self.module, device_ids=[self.device.index], output_device=self.device.index,
                 bucket_cap_mb=bucket_cap_mb,
