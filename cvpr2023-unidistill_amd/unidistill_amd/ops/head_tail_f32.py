@@ -1,9 +1,12 @@
 """fp32 mode of the second SepHead convolutions (reference layers/head/det3d/center_head.py:311-362): the 42
 (conv3x3 64 -> k <= 3) stacks as ONE grouped convolution on the channels-last fp32 hidden tensor
 (ud_head_tail_f32_fwd / _dgrad / _wgrad: exact fp32 FMAs, HBM-bound streaming kernels, deterministic)."""
+import os
+
 import torch
 
 from .. import _lib
+from . import wgrad_stream
 
 
 def supported(a, head_conv, kmax, k):
@@ -84,6 +87,7 @@ class _BnReluGroupTail(torch.autograd.Function):
                    "ud_head_tail_f32_bn_fwd")
         ctx.save_for_backward(y, vec, wt)
         ctx.cfg = (G, KM, bias is not None, bool(training))
+        ctx.weight_param = weight
         return z
 
     @staticmethod
@@ -102,12 +106,16 @@ class _BnReluGroupTail(torch.autograd.Function):
         v0, row = vec.data_ptr(), 4 * C
         dy = dgamma = dbeta = dw = db = None
         if ctx.needs_input_grad[10]:
-            need = lib.ud_head_tail_f32_wgrad_workspace_bytes(B, H, W, G, KM)
-            ws = _lib.workspace(y.device, need, "head_tail_f32")
-            dwt = torch.empty((G * KM, 3, 3, 64), dtype=torch.float32, device=y.device)
-            _lib.check(lib.ud_head_tail_f32_bn_wgrad(_lib.ptr(y), v0 + 3 * row, v0 + 4 * row, _lib.ptr(dz), _lib.ptr(dwt), B, H, W,
-                                                     G, KM, _lib.ptr(ws), ws.numel(), st), "ud_head_tail_f32_bn_wgrad")
-            dw = dwt.permute(0, 3, 1, 2)
+            def wgrad():
+                need = lib.ud_head_tail_f32_wgrad_workspace_bytes(B, H, W, G, KM)
+                ws = _lib.workspace(y.device, need, "head_tail_f32")
+                dwt = torch.empty((G * KM, 3, 3, 64), dtype=torch.float32, device=y.device)
+                _lib.check(lib.ud_head_tail_f32_bn_wgrad(_lib.ptr(y), v0 + 3 * row, v0 + 4 * row, _lib.ptr(dz), _lib.ptr(dwt), B, H, W,
+                                                         G, KM, _lib.ptr(ws), ws.numel(), _lib.stream_of(y)),
+                           "ud_head_tail_f32_bn_wgrad")
+                return dwt.permute(0, 3, 1, 2)
+            # (reads y and dz only: beside the BatchNorm-backward passes below on the weight-gradient stream, ops/wgrad_stream.py)
+            dw = wgrad_stream.defer(ctx.weight_param, wgrad, y, dz, vec) if os.environ.get("UD_TAIL_WGRAD_STREAM", "1") == "1" else wgrad()
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
             g0 = dgb.data_ptr()
