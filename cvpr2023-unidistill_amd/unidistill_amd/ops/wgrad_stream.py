@@ -67,7 +67,11 @@ def defer(weight, thunk, *keep):
     for t in keep:
         t.record_stream(side)                           # their blocks must not be handed out again before this stream has read them
     g.record_stream(cur)                                # allocated in the side stream's pool, read by the optimizer on the caller's
-    if not _pending:
-        Variable._execution_engine.queue_callback(join)
+    first = not _pending
     _pending.add(idx)
+    if first:
+        try:
+            Variable._execution_engine.queue_callback(join)
+        except RuntimeError:                            # not inside an autograd backward pass (a Function's backward called by hand)
+            join()
     return g
