@@ -111,6 +111,8 @@ def roofline_leg(device, batch):
     # feat from the Infinity Cache first with a READ of 512 MB (clean lines: honest HBM reads, nothing else in flight);
     # the same after a 512 MB memset instead (rounds 1-3's protocol: the memset's dirty lines are written back WHILE the op
     # runs -- reported as op_avg_us_dirty_scrub); then the launches with the brackets for the kernel's own duration
+    k_each = []
+    _lib.prof_read("bev_pool.k_pool")
     for mode in ("clean", "dirty", "prof"):
         _lib.prof_enable(mode == "prof")
         for _ in range(reps):
@@ -126,10 +128,31 @@ def roofline_leg(device, batch):
                 op_ms += e0.elapsed_time(e1)
             elif mode == "dirty":
                 op_dirty_ms += e0.elapsed_time(e1)
+            else:
+                k_each.append(_lib.prof_read("bev_pool.k_pool")[0] * 1e3)      # this launch alone (the spread over a box's clocks)
     _lib.prof_enable(False)
-    k_ms, k_calls = _lib.prof_read("bev_pool.k_pool")
+    k_ms, k_calls = sum(k_each) * 1e-3, len(k_each)
     alg = B * N * (12 + C * 4 + 12) + B * ny * nx * C * 4          # SURVEY 8d bev_pool fwd row
     k_us = k_ms / max(k_calls, 1) * 1e3
+    # SURVEY 8d's other row, reported separately: the fused lift + splat the TRAINING STEP runs (ud_lss_depth_ctx +
+    # ud_lss_splat_fwd: softmax / context split, list building, k_pool<SrcLift>; the [B, N, C] tensor never exists),
+    # 45.07 MB algorithmic per 6-camera sample, L2-bound
+    from unidistill_amd.ops import lss as lss_ops
+    D = N // (6 * 16 * 44)
+    dfeat = torch.randn(B * 6, D + C, 16, 44, device=device)
+    bins = geom.contiguous()
+    fused_ms = 0.0
+    with torch.no_grad():
+        for i in range(reps + 2):
+            scrub64.sum()
+            e0.record()
+            lss_ops.lift_splat(dfeat, bins, B, 6, D, C, nx, ny, 1)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                fused_ms += e0.elapsed_time(e1)
+    fused_us = fused_ms / reps * 1e3
+    fused_alg = B * 6 * (D + C) * 16 * 44 * 4 + B * N * 12 + B * ny * nx * C * 4
     pf = profile_figures().get("bev_pool.k_pool", {})
     traffic = pf.get("hbm_bytes") if pf.get("shape") == {"C": C, "nx": nx, "ny": ny, "N": N, "B": B} else None
     achieved = alg / (k_us * 1e-6) / 1e9
@@ -141,7 +164,10 @@ def roofline_leg(device, batch):
             "in_grid_fraction": in_grid,
             "frac_meaning": "algorithmic bytes (all %d rows, %.0f %% of them in-grid and actually read) / kernel time / 8 TB/s; "
                             "HBM throughput of the kernel itself = frac_counter_bytes" % (B * N, 100 * in_grid),
-            "avg_kernel_us": k_us, "launches": k_calls, "algorithmic_bytes_per_launch": alg,
+            "avg_kernel_us": k_us, "kernel_us_min": min(k_each), "kernel_us_max": max(k_each), "launches": k_calls,
+            "algorithmic_bytes_per_launch": alg,
+            "lift_splat_fused_us": fused_us, "lift_splat_fused_GBps": fused_alg / (fused_us * 1e-6) / 1e9,
+            "lift_splat_fused_algorithmic_bytes": fused_alg,
             "op_avg_us": op_ms / reps * 1e3, "op_GBps": alg / (op_ms / reps * 1e-3) / 1e9,
             "op_avg_us_dirty_scrub": op_dirty_ms / reps * 1e3,
             # whole op (memset of the cell counts + k_bin + k_pool) against the same algorithmic bytes
@@ -667,6 +693,11 @@ def main():
     ac = torch.bfloat16 if args.autocast == "bf16" else None
     trainer = train.Trainer(step, device=device, autocast_dtype=ac, channels_last=not args.nchw)
     dt, loss = timed_steps(trainer, batch, args, world, device)
+    from unidistill_amd.ops import wgrad_stream
+    wgrad_state = wgrad_stream.state()
+    if wgrad_state == "ddp":
+        wgrad_state = "ddp (%d gradients written into bucket views, %d inline while the views settled)" % (
+            wgrad_stream.STATS["ddp_direct"], wgrad_stream.STATS["ddp_inline"])
     # second precision + the MFMA legs take extra (collective) training steps: EVERY rank runs them
     bf16, mfma, mfma32 = None, None, None
     if ac is None and not args.no_roofline:
@@ -703,6 +734,9 @@ def main():
                        "precision": PRECISION_NOTE[ac],
                        "layout": "NCHW" if args.nchw else "channels-last dense convs",
                        "executor": "eager+DDP", "strict_no_library_fallthrough": os.environ.get("UD_STRICT") == "1",
+                       # weight gradients on their own HIP stream (ops/wgrad_stream.py): "on", "off", or "ddp" (kept under
+                       # DistributedDataParallel by writing into the bucket views + a per-bucket join in a communication hook)
+                       "wgrad_stream": wgrad_state,
                        "ranks": dist.get_world_size() if world > 1 else 1,
                        "dist_backend": dist.get_backend() if world > 1 else "none (single process)"},
         }
@@ -718,10 +752,14 @@ def main():
                                     voxelize_small_cloud_us=rv["small_cloud_us"])
             if mfma32 is not None:
                 line["roofline_mfma_f32"] = mfma32
+                line["roofline"].update(trunk_mfma_f32_frac_executed=mfma32["frac"],
+                                        trunk_direct_equiv_TFLOPs=mfma32["algorithmic_equivalent"]["TFLOP/s"])
             if "points" in batch:
                 line["roofline_spconv"] = spconv_leg(device, batch)
+                line["roofline"].update(spconv_frac=line["roofline_spconv"].get("frac"))
             if mfma is not None:
                 line["roofline_mfma"] = mfma
+                line["roofline"].update(trunk_mfma_bf16_frac=mfma["frac"])
         if world == 1 and not args.no_roofline and wl["kind"] == "distill":
             host = host_enqueue_leg(args.workload, args.batch, False)
             line["host_enqueue_ms"], line["host_enqueue"] = host.get("host_enqueue_ms"), host

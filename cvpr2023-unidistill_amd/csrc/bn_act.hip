@@ -304,6 +304,88 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const T* __restrict__ x, cons
   }
 }
 
+
+// ---- column sums: out[c] = sum_p x[p * ld + c] -- the bias gradient of a convolution (sum of dy over batch and pixels:
+// center_head.py:64,339,353 bias=True; the depth net's 1x1) as two HBM-rate passes in a fixed order.  (ATen's reduce_kernel
+// ran a channels-last [P][64..2688] sum on 11 workgroups: 0.65 TB/s.)
+// vector pass: thread = (8-channel chunk, pixel lane), grid (pixel slices, channel blocks)
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum_partial(const T* __restrict__ x, long long P, int C, long long ld, int CH,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x, ck = tid % CH, lanes = 256 / CH, pl = tid / CH;
+  const int chunk = blockIdx.y * CH + ck;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (chunk * 8 < C) {
+    const T* xp = x + chunk * 8;
+    long long p = (long long)blockIdx.x * lanes + pl;
+    const long long step = (long long)gridDim.x * lanes;
+    for (; p + step < P; p += 2 * step) {          // two independent rows in flight
+      float v[8], u[8];
+      ld8(xp + (size_t)p * ld, v);
+      ld8(xp + (size_t)(p + step) * ld, u);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += u[e];
+    }
+    if (p < P) {
+      float v[8];
+      ld8(xp + (size_t)p * ld, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[pl * (CH * 8) + ck * 8 + e] = s[e];
+  __syncthreads();
+  for (int c = tid; c < CH * 8; c += 256) {
+    const int cc = blockIdx.y * CH * 8 + c;
+    if (cc >= C) break;
+    float a = 0.f;
+    for (int i = 0; i < lanes; ++i) a += red[i * (CH * 8) + c];
+    partial[(size_t)blockIdx.x * C + cc] = a;
+  }
+}
+
+// any C / ld / alignment: thread = (row of the pass, channel), 4-byte (2-byte) loads
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum_partial_scalar(const T* __restrict__ x, long long P, int C, long long ld,
+                                                               float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x, cb0 = blockIdx.y * 256, cw = min(256, C - cb0), R = 256 / cw;
+  const int c = tid % cw, r = tid / cw;
+  float a0 = 0.f, a1 = 0.f;
+  if (r < R) {
+    const T* xp = x + cb0 + c;
+    long long p = (long long)blockIdx.x * R + r;
+    const long long step = (long long)gridDim.x * R;
+    for (; p + step < P; p += 2 * step) {
+      a0 += elem_f(xp[(size_t)p * ld]);
+      a1 += elem_f(xp[(size_t)(p + step) * ld]);
+    }
+    if (p < P) a0 += elem_f(xp[(size_t)p * ld]);
+  }
+  red[tid] = a0 + a1;
+  __syncthreads();
+  if (tid < cw) {
+    float a = 0.f;
+    for (int i = 0; i < R; ++i) a += red[i * cw + tid];
+    partial[(size_t)blockIdx.x * C + cb0 + tid] = a;
+  }
+}
+
+__global__ void k_colsum_final(const float* __restrict__ partial, int slices, int C, float* __restrict__ out) {
+  const int c = blockIdx.x, lane = threadIdx.x;      // one wave per channel, fixed-order reduction
+  float a = 0.f;
+  for (int s = lane; s < slices; s += 64) a += partial[(size_t)s * C + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) out[c] = a;
+}
+
 struct BnWs { float *partial, *k0, *k2; };
 size_t carve(UdArena& ar, int C, BnWs* w) {
   w->partial = ar.take<float>((size_t)kMaxSlices * C * 2);
@@ -398,6 +480,43 @@ int bn_bwd_impl(const T* x, const T* y, const T* dy, const float* scale, const f
   stream_grid(P, C, &CH, &grid);
   UdProfScope prof("bn_act.k_bwd_dx", stream);
   k_bn_bwd_dx<T><<<grid, 256, 0, stream>>>(x, y, dy, scale, shift, w.k0, w.k2, dx, dresidual, P, C, CH, relu, dy_ld);
+  UD_LAUNCH_CHECK();
+  return UD_OK;
+}
+
+template <typename T>
+int colsum_impl(const T* x, long long P, int C, long long ld, float* out, void* workspace, size_t workspace_bytes,
+                hipStream_t stream) {
+  if (!x || !out || P <= 0 || C <= 0 || ld < C) return UD_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < (size_t)kMaxSlices * C * sizeof(float)) return UD_ERR_WORKSPACE;
+  float* partial = (float*)workspace;
+  UdProfScope prof("bn_act.k_colsum", stream);
+  int slices;
+  const bool vec = C % 8 == 0 && (ld * sizeof(T)) % 16 == 0 && ((size_t)x & 15) == 0;
+  if (vec) {
+    const int chunks = C / 8;
+    int ch = 1;
+    while (ch < chunks && ch < 256) ch <<= 1;
+    const int lanes = 256 / ch, cblocks = (chunks + ch - 1) / ch;
+    long long s = (P + 2 * lanes - 1) / (2 * lanes);
+    const long long want = 2048 / cblocks > 0 ? 2048 / cblocks : 1;
+    if (s > want) s = want;
+    if (s > kMaxSlices) s = kMaxSlices;
+    if (s < 1) s = 1;
+    slices = (int)s;
+    k_colsum_partial<T><<<dim3(slices, cblocks), 256, 0, stream>>>(x, P, C, ld, ch, partial);
+  } else {
+    const int cblocks = (C + 255) / 256, cw = C < 256 ? C : 256, R = 256 / cw;
+    long long s = (P + 2 * R - 1) / (2 * R);
+    const long long want = 2048 / cblocks > 0 ? 2048 / cblocks : 1;
+    if (s > want) s = want;
+    if (s > kMaxSlices) s = kMaxSlices;
+    if (s < 1) s = 1;
+    slices = (int)s;
+    k_colsum_partial_scalar<T><<<dim3(slices, cblocks), 256, 0, stream>>>(x, P, C, ld, partial);
+  }
+  UD_LAUNCH_CHECK();
+  k_colsum_final<<<C, 64, 0, stream>>>(partial, slices, C, out);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }
@@ -497,6 +616,16 @@ int ud_bn_act_bwd_ld_f32(const float* x, const float* y, const float* dy, long l
                          size_t workspace_bytes, ud_stream_t stream) {
   return bn_bwd_impl<float>(x, y, dy, scale, shift, mean, invstd, dx, dresidual, dgamma, dbeta, P, C, relu, dy_ld,
                             workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t ud_colsum_workspace_bytes(int C) { return C > 0 ? ud_align_up((size_t)kMaxSlices * C * sizeof(float)) : 0; }
+int ud_colsum_f32(const float* x, long long P, int C, long long ld, float* out, void* workspace, size_t workspace_bytes,
+                  ud_stream_t stream) {
+  return colsum_impl<float>(x, P, C, ld, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int ud_colsum_bf16(const void* x, long long P, int C, long long ld, float* out, void* workspace, size_t workspace_bytes,
+                   ud_stream_t stream) {
+  return colsum_impl<bf16_t>((const bf16_t*)x, P, C, ld, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

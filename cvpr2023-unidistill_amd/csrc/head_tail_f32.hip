@@ -169,10 +169,14 @@ __global__ __launch_bounds__(256) void k_gtail_fwd(const float* __restrict__ a, 
 // MODE 0 stores da.  MODE 1 / 2 are the BatchNorm backward of the fused (relu(bn(y)) -> tail) block computed ON the data
 // gradient instead of after it: da is recomputed in both passes and never stored (1.39 GB at B = 4, written once and read
 // twice by the separate kernels).  MODE 1: partial[slice][c] = (sum dr, sum dr * (y - mean)) with dr = da where
-// y * scale + shift > 0; MODE 2: dy = scale * dr + k2 * y + k0 (k0 / k2 from k_gtail_bn_final).
+// y * scale + shift > 0; MODE 2: dy = scale * dr + k2 * y + k0 (k0 / k2 from k_gtail_bn_final).  MODE 3 = MODE 2 + the per-channel
+// sums of the dy values it stores (colsum[slice][c]; k_gtail_colsum_final adds the slices in order): the bias gradient of the
+// convolution that produced y (center_head.py:339: bias=True in front of the BatchNorm), which otherwise is one more pass
+// over the 1.39 GB gradient (ATen's reduce_kernel ran it on 11 workgroups: 2.1 ms per step).
 struct GTailBn {
   const float *y, *scale, *shift, *mean, *k0, *k2;
   float* partial;
+  float* colsum;
 };
 
 template <int KM, int MODE>
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ d
     bs = *reinterpret_cast<const float4*>(bn.scale + c0);
     bt = *reinterpret_cast<const float4*>(bn.shift + c0);
     if (MODE == 1) bm = *reinterpret_cast<const float4*>(bn.mean + c0);
-    if (MODE == 2) {
+    if (MODE >= 2) {
       b0 = *reinterpret_cast<const float4*>(bn.k0 + c0);
       b2 = *reinterpret_cast<const float4*>(bn.k2 + c0);
     }
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ d
             r.z = fmaf(bs.z, o.z, fmaf(b2.z, yv.z, b0.z));
             r.w = fmaf(bs.w, o.w, fmaf(b2.w, yv.w, b0.w));
             *reinterpret_cast<float4*>(po) = r;
+            if (MODE == 3) { s1.x += r.x; s1.y += r.y; s1.z += r.z; s1.w += r.w; }
           }
         }
       }
@@ -313,6 +318,28 @@ __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ d
       bn.partial[((size_t)blockIdx.y * Ct + g * kHC + c) * 2 + which] = a;
     }
   }
+  if (MODE == 3) {
+    __shared__ float4 red3[16][16];
+    red3[4 * wave + ps][cq] = s1;
+    __syncthreads();
+    if (tid < 64) {
+      const float* rp = reinterpret_cast<const float*>(&red3[0][0]) + tid;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += rp[i * 64];
+      bn.colsum[(size_t)blockIdx.y * Ct + g * kHC + tid] = a;
+    }
+  }
+}
+
+// out[c] = sum over the slices (in slice order within a lane, fixed tree across the lanes) of colsum[slice][c]
+__global__ void k_gtail_colsum_final(const float* __restrict__ colsum, int slices, int C, float* __restrict__ out) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float a = 0.f;
+  for (int s = lane; s < slices; s += 64) a += colsum[(size_t)s * C + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) out[c] = a;
 }
 
 // dgamma / dbeta and the two per-channel constants of the dy pass (the k_bn_bwd_final of bn_act.hip on this layout)
@@ -555,13 +582,13 @@ extern "C" size_t ud_head_tail_f32_bn_bwd_workspace_bytes(int B, int H, int W, i
   int strip_rows, strips;
   gtail_bn_grid(t, &strip_rows, &strips);
   const size_t C = (size_t)G * kHC;
-  return ud_align_up(((size_t)B * t.tiles_x * strips * C * 2 + 2 * C) * sizeof(float));
+  return ud_align_up(((size_t)B * t.tiles_x * strips * C * 3 + 2 * C) * sizeof(float));
 }
 
 extern "C" int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const float* y, const float* bn_scale,
                                        const float* bn_shift, const float* mean, const float* invstd, float* dy,
-                                       float* dgamma, float* dbeta, int B, int H, int W, int G, int KM, void* workspace,
-                                       size_t workspace_bytes, ud_stream_t stream_) {
+                                       float* dgamma, float* dbeta, float* dy_colsum, int B, int H, int W, int G, int KM,
+                                       void* workspace, size_t workspace_bytes, ud_stream_t stream_) {
   if (!dz || !w || !y || !bn_scale || !bn_shift || !mean || !invstd || !dy || !dgamma || !dbeta || !gtail_ok(B, H, W, G, KM))
     return UD_ERR_INVALID_ARG;
   if (!workspace || workspace_bytes < ud_head_tail_f32_bn_bwd_workspace_bytes(B, H, W, G, KM)) return UD_ERR_WORKSPACE;
@@ -574,7 +601,8 @@ extern "C" int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const fl
   float* partial = (float*)workspace;
   float* k0 = partial + (size_t)slices * C * 2;
   float* k2 = k0 + C;
-  GTailBn bn{y, bn_scale, bn_shift, mean, k0, k2, partial};
+  float* colsum = k2 + C;
+  GTailBn bn{y, bn_scale, bn_shift, mean, k0, k2, partial, colsum};
   {
     UdProfScope prof("head_tail.k_gtail_bn_bwd_reduce", stream);
     switch (KM) {
@@ -589,6 +617,18 @@ extern "C" int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const fl
     UD_LAUNCH_CHECK();
   }
   UdProfScope prof("head_tail.k_gtail_bn_bwd_dx", stream);
+  if (dy_colsum) {
+    switch (KM) {
+      case 1: k_gtail_dgrad<1, 3><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+      case 2: k_gtail_dgrad<2, 3><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+      case 3: k_gtail_dgrad<3, 3><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+      default: k_gtail_dgrad<4, 3><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
+    }
+    UD_LAUNCH_CHECK();
+    k_gtail_colsum_final<<<C, 64, 0, stream>>>(colsum, slices, C, dy_colsum);
+    UD_LAUNCH_CHECK();
+    return UD_OK;
+  }
   switch (KM) {
     case 1: k_gtail_dgrad<1, 2><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
     case 2: k_gtail_dgrad<2, 2><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;

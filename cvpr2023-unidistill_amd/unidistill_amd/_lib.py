@@ -175,7 +175,10 @@ _SIGS = {
     "ud_head_tail_f32_bn_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_f32_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "ud_head_tail_f32_bn_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
-    "ud_head_tail_f32_bn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "ud_head_tail_f32_bn_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "ud_colsum_workspace_bytes": (c_size_t, [c_int]),
+    "ud_colsum_f32": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ud_colsum_bf16": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ud_head_tail_f32_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "ud_head_tail_f32_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ud_bn_stats_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from ..ops import spconv as sp
-from ..ops.voxelize import MeanVFE, Voxelization, voxelize_deferred, voxelize_dirty
+from ..ops.voxelize import MeanVFE, Voxelization, voxelize_confirm, voxelize_deferred, voxelize_dirty
 
 
 def _conv_bn_relu(cin, cout, kernel, norm_fn, *, stride=1, padding=0, key=None, kind="subm"):
@@ -166,6 +166,7 @@ class LidarEncoder(nn.Module):
             pyr = sp.DeferredPyramid(coords_cap, m_out[B:B + 1], bb.sparse_shape, B, geoms)
             host = torch.cat([m_out[B:B + 2]] + pyr.counts()).cpu()         # THE host read of this encoder pass
             if int(host[1]) == 0:                                           # no partition overflow in the voxelizer
+                voxelize_confirm(batch.device)                              # (its workspace is in the clean state algo 3 starts from)
                 M = int(host[0])
                 sites = pyr.finalize(M, host[2:].tolist())
                 return sp.SparseConvTensor(mean_cap[:M], None, None, None, _sites=sites)

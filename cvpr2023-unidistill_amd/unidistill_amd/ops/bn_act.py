@@ -115,6 +115,44 @@ def batch_stats(x, gamma, beta, running_mean, running_var, training, momentum, e
     return vec
 
 
+def attach_colsum(g, sums):
+    """The producer of gradient tensor ``g`` already holds its per-channel sums (emitted by the pass that wrote g): leave them
+    on the tensor object for the bias gradient of the convolution that receives g (bias_grad below)."""
+    try:
+        g._ud_colsum = (g._version, g.data_ptr(), sums)
+    except (AttributeError, RuntimeError):
+        pass
+    return g
+
+
+def drop_colsum(g):
+    """g is about to be modified in place through a raw pointer (no version bump): its recorded sums no longer hold."""
+    if getattr(g, "_ud_colsum", None) is not None:
+        g._ud_colsum = None
+
+
+def bias_grad(gy):
+    """f32 [C] = gy.sum over everything but the channel axis -- the bias gradient of a convolution (nn.Conv2d(bias=True):
+    center_head.py:64,339,353) -- for a channels-last [B, C, H, W] map or an [M, C] row tensor, fp32 or bf16: ud_colsum_* (two
+    HBM-rate passes in a fixed order), or the sums its producer left on the tensor (attach_colsum)."""
+    hit = getattr(gy, "_ud_colsum", None)
+    if hit is not None and hit[0] == gy._version and hit[1] == gy.data_ptr():
+        return hit[2]
+    C = gy.shape[1]
+    rows = gy.dim() == 2 and gy.is_contiguous()
+    maps = gy.dim() == 4 and gy.is_contiguous(memory_format=torch.channels_last)
+    if not (gy.is_cuda and gy.dtype in (torch.float32, torch.bfloat16) and (rows or maps) and gy.numel() > 0):
+        dims = (0,) if gy.dim() == 2 else (0, 2, 3)
+        return gy.sum(dims, dtype=torch.float32)
+    lib = _lib.load()
+    out = torch.empty(C, dtype=torch.float32, device=gy.device)
+    ws = _lib.workspace(gy.device, lib.ud_colsum_workspace_bytes(C), "colsum")
+    fn = lib.ud_colsum_f32 if gy.dtype == torch.float32 else lib.ud_colsum_bf16
+    _lib.check(fn(gy.data_ptr(), gy.numel() // C, C, C, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_of(gy)),
+               "ud_colsum")
+    return out
+
+
 class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, training, momentum, eps, relu,

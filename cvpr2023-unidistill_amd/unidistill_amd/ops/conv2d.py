@@ -12,7 +12,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from . import wgrad_stream
+from . import bn_act, wgrad_stream
 
 
 def supported(x, weight, stride=1, padding=1, dilation=1, groups=1):
@@ -156,7 +156,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = wgrad_stream.defer(weight, lambda: weight_grad(x, gy, weight), x, gy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3), dtype=torch.float32)
+            gb = bn_act.bias_grad(gy)
         return gx, gw, gb, None
 
 
@@ -327,7 +327,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = wgrad_stream.defer(weight, lambda: weight_grad_1x1(x, gy, weight), x, gy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3), dtype=torch.float32)
+            gb = bn_act.bias_grad(gy)
         return gx, gw, gb, None, None
 
 

@@ -10,7 +10,7 @@ import os
 import torch
 
 from .. import _lib
-from . import wgrad_stream
+from . import bn_act, wgrad_stream
 
 
 def _nhwc(t):
@@ -356,7 +356,7 @@ class _ConvF32(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = wgrad_stream.defer(weight, lambda: weight_grad(x, gy, w, ks), x, gy)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
+            gb = bn_act.bias_grad(gy)
         return gx, gw, gb, None, None, None
 
 

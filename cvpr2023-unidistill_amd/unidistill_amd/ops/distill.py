@@ -58,12 +58,15 @@ class _FeatureTap(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, tap):
         ctx.tap = tap
+        ctx.set_materialize_grads(False)        # an unused x_loss (plain detector training) costs no zero map and no add
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
     def backward(ctx, g_net, g_loss):
         tap = ctx.tap
         pending, tap.pending = tap.pending, []
+        if g_loss is not None and all(st == 0 for st in g_loss.stride()) and pending:
+            g_loss = None                       # _BoxDistill's stride-0 placeholder: its real gradient is in `pending`
         if not pending:
             if g_net is None:
                 return g_loss, None
@@ -71,6 +74,12 @@ class _FeatureTap(torch.autograd.Function):
         g = g_net
         if g is None or g.dtype != torch.float32 or not g.is_cuda or any(st == 0 for st in g.stride()):
             g = torch.zeros_like(pending[0][1], dtype=torch.float32) if g is None else g.float().contiguous()
+        elif not _exclusively_owned(g):
+            g = g.clone()                       # the producer handed this tensor to another branch too: never add into it
+        if g_loss is not None:
+            g = g + g_loss                      # a consumer of x_loss other than the box losses
+        from . import bn_act
+        bn_act.drop_colsum(g)                   # (modified below through its raw pointer: column sums recorded on it are stale)
         lib = _lib.load()
         for kind, sx, tx, corners, valid_u8, gscale in pending:
             B, C, H, W = sx.shape
@@ -80,6 +89,20 @@ class _FeatureTap(torch.autograd.Function):
                                                   _lib.ptr(valid_u8), B, M, C, H, W, _lib.ptr(gscale), _lib.ptr(g), _strides(g),
                                                   _lib.ptr(ws), ws.numel(), _lib.stream_of(sx)), "ud_distill_box_bwd_acc")
         return g, None
+
+
+OWNED_USE_COUNT = 2      # the engine's input vector + this Python wrapper
+TAP_STATS = {"in_place": 0, "cloned": 0}
+
+
+def _exclusively_owned(g):
+    """True when nothing but the autograd engine's argument list (and the Python object made for this call) refers to g: a
+    producer that returned ONE tensor for two of its inputs (e.g. a residual join handing dy to both branches) leaves a third
+    reference in the other branch's input buffer, and an in-place add here would corrupt that branch."""
+    count = getattr(g, "_use_count", None)
+    ok = count is not None and count() <= OWNED_USE_COUNT and g._base is None
+    TAP_STATS["in_place" if ok else "cloned"] += 1
+    return ok
 
 
 def feature_tap(x):

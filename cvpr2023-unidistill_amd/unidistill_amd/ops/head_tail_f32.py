@@ -6,7 +6,7 @@ import os
 import torch
 
 from .. import _lib
-from . import wgrad_stream
+from . import bn_act, wgrad_stream
 
 
 def supported(a, head_conv, kmax, k):
@@ -53,7 +53,7 @@ class _GroupTail(torch.autograd.Function):
                                                   _lib.ptr(ws), ws.numel(), st), "ud_head_tail_f32_wgrad")
             dw = dwt.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dz.sum((0, 2, 3))
+            db = bn_act.bias_grad(dz)
         return da, dw, db, None, None
 
 
@@ -61,6 +61,7 @@ def group_tail(a, weight, bias, G, KM):
     return _GroupTail.apply(a, weight, bias, G, KM)
 
 
+EMIT_COLSUM = True      # False: the first convolution sums its bias gradient itself (ud_colsum_f32 over dy)
 FUSED_BN_BWD = True     # False: tail dgrad -> stored gradient -> ud_bn_act_bwd_f32 (the measured alternative)
 
 
@@ -72,7 +73,6 @@ class _BnReluGroupTail(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, tracked, partial, weight, bias, G, KM):
-        from . import bn_act
         _lib.require_gpu(y, weight)
         y = y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
         B, C, H, W = y.shape
@@ -92,7 +92,6 @@ class _BnReluGroupTail(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
-        from . import bn_act
         y, vec, wt = ctx.saved_tensors
         G, KM, has_bias, training = ctx.cfg
         if not training:
@@ -122,9 +121,14 @@ class _BnReluGroupTail(torch.autograd.Function):
             dy = torch.empty_like(y)
             if FUSED_BN_BWD:     # the tail's data gradient is recomputed inside both BatchNorm-backward passes, never stored
                 bws = _lib.workspace(y.device, lib.ud_head_tail_f32_bn_bwd_workspace_bytes(B, H, W, G, KM), "head_tail_f32_bn")
+                # + the per-channel sums of dy from the pass that stores it: the bias gradient of the first convolution
+                # (center_head.py:339: bias=True in front of the BatchNorm) without another pass over the 1.39 GB gradient
+                colsum = torch.empty(C, dtype=torch.float32, device=y.device) if EMIT_COLSUM else None
                 _lib.check(lib.ud_head_tail_f32_bn_bwd(_lib.ptr(dz), _lib.ptr(wt), y.data_ptr(), v0 + 3 * row, v0 + 4 * row, v0,
-                                                       v0 + 2 * row, dy.data_ptr(), g0, g0 + row, B, H, W, G, KM,
+                                                       v0 + 2 * row, dy.data_ptr(), g0, g0 + row, _lib.ptr(colsum), B, H, W, G, KM,
                                                        _lib.ptr(bws), bws.numel(), st), "ud_head_tail_f32_bn_bwd")
+                if colsum is not None:
+                    bn_act.attach_colsum(dy, colsum)
             else:
                 da = torch.empty_like(y)                     # gradient at relu(bn(y))
                 _lib.check(lib.ud_head_tail_f32_dgrad(_lib.ptr(dz), _lib.ptr(wt), _lib.ptr(da), B, H, W, G, KM, st),
@@ -135,7 +139,7 @@ class _BnReluGroupTail(torch.autograd.Function):
                                                  bws.numel(), st), "ud_bn_act_bwd")
             dgamma, dbeta = dgb[0], dgb[1]
         if has_bias and ctx.needs_input_grad[11]:
-            db = dz.sum((0, 2, 3))
+            db = bn_act.bias_grad(dz)
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, dw, db, None, None
 
 

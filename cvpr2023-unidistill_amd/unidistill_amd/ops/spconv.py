@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from .. import _lib
+from . import bn_act
 
 
 def _triple(v):
@@ -412,7 +413,7 @@ class _SparseConvFn(torch.autograd.Function):
                                                     _lib.ptr(row_order), _lib.ptr(tile_masks(nbr)), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad_bf16")
             if has_bias and ctx.needs_input_grad[2]:
-                gb = gout.float().sum(0)
+                gb = bn_act.bias_grad(gout)
             return gin, gw, gb, None, None, None, None
         gout = gout.contiguous().float()
         if ctx.needs_input_grad[0]:
@@ -435,7 +436,7 @@ class _SparseConvFn(torch.autograd.Function):
                                                _lib.ptr(gw), Mout, K, cin, cout, algo, _lib.ptr(ws),
                                                ws.numel(), _lib.stream_of(w)), "ud_spconv_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gout.sum(0)
+            gb = bn_act.bias_grad(gout)
         return gin, gw, gb, None, None, None, None
 
 

@@ -21,24 +21,32 @@ ALGO = None      # None: by size (below), hash fallback on overflow; 0 / 1 / 2: 
 SMALL_CLOUD = 160000   # points: below this the atomic hash (3 launches, ~15 us of atomics) beats the 6-launch partition path
 SMALL_TILES = 256      # algo 2 (three launches, self-cleaning workspace): at most this many 1 024-point tiles, P <= 16, B <= 64
 
-# algo 2 leaves its workspace in the clean state its next call starts from: (buffer address, bytes) -> sizes of the last algo-2/3
-# call on it.  Any other algorithm on the buffer, or an exception, drops the entry (the next small call then pays the memset).
-_CLEAN = {}
-
-
+# algo 2 leaves its workspace in the clean state its next call starts from.  The note -- the sizes of the last algo-2/3 call -- is
+# an ATTRIBUTE OF THE WORKSPACE TENSOR (`_ud_clean`), so a re-allocated (grown) workspace, or a block the caching allocator hands out
+# again at the same address to another scope, can never inherit it.  Any other algorithm on the buffer, an exception, or an
+# overflow drops it (the next small call then pays the memset); a deferred call's note stays `_ud_clean_pending` until the caller
+# has seen m_out[B + 1] == 0 (voxelize_confirm).
 def _small_algo(ws, B, N, P, max_voxels):
     """2 (memset first) or 3 (the workspace is known clean) for the three-launch small-cloud path, or None if it does not apply."""
     if B * N >= SMALL_CLOUD or (B * N + 1023) // 1024 > SMALL_TILES or P > 16 or B > 64:
         return None
-    return 3 if _CLEAN.get((ws.data_ptr(), ws.numel())) == (B, N, P, max_voxels) else 2
+    return 3 if getattr(ws, "_ud_clean", None) == (B, N, P, max_voxels) else 2
 
 
-def _note_algo(ws, algo, B, N, P, max_voxels):
-    key = (ws.data_ptr(), ws.numel())
+def _forget(ws):
+    ws._ud_clean = None
+    ws._ud_clean_pending = None
+
+
+def _note_algo(ws, algo, B, N, P, max_voxels, pending=False):
+    _forget(ws)
     if algo in (2, 3):
-        _CLEAN[key] = (B, N, P, max_voxels)
-    else:
-        _CLEAN.pop(key, None)
+        setattr(ws, "_ud_clean_pending" if pending else "_ud_clean", (B, N, P, max_voxels))
+
+
+def _device_workspaces(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return [buf for (dev, _scope, slot), buf in _lib._workspaces.items() if dev == idx and slot == "voxelize"]
 
 
 def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_voxels=True,
@@ -73,7 +81,7 @@ def voxelize_batch(points, voxel_size, pc_range, max_points, max_voxels, want_vo
     order = (algo if algo != 2 else small,) if algo is not None else ((small, 2) if small is not None else
                                                                       ((1,) if B * N < SMALL_CLOUD else (0, 1)))
     for a in order:
-        _CLEAN.pop((ws.data_ptr(), ws.numel()), None)        # unknown until the call has returned
+        _forget(ws)                                          # unknown until the call has returned
         _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range),
                                    int(max_points), int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords),
                                    _lib.ptr(num), _lib.ptr(mean), _lib.ptr(m_out), _lib.ptr(ws),
@@ -120,18 +128,29 @@ def voxelize_deferred(points, voxel_size, pc_range, max_points, max_voxels, want
         if small is None:
             raise ValueError("ud_voxelize: algo 2 takes at most 256 tiles of 1 024 points, P <= 16, B <= 64")
         algo = small
-    _CLEAN.pop((ws.data_ptr(), ws.numel()), None)
+    _forget(ws)
     _lib.check(lib.ud_voxelize(_lib.ptr(points), B, N, F, _f3(voxel_size), _f3(pc_range), int(max_points),
                                int(max_voxels), _lib.ptr(voxels), _lib.ptr(coords), _lib.ptr(num), _lib.ptr(mean),
                                _lib.ptr(m_out), _lib.ptr(ws), ws.numel(), algo, _lib.stream_of(points)), "ud_voxelize")
-    # (the caller reads m_out[B + 1]; a refused / overflowed call leaves the workspace dirty: voxelize_dirty() below)
-    _note_algo(ws, algo, B, N, int(max_points), int(max_voxels))
+    # the caller reads m_out[B + 1] and answers with voxelize_confirm (== 0) or voxelize_dirty (refused / overflowed: the workspace is
+    # dirty); until then the note is pending and the next small call runs algo 2 (memset first)
+    _note_algo(ws, algo, B, N, int(max_points), int(max_voxels), pending=True)
     return voxels, coords, num, mean, m_out, algo
 
 
+def voxelize_confirm(device):
+    """The caller of voxelize_deferred has seen m_out[B + 1] == 0: the pending clean-state notes of this device's voxelizer
+    workspaces hold."""
+    for ws in _device_workspaces(device):
+        pend = getattr(ws, "_ud_clean_pending", None)
+        if pend is not None:
+            ws._ud_clean, ws._ud_clean_pending = pend, None
+
+
 def voxelize_dirty(device):
-    """A deferred call reported a non-zero overflow word: forget every clean-state note of this device's workspaces."""
-    _CLEAN.clear()
+    """A deferred call reported a non-zero overflow word: forget the clean-state notes of THIS device's voxelizer workspaces."""
+    for ws in _device_workspaces(device):
+        _forget(ws)
 
 
 class PointToVoxel:

@@ -61,6 +61,9 @@ class DistillStep(nn.Module):
         # mode (BN batch statistics); teacher_train_mode reproduces that, default is eval.
         self.teacher_train_mode = teacher_train_mode
         self.teacher_model.train(self.training and teacher_train_mode)   # frozen teacher: eval from the start
+        # the reference loads the teacher with self.teacher_model.load_state_dict(ckpt) (..._distill_lidar.py:424): a (late) load
+        # into the submodule must not be undone by a snapshot taken before it
+        self.teacher_model.register_load_state_dict_post_hook(self._drop_teacher_snapshot)
 
     def train(self, mode=True):
         super().train(mode)
@@ -110,25 +113,42 @@ class DistillStep(nn.Module):
     def _reset_teacher_buffers(self):
         """teacher_train_mode: the reference reloads the teacher's checkpoint before every teacher pass
         (training_step, ..._distill_lidar.py:463: load_state_dict(self.checkpoint_state_dict)), which undoes the running-statistics
-        update of the previous step's train-mode BatchNorms.  Here: a snapshot of the buffers (taken at the first step, dropped
-        by load_state_dict) copied back with one foreach launch."""
+        update of the previous step's train-mode BatchNorms.  Here: a snapshot of the buffers copied back with one foreach launch.
+        The snapshot is the state the buffers had when they were last set from OUTSIDE the step: it is retaken when anybody but
+        the teacher pass itself has written them since (a checkpoint loaded into self.teacher_model or into this module, .to(), a
+        manual edit) -- detected by the buffers' version counters, which the statistics kernels bump (ops/bn_act.py) -- and
+        dropped by the load_state_dict hooks below."""
         bufs = [b for b in self.teacher_model.buffers()]
         snap = getattr(self, "_teacher_snapshot", None)
-        if snap is None or len(snap) != len(bufs) or any(a.device != b.device for a, b in zip(snap, bufs)):
+        seen = getattr(self, "_teacher_versions", None)
+        stale = (snap is None or len(snap) != len(bufs) or seen is None
+                 or any(a.device != b.device or a.shape != b.shape or a.dtype != b.dtype for a, b in zip(snap, bufs))
+                 or any(b._version != v for b, v in zip(bufs, seen)))
+        if stale:
             self._teacher_snapshot = [b.detach().clone() for b in bufs]
-            return
-        torch._foreach_copy_(bufs, snap)
+        else:
+            torch._foreach_copy_(bufs, snap)
+        return bufs
+
+    def _note_teacher_versions(self, bufs):
+        self._teacher_versions = [b._version for b in bufs]
+
+    def _drop_teacher_snapshot(self, *_):
+        self._teacher_snapshot = None
+        self._teacher_versions = None
 
     def load_state_dict(self, *a, **k):
-        self._teacher_snapshot = None
+        self._drop_teacher_snapshot()
         return super().load_state_dict(*a, **k)
 
     @torch.no_grad()
     def teacher(self, batch, prep, lidar_prepared=None):
-        if self.teacher_train_mode and self.teacher_model.training:
-            self._reset_teacher_buffers()
-        return self.teacher_model(self._points(batch), batch.get("imgs"), batch.get("mats_dict"),
-                                  prep["gt"], return_feature=True, lidar_prepared=lidar_prepared)
+        bufs = self._reset_teacher_buffers() if (self.teacher_train_mode and self.teacher_model.training) else None
+        out = self.teacher_model(self._points(batch), batch.get("imgs"), batch.get("mats_dict"),
+                                 prep["gt"], return_feature=True, lidar_prepared=lidar_prepared)
+        if bufs is not None:
+            self._note_teacher_versions(bufs)      # what the teacher pass itself left: anything newer came from outside
+        return out
 
     @torch.no_grad()
     def teacher_geometry(self, batch):
@@ -239,12 +259,17 @@ class Trainer:
                 if p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1 and p.is_contiguous():
                     p.register_hook(lambda g, st=p.stride(): g.as_strided(g.shape, st)
                                     if (g.stride() != st and g.is_contiguous()) else g)
+                    p._ud_hooks_stream_safe = True      # a view, no kernel: ops/wgrad_stream.py may still defer this gradient
             # gradients are all-reduced over RCCL/xGMI in ~64 MB buckets, overlapped with backward
-            wgrad_stream.disable()          # DDP's reducer hook reads each gradient on this stream right after AccumulateGrad
             self.ddp = nn.parallel.DistributedDataParallel(
-                self.module, device_ids=[self.device.index], output_device=self.device.index,
+                self.module, device_ids=[self.device.index] if self.device.type == "cuda" else None,
+                output_device=self.device.index if self.device.type == "cuda" else None,
                 bucket_cap_mb=bucket_cap_mb,
                 gradient_as_bucket_view=True, broadcast_buffers=False, find_unused_parameters=False)
+            # DDP's reducer reads each gradient on the autograd stream right after AccumulateGrad: the weight-gradient stream
+            # stays on by writing into the bucket views and joining per bucket in a communication hook (ops/wgrad_stream.py)
+            if wgrad_stream.ENABLED and self.device.type == "cuda":
+                wgrad_stream.attach_ddp(self.ddp)
         self.opt = torch.optim.AdamW(trainable, lr=lr, weight_decay=weight_decay, fused=True)
         self.scheduler = None
         if lr_milestones:

@@ -462,11 +462,22 @@ int ud_head_tail_f32_bn_fwd(const float* a, const float* bn_scale, const float* 
 int ud_head_tail_f32_bn_wgrad(const float* a, const float* bn_scale, const float* bn_shift, const float* dz, float* dw, int B,
                               int H, int W, int G, int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream);
 /* Backward of relu(bn(y)) -> second convolutions down to y in two passes that RECOMPUTE the tail's data gradient instead of
- * storing it: dgamma / dbeta [G*64] (training-mode statistics: mean / invstd of y, folded scale / shift) and dy [B, H, W, G*64]. */
+ * storing it: dgamma / dbeta [G*64] (training-mode statistics: mean / invstd of y, folded scale / shift) and dy [B, H, W, G*64].
+ * dy_colsum (optional, [G*64]): the per-channel sums of the dy values stored, in a fixed order -- the bias gradient of the
+ * convolution that produced y (center_head.py:339 bias=True), emitted by the pass that writes dy instead of a third pass over it. */
 size_t ud_head_tail_f32_bn_bwd_workspace_bytes(int B, int H, int W, int G, int KM);
 int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const float* y, const float* bn_scale, const float* bn_shift,
-                            const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W,
-                            int G, int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+                            const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta, float* dy_colsum,
+                            int B, int H, int W, int G, int KM, void* workspace, size_t workspace_bytes, ud_stream_t stream);
+/* Column sums of a channels-last tensor, out[c] = sum_p x[p * ld + c] (ld >= C elements between rows): the bias gradient of a
+ * convolution = the sum of its output gradient over batch and pixels (reference: autograd of nn.Conv2d(bias=True),
+ * center_head.py:64,339,353; lss_fpn.py:160 depth net).  Two HBM-rate passes, fixed summation order (deterministic); any C
+ * (16-byte vector loads when C % 8 == 0 and the rows are 16-byte aligned). */
+size_t ud_colsum_workspace_bytes(int C);
+int ud_colsum_f32(const float* x, long long P, int C, long long ld, float* out, void* workspace, size_t workspace_bytes,
+                  ud_stream_t stream);
+int ud_colsum_bf16(const void* x, long long P, int C, long long ld, float* out, void* workspace, size_t workspace_bytes,
+                   ud_stream_t stream);
 
 /* ---- Dense 3x3 / stride 1 / pad 1 convolution, channels-last bf16 (BEV trunk + head convs) ----------
  * Replaces nn.Conv2d(k=3, s=1, p=1) of BaseBEVBackbone (reference unidistill/layers/blocks_2d/det3d/

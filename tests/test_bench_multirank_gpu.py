@@ -52,18 +52,26 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)                                  # both ranks share the box's one GPU
 dist.init_process_group("gloo")
 from unidistill_amd import train
+from unidistill_amd.ops import wgrad_stream
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)                                      # same initial weights on every rank
 tr = train.Trainer(train.DistillStep({workload!r}), device=dev, channels_last=True)
 assert tr.ddp is not None
 batch = train.synthetic_batch(dev, 1, rank=rank)          # rank-specific data: gradients differ before the all-reduce
-for _ in range(3):
+for _ in range(6):
     out = tr.step(batch)
     assert torch.isfinite(out["loss"])
 flat = torch.cat([p.detach().flatten() for p in tr.params])
 ref = flat.clone()
 dist.broadcast(ref, 0)
 assert torch.equal(flat, ref), "ranks diverged: max |d| = %g" % float((flat - ref).abs().max())
+# the weight-gradient stream under DDP (ops/wgrad_stream.py): steps 1-3 inline while the bucket views settle (DDP re-buckets
+# before its second forward), from step 4 on the side stream writes dW straight into the bucket views
+if os.environ.get("UD_WGRAD_STREAM", "1") == "1":
+    assert wgrad_stream.state() == "ddp" and wgrad_stream.STATS["ddp_direct"] > 50, wgrad_stream.STATS
+else:
+    assert wgrad_stream.STATS["ddp_direct"] == 0 and wgrad_stream.STATS["deferred"] == 0
+torch.save(flat.cpu(), os.environ["UD_TEST_OUT"] + ".rank%d.pt" % rank)
 losses = [None, None]
 dist.all_gather_object(losses, float(out["loss"]))
 assert losses[0] != losses[1], "ranks saw the same batch"
@@ -74,19 +82,28 @@ print("GLOO_DISTILL_OK", rank)
 
 @pytest.mark.parametrize("workload,port", [("camera_exp_distill_lidar", 29541), ("lidar_exp_distill_fusion", 29542)])
 def test_two_rank_distill_steps_keep_ranks_identical(hip_lib, tmp_path, workload, port):
-    """Two data-parallel ranks (gloo collectives, both on GPU 0: the one-GPU box cannot host two RCCL ranks) run three
+    """Two data-parallel ranks (gloo collectives, both on GPU 0: the one-GPU box cannot host two RCCL ranks) run six
     distillation steps of the two multi-GPU BASELINE workloads on DIFFERENT batches: DDP buckets (bucket views,
     find_unused_parameters=False, a LiDAR student with data-dependent rulebooks), the packed normaliser all-reduce and
-    the fused optimizer must leave every trainable parameter bit-identical on both ranks."""
+    the fused optimizer must leave every trainable parameter bit-identical on both ranks -- with the weight gradients on their
+    own stream, written straight into DDP's bucket views (the reference's launch mode IS ddp: exps/base_cli.py:40-45), AND
+    bit-identical to the same job with every weight gradient inline (UD_WGRAD_STREAM=0)."""
+    import torch
     from conftest import PKG
     path = tmp_path / "gloo_distill.py"
     path.write_text(_GLOO_DISTILL.format(root=ROOT, pkg=PKG, workload=workload))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UD_RANDOM_INIT="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(path)]
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0 and res.stdout.count("GLOO_DISTILL_OK") == 2, res.stdout[-1500:] + res.stderr[-3000:]
-    assert "Grad strides do not match bucket view strides" not in res.stderr, res.stderr[-1500:]
+    final = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / ("params_stream" + mode))
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UD_RANDOM_INIT="1", UD_WGRAD_STREAM=mode, UD_TEST_OUT=out)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port + (10 if mode == "0" else 0)), str(path)]
+        res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0 and res.stdout.count("GLOO_DISTILL_OK") == 2, res.stdout[-1500:] + res.stderr[-3000:]
+        assert "Grad strides do not match bucket view strides" not in res.stderr, res.stderr[-1500:]
+        final[mode] = torch.load(out + ".rank0.pt")
+    assert torch.equal(final["1"], final["0"]), \
+        "weight-gradient stream under DDP changed the result: max |d| = %g" % float((final["1"] - final["0"]).abs().max())
 
 
 _NCCL_SCRIPT = r'''
@@ -144,9 +161,12 @@ torch.manual_seed(0)
 tr = train.Trainer(train.DistillStep("camera_exp_distill_lidar"), device=torch.device("cuda", 0), channels_last=True)
 assert tr.ddp is not None, "UD_FORCE_DDP did not wrap the step"
 batch = train.synthetic_batch(torch.device("cuda", 0), 1, rank=0)
-for _ in range(2):                              # the second step is the one that trips over unused parameters
+from unidistill_amd.ops import wgrad_stream
+for _ in range(5):                              # the second step is the one that trips over unused parameters
     out = tr.step(batch)
 assert torch.isfinite(out["loss"])
+# the weight-gradient stream stays on under DDP: from the fourth step the gradients are written into RCCL's bucket views
+assert wgrad_stream.state() == "ddp" and wgrad_stream.STATS["ddp_direct"] > 50, wgrad_stream.STATS
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_ONE_RANK_OK")
 '''

@@ -264,3 +264,41 @@ def test_bev_backbone_fused_concatenation_equals_torch_cat(hip_lib, autocast):
     assert outs[0][0].shape == (2, 256, 24, 40)
     for u, v in zip(*outs):
         assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(4, 64, 45, 45), (2, 126, 60, 44), (1, 2688, 30, 20), (2, 16, 33, 17), (3, 368, 16, 44),
+                                   (1, 8, 1, 1), (2, 300, 9, 7)])
+def test_bias_gradient_column_sums(hip_lib, dtype, shape):
+    """ud_colsum_f32 / _bf16 (the bias gradient of a convolution: gy.sum((0, 2, 3)), center_head.py:64,339,353) vs a float64 sum:
+    within fp32 summation error of the column's absolute sum, bitwise the same on a second call, also for [M, C] row tensors and
+    channel counts that take the scalar kernel (126 = the 42 packed heads x 3)."""
+    from unidistill_amd.ops import bn_act
+    B, C, H, W = shape
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    torch.manual_seed(C + H)
+    g = (torch.randn(B, C, H, W, device="cuda") * 2 + 0.1).to(dt).contiguous(memory_format=torch.channels_last)
+    got = bn_act.bias_grad(g)
+    ref = g.double().sum((0, 2, 3))
+    bound = 4e-6 * g.double().abs().sum((0, 2, 3)) + 1e-6
+    assert got.dtype == torch.float32 and got.shape == (C,)
+    assert bool(((got.double() - ref).abs() <= bound).all())
+    assert torch.equal(got, bn_act.bias_grad(g))
+    rows = g.permute(0, 2, 3, 1).reshape(-1, C)
+    assert rows.is_contiguous()
+    assert torch.equal(bn_act.bias_grad(rows), got)
+
+
+@pytest.mark.gpu
+def test_bias_gradient_sums_left_by_the_producer_are_used_and_invalidated(hip_lib):
+    from unidistill_amd.ops import bn_act
+    g = torch.randn(2, 32, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    marker = torch.full((32,), 7.0, device="cuda")
+    bn_act.attach_colsum(g, marker)
+    assert bn_act.bias_grad(g) is marker
+    g.add_(1.0)                                            # version moved: the recorded sums are stale
+    assert torch.allclose(bn_act.bias_grad(g), g.sum((0, 2, 3)), rtol=1e-5, atol=1e-4)
+    bn_act.attach_colsum(g, marker)
+    bn_act.drop_colsum(g)                                  # (what a raw-pointer in-place writer calls)
+    assert bn_act.bias_grad(g) is not marker

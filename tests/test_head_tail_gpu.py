@@ -170,6 +170,16 @@ def test_fp32_bn_relu_group_tail_vs_torch(hip_lib, shape, training):
     ref = torch.autograd.grad(zr, (y, gamma, beta, w, b), gz)
     for a, r, name in zip(got, ref, ("dy", "dgamma", "dbeta", "dw", "db")):
         assert (a - r).abs().max() <= 1e-4 * r.abs().max() + 1e-6, name
+    # the pass that stores dy also leaves its per-channel sums (the first convolution's bias gradient) on the tensor: equal to
+    # a float64 sum of the stored values within fp32 summation error (the sums themselves are rounding noise around 0: the
+    # gradient of a bias in front of a training-mode BatchNorm vanishes)
+    from unidistill_amd.ops import bn_act
+    dy = got[0]
+    assert getattr(dy, "_ud_colsum", None) is not None
+    sums = bn_act.bias_grad(dy)
+    assert sums is dy._ud_colsum[2]
+    ref64 = dy.double().sum((0, 2, 3))
+    assert bool(((sums.double() - ref64).abs() <= 4e-6 * dy.double().abs().sum((0, 2, 3)) + 1e-6).all())
 
 
 @pytest.mark.parametrize("fused_bn", [True, False])

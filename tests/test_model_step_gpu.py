@@ -161,6 +161,7 @@ def test_distill_step_with_train_mode_teacher_vs_reference(golden, hip_lib, leni
     step.overlap_teacher = False
     step.cuda().train()
     assert step.teacher_model.training and step.model.training
+    ckpt = {k: v.detach().clone() for k, v in teacher.state_dict().items()}
     out = step(_batch(g))
     out["loss"].backward()
     _close(out["loss"], gt_["loss"], what="total loss, teacher in train mode")
@@ -195,6 +196,35 @@ def test_distill_step_with_train_mode_teacher_vs_reference(golden, hip_lib, leni
                 assert int(sd[name]) == int(gt_[k]), name
             else:
                 _close(sd[name], gt_[k], rtol=1e-4, what=k)
+    # a checkpoint loaded into the teacher AFTER steps have run (the reference: self.teacher_model.load_state_dict(ckpt),
+    # ..._distill_lidar.py:424 -- a resume, a late teacher load) must not be undone by the buffers remembered before it: with
+    # shifted running statistics loaded, the next step's reset starts from THEM
+    shifted = {k: (v + 0.25 if k.endswith("running_mean") else v.clone()) for k, v in ckpt.items()}
+    teacher.load_state_dict(shifted)
+    student.zero_grad(set_to_none=True)
+    step(_batch(g))
+    step(_batch(g))
+    sd = teacher.state_dict()
+    momentum = {n_ + ".running_mean": m_.momentum for n_, m_ in teacher.named_modules() if hasattr(m_, "running_mean")}
+    momentum.update({n_ + ".bn_running_mean": m_.bn_momentum for n_, m_ in teacher.named_modules() if hasattr(m_, "bn_momentum")})
+    checked = 0
+    for k in gt_.files:
+        name = k[len("teacher_after/"):]
+        if k.startswith("teacher_after/") and name.endswith("running_mean") and name in momentum:
+            # one momentum step from the SHIFTED buffers instead of from the original ones: + (1 - momentum) * 0.25
+            _close(sd[name], gt_[k] + (1 - momentum[name]) * 0.25, rtol=1e-4, what=k + " after a late load")
+            checked += 1
+    assert checked > 10
+    # ... and buffers written from outside without any load (a manual edit) are picked up as well
+    with torch.no_grad():
+        for n_, b_ in teacher.named_buffers():
+            b_.copy_(ckpt[n_])
+    step(_batch(g))
+    sd = teacher.state_dict()
+    for k in gt_.files:
+        name = k[len("teacher_after/"):]
+        if k.startswith("teacher_after/") and name.endswith("running_mean"):
+            _close(sd[name], gt_[k], rtol=1e-4, atol_frac=1e-5, what=k + " after a manual edit")
 
 
 def test_student_forward_outputs_vs_reference(golden, hip_lib, lenient):

@@ -141,13 +141,13 @@ def test_three_launch_path_cleans_its_workspace_and_refuses_a_foreign_one():
     from unidistill_amd import _lib
     from unidistill_amd.ops import voxelize as V
     g = syn.rng(31)
-    V._CLEAN.clear()
+    V.voxelize_dirty(torch.device("cuda", torch.cuda.current_device()))
     seen = []
     orig = V._note_algo
 
-    def spy(ws, algo, *a):
+    def spy(ws, algo, *a, **k):
         seen.append(algo)
-        return orig(ws, algo, *a)
+        return orig(ws, algo, *a, **k)
     V._note_algo = spy
     try:
         clouds = syn.pad_clouds([syn.lidar_cloud(g, 30000, 1) for _ in range(5)])       # one shape
@@ -162,6 +162,28 @@ def test_three_launch_path_cleans_its_workspace_and_refuses_a_foreign_one():
     finally:
         V._note_algo = orig
     assert seen == [2, 3, 3, 3, 3], seen
+    # the clean-state note lives on the workspace TENSOR: a re-allocated (grown) workspace starts without it, whatever its address
+    key = next(k for k in _lib._workspaces if k[2] == "voxelize" and k[1] == "eager")
+    old = _lib._workspaces[key]
+    assert old._ud_clean is not None
+    _lib._workspaces[key] = torch.empty_like(old)
+    try:
+        seen.clear()
+        V._note_algo = spy
+        _gpu(clouds[0:1], algo=None)
+        _gpu(clouds[1:2], algo=None)
+        assert seen == [2, 3], seen
+    finally:
+        V._note_algo = orig
+    # a deferred call's note is pending until the caller has seen the overflow word
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t0 = torch.from_numpy(clouds[0:1]).cuda()
+    assert V.voxelize_deferred(t0, VS, RG, 10, 120000)[5] == 3
+    assert V.voxelize_deferred(t0, VS, RG, 10, 120000)[5] == 2          # not confirmed: memset first
+    V.voxelize_confirm(dev)
+    assert V.voxelize_deferred(t0, VS, RG, 10, 120000)[5] == 3
+    V.voxelize_dirty(dev)
+    assert V.voxelize_deferred(t0, VS, RG, 10, 120000)[5] == 2
     # a foreign workspace under the "known clean" claim
     lib = _lib.load()
     t = torch.from_numpy(syn.lidar_cloud(g, 30000, 1)[None]).cuda()

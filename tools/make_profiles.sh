@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 T=$GRAFT_REPO_ROOT/tools
 # 1. the bench command itself: kernel trace; summary restricted to the steady state (no warm-up / MIOpen find kernels)
 rm -rf /tmp/p_bench; rocprofv3 --kernel-trace --stats -d /tmp/p_bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_stdout.txt 2>&1
-DB=$(ls /tmp/p_bench/*/*.db | head -1)
+DB=$(ls -S /tmp/p_bench/*/*.db | head -1)   # the bench process itself: the LARGEST database (bench.py times the host enqueue in a child process, whose trace is a second, smaller file)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline  ($R)"; echo; echo "The JSON line below was measured UNDER the tracer (about 8 us added per launch, ~2 000 launches per step: ms_per_step is ~15 ms above the un-instrumented run that bench.py / the driver reports); it is kept for the kernel table's context, not as the result."; echo;
   echo '```'; grep "^{\"metric\"" $OUT/bench_stdout.txt | cut -c1-3000; echo '```'; echo;
   echo "## Roofline kernels of the bench legs (rocprofv3 durations; bench.py's own HIP-event figures are in the JSON above)"; echo;
