@@ -6,14 +6,17 @@
 //   k_row_masks     bit position of offset k = its rank by descending frequency (ties: lower k first) -- the rarest offsets
 //                   (the corners of a 3x3x3 kernel) get the top bits, so rows group by their rare neighbours first (20.2
 //                   instead of 20.6 active offsets per tile at the 128-channel level of the LiDAR encoder);
-//                   mask[r] = OR over k of (nbr[r][k] >= 0) << bitpos[k];  iota[r] = r
-//   rocprim::radix_sort_pairs over the K mask bits (stable: equal masks keep their row order) -> order[]
+//                   mask[r] = OR over k of (nbr[r][k] >= 0) << bitpos[k]
+//   stable LSD radix sort of (mask, row) over the K mask bits (equal masks keep their row order) -> order[]: ceil(K / 9) passes of
+//                   k_rs_hist (per-chunk digit counts) -> k_rs_scan (one workgroup: digit-major, chunk-minor exclusive scan) ->
+//                   k_rs_scatter (a wave owns 512 consecutive keys: rank inside the wave by ballots, running per-digit counters
+//                   in LDS) -- integer counting only, no library primitive (rounds 1-5 called rocprim::radix_sort_pairs here:
+//                   the last library kernel on the product path)
 // One call from the host side instead of ~16 tensor-library launches per rulebook (nine rulebooks per encoder pass).
 #include "ud_common.h"
 #include "ud_prof.h"
 #include <algorithm>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -33,10 +36,9 @@ __global__ __launch_bounds__(256) void k_offset_counts(const int32_t* __restrict
 }
 
 // bit position of offset k = its rank by descending frequency (ties: lower k first), recomputed by every workgroup from the K
-// counters; mask[r] = OR over k of (nbr[r][k] >= 0) << bitpos[k];  iota[r] = r
+// counters; mask[r] = OR over k of (nbr[r][k] >= 0) << bitpos[k]
 __global__ __launch_bounds__(256) void k_row_masks(const int32_t* __restrict__ nbr, int M, int K,
-                                                   const unsigned* __restrict__ cnt, unsigned* __restrict__ mask,
-                                                   int32_t* __restrict__ iota) {
+                                                   const unsigned* __restrict__ cnt, unsigned* __restrict__ mask) {
   __shared__ unsigned s_c[32];
   __shared__ int s_pos[32];
   if ((int)threadIdx.x < K) s_c[threadIdx.x] = cnt[threadIdx.x];
@@ -55,31 +57,150 @@ __global__ __launch_bounds__(256) void k_row_masks(const int32_t* __restrict__ n
   unsigned m = 0u;
   for (int k = 0; k < K; ++k) m |= (unsigned)(row[k] >= 0) << s_pos[k];
   mask[r] = m;
-  iota[r] = r;
+}
+
+// ---- stable LSD radix sort of (key, row) pairs: digits of at most 9 bits, chunks of 2 048 keys ------------------------------
+constexpr int kRsChunk = 2048, kRsBinsMax = 512, kRsWave = kRsChunk / 4;      // a wave owns 512 consecutive keys of its chunk
+
+// hist[digit * nblk + chunk] = number of keys of the chunk with that digit
+__global__ __launch_bounds__(256) void k_rs_hist(const unsigned* __restrict__ keys, int M, int shift, int bins, int nblk,
+                                                 unsigned* __restrict__ hist) {
+  __shared__ unsigned s_h[kRsBinsMax];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < bins; i += 256) s_h[i] = 0u;
+  __syncthreads();
+  const unsigned dm = (unsigned)bins - 1u;
+#pragma unroll
+  for (int r = 0; r < kRsChunk / 256; ++r) {
+    const int i = b * kRsChunk + r * 256 + tid;
+    if (i < M) atomicAdd(&s_h[(keys[i] >> shift) & dm], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < bins; i += 256) hist[(size_t)i * nblk + b] = s_h[i];
+}
+
+// exclusive scan of hist[0 .. n) in place (digit-major, chunk-minor = the destination of every (digit, chunk) group); one workgroup
+__global__ __launch_bounds__(1024) void k_rs_scan(unsigned* __restrict__ hist, int n) {
+  __shared__ unsigned s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(n, i0 + per);
+  unsigned sum = 0u;
+  for (int i = i0; i < i1; ++i) sum += hist[i];
+  unsigned inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned a = __shfl_up(inc, o);
+    if (lane >= o) inc += a;
+  }
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  unsigned off = inc - sum;
+  for (int k = 0; k < wv; ++k) off += s_w[k];
+  for (int i = i0; i < i1; ++i) {
+    const unsigned v = hist[i];
+    hist[i] = off;
+    off += v;
+  }
+}
+
+// keys_out / vals_out[destination] = the pair, destinations in (digit, chunk, position inside the chunk) order: stable.
+// vals_in == nullptr: the value of key i is i (first pass); keys_out == nullptr: only the values are needed (last pass).
+__global__ __launch_bounds__(256) void k_rs_scatter(const unsigned* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int M,
+                                                    int shift, int bins, int nblk, const unsigned* __restrict__ hist,
+                                                    unsigned* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+  __shared__ unsigned s_run[4][kRsBinsMax];          // per wave: its keys per digit, then the running destination per digit
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned dm = (unsigned)bins - 1u;
+  for (int i = tid; i < 4 * bins; i += 256) s_run[i / bins][i % bins] = 0u;
+  __syncthreads();
+  const int w0 = b * kRsChunk + wv * kRsWave;
+  unsigned key[kRsWave / 64];
+#pragma unroll
+  for (int r = 0; r < kRsWave / 64; ++r) {
+    const int i = w0 + r * 64 + lane;
+    key[r] = i < M ? keys_in[i] : 0u;
+    if (i < M) atomicAdd(&s_run[wv][(key[r] >> shift) & dm], 1u);
+  }
+  __syncthreads();
+  for (int d = tid; d < bins; d += 256) {            // wave bases of digit d: the chunk's group start + the earlier waves' keys
+    unsigned base = hist[(size_t)d * nblk + b];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned c = s_run[w][d];
+      s_run[w][d] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < kRsWave / 64; ++r) {
+    const int i = w0 + r * 64 + lane;
+    const bool ok = i < M;
+    const unsigned d = (key[r] >> shift) & dm;
+    unsigned long long peers = __ballot(ok);          // lanes of this round with my digit
+    for (int bit = 0; (1 << bit) < bins; ++bit) {
+      const unsigned long long bal = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? bal : ~bal;
+    }
+    unsigned pos = 0u;
+    if (ok) pos = s_run[wv][d] + (unsigned)__popcll(peers & below);
+    __builtin_amdgcn_wave_barrier();                  // every lane has read the counter before the group's first lane moves it
+    if (ok && (peers & below) == 0ull) s_run[wv][d] += (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the update has landed before the next round reads it
+    if (ok) {
+      if (keys_out) keys_out[pos] = key[r];
+      vals_out[pos] = vals_in ? vals_in[i] : i;
+    }
+  }
 }
 
 struct OrderWs {
   unsigned* cnt;
   unsigned* mask;
-  unsigned* mask_sorted;
-  int32_t* iota;
-  void* sort_tmp;
-  size_t sort_bytes, total_bytes;
+  unsigned* keys[2];
+  int32_t* vals[2];
+  unsigned* hist;
+  int nblk;
+  size_t total_bytes;
 };
 
 OrderWs carve_order(void* ws, int M, int K) {
+  (void)K;
   UdArena a(ws, (size_t)-1);
   OrderWs w;
+  w.nblk = ud_div_up(M, kRsChunk);
   w.cnt = a.take<unsigned>(32);
   w.mask = a.take<unsigned>(M);
-  w.mask_sorted = a.take<unsigned>(M);
-  w.iota = a.take<int32_t>(M);
-  w.sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, w.sort_bytes, (const unsigned*)nullptr, (unsigned*)nullptr,
-                                  (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)M, 0u, (unsigned)K, (hipStream_t)0);
-  w.sort_tmp = a.take<char>(w.sort_bytes);
+  w.keys[0] = a.take<unsigned>(M);
+  w.keys[1] = a.take<unsigned>(M);
+  w.vals[0] = a.take<int32_t>(M);
+  w.vals[1] = a.take<int32_t>(M);
+  w.hist = a.take<unsigned>((size_t)kRsBinsMax * w.nblk);
   w.total_bytes = a.used;
   return w;
+}
+
+// order[] = row indices sorted (stably) by the low `bits` bits of key[]
+int radix_order(const OrderWs& w, int M, int bits, int32_t* order, hipStream_t stream) {
+  const int passes = std::max(1, ud_div_up(bits, 9)), db = ud_div_up(std::max(bits, 1), passes);
+  const unsigned* kin = w.mask;
+  const int32_t* vin = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = p * db, bins = 1 << std::min(db, bits - shift > 0 ? bits - shift : 1);
+    const bool last = p + 1 == passes;
+    unsigned* kout = last ? nullptr : w.keys[p & 1];
+    int32_t* vout = last ? order : w.vals[p & 1];
+    k_rs_hist<<<w.nblk, 256, 0, stream>>>(kin, M, shift, bins, w.nblk, w.hist);
+    UD_LAUNCH_CHECK();
+    k_rs_scan<<<1, 1024, 0, stream>>>(w.hist, bins * w.nblk);
+    UD_LAUNCH_CHECK();
+    k_rs_scatter<<<w.nblk, 256, 0, stream>>>(kin, vin, M, shift, bins, w.nblk, w.hist, kout, vout);
+    UD_LAUNCH_CHECK();
+    kin = kout, vin = vout;
+  }
+  return UD_OK;
 }
 
 }  // namespace
@@ -101,10 +222,7 @@ extern "C" int ud_spconv_mask_order(const int32_t* nbr, int M, int K, int32_t* o
   const long long sampled = (long long)((M + step - 1) / step) * K;
   k_offset_counts<<<(unsigned)std::min<long long>(64, (sampled + 2047) / 2048), 256, 0, stream>>>(nbr, M, K, step, w.cnt);
   UD_LAUNCH_CHECK();
-  k_row_masks<<<ud_div_up(M, 256), 256, 0, stream>>>(nbr, M, K, w.cnt, w.mask, w.iota);
+  k_row_masks<<<ud_div_up(M, 256), 256, 0, stream>>>(nbr, M, K, w.cnt, w.mask);
   UD_LAUNCH_CHECK();
-  size_t bytes = w.sort_bytes;
-  UD_HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp, bytes, (const unsigned*)w.mask, w.mask_sorted, (const int32_t*)w.iota,
-                                       order, (size_t)M, 0u, (unsigned)K, stream));
-  return UD_OK;
+  return radix_order(w, M, K, order, stream);
 }

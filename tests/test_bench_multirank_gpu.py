@@ -68,7 +68,7 @@ assert torch.equal(flat, ref), "ranks diverged: max |d| = %g" % float((flat - re
 # the weight-gradient stream under DDP (ops/wgrad_stream.py): steps 1-3 inline while the bucket views settle (DDP re-buckets
 # before its second forward), from step 4 on the side stream writes dW straight into the bucket views
 if os.environ.get("UD_WGRAD_STREAM", "1") == "1":
-    assert wgrad_stream.state() == "ddp" and wgrad_stream.STATS["ddp_direct"] > 50, wgrad_stream.STATS
+    assert wgrad_stream.state() == "ddp" and wgrad_stream.STATS["ddp_direct"] >= 30, wgrad_stream.STATS
 else:
     assert wgrad_stream.STATS["ddp_direct"] == 0 and wgrad_stream.STATS["deferred"] == 0
 torch.save(flat.cpu(), os.environ["UD_TEST_OUT"] + ".rank%d.pt" % rank)

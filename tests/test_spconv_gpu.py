@@ -366,7 +366,7 @@ def test_bf16_weight_gradient_many_tiles_per_chunk(cin, cout):
     np.testing.assert_allclose(c.cpu().numpy(), ref, **_tol(ref))
 
 
-@pytest.mark.parametrize("M,K", [(1251, 27), (70000, 27), (5, 3), (4096 * 3 + 17, 8)])
+@pytest.mark.parametrize("M,K", [(1251, 27), (70000, 27), (5, 3), (4096 * 3 + 17, 8), (400003, 27), (2049, 31), (3000, 1), (513, 10)])
 def test_mask_order_vs_numpy(M, K):
     """ud_spconv_mask_order (offset ranks from sampled rows, rarity-weighted masks, stable radix sort) bit for bit against
     its numpy restatement -- index work: exact."""

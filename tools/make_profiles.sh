@@ -4,7 +4,7 @@
 # bench.py reads for its `traffic` figures.
 #   gpurun --timeout 2400 -- 'bash tools/make_profiles.sh r04'
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -23,8 +23,12 @@ for AC in "" bf16; do
   TAG=${AC:-fp32}
   rm -rf /tmp/p_step; B=4 CL=1 AC=$AC STEPS=6 rocprofv3 --kernel-trace -d /tmp/p_step -- python $T/profile_step.py > $OUT/step_stdout_$TAG.txt 2>&1
   { echo "# Steady-state distillation step, B=4, $TAG, channels-last (6 steps between marker kernels) ($R)"; echo; echo '```'; grep "samples/s" $OUT/step_stdout_$TAG.txt; echo '```'; echo;
-    TOP=30 python $T/rocpd_categories.py $(ls /tmp/p_step/*/*.db | head -1) 6 --top | cut -c1-180; } > $OUT/${R}_step_categories_$TAG.md
+    TOP=30 python $T/rocpd_categories.py $(ls -S /tmp/p_step/*/*.db | head -1) 6 --top | cut -c1-180; } > $OUT/${R}_step_categories_$TAG.md
+  # 2b. the same trace as a per-stream timeline of its last step (tools/rocpd_timeline.py) + the UNTRACED phase clock (tools/stream_phases.py)
+  { echo "## $TAG step: streams of the last traced step (rocprofv3 --kernel-trace; the tracer adds ~8 us of host time per launch, so the traced step is host-paced: the teacher stream starts only when the host gets to it)"; echo; python $T/rocpd_timeline.py $(ls -S /tmp/p_step/*/*.db | head -1) 2; echo; echo '```'; python $T/rocpd_busy.py $(ls -S /tmp/p_step/*/*.db | head -1) 6; echo '```'; echo;
+    echo "## $TAG step WITHOUT a tracer: HIP events on the stream that runs each phase (tools/stream_phases.py; ms since the step started on the GPU)"; echo; echo '```'; B=4 CL=1 AC=$AC python $T/stream_phases.py 2>&1 | tail -17; echo '```'; echo; } > $OUT/timeline_$TAG.md
 done
+{ echo "# Per-stream timeline of the distillation step, B = 4 ($R): main stream, weight-gradient stream, teacher stream"; echo; cat $OUT/timeline_fp32.md $OUT/timeline_bf16.md; } > $OUT/${R}_step_timeline.md
 # 3. bev_pool / voxelize / dense() op level + the streaming reference points
 { echo "# bev_pool + voxelize + dense() op-level timings ($R)"; echo; echo '```'; python $T/time_bev_pool.py 2>&1 | tail -4; echo "-- voxelize, algo 0 (hash partition + LDS):"; python $T/time_voxelize.py 2>&1 | tail -16; echo "-- voxelize, algo 1 (atomic hash):"; ALGO=1 python $T/time_voxelize.py 2>&1 | tail -16; echo "-- voxelize, algo 3 (atomic hash in three launches, self-cleaning workspace; clouds of at most 256 tiles):"; ALGO=3 python $T/time_voxelize.py 2>&1 | grep -A1 "^B="; python $T/time_dense.py 2>&1 | tail -2; python $T/time_stream.py 2>&1 | tail -5; echo "-- device-scope atomics vs plain accesses (tools/atomic_rate.hip):"; hipcc --offload-arch=gfx950 -O3 $T/atomic_rate.hip -o /tmp/atomic_rate 2>/dev/null && /tmp/atomic_rate; echo '```'; } > $OUT/${R}_bevpool_voxelize_ops.md
 rm -rf /tmp/p_vox; rocprofv3 --kernel-trace --stats -d /tmp/p_vox -- python $T/time_voxelize.py > /dev/null 2>&1
