@@ -250,22 +250,47 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ x, 
   }
 }
 
-__global__ void k_bn_bwd_final(const float* __restrict__ partial, int slices, int C, long long P,
-                               const float* __restrict__ scale, const float* __restrict__ mean,
-                               const float* __restrict__ invstd, float* __restrict__ dgamma,
-                               float* __restrict__ dbeta, float* __restrict__ k0, float* __restrict__ k2) {
-  const int c = blockIdx.x, lane = threadIdx.x;      // one wave per channel, fixed-order reduction
-  float a = 0.f, q = 0.f;
-  for (int s = lane; s < slices; s += 64) {
-    a += partial[((size_t)s * C + c) * 2];
-    q += partial[((size_t)s * C + c) * 2 + 1];
+// One workgroup of T threads per channel; every thread adds rows t, t + T, ... with FOUR independent loads in flight, then a fixed
+// tree.  (Rounds 2-5: one wave per channel walking up to 1 024 partial rows in 16 dependent trips -- 3 us on an idle chip, 26 us
+// on average inside the step, where every trip waits behind the other streams' memory traffic: 71 of them sit on the main
+// stream's backward chain between a layer's reduction pass and its dx pass.)
+template <int T>
+__global__ __launch_bounds__(T) void k_bn_bwd_final(const float* __restrict__ partial, int slices, int C, long long P,
+                                                    const float* __restrict__ scale, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, float* __restrict__ k0, float* __restrict__ k2) {
+  __shared__ float red[T / 64][2];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  auto ld = [&](int s) { return *reinterpret_cast<const float2*>(partial + ((size_t)s * C + c) * 2); };
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  int s = tid;
+  for (; s + 3 * T < slices; s += 4 * T) {
+    const float2 v0 = ld(s), v1 = ld(s + T), v2 = ld(s + 2 * T), v3 = ld(s + 3 * T);
+    a0 += v0.x; q0 += v0.y;
+    a1 += v1.x; q1 += v1.y;
+    a2 += v2.x; q2 += v2.y;
+    a3 += v3.x; q3 += v3.y;
   }
+  for (; s < slices; s += T) {
+    const float2 v = ld(s);
+    a0 += v.x; q0 += v.y;
+  }
+  float a = (a0 + a1) + (a2 + a3), q = (q0 + q1) + (q2 + q3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     a += __shfl_xor(a, o);
     q += __shfl_xor(q, o);
   }
-  if (lane != 0) return;
+  if (T > 64) {
+    if (lane == 0) { red[wv][0] = a; red[wv][1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+      a = red[0][0], q = red[0][1];
+#pragma unroll
+      for (int w = 1; w < T / 64; ++w) { a += red[w][0]; q += red[w][1]; }
+    }
+  }
+  if (tid != 0) return;
   const float is = invstd[c], dg = q * is, inv_p = 1.0f / (float)P;
   dbeta[c] = a;
   dgamma[c] = dg;
@@ -377,13 +402,31 @@ __global__ __launch_bounds__(256) void k_colsum_partial_scalar(const T* __restri
   }
 }
 
-__global__ void k_colsum_final(const float* __restrict__ partial, int slices, int C, float* __restrict__ out) {
-  const int c = blockIdx.x, lane = threadIdx.x;      // one wave per channel, fixed-order reduction
-  float a = 0.f;
-  for (int s = lane; s < slices; s += 64) a += partial[(size_t)s * C + c];
+template <int T>
+__global__ __launch_bounds__(T) void k_colsum_final(const float* __restrict__ partial, int slices, int C, float* __restrict__ out) {
+  __shared__ float red[T / 64];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;      // T threads per channel, fixed-order reduction
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = tid;
+  for (; s + 3 * T < slices; s += 4 * T) {
+    const float v0 = partial[(size_t)s * C + c], v1 = partial[(size_t)(s + T) * C + c], v2 = partial[(size_t)(s + 2 * T) * C + c],
+                v3 = partial[(size_t)(s + 3 * T) * C + c];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; s < slices; s += T) a0 += partial[(size_t)s * C + c];
+  float a = (a0 + a1) + (a2 + a3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-  if (lane == 0) out[c] = a;
+  if (T > 64) {
+    if (lane == 0) red[wv] = a;
+    __syncthreads();
+    if (tid == 0) {
+      a = red[0];
+#pragma unroll
+      for (int w = 1; w < T / 64; ++w) a += red[w];
+    }
+  }
+  if (tid == 0) out[c] = a;
 }
 
 struct BnWs { float *partial, *k0, *k2; };
@@ -472,7 +515,10 @@ int bn_bwd_impl(const T* x, const T* y, const T* dy, const float* scale, const f
     else
       k_bn_bwd_reduce<16, T><<<dim3(slices, C / 16), 256, 0, stream>>>(x, y, dy, scale, shift, mean, P, C, relu, w.partial, dy_ld);
     UD_LAUNCH_CHECK();
-    k_bn_bwd_final<<<C, 64, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd, dgamma, dbeta, w.k0, w.k2);
+    if (slices > 128)
+      k_bn_bwd_final<256><<<C, 256, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd, dgamma, dbeta, w.k0, w.k2);
+    else
+      k_bn_bwd_final<64><<<C, 64, 0, stream>>>(w.partial, slices, C, P, scale, mean, invstd, dgamma, dbeta, w.k0, w.k2);
     UD_LAUNCH_CHECK();
   }
   int CH;
@@ -516,7 +562,8 @@ int colsum_impl(const T* x, long long P, int C, long long ld, float* out, void* 
     k_colsum_partial_scalar<T><<<dim3(slices, cblocks), 256, 0, stream>>>(x, P, C, ld, partial);
   }
   UD_LAUNCH_CHECK();
-  k_colsum_final<<<C, 64, 0, stream>>>(partial, slices, C, out);
+  if (slices > 128) k_colsum_final<256><<<C, 256, 0, stream>>>(partial, slices, C, out);
+  else k_colsum_final<64><<<C, 64, 0, stream>>>(partial, slices, C, out);
   UD_LAUNCH_CHECK();
   return UD_OK;
 }

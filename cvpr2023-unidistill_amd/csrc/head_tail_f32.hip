@@ -332,33 +332,73 @@ __global__ __launch_bounds__(256) void k_gtail_dgrad(const float* __restrict__ d
   }
 }
 
-// out[c] = sum over the slices (in slice order within a lane, fixed tree across the lanes) of colsum[slice][c]
-__global__ void k_gtail_colsum_final(const float* __restrict__ colsum, int slices, int C, float* __restrict__ out) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  float a = 0.f;
-  for (int s = lane; s < slices; s += 64) a += colsum[(size_t)s * C + c];
+// out[c] = sum over the slices of colsum[slice][c]: T threads per channel, four loads in flight per thread, fixed tree
+template <int T>
+__global__ __launch_bounds__(T) void k_gtail_colsum_final(const float* __restrict__ colsum, int slices, int C, float* __restrict__ out) {
+  __shared__ float red[T / 64];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = tid;
+  for (; s + 3 * T < slices; s += 4 * T) {
+    const float v0 = colsum[(size_t)s * C + c], v1 = colsum[(size_t)(s + T) * C + c], v2 = colsum[(size_t)(s + 2 * T) * C + c],
+                v3 = colsum[(size_t)(s + 3 * T) * C + c];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; s < slices; s += T) a0 += colsum[(size_t)s * C + c];
+  float a = (a0 + a1) + (a2 + a3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-  if (lane == 0) out[c] = a;
+  if (T > 64) {
+    if (lane == 0) red[wv] = a;
+    __syncthreads();
+    if (tid == 0) {
+      a = red[0];
+#pragma unroll
+      for (int w = 1; w < T / 64; ++w) a += red[w];
+    }
+  }
+  if (tid == 0) out[c] = a;
 }
 
 // dgamma / dbeta and the two per-channel constants of the dy pass (the k_bn_bwd_final of bn_act.hip on this layout)
-__global__ void k_gtail_bn_final(const float* __restrict__ partial, int slices, int C, long long P,
-                                 const float* __restrict__ scale, const float* __restrict__ mean,
-                                 const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                 float* __restrict__ k0, float* __restrict__ k2) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  float a = 0.f, q = 0.f;
-  for (int s = lane; s < slices; s += 64) {
-    a += partial[((size_t)s * C + c) * 2];
-    q += partial[((size_t)s * C + c) * 2 + 1];
+template <int T>
+__global__ __launch_bounds__(T) void k_gtail_bn_final(const float* __restrict__ partial, int slices, int C, long long P,
+                                                      const float* __restrict__ scale, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, float* __restrict__ k0, float* __restrict__ k2) {
+  // T threads per channel, four independent row loads in flight per thread, fixed tree (see k_bn_bwd_final of bn_act.hip)
+  __shared__ float red[T / 64][2];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  auto ld = [&](int s) { return *reinterpret_cast<const float2*>(partial + ((size_t)s * C + c) * 2); };
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  int s = tid;
+  for (; s + 3 * T < slices; s += 4 * T) {
+    const float2 v0 = ld(s), v1 = ld(s + T), v2 = ld(s + 2 * T), v3 = ld(s + 3 * T);
+    a0 += v0.x; q0 += v0.y;
+    a1 += v1.x; q1 += v1.y;
+    a2 += v2.x; q2 += v2.y;
+    a3 += v3.x; q3 += v3.y;
   }
+  for (; s < slices; s += T) {
+    const float2 v = ld(s);
+    a0 += v.x; q0 += v.y;
+  }
+  float a = (a0 + a1) + (a2 + a3), q = (q0 + q1) + (q2 + q3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     a += __shfl_xor(a, o);
     q += __shfl_xor(q, o);
   }
-  if (lane != 0) return;
+  if (T > 64) {
+    if (lane == 0) { red[wv][0] = a; red[wv][1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+      a = red[0][0], q = red[0][1];
+#pragma unroll
+      for (int w = 1; w < T / 64; ++w) { a += red[w][0]; q += red[w][1]; }
+    }
+  }
+  if (tid != 0) return;
   const float is = invstd[c], dg = q * is, inv_p = 1.0f / (float)P;
   dbeta[c] = a;
   dgamma[c] = dg;
@@ -612,8 +652,12 @@ extern "C" int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const fl
       default: k_gtail_dgrad<4, 1><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
     }
     UD_LAUNCH_CHECK();
-    k_gtail_bn_final<<<C, 64, 0, stream>>>(partial, slices, C, (long long)B * H * W, bn_scale, mean, invstd, dgamma, dbeta,
-                                           k0, k2);
+    if (slices > 128)
+      k_gtail_bn_final<256><<<C, 256, 0, stream>>>(partial, slices, C, (long long)B * H * W, bn_scale, mean, invstd, dgamma, dbeta,
+                                                   k0, k2);
+    else
+      k_gtail_bn_final<64><<<C, 64, 0, stream>>>(partial, slices, C, (long long)B * H * W, bn_scale, mean, invstd, dgamma, dbeta,
+                                                 k0, k2);
     UD_LAUNCH_CHECK();
   }
   UdProfScope prof("head_tail.k_gtail_bn_bwd_dx", stream);
@@ -625,7 +669,8 @@ extern "C" int ud_head_tail_f32_bn_bwd(const float* dz, const float* w, const fl
       default: k_gtail_dgrad<4, 3><<<grid, 256, 0, stream>>>(dz, w, dy, t, strip_rows, strips, bn); break;
     }
     UD_LAUNCH_CHECK();
-    k_gtail_colsum_final<<<C, 64, 0, stream>>>(colsum, slices, C, dy_colsum);
+    if (slices > 128) k_gtail_colsum_final<256><<<C, 256, 0, stream>>>(colsum, slices, C, dy_colsum);
+    else k_gtail_colsum_final<64><<<C, 64, 0, stream>>>(colsum, slices, C, dy_colsum);
     UD_LAUNCH_CHECK();
     return UD_OK;
   }

@@ -702,27 +702,31 @@ struct VoxRec {
 // (First version: bitonic sort of the (key, id) pairs -- 78 barrier-separated stages, 35 us per workgroup.)
 constexpr int kLgTab = 12, kTab = 1 << kLgTab;      // hash slots: load factor <= 0.75 at the cap, ~0.25-0.5 typically
 static_assert(kCap * 4 == kTab * 3, "kCap = 3/4 kTab");
+constexpr int kScr = kCap + kCap / 2 + 2048;         // words: point ids, 16-bit slots, the gather's offsets; then the compacted slot list
 
-__global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __restrict__ pairs,
+__global__ __launch_bounds__(1024, 8) void k_vp_bucket(const unsigned long long* __restrict__ pairs,
                                                     const unsigned* __restrict__ tab, int nchunks, int P, int TS,
                                                     unsigned* __restrict__ vtop, VoxRec* __restrict__ rec,
                                                     unsigned* __restrict__ nrec, unsigned char* __restrict__ flags,
                                                     int32_t* __restrict__ ovf) {
   __shared__ unsigned s_key[kCap];        // keys of the gathered pairs; later the ids grouped by voxel
-  __shared__ unsigned s_pid[kCap];
-  __shared__ unsigned short s_slot[kCap];
+  // one block for the arrays that are dead after step 4 (point ids, slots, the gather's offsets): step 5 stages its output there
+  __shared__ __attribute__((aligned(16))) unsigned s_scr[kScr];
+  unsigned* const s_pid = s_scr;
+  unsigned short* const s_slot = reinterpret_cast<unsigned short*>(s_scr + kCap);
+  unsigned* const s_cpos = s_scr + kCap + kCap / 2;
+  unsigned* const s_csrc = s_cpos + 1024;
   __shared__ unsigned s_tkey[kTab];
   __shared__ unsigned s_tcnt[kTab + 1];    // counts, then exclusive offsets
-  __shared__ int s_ws[16];
-  __shared__ unsigned s_cpos[1024], s_csrc[1024];
-  __shared__ unsigned s_nv, s_ctr, s_base, s_nheavy;
+  __shared__ int s_ws[16], s_wo[16];
+  __shared__ unsigned s_nv, s_base, s_nheavy;
   __shared__ unsigned s_heavy[kCap / 5 + 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int i = tid; i < kTab; i += 1024) {
     s_tkey[i] = kEmpty;
     s_tcnt[i] = 0u;
   }
-  if (tid == 0) s_nv = s_ctr = s_nheavy = 0u;
+  if (tid == 0) s_nheavy = 0u;
   // 1. segment offsets (exclusive scan of the chunk counts of this bucket) + gather into LDS.  The copy is FLAT over the
   //    pairs (pair i -> its chunk by binary search in the offsets): a thread-per-chunk copy loop waits for its longest
   //    segment, one memory round trip per pair (12 of them for a Poisson(4) maximum: most of the first version's 19 us).
@@ -789,7 +793,9 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
     }
   }
   __syncthreads();
-  // 3. exclusive scan of the slot counts (thread t owns slots [8 t, 8 t + 8)); occupied slots = voxels
+  // 3. exclusive scan of the slot counts (thread t owns slots [4 t, 4 t + 4)); occupied slots = voxels: their exclusive count in
+  //    slot order = the voxel's record index inside the bucket
+  unsigned occ_off;
   {
     unsigned v[kTab / 1024], sum = 0u, occ = 0u;
 #pragma unroll
@@ -798,27 +804,34 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
       sum += v[k];
       occ += v[k] != 0u;
     }
-    unsigned inc = sum;
+    unsigned inc = sum, oinc = occ;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const unsigned a2 = __shfl_up(inc, o);
-      if (lane >= o) inc += a2;
+      const unsigned a2 = __shfl_up(inc, o), o2 = __shfl_up(oinc, o);
+      if (lane >= o) inc += a2, oinc += o2;
     }
-    if (lane == 63) s_ws[wv] = (int)inc;
-    occ = (unsigned)ud_wave_sum_i((int)occ);
-    if (lane == 0 && occ) atomicAdd(&s_nv, occ);
+    if (lane == 63) s_ws[wv] = (int)inc, s_wo[wv] = (int)oinc;
     __syncthreads();
     unsigned off = inc - sum;
-    for (int k = 0; k < wv; ++k) off += (unsigned)s_ws[k];
+    occ_off = oinc - occ;
+    unsigned tot_occ = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < wv) off += (unsigned)s_ws[k], occ_off += (unsigned)s_wo[k];
+      tot_occ += (unsigned)s_wo[k];
+    }
 #pragma unroll
     for (int k = 0; k < kTab / 1024; ++k) {
       s_tcnt[tid * (kTab / 1024) + k] = off;
       off += v[k];
     }
     if (tid == 1023) s_tcnt[kTab] = off;
+    if (tid == 0) {
+      s_nv = tot_occ;
+      s_base = atomicAdd(nrec, tot_occ);      // the ONE global atomic of this workgroup
+    }
   }
   __syncthreads();
-  if (tid == 0) s_base = atomicAdd(nrec, s_nv);      // the ONE global atomic of this workgroup
   // 4. ids grouped by voxel (s_key is free: the keys live in the table now)
 #pragma unroll
   for (int u = 0; u < kCap / 1024; ++u) {
@@ -826,43 +839,62 @@ __global__ __launch_bounds__(1024) void k_vp_bucket(const unsigned long long* __
     if (i < n) s_key[s_tcnt[s_slot[i]] + rk[u]] = s_pid[i];
   }
   __syncthreads();
-  // 5. a thread per occupied slot: the P smallest ids in ascending order (ids are unique), record, first-point flag
-  const unsigned rbase = s_base;
-#pragma unroll 1
-  for (int k = 0; k < kTab / 1024; ++k) {
-    const int h = tid + 1024 * k;
-    const unsigned key = s_tkey[h];
-    if (key == kEmpty) continue;
+  // 5. the occupied slots are COMPACTED (slot order = record order inside the bucket), then a thread per voxel: its P smallest ids
+  //    in ascending order (ids are unique), the record and the first-point flag.  Rounds 2-5 walked the 4 096 slots four per
+  //    thread with ~23 % of them occupied: every wave ran the selection body four times with a quarter of its lanes, and a
+  //    voxel's record / id words left as single scattered stores in arrival order -- 2.2 M of them per 480 k voxels, 126 MB of
+  //    HBM traffic for 31 MB of payload (profiles/traffic.json).  Now consecutive lanes hold consecutive records: the body runs
+  //    once per 1 024 voxels with every lane busy, the record is one coalesced 16-byte store per lane and the sorted ids leave
+  //    as 16-byte words of a contiguous row block.  Measured at 1.19 M points (round 6, early exits after each step, ~6 us of
+  //    dispatch included): gather 13.4 us, + hash 17.2, + scan 19.8, + counting sort 20.1, + this step 36.1 -- the same 36 us as
+  //    the slot walk (the small clouds gained 2 us): what this step costs is its 480 k first-point byte flags (random
+  //    single-byte stores: a 64-byte sector read-modify-write each) and draining ~16 MB of records + id words, not instructions.
+  const unsigned rbase = s_base, nv = s_nv;
+  unsigned short* const s_list = reinterpret_cast<unsigned short*>(s_scr);      // [kTab]: slot of record lj (s_scr is free after step 4)
+  {
+    unsigned lj = occ_off;
+#pragma unroll
+    for (int k = 0; k < kTab / 1024; ++k) {
+      const int h = tid * (kTab / 1024) + k;
+      if (s_tkey[h] != kEmpty) s_list[lj++] = (unsigned short)h;
+    }
+  }
+  __syncthreads();
+  for (unsigned lj = tid; lj < nv; lj += 1024) {
+    const unsigned h = s_list[lj];
     const unsigned o0 = s_tcnt[h], cnt = s_tcnt[h + 1] - o0;
-    const unsigned j_rec = rbase + atomicAdd(&s_ctr, 1u);
-    unsigned* top = vtop + (size_t)j_rec * TS;       // id lists: TS = P rounded up to 4 words, written 16 bytes at a time
-    unsigned first;
-    if (cnt <= 8u) {
-      // the common case (2-3 ids per voxel): all reads independent, position of an id = number of smaller ids
-      unsigned v[8];
-#pragma unroll
-      for (int a2 = 0; a2 < 8; ++a2) v[a2] = (unsigned)a2 < cnt ? s_key[o0 + a2] : kEmpty;
-      first = kEmpty;
-#pragma unroll
-      for (int a2 = 0; a2 < 8; ++a2) {
-        unsigned r2 = 0u;
-#pragma unroll
-        for (int c2 = 0; c2 < 8; ++c2) r2 += v[c2] < v[a2];
-        if ((unsigned)a2 < cnt && r2 < (unsigned)P) top[r2] = v[a2];
-        first = min(first, v[a2]);
-      }
-    } else {
+    const unsigned j_rec = rbase + lj;
+    if (cnt > 8u) {
       const unsigned e = atomicAdd(&s_nheavy, 1u);      // <= kCap / 9 = 341 such voxels in a bucket
-      s_heavy[e] = (unsigned)h | ((j_rec - rbase) << 16);
+      s_heavy[e] = h | (lj << 16);
       continue;
     }
+    // the common case (2-3 ids per voxel): all reads independent; rank of an id = number of smaller ids; the sorted list is
+    // assembled in registers (out[p] = the id of rank p) and stored 16 bytes at a time
+    unsigned v[8], out[8];
+#pragma unroll
+    for (int a2 = 0; a2 < 8; ++a2) v[a2] = (unsigned)a2 < cnt ? s_key[o0 + a2] : kEmpty;
+#pragma unroll
+    for (int p2 = 0; p2 < 8; ++p2) out[p2] = kEmpty;
+#pragma unroll
+    for (int a2 = 0; a2 < 8; ++a2) {
+      unsigned r2 = 0u;
+#pragma unroll
+      for (int c2 = 0; c2 < 8; ++c2) r2 += v[c2] < v[a2];
+#pragma unroll
+      for (int p2 = 0; p2 < 8; ++p2) out[p2] = (r2 == (unsigned)p2 && (unsigned)a2 < cnt) ? v[a2] : out[p2];
+    }
+    const unsigned keep = min(cnt, (unsigned)P);
+    uint4* trow = reinterpret_cast<uint4*>(vtop + (size_t)j_rec * TS);       // TS % 4 == 0: 16-byte aligned rows
+    trow[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    if (keep > 4u) trow[1] = make_uint4(out[4], out[5], out[6], out[7]);
     VoxRec r;
-    r.key = key;
-    r.first = first;
+    r.key = s_tkey[h];
+    r.first = out[0];
     r.count = cnt;
     r.pad = 0u;
     *reinterpret_cast<uint4*>(rec + j_rec) = *reinterpret_cast<const uint4*>(&r);
-    flags[first] = 1;
+    flags[out[0]] = 1;
   }
   // voxels with more than 8 points (zero-padded tails, coarse grids): a WAVE per voxel -- every lane scans a strided part of
   // the segment, the wave takes the minimum; P rounds.  (Left to one thread, a 400-point voxel kept its whole workgroup --
