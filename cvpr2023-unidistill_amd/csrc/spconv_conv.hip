@@ -1486,7 +1486,13 @@ __global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__
 // 16-byte slots, XOR-swizzled with (row & 15) on the SOURCE address, so the b128 fragment reads (16 lanes = 16 rows, same
 // logical slot) touch 16 distinct slots.  Waves: 4 (32 rows) x 2 (Cout / 2 columns); per 16-channel group a wave reads 2 A + NT B
 // fragments for 8 NT MFMAs (a lane's 16-byte piece feeds four MFMAs, see conv2d_f32.hip).
-__device__ __attribute__((aligned(16))) unsigned int g_zero16s[4];
+constexpr unsigned kDmaOob = 0xFFFF0000u;      // size of the buffer descriptors of k_conv_dma_f32 = the byte offset that reads zeros
+// LDS-DMA of 16 bytes per lane through a raw buffer descriptor: LDS[lds_wave_base + lane * 16] = buffer[voff + soff]; an offset past
+// the descriptor's size reads zeros.  (A __device__ function: the builtin does not exist in the host pass, and a lambda of a
+// kernel is compiled for both sides -- called from the lambda directly it silently drops the kernel's host stub.)
+__device__ __forceinline__ void sp_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(size_t)lds_wave_base, 16, voff, soff, 0, 0);
+}
 
 // (A three-buffer ring for the 64 -> 64 layers -- two stages in flight under a counted vmcnt -- was measured in round 4 and
 // removed in round 5: 670 us against k_conv_mfma_v2's 620 us on the step's four layers.)
@@ -1508,7 +1514,6 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
   const int g = lane >> 4, li = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
   const int row0 = (int)(gridDim.x - 1u - blockIdx.x) * kTM2;   // mask-sorted rows: the tiles with the most active offsets sit at the end -> dispatch them first (longest first)
-  const float* zero = reinterpret_cast<const float*>(g_zero16s);
   if (tid == 0) s_active = 0u;
   if (tid < kTM2) {
     const int p = row0 + tid;
@@ -1540,9 +1545,20 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // DMA of one stage: pieces are dealt to the 8 waves round-robin; lane -> (row 4 p + g, LDS slot li <- source slot li ^ (row & 15))
+  // DMA of one stage: pieces are dealt to the 8 waves round-robin; lane -> (row 4 p + g, LDS slot li <- source slot li ^ (row & 15)).
+  // Sources go through raw buffer descriptors (round 6): a lane's byte offset is ONE shift-add of the gathered row id (rows are
+  // CIN * 4 = 256 / 512 bytes) -- or an out-of-range offset, which reads zeros, for a missing neighbour -- and the (offset, half)
+  // part of a weight address rides in the scalar offset; the per-lane weight offsets are fixed for the whole launch.  With
+  // 64-bit pointer arithmetic a stage cost every wave ~90 vector + ~70 scalar instructions beside its 128 MFMAs, and on this
+  // chip every issued instruction of an fp32-MFMA kernel is paid in MFMA issue time (SQ counters, profiles/r06_spconv_encoder.md).
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)kDmaOob, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)kDmaOob, 0x00020000);
+  const unsigned swz = (unsigned)((li ^ ((4 * wave + g) & 15)) << 4);      // (4 (wave + 8 i) + g) & 15 does not depend on i
+  unsigned wvo[kWPieces / 8];
+#pragma unroll
+  for (int i = 0; i < kWPieces / 8; ++i) wvo[i] = (unsigned)(4 * (wave + 8 * i) + g) * (unsigned)ws.sn * 4u + swz;
   auto stage = [&](int k, int half, int buf) {
-    char* sb = smem + buf * kStage;
+    const unsigned sb = (unsigned)(size_t)smem + buf * kStage;
     int rr[kAPieces / 8];
     {
       const unsigned na = NBUF * kStage + (unsigned)(k * kTM2 + 4 * wave + g) * 4u;              // one LDS round trip, not four
@@ -1552,19 +1568,18 @@ __global__ __launch_bounds__(512) void k_conv_dma_f32(const float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < kAPieces / 8; ++i) asm volatile("" : "+v"(rr[i]));
     }
+    const unsigned sa = (unsigned)half * 256u;
+    const unsigned sw = __builtin_amdgcn_readfirstlane((unsigned)k * (unsigned)ws.sk * 4u + (unsigned)half * 256u);
 #pragma unroll
     for (int i = 0; i < kAPieces / 8; ++i) {
-      const int p = wave + 8 * i, r = 4 * p + g;
-      const float* src = rr[i] >= 0 ? in + (size_t)rr[i] * CIN + half * 64 + ((li ^ (r & 15)) << 2) : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sb + p * 1024), 16, 0, 0);
+      const int p = wave + 8 * i;
+      const unsigned vo = rr[i] >= 0 ? (unsigned)rr[i] * (unsigned)(CIN * 4) + swz : kDmaOob;
+      sp_dma16(rin, vo, sa, sb + p * 1024);
     }
 #pragma unroll
     for (int i = 0; i < kWPieces / 8; ++i) {
-      const int p = wave + 8 * i, n = 4 * p + g;
-      const float* src = W + (size_t)n * ws.sn + (size_t)k * ws.sk + half * 64 + ((li ^ (n & 15)) << 2);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sb + kAB + p * 1024), 16, 0, 0);
+      const int p = wave + 8 * i;
+      sp_dma16(rw, wvo[i], sw, sb + kAB + p * 1024);
     }
   };
   // fragment byte offsets inside a stage buffer, per 16-channel group cb: slot (4 cb + g) ^ li of row (tile * 16 + li)
@@ -1782,7 +1797,11 @@ int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror,
   // stage buffers 700 us (round 3), with a three-stage ring 670 us (round 4; removed).
   if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128) && !(CIN_P == 64 && COUT_P == 64)) {
     static const bool no_dma = getenv("UD_SPCONV_NO_DMA") != nullptr;       // A/B timing
-    if (!no_dma && K <= 32 && algo == 0 && cin == CIN_P && cout == COUT_P && ws.sc == 1 && (ws.sn & 3) == 0 && (ws.sk & 3) == 0)
+    // (32-bit byte offsets into W through a buffer descriptor; the INPUT tensor must be smaller than 4 GiB - 64 KiB as well --
+    // the entry point does not know its row count: include/unidistill_hip.h states the limit, ops/spconv.py enforces it)
+    const long long w_span = ((long long)(cout - 1) * ws.sn + (long long)(K - 1) * ws.sk + cin) * 4;
+    if (!no_dma && K <= 32 && algo == 0 && cin == CIN_P && cout == COUT_P && ws.sc == 1 && (ws.sn & 3) == 0 && (ws.sk & 3) == 0 &&
+        ws.sn >= 0 && ws.sk >= 0 && w_span < (long long)kDmaOob && ((size_t)W & 15) == 0 && ((size_t)in & 15) == 0)
       return launch_conv_dma_f32<CIN_P, COUT_P>(in, nbr, K, mirror, W, ws, bias, out, Mout, order, ep, stream);
   }
   // activity masks are 32-bit; the LDS rulebook slice must fit next to the tiles

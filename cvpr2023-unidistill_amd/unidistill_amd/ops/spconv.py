@@ -229,6 +229,8 @@ def _conv(feat, nbr, weight, w_strides, mirror, bias, cin, cout, algo=0, scale=N
         CONV_LOG.append((nbr, cin, cout, "f32"))
     out = torch.empty((Mout, cout), dtype=torch.float32, device=feat.device)
     order = mask_order(nbr, mirror) if algo in (0, 3) else None
+    if feat.numel() * feat.element_size() >= 0xFFFF0000:
+        raise ValueError("ud_spconv_conv: the input feature tensor must be smaller than 4 GiB - 64 KiB (32-bit byte offsets)")
     _lib.check(_lib.load().ud_spconv_conv(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(weight),
                                           w_strides[0], w_strides[1], w_strides[2],
                                           1 if mirror else 0, _lib.ptr(bias), _lib.ptr(out), Mout, K,

@@ -264,6 +264,8 @@ int ud_spconv_down_rulebook(const void* in_index, int in_rows_sorted, int Min, i
  * row_order (optional, may be NULL): a permutation i32[Mout] of the output rows; tiles are formed
  * over row_order so rows with similar neighbour masks share a tile (same results, fewer active
  * kernel offsets per tile; only the wide-channel MFMA kernel uses it).
+ * Size limit: `in` must be smaller than 4 GiB - 64 KiB (0xFFFF0000 bytes): the 64 / 128-channel fp32 kernel addresses the gathered
+ * rows with 32-bit byte offsets through a buffer descriptor (the entry point is not told the input's row count).
  */
 int ud_spconv_conv(const float* in, const int32_t* nbr, const float* W, int64_t w_sn, int64_t w_sk,
                    int64_t w_sc, int mirror, const float* bias, float* out, int Mout, int K,
