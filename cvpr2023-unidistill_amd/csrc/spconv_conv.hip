@@ -1794,7 +1794,7 @@ int launch_conv(const float* in, int cin, const int32_t* nbr, int K, int mirror,
   // fp32, 64 / 128 channels exactly, channel-contiguous 16-byte-aligned weights: the LDS-DMA kernel
   // 64 -> 64 stays on k_conv_mfma_v2: a stage there is 64 MFMAs per wave, shorter than the DMA round trip and than the skew of
   // an 8-wave barrier.  Measured on the step's four 64 -> 64 layers (394 k rows, 5.45 M pairs): v2 620 us, this kernel with two
-  // stage buffers 700 us (round 3), with a three-stage ring 670 us (round 4; removed).
+  // stage buffers 700 us (round 3), with a three-stage ring 670 us (round 4; removed), with the round-6 descriptor addressing 660 us.
   if constexpr ((CIN_P == 64 || CIN_P == 128) && (COUT_P == 64 || COUT_P == 128) && !(CIN_P == 64 && COUT_P == 64)) {
     static const bool no_dma = getenv("UD_SPCONV_NO_DMA") != nullptr;       // A/B timing
     // (32-bit byte offsets into W through a buffer descriptor; the INPUT tensor must be smaller than 4 GiB - 64 KiB as well --
