@@ -10,6 +10,8 @@ arguments, buffers (voxel_size / voxel_coord / voxel_num / frustum), sub-module 
     written twice per step in the reference) never exists; backward likewise.
 ``materialise=True`` switches to the reference's op boundary (lift -> voxel_pooling) for A/B.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -53,6 +55,10 @@ class LSSFPN(nn.Module):
         self.timestamp_net = None
         self.img_neck.init_weights()
         self.img_backbone.init_weights()
+        # UD_GRAPH_IMAGE=1 / graph_image_branch: the shape-static image branch (backbone + neck + depth net, forward and backward)
+        # replayed as two hipGraphs in training (ops/graphed.py); not a registered submodule: the state_dict keys stay the reference's
+        object.__setattr__(self, "_image_graph", None)
+        self.graph_image_branch = os.environ.get("UD_GRAPH_IMAGE", "0") == "1"
 
     def _configure_depth_net(self, conf):
         out_ch = self.depth_channels + self.output_channels
@@ -94,22 +100,39 @@ class LSSFPN(nn.Module):
     def get_geometry(self, sensor2ego_mat, intrin_mat, ida_mat, bda_mat):
         return self.get_geometry_bins(sensor2ego_mat, intrin_mat, ida_mat, bda_mat, True)[1]
 
-    def get_cam_feats(self, imgs):
-        B, S, N, C, H, W = imgs.shape
-        x = imgs.reshape(B * S * N, C, H, W)
+    def _backbone_neck(self, x):
         w = next((p for p in self.img_backbone.parameters() if p.dim() == 4), None)   # the stem convolution
         any_layout = getattr(self.img_backbone, "stem_takes_any_layout", None)
         if any_layout is not None and any_layout(x):
             pass                                                       # the HIP stem reads the images through their strides
         elif w is not None and w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous():
             x = x.contiguous(memory_format=torch.channels_last)        # NHWC model -> NHWC input
-        f = self.img_neck(self.img_backbone(x))[0]
+        return self.img_neck(self.img_backbone(x))[0]
+
+    def get_cam_feats(self, imgs):
+        B, S, N, C, H, W = imgs.shape
+        f = self._backbone_neck(imgs.reshape(B * S * N, C, H, W))
         return f.reshape(B, S, N, f.shape[1], f.shape[2], f.shape[3])
+
+    def _image_branch(self, x):
+        """images [B * ncam, 3, H, W] -> depth feature [B * ncam, D + C, fH, fW]: get_cam_feats + depth_net of one sweep."""
+        return self.depth_net(self._backbone_neck(x))
+
+    def _depth_feature(self, sweep_imgs):
+        B, S, ncam = sweep_imgs.shape[:3]
+        if self.graph_image_branch and S == 1 and self.training and torch.is_grad_enabled() and sweep_imgs.is_cuda:
+            from ..ops.graphed import GraphedModule
+            if self._image_graph is None:
+                object.__setattr__(self, "_image_graph", GraphedModule("image_branch", self._image_branch,
+                                                                      [self.img_backbone, self.img_neck, self.depth_net]))
+            C, H, W = sweep_imgs.shape[3:]
+            return self._image_graph(sweep_imgs.reshape(B * S * ncam, C, H, W))
+        feats = self.get_cam_feats(sweep_imgs)[:, 0]
+        return self.depth_net(feats.reshape(B * ncam, *feats.shape[2:]))
 
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, is_return_depth=False):
         B, S, ncam = sweep_imgs.shape[:3]
-        feats = self.get_cam_feats(sweep_imgs)[:, 0]
-        depth_feature = self.depth_net(feats.reshape(B * ncam, *feats.shape[2:]))
+        depth_feature = self._depth_feature(sweep_imgs)
         D, C = self.depth_channels, self.output_channels
         geo = (mats_dict["sensor2ego_mats"][:, sweep_index], mats_dict["intrin_mats"][:, sweep_index],
                mats_dict["ida_mats"][:, sweep_index], mats_dict.get("bda_mat", None))

@@ -52,6 +52,11 @@ _ddp = {"on": False, "views": {}, "buffers": {}}
 STATS = {"deferred": 0, "inline_repeat": 0, "ddp_direct": 0, "ddp_inline": 0}
 
 _DEBUG = os.environ.get("UD_WGRAD_DEBUG")
+# hipGraph capture (ops/graphed.py): the side stream may JOIN a capture -- the fork (side.wait_stream) and the join (the engine
+# callback at the end of the captured backward) both land inside it -- with scratch buffers of the capture's own (SCOPE): the
+# captured weight gradients run beside whatever the eager weight-gradient stream is doing at replay time
+CAPTURE_OK = False
+SCOPE = ["wgrad_stream"]
 
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
 
@@ -189,7 +194,7 @@ def defer(weight, thunk, *keep):
     """dW of ``weight`` = thunk(), computed on the weight-gradient stream when that is safe (see the module text)."""
     if not (ENABLED and weight.is_cuda and weight.is_leaf and weight.grad is None and not torch.is_grad_enabled()
             and _hooks_are_stream_safe(weight) and not getattr(weight, "_post_accumulate_grad_hooks", None)
-            and not torch.cuda.is_current_stream_capturing()):
+            and (CAPTURE_OK or not torch.cuda.is_current_stream_capturing())):
         return thunk()      # (a hook on the parameter would read the gradient on the caller's stream)
     view = None
     if _ddp["on"]:
@@ -214,7 +219,7 @@ def defer(weight, thunk, *keep):
         STATS["inline_repeat"] += 1
         return thunk()
     side.wait_stream(cur)
-    with torch.cuda.stream(side), _lib.workspace_scope("wgrad_stream"):
+    with torch.cuda.stream(side), _lib.workspace_scope(SCOPE[0]):
         g = thunk()
         if view is not None:
             out = view.detach()                         # a fresh alias of the DDP bucket view: nobody else holds THIS tensor
