@@ -574,7 +574,7 @@ extern "C" int ud_conv3x3_wino_nhwc_f32(const float* x, const float* U, float* y
     const size_t rows = (size_t)nblocks + 4 * (size_t)split;
     if (!slices || partial_bytes < rows * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;
     *slices = (int)rows;
-    if (split) UD_HIP_TRY(hipMemsetAsync(partial + (size_t)nblocks * Cout * 2, 0, 4 * (size_t)split * Cout * 2 * sizeof(float), stream));
+    if (split) ud_zero_f32_async(partial + (size_t)nblocks * Cout * 2, 4 * (size_t)split * Cout * 2, stream);
   }
   static UdDeviceOnce attr_set;
   if (const unsigned long long attr_set_bit = attr_set.pending()) {

@@ -803,7 +803,7 @@ extern "C" int ud_conv3x3_wino4_nhwc_f32(const float* x, const float* U, float* 
     if (!slices || partial_bytes < rows * Cout * 2 * sizeof(float)) return UD_ERR_WORKSPACE;
     *slices = (int)rows;
     if (rows > (size_t)nblocks)
-      UD_HIP_TRY(hipMemsetAsync(partial + (size_t)nblocks * Cout * 2, 0, (rows - nblocks) * Cout * 2 * sizeof(float), stream));
+      ud_zero_f32_async(partial + (size_t)nblocks * Cout * 2, (rows - nblocks) * (size_t)Cout * 2, stream);
   }
   static UdDeviceOnce attr_set;
   if (const unsigned long long attr_set_bit = attr_set.pending()) {

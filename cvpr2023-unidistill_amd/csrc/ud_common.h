@@ -38,6 +38,22 @@ struct UdArena {
 
 static inline int ud_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+#ifdef __HIPCC__
+// Zero n floats with a KERNEL instead of hipMemsetAsync.  Inside a captured hipGraph (ops/graphed.py) the memset NODES that cleared the
+// BatchNorm partial rows of the Winograd launchers were not ordered like their stream counterparts on ROCm 7.2: the replayed fp32
+// step diverged from the eager one from the fifth replay on, and stayed bit-identical with either launcher's memset gone
+// (UD_WINO_NO_SPLIT=1 / UD_WINO4_SK=0) -- a kernel node keeps the stream order.
+static __global__ void k_ud_zero_f32(float* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+static inline void ud_zero_f32_async(float* p, size_t n, hipStream_t stream) {
+  if (!n) return;
+  const size_t blocks = (n + 255) / 256;
+  k_ud_zero_f32<<<(unsigned)(blocks < 1024 ? blocks : 1024), 256, 0, stream>>>(p, n);
+}
+#endif
+
+
 // Guard for "set once" HIP state that is really PER DEVICE (hipFuncSetAttribute: a process that drives several GPUs,
 // or several host threads, must not skip it on a device that has not seen it): a bit per device ordinal; racing
 // threads may both run the guarded block (idempotent calls), none can skip it.

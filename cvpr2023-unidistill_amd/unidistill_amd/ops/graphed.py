@@ -73,8 +73,7 @@ class GraphedModule:
             wgrad_stream.CAPTURE_OK, wgrad_stream.SCOPE[0], wgrad_stream.ENABLED = was
         with torch.no_grad():
             torch._foreach_copy_(bufs, saved)          # warm-up + capture advanced the running statistics: put them back
-        seg.forward = seg.__class__.forward.__get__(seg)       # (make_graphed_callables replaced the INSTANCE's forward)
-        return g
+        return g           # == seg, whose instance-level forward now replays the graphs (the eager path calls seg._fn directly)
 
     def _make(self, seg, sample):
         with _lib.workspace_scope("graph:" + self.name), torch.autocast("cuda", enabled=torch.is_autocast_enabled(),
@@ -92,4 +91,4 @@ class GraphedModule:
         if g is None:
             g = self.graphed[key] = self._capture(x)
         self.replays += 1
-        return g(x)
+        return g(x)        # a torch.autograd.Function that copies x into the static input and replays the forward graph

@@ -1,13 +1,15 @@
 """GPU: the shape-static image branch (ResNet-50 + SECONDFPN + depth net, forward and backward) replayed as two hipGraphs
 (ops/graphed.py, UD_GRAPH_IMAGE / LSSFPN.graph_image_branch) gives the SAME BITS as the eager path: loss, every gradient,
-parameters and BatchNorm buffers after three optimizer steps -- fp32 and bf16 autocast."""
+parameters and BatchNorm buffers after EIGHT optimizer steps -- fp32 and bf16 autocast.  (Eight: hipMemsetAsync captured as a
+memset node is not ordered like its stream counterpart on ROCm 7.2; with the two memsets of the Winograd launchers in the graph the
+fp32 step diverged from the fifth replay on -- three steps did not see it.  They are a zeroing kernel now.)"""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 
-def _steps(graph, ac, n=3):
+def _steps(graph, ac, n=8):
     from unidistill_amd import train
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -31,7 +33,7 @@ def _steps(graph, ac, n=3):
 def test_graphed_image_branch_is_bit_identical_to_eager(hip_lib, ac):
     l0, g0, p0, b0, r0 = _steps(False, ac)
     l1, g1, p1, b1, r1 = _steps(True, ac)
-    assert r0 == 0 and r1 == 3
+    assert r0 == 0 and r1 == 8
     assert l0 == l1, (l0, l1)
     assert set(g0) == set(g1) and len(g0) > 150
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
