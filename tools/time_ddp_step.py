@@ -21,8 +21,10 @@ ac = {"bf16": torch.bfloat16, "": None}[os.environ.get("AC", "")]
 tr = train.Trainer(train.DistillStep("camera_exp_distill_lidar"), device=dev, autocast_dtype=ac, channels_last=True)
 assert (tr.ddp is not None) == DDP
 batch = train.synthetic_batch(dev, 4)
-for _ in range(6):
-    tr.step(batch)
+for i in range(6):
+    o = tr.step(batch)
+    if os.environ.get("LOSSES"):
+        print("warm", i, float(o["loss"].detach()).hex())
 torch.cuda.synchronize()
 n = int(os.environ.get("STEPS", 20))
 t0 = time.perf_counter()
